@@ -1,0 +1,144 @@
+"""ctypes binding of include/edgegan_hip.h."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libedgegan_hip.so')
+
+
+class EdgeGANLibError(RuntimeError):
+    pass
+
+
+class _CConfig(C.Structure):
+    _fields_ = [('batch_size', C.c_int), ('height', C.c_int), ('width', C.c_int), ('num_classes', C.c_int),
+                ('z_dim', C.c_int), ('gf_dim', C.c_int), ('df_dim', C.c_int), ('c_dim', C.c_int),
+                ('dis_size', C.c_int), ('lambda_gp', C.c_float), ('zl_weight', C.c_float),
+                ('learning_rate', C.c_float), ('joint_dweight', C.c_float), ('image_dweight', C.c_float),
+                ('edge_dweight', C.c_float), ('device', C.c_int)]
+
+
+@dataclass
+class Config:
+    """Flags of the reference's edgegan/train.py:14-74 that shape the graph."""
+    batch_size: int = 64
+    height: int = 64
+    width: int = 128
+    num_classes: int = 14      # 0 == --nomulticlasses
+    z_dim: int = 100
+    gf_dim: int = 64
+    df_dim: int = 64
+    c_dim: int = 3
+    dis_size: int = 128
+    lambda_gp: float = 10.0
+    zl_weight: float = 10.0
+    learning_rate: float = 2e-4
+    joint_dweight: float = 1.0
+    image_dweight: float = 1.0
+    edge_dweight: float = 1.0
+    device: int = 0
+
+    @property
+    def multiclasses(self) -> bool:
+        return self.num_classes > 0
+
+    @property
+    def z_cols(self) -> int:
+        return self.z_dim + (1 if self.multiclasses else 0)
+
+    def to_c(self) -> _CConfig:
+        return _CConfig(self.batch_size, self.height, self.width, self.num_classes, self.z_dim, self.gf_dim,
+                        self.df_dim, self.c_dim, self.dis_size, self.lambda_gp, self.zl_weight,
+                        self.learning_rate, self.joint_dweight, self.image_dweight, self.edge_dweight, self.device)
+
+
+EXPORTS = ['eg_default_config', 'eg_variable_count', 'eg_variable_info', 'eg_create', 'eg_destroy',
+           'eg_last_error', 'eg_set_variable', 'eg_get_variable', 'eg_upload_batch', 'eg_substep',
+           'eg_train_step', 'eg_read_losses', 'eg_infer', 'eg_sync', 'eg_comm_unique_id', 'eg_comm_init',
+           'eg_profile_begin', 'eg_profile_end', 'eg_memory_stats', 'eg_test_op', 'eg_net_forward']
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads libedgegan_hip.so (built in-tree by __graft_entry__.build()).  No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EdgeGANLibError(f'{LIB_PATH} is missing: build it with `make -C edgegan_amd/csrc` '
+                              '(or __graft_entry__.build()); there is no CPU fallback')
+    lib = C.CDLL(LIB_PATH)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    lib.eg_last_error.restype = C.c_char_p
+    lib.eg_last_error.argtypes = [C.c_void_p]
+    lib.eg_variable_count.argtypes = [C.POINTER(_CConfig)]
+    lib.eg_variable_info.argtypes = [C.POINTER(_CConfig), C.c_int, C.c_char_p, C.c_int, ip, ip, ip, ip, fp]
+    lib.eg_create.argtypes = [C.POINTER(_CConfig), C.POINTER(C.c_void_p)]
+    lib.eg_destroy.argtypes = [C.c_void_p]
+    lib.eg_set_variable.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_longlong]
+    lib.eg_get_variable.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_longlong]
+    lib.eg_upload_batch.argtypes = [C.c_void_p, fp, fp, fp, fp]
+    lib.eg_substep.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.eg_train_step.argtypes = [C.c_void_p]
+    lib.eg_read_losses.argtypes = [C.c_void_p, fp]
+    lib.eg_infer.argtypes = [C.c_void_p, fp, ip, C.c_int, fp, fp, fp]
+    lib.eg_sync.argtypes = [C.c_void_p]
+    lib.eg_comm_unique_id.argtypes = [C.c_void_p, C.c_char_p]
+    lib.eg_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    lib.eg_profile_begin.argtypes = [C.c_void_p]
+    lib.eg_profile_end.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.eg_memory_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    lib.eg_test_op.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(fp), C.POINTER(C.c_longlong), C.c_int, ip,
+                               C.c_int, C.POINTER(fp), C.POINTER(C.c_longlong)]
+    lib.eg_net_forward.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fp,
+                                   C.c_longlong]
+    _lib = lib
+    return lib
+
+
+def fptr(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def iptr(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+@dataclass
+class VarSpec:
+    name: str
+    shape: Tuple[int, ...]
+    trainable: bool
+    init_kind: int      # 0 const, 1 normal, 2 truncated normal, 3 xavier uniform
+    init_param: float
+
+
+def variable_specs(cfg: Config) -> List[VarSpec]:
+    """The engine's variable registry (TF names / shapes of SURVEY.md Appendix C).  Needs no GPU."""
+    lib = load_library()
+    cc = cfg.to_c()
+    n = lib.eg_variable_count(C.byref(cc))
+    if n < 0:
+        raise EdgeGANLibError('eg_variable_count failed')
+    out = []
+    name = C.create_string_buffer(256)
+    shape = (C.c_int * 4)()
+    ndim, tr, kind = C.c_int(), C.c_int(), C.c_int()
+    par = C.c_float()
+    for i in range(n):
+        rc = lib.eg_variable_info(C.byref(cc), i, name, 256, shape, C.byref(ndim), C.byref(tr), C.byref(kind),
+                                  C.byref(par))
+        if rc != 0:
+            raise EdgeGANLibError(lib.eg_last_error(None).decode())
+        out.append(VarSpec(name.value.decode(), tuple(shape[j] for j in range(ndim.value)), bool(tr.value),
+                           kind.value, par.value))
+    return out

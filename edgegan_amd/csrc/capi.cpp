@@ -1,0 +1,595 @@
+// C ABI of libedgegan_hip.so (see include/edgegan_hip.h).  Translates exceptions to error codes.
+#include <algorithm>
+#include <sstream>
+
+#include "../../include/edgegan_hip.h"
+#include "engine.h"
+
+using namespace eg;
+
+struct eg_ctx {
+  Ctx c;
+  std::deque<Param> tmp_params;  // per-op test scaffolding
+};
+
+static thread_local std::string g_create_error;
+
+static Config to_config(const eg_config* k) {
+  Config c;
+  c.B = k->batch_size;
+  c.H = k->height;
+  c.W = k->width;
+  c.num_classes = k->num_classes;
+  c.z_dim = k->z_dim;
+  c.gf = k->gf_dim;
+  c.df = k->df_dim;
+  c.c_dim = k->c_dim;
+  c.dis_size = k->dis_size;
+  c.lambda_gp = k->lambda_gp;
+  c.zl_weight = k->zl_weight;
+  c.lr = k->learning_rate;
+  c.joint_dweight = k->joint_dweight;
+  c.image_dweight = k->image_dweight;
+  c.edge_dweight = k->edge_dweight;
+  c.device = k->device;
+  return c;
+}
+
+#define EG_API_BEGIN try {
+#define EG_API_END(ctxp)                                  \
+  }                                                       \
+  catch (const eg::Error& e) {                            \
+    if (ctxp) (ctxp)->c.last_error = e.what();            \
+    else g_create_error = e.what();                       \
+    return e.code;                                        \
+  }                                                       \
+  catch (const std::exception& e) {                       \
+    if (ctxp) (ctxp)->c.last_error = e.what();            \
+    else g_create_error = e.what();                       \
+    return 99;                                            \
+  }                                                       \
+  return 0;
+
+extern "C" {
+
+int eg_default_config(eg_config* k) {
+  if (!k) return 1;
+  *k = eg_config{64, 64, 128, 14, 100, 64, 64, 3, 128, 10.f, 10.f, 2e-4f, 1.f, 1.f, 1.f, 0};
+  return 0;
+}
+
+int eg_variable_count(const eg_config* k) {
+  try {
+    return (int)enumerate_variables(to_config(k)).size();
+  } catch (...) {
+    return -1;
+  }
+}
+
+int eg_variable_info(const eg_config* k, int index, char* name, int name_cap, int* shape, int* ndim, int* trainable,
+                     int* init_kind, float* init_param) {
+  eg_ctx* none = nullptr;
+  EG_API_BEGIN
+  auto v = enumerate_variables(to_config(k));
+  EG_CHECK(index >= 0 && index < (int)v.size(), "variable index out of range");
+  const VarInfo& vi = v[index];
+  EG_CHECK((int)vi.name.size() + 1 <= name_cap, "name buffer too small");
+  strcpy(name, vi.name.c_str());
+  *ndim = (int)vi.shape.size();
+  for (size_t i = 0; i < vi.shape.size() && i < 4; ++i) shape[i] = vi.shape[i];
+  *trainable = vi.trainable ? 1 : 0;
+  *init_kind = vi.init_kind;
+  *init_param = vi.init_param;
+  EG_API_END(none)
+}
+
+int eg_create(const eg_config* k, eg_ctx** out) {
+  eg_ctx* none = nullptr;
+  eg_ctx* ctx = nullptr;
+  try {
+    EG_CHECK(k && out, "null argument");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+      fail(2, "no HIP device available (%s); the engine has no CPU fallback", hipGetErrorString(e));
+    ctx = new eg_ctx();
+    ctx->c.cfg = to_config(k);
+    build_context(ctx->c);
+    *out = ctx;
+    return 0;
+  } catch (const eg::Error& e) {
+    g_create_error = e.what();
+    delete ctx;
+    return e.code;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    delete ctx;
+    return 99;
+  }
+  (void)none;
+}
+
+int eg_destroy(eg_ctx* ctx) {
+  if (!ctx) return 0;
+  try {
+    (void)hipStreamSynchronize(ctx->c.stream);
+    comm_destroy(ctx->c);
+  } catch (...) {
+  }
+  delete ctx;
+  return 0;
+}
+
+const char* eg_last_error(eg_ctx* ctx) { return ctx ? ctx->c.last_error.c_str() : g_create_error.c_str(); }
+
+static bool ends_with(const std::string& s, const std::string& suf) {
+  return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+static float* resolve_var(Ctx& c, const std::string& name, size_t* numel, bool for_set) {
+  std::string base = name;
+  int which = 0;  // 0 w, 1 ms, 2 mom, 3 grad
+  if (ends_with(name, "/RMSProp_1")) {
+    base = name.substr(0, name.size() - 10);
+    which = 2;
+  } else if (ends_with(name, "/RMSProp")) {
+    base = name.substr(0, name.size() - 8);
+    which = 1;
+  } else if (ends_with(name, "/grad")) {
+    base = name.substr(0, name.size() - 5);
+    which = 3;
+  }
+  Param* p = P(c, base);
+  *numel = p->numel;
+  if (which == 0) return p->w;
+  EG_CHECK(p->trainable, "%s has no optimizer slot / gradient", base.c_str());
+  if (which == 3) {
+    EG_CHECK(!for_set, "gradients are read-only");
+    EG_CHECK(p->g_set, "no gradient recorded for %s", base.c_str());
+    return p->g;
+  }
+  return which == 1 ? p->ms : p->mom;
+}
+
+int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long numel) {
+  EG_API_BEGIN
+  size_t n;
+  float* d = resolve_var(ctx->c, name, &n, true);
+  EG_CHECK((size_t)numel == n, "size mismatch for %s: got %lld, want %zu", name, numel, n);
+  EG_HIP(hipMemcpyAsync(d, host, n * 4, hipMemcpyHostToDevice, ctx->c.stream));
+  EG_HIP(hipStreamSynchronize(ctx->c.stream));
+  ctx->c.sn_prepared = false;
+  EG_API_END(ctx)
+}
+
+int eg_get_variable(eg_ctx* ctx, const char* name, float* host, long long numel) {
+  EG_API_BEGIN
+  size_t n;
+  float* d = resolve_var(ctx->c, name, &n, false);
+  EG_CHECK((size_t)numel == n, "size mismatch for %s: got %lld, want %zu", name, numel, n);
+  EG_HIP(hipMemcpyAsync(host, d, n * 4, hipMemcpyDeviceToHost, ctx->c.stream));
+  EG_HIP(hipStreamSynchronize(ctx->c.stream));
+  EG_API_END(ctx)
+}
+
+int eg_upload_batch(eg_ctx* ctx, const float* images, const float* z, const float* alpha, const float* eps) {
+  EG_API_BEGIN
+  Ctx& c = ctx->c;
+  const Config& cfg = c.cfg;
+  EG_CHECK(images && z && alpha && eps, "null batch pointer");
+  const size_t zc = cfg.multiclasses() ? cfg.z_dim + 1 : cfg.z_dim;
+  EG_HIP(hipMemcpyAsync(c.d_images, images, (size_t)cfg.B * cfg.H * cfg.W * cfg.c_dim * 4, hipMemcpyHostToDevice,
+                        c.stream));
+  EG_HIP(hipMemcpyAsync(c.d_z, z, (size_t)cfg.B * zc * 4, hipMemcpyHostToDevice, c.stream));
+  EG_HIP(hipMemcpyAsync(c.d_alpha, alpha, (size_t)3 * cfg.B * 4, hipMemcpyHostToDevice, c.stream));
+  EG_HIP(hipMemcpyAsync(c.d_eps, eps, 4, hipMemcpyHostToDevice, c.stream));
+  EG_HIP(hipStreamSynchronize(c.stream));
+  EG_API_END(ctx)
+}
+
+int eg_substep(eg_ctx* ctx, int k, int apply) {
+  EG_API_BEGIN
+  run_substep(ctx->c, k, apply != 0);
+  EG_API_END(ctx)
+}
+
+int eg_train_step(eg_ctx* ctx) {
+  EG_API_BEGIN
+  train_step(ctx->c);
+  EG_API_END(ctx)
+}
+
+int eg_read_losses(eg_ctx* ctx, float* out12) {
+  EG_API_BEGIN
+  EG_HIP(hipMemcpyAsync(out12, ctx->c.d_losses, L_COUNT * 4, hipMemcpyDeviceToHost, ctx->c.stream));
+  EG_HIP(hipStreamSynchronize(ctx->c.stream));
+  EG_API_END(ctx)
+}
+
+int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const float* eps2, float* edge_out,
+             float* image_out) {
+  EG_API_BEGIN
+  Ctx& c = ctx->c;
+  const Config& cfg = c.cfg;
+  EG_CHECK(nb >= 1 && nb <= 4096, "nb out of range");
+  EG_CHECK(!cfg.multiclasses() || classes, "classes required");
+  const size_t in_n = (size_t)nb * cfg.H * cfg.W * cfg.c_dim, out_n = in_n / 2;
+  float *d_in, *d_e, *d_i, *d_eps;
+  int* d_cls;
+  EG_HIP(hipMalloc(&d_in, in_n * 4));
+  EG_HIP(hipMalloc(&d_e, out_n * 4));
+  EG_HIP(hipMalloc(&d_i, out_n * 4));
+  EG_HIP(hipMalloc(&d_eps, 8));
+  EG_HIP(hipMalloc(&d_cls, (size_t)nb * 4));
+  EG_HIP(hipMemcpyAsync(d_in, images, in_n * 4, hipMemcpyHostToDevice, c.stream));
+  EG_HIP(hipMemcpyAsync(d_eps, eps2, 8, hipMemcpyHostToDevice, c.stream));
+  if (classes) EG_HIP(hipMemcpyAsync(d_cls, classes, (size_t)nb * 4, hipMemcpyHostToDevice, c.stream));
+  infer(c, d_in, d_cls, nb, d_eps, d_e, d_i);
+  EG_HIP(hipMemcpyAsync(edge_out, d_e, out_n * 4, hipMemcpyDeviceToHost, c.stream));
+  EG_HIP(hipMemcpyAsync(image_out, d_i, out_n * 4, hipMemcpyDeviceToHost, c.stream));
+  EG_HIP(hipStreamSynchronize(c.stream));
+  (void)hipFree(d_in);
+  (void)hipFree(d_e);
+  (void)hipFree(d_i);
+  (void)hipFree(d_eps);
+  (void)hipFree(d_cls);
+  EG_API_END(ctx)
+}
+
+int eg_sync(eg_ctx* ctx) {
+  EG_API_BEGIN
+  EG_HIP(hipStreamSynchronize(ctx->c.stream));
+  EG_API_END(ctx)
+}
+
+int eg_comm_unique_id(eg_ctx* ctx, char* out128) {
+  EG_API_BEGIN
+  comm_unique_id(ctx->c, out128);
+  EG_API_END(ctx)
+}
+int eg_comm_init(eg_ctx* ctx, const char* id128, int rank, int nranks) {
+  EG_API_BEGIN
+  comm_init(ctx->c, id128, rank, nranks);
+  EG_API_END(ctx)
+}
+
+int eg_profile_begin(eg_ctx* ctx) {
+  EG_API_BEGIN
+  Ctx& c = ctx->c;
+  EG_HIP(hipStreamSynchronize(c.stream));
+  for (auto& r : c.prof) {
+    c.ev_pool.push_back(r.a);
+    c.ev_pool.push_back(r.b);
+  }
+  c.prof.clear();
+  c.prof_on = true;
+  EG_API_END(ctx)
+}
+
+int eg_profile_end(eg_ctx* ctx, char* buf, int cap) {
+  EG_API_BEGIN
+  Ctx& c = ctx->c;
+  EG_HIP(hipStreamSynchronize(c.stream));
+  c.prof_on = false;
+  struct Agg {
+    long long n = 0;
+    double ms = 0, flops = 0;
+  };
+  std::map<std::string, Agg> agg;
+  for (auto& r : c.prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    Agg& a = agg[r.name];
+    a.n += 1;
+    a.ms += ms;
+    a.flops += r.flops;
+  }
+  std::ostringstream os;
+  os << "{\"kernels\":[";
+  bool first = true;
+  for (auto& kv : agg) {
+    if (!first) os << ",";
+    first = false;
+    os << "{\"name\":\"" << kv.first << "\",\"launches\":" << kv.second.n << ",\"ms\":" << kv.second.ms
+       << ",\"flops\":" << kv.second.flops << "}";
+  }
+  os << "]}";
+  const std::string s = os.str();
+  EG_CHECK((int)s.size() + 1 <= cap, "profile buffer too small");
+  strcpy(buf, s.c_str());
+  EG_API_END(ctx)
+}
+
+int eg_memory_stats(eg_ctx* ctx, long long* peak, long long* reserved) {
+  EG_API_BEGIN
+  *peak = (long long)ctx->c.arena.peak();
+  *reserved = (long long)ctx->c.arena.reserved();
+  EG_API_END(ctx)
+}
+
+// -------------------------------------------------------------------------------------------------
+// per-op test scaffolding
+// -------------------------------------------------------------------------------------------------
+namespace {
+struct OpIO {
+  Ctx& c;
+  eg_ctx* ctx;
+  int n_in;
+  const float* const* in;
+  const long long* in_n;
+  int n_out;
+  float* const* out;
+  const long long* out_n;
+  bool has(int i) const { return i < n_in && in_n[i] > 0 && in[i]; }
+  float* up(int i) {
+    EG_CHECK(has(i), "test op input %d missing", i);
+    float* d = c.arena.allocf((size_t)in_n[i]);
+    EG_HIP(hipMemcpyAsync(d, in[i], (size_t)in_n[i] * 4, hipMemcpyHostToDevice, c.stream));
+    return d;
+  }
+  T tensor(int i, int n, int h, int w, int ch, bool grad) {
+    EG_CHECK((long long)n * h * w * ch == in_n[i], "test op input %d has %lld elements, expected %lld", i, in_n[i],
+             (long long)n * h * w * ch);
+    T t = wrap_tensor(c, up(i), n, h, w, ch);
+    t->needs_grad = grad;
+    return t;
+  }
+  Param* param(int i, bool want) {
+    ctx->tmp_params.emplace_back();
+    Param* p = &ctx->tmp_params.back();
+    p->name = "tmp" + std::to_string(i);
+    p->numel = (size_t)in_n[i];
+    p->w = up(i);
+    p->g = c.arena.allocf(p->numel);
+    p->want_grad = want;
+    return p;
+  }
+  void seed(T y, int i) {
+    EG_CHECK((long long)y->numel() == in_n[i], "cotangent %d size %lld vs output %zu", i, in_n[i], y->numel());
+    seed_grad(c, y);
+    EG_HIP(hipMemcpyAsync(y->g, in[i], y->numel() * 4, hipMemcpyHostToDevice, c.stream));
+  }
+  void down(int o, const float* d, size_t n) {
+    if (o >= n_out || !out[o] || out_n[o] == 0) return;
+    EG_CHECK((size_t)out_n[o] == n, "test op output %d has %lld elements, expected %zu", o, out_n[o], n);
+    EG_HIP(hipMemcpyAsync(out[o], d, n * 4, hipMemcpyDeviceToHost, c.stream));
+  }
+  void down_grad(int o, T t) {
+    if (o >= n_out || !out[o] || out_n[o] == 0) return;
+    EG_CHECK(t->g_set, "no gradient reached test op input for output %d", o);
+    down(o, t->g, t->numel());
+  }
+  void down_pgrad(int o, Param* p) {
+    if (o >= n_out || !out[o] || out_n[o] == 0) return;
+    EG_CHECK(p->g_set, "no gradient reached test op parameter for output %d", o);
+    down(o, p->g, p->numel);
+  }
+};
+}  // namespace
+
+int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* inputs, const long long* in_numel,
+               int n_ip, const int* ip, int n_out, float* const* outputs, const long long* out_numel) {
+  EG_API_BEGIN
+  Ctx& c = ctx->c;
+  reset_step(c);
+  ctx->tmp_params.clear();
+  OpIO io{c, ctx, n_in, inputs, in_numel, n_out, outputs, out_numel};
+  const std::string op = op_;
+  auto need_ip = [&](int n) { EG_CHECK(n_ip >= n, "op %s needs %d int params", op_, n); };
+  if (op == "conv2d") {  // ip: NB,H,W,C,N,k,stride,pad ; in: x,w,b?,dy? ; out: y,dx,dw,db
+    need_ip(8);
+    T x = io.tensor(0, ip[0], ip[1], ip[2], ip[3], io.has(3));
+    Param* w = io.param(1, io.has(3));
+    Param* b = io.has(2) ? io.param(2, io.has(3)) : nullptr;
+    T y = conv2d(c, x, wref_param(c, w, ip[5] * ip[5], ip[3], ip[4]), b, ip[5], ip[6], ip[7]);
+    io.down(0, y->d, y->numel());
+    if (io.has(3)) {
+      io.seed(y, 3);
+      c.tape.backward();
+      io.down_grad(1, x);
+      io.down_pgrad(2, w);
+      if (b) io.down_pgrad(3, b);
+    }
+  } else if (op == "deconv2d") {  // ip: NB,H,W,Cin,Cout ; in: x,w,b,dy? ; out: y,dx,dw,db
+    need_ip(5);
+    T x = io.tensor(0, ip[0], ip[1], ip[2], ip[3], io.has(3));
+    Param* w = io.param(1, io.has(3));
+    Param* b = io.param(2, io.has(3));
+    T y = deconv2d(c, x, wref_param(c, w, 25, ip[4], ip[3]), b, ip[4]);
+    io.down(0, y->d, y->numel());
+    if (io.has(3)) {
+      io.seed(y, 3);
+      c.tape.backward();
+      io.down_grad(1, x);
+      io.down_pgrad(2, w);
+      io.down_pgrad(3, b);
+    }
+  } else if (op == "in_act" || op == "act") {  // ip: NB,H,W,C,act ; in: x,dy? ; out: y,dx
+    need_ip(5);
+    T x = io.tensor(0, ip[0], ip[1], ip[2], ip[3], io.has(1));
+    T y = op == "act" ? act(c, x, ip[4]) : in_act(c, x, ip[4]);
+    io.down(0, y->d, y->numel());
+    if (io.has(1)) {
+      io.seed(y, 1);
+      c.tape.backward();
+      io.down_grad(1, x);
+    }
+  } else if (op == "in_tangent") {  // ip: NB,H,W,C,act ; in: x,tx,dty ; out: y,ty,dtx,dx
+    need_ip(5);
+    T x = io.tensor(0, ip[0], ip[1], ip[2], ip[3], true);
+    T tx = io.tensor(1, ip[0], ip[1], ip[2], ip[3], true);
+    T st;
+    T y = in_act(c, x, ip[4], &st);
+    T ty = in_act_tangent(c, tx, x, y, st, ip[4]);
+    io.down(0, y->d, y->numel());
+    io.down(1, ty->d, ty->numel());
+    if (io.has(2)) {
+      io.seed(ty, 2);
+      c.tape.backward();
+      io.down_grad(2, tx);
+      io.down_grad(3, x);
+    }
+  } else if (op == "bn_relu") {  // ip: NB,H,W,C ; in: x,gamma,beta,dy? ; out: y,dx,dgamma,dbeta
+    need_ip(4);
+    T x = io.tensor(0, ip[0], ip[1], ip[2], ip[3], io.has(3));
+    Param* g = io.param(1, io.has(3));
+    Param* b = io.param(2, io.has(3));
+    T y = bn_relu(c, x, g, b, nullptr, nullptr, 0);
+    io.down(0, y->d, y->numel());
+    if (io.has(3)) {
+      io.seed(y, 3);
+      c.tape.backward();
+      io.down_grad(1, x);
+      io.down_pgrad(2, g);
+      io.down_pgrad(3, b);
+    }
+  } else if (op == "resize" || op == "pool2" || op == "gmean" || op == "minmax") {
+    need_ip(5);  // ip: NB,H,W,C,(size | pre_relu | unused) ; in: x,dy? ; out: y,dx
+    T x = io.tensor(0, ip[0], ip[1], ip[2], ip[3], io.has(1));
+    T y = op == "resize" ? resize(c, x, ip[4])
+          : op == "pool2" ? pool2(c, x)
+          : op == "gmean" ? gmean(c, x, ip[4] != 0)
+                          : minmax(c, x);
+    io.down(0, y->d, y->numel());
+    if (io.has(1)) {
+      io.seed(y, 1);
+      c.tape.backward();
+      io.down_grad(1, x);
+    }
+  } else if (op == "prelu") {  // ip: n ; in: x,leak,dy? ; out: y,dx,dleak
+    need_ip(1);
+    T x = io.tensor(0, 1, 1, 1, ip[0], io.has(2));
+    Param* lk = io.param(1, io.has(2));
+    T y = prelu(c, x, lk, 0.f);
+    io.down(0, y->d, y->numel());
+    if (io.has(2)) {
+      io.seed(y, 2);
+      c.tape.backward();
+      io.down_grad(1, x);
+      io.down_pgrad(2, lk);
+    }
+  } else if (op == "gate") {  // ip: n ; in: h,rg,img,dy ; out: y,dh,drg,dimg
+    need_ip(1);
+    T h = io.tensor(0, 1, 1, 1, ip[0], true);
+    T rg = io.tensor(1, 1, 1, 1, ip[0], true);
+    T im = io.tensor(2, 1, 1, 1, ip[0], true);
+    T y = gate(c, h, rg, im);
+    io.down(0, y->d, y->numel());
+    if (io.has(3)) {
+      io.seed(y, 3);
+      c.tape.backward();
+      io.down_grad(1, h);
+      io.down_grad(2, rg);
+      io.down_grad(3, im);
+    }
+  } else if (op == "linear1") {  // ip: NB,K ; in: x,w,b,dy? ; out: y,dx,dw,db
+    need_ip(2);
+    T x = io.tensor(0, ip[0], 1, 1, ip[1], io.has(3));
+    Param* w = io.param(1, io.has(3));
+    Param* b = io.param(2, io.has(3));
+    T y = linear1(c, x, w, b);
+    io.down(0, y->d, y->numel());
+    if (io.has(3)) {
+      io.seed(y, 3);
+      c.tape.backward();
+      io.down_grad(1, x);
+      io.down_pgrad(2, w);
+      io.down_pgrad(3, b);
+    }
+  } else if (op == "sn") {  // ip: K,Co ; in: W,u,dWbar? ; out: Wbar,dW,sigma
+    need_ip(2);
+    const int K = ip[0], Co = ip[1];
+    SNDesc d{};
+    float* W = io.up(0);
+    d.W = W;
+    d.u = io.up(1);
+    d.Wbar = c.arena.allocf((size_t)K * Co);
+    d.t = c.arena.allocf(K);
+    d.dv = c.arena.allocf(K);
+    d.sv = c.arena.allocf(Co);
+    d.scal = c.arena.allocf(80);
+    d.dW = c.arena.allocf((size_t)K * Co);
+    d.dWbar = io.has(2) ? io.up(2) : nullptr;
+    d.K = K;
+    d.Co = Co;
+    d.acc_dW = 0;
+    SNDesc* tab = (SNDesc*)c.arena.alloc(sizeof(SNDesc));
+    EG_HIP(hipMemcpyAsync(tab, &d, sizeof(SNDesc), hipMemcpyHostToDevice, c.stream));
+    EG_HIP(hipStreamSynchronize(c.stream));
+    launch_sn_fwd(tab, 1, K, Co, c.stream);
+    io.down(0, d.Wbar, (size_t)K * Co);
+    io.down(2, d.scal + 2, 1);
+    if (io.has(2)) {
+      launch_sn_bwd(tab, 1, K, Co, c.stream);
+      io.down(1, d.dW, (size_t)K * Co);
+    }
+  } else if (op == "acgan") {  // ip: B,NC,mode ; in: logits,labels ; out: loss,dlogits
+    need_ip(3);
+    float* lg = io.up(0);
+    float* lab = io.up(1);
+    float* loss = c.arena.allocf(1);
+    float* dl = c.arena.allocf((size_t)ip[0] * ip[1]);
+    launch_acgan_loss(lg, lab, 1, loss, dl, ip[0], ip[1], ip[2], c.scratch, c.stream);
+    io.down(0, loss, 1);
+    io.down(1, dl, (size_t)ip[0] * ip[1]);
+  } else if (op == "gp") {  // ip: B,per ; in: g ; out: v,norms,gp
+    need_ip(2);
+    float* g = io.up(0);
+    float* v = c.arena.allocf((size_t)ip[0] * ip[1]);
+    float* nr = c.arena.allocf(ip[0]);
+    float* gp = c.arena.allocf(1);
+    launch_gp_v(g, v, nr, gp, ip[0], (size_t)ip[1], c.cfg.lambda_gp, c.stream);
+    io.down(0, v, (size_t)ip[0] * ip[1]);
+    io.down(1, nr, ip[0]);
+    io.down(2, gp, 1);
+  } else if (op == "rmsprop") {  // ip: n ; in: w,g,ms,mom,lr ; out: w,ms,mom
+    need_ip(1);
+    float* w = io.up(0);
+    float* g = io.up(1);
+    float* ms = io.up(2);
+    float* mom = io.up(3);
+    launch_rmsprop(w, g, ms, mom, (size_t)ip[0], inputs[4][0], 1.f, c.stream);
+    io.down(0, w, ip[0]);
+    io.down(1, ms, ip[0]);
+    io.down(2, mom, ip[0]);
+  } else {
+    fail(1, "unknown test op '%s'", op_);
+  }
+  EG_HIP(hipStreamSynchronize(c.stream));
+  EG_API_END(ctx)
+}
+
+int eg_net_forward(eg_ctx* ctx, const char* net_, const float* input, int nb, int h, int w, int ch, float eps,
+                   float* out, long long out_numel) {
+  EG_API_BEGIN
+  Ctx& c = ctx->c;
+  reset_step(c);
+  for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);
+  const std::string net = net_;
+  const size_t n = (size_t)nb * h * w * ch;
+  float* d = c.arena.allocf(n);
+  EG_HIP(hipMemcpyAsync(d, input, n * 4, hipMemcpyHostToDevice, c.stream));
+  T x = wrap_tensor(c, d, nb, h, w, ch);
+  T y = nullptr;
+  if (net == "G1" || net == "G2") {
+    y = generator_forward(c, net == "G1" ? G_G1 : G_G2, x, 0);
+  } else if (net == "D" || net == "D_patch2" || net == "D_patch3") {
+    y = disc_forward(c, net == "D" ? G_D : (net == "D_patch2" ? G_DP2 : G_DP3), x, nullptr, nullptr);
+  } else if (net == "E") {
+    float* de = c.arena.allocf(1);
+    EG_HIP(hipMemcpyAsync(de, &eps, 4, hipMemcpyHostToDevice, c.stream));
+    y = encoder_forward(c, x, de);
+  } else if (net == "D2") {
+    EG_CHECK(c.cfg.multiclasses(), "classifier absent without classes");
+    y = classifier_forward(c, x);
+  } else {
+    fail(1, "unknown net '%s'", net_);
+  }
+  EG_CHECK((long long)y->numel() == out_numel, "output has %zu elements, caller expects %lld", y->numel(),
+           out_numel);
+  EG_HIP(hipMemcpyAsync(out, y->d, y->numel() * 4, hipMemcpyDeviceToHost, c.stream));
+  EG_HIP(hipStreamSynchronize(c.stream));
+  EG_API_END(ctx)
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Data-parallel gradient exchange: one process per GPU, ONE RCCL all-reduce (sum, fp32) per
+// optimised network group over xGMI.  RCCL is bound lazily with dlopen so that
+// single-GPU use has no dependency on it, and so that a host process that already carries a
+// librccl (e.g. through torch) shares that copy instead of loading a second one.
+#include <dlfcn.h>
+
+#include "engine.h"
+
+namespace eg {
+
+namespace {
+struct NcclUniqueId {
+  char internal[128];
+};
+typedef int (*fn_get_id)(NcclUniqueId*);
+typedef int (*fn_init_rank)(void**, int, NcclUniqueId, int);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+typedef const char* (*fn_errstr)(int);
+
+void* load_lib(Ctx& c) {
+  if (c.nccl_lib) return c.nccl_lib;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    c.nccl_lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (c.nccl_lib) return c.nccl_lib;
+  }
+  fail(3, "cannot load librccl: %s", dlerror());
+}
+template <class F>
+F sym(Ctx& c, const char* name) {
+  void* p = dlsym(load_lib(c), name);
+  if (!p) fail(3, "librccl lacks %s", name);
+  return reinterpret_cast<F>(p);
+}
+void check(Ctx& c, int r, const char* what) {
+  if (r != 0) {
+    const char* msg = "?";
+    if (void* p = dlsym(c.nccl_lib, "ncclGetErrorString")) msg = reinterpret_cast<fn_errstr>(p)(r);
+    fail(3, "RCCL %s failed: %d (%s)", what, r, msg);
+  }
+}
+}  // namespace
+
+void comm_unique_id(Ctx& c, char* out128) {
+  NcclUniqueId id;
+  check(c, sym<fn_get_id>(c, "ncclGetUniqueId")(&id), "ncclGetUniqueId");
+  memcpy(out128, id.internal, 128);
+}
+
+void comm_init(Ctx& c, const char* id128, int rank, int nranks) {
+  EG_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank/nranks");
+  NcclUniqueId id;
+  memcpy(id.internal, id128, 128);
+  EG_HIP(hipSetDevice(c.cfg.device));
+  check(c, sym<fn_init_rank>(c, "ncclCommInitRank")(&c.nccl_comm, nranks, id, rank), "ncclCommInitRank");
+  c.rank = rank;
+  c.nranks = nranks;
+}
+
+void comm_allreduce(Ctx& c, float* buf, size_t n) {
+  if (c.nranks <= 1) return;
+  EG_CHECK(c.nccl_comm, "comm_allreduce without comm_init");
+  // ncclFloat32 = 7, ncclSum = 0
+  check(c, sym<fn_allreduce>(c, "ncclAllReduce")(buf, buf, n, 7, 0, c.nccl_comm, c.stream), "ncclAllReduce");
+}
+
+void comm_destroy(Ctx& c) {
+  if (c.nccl_comm) {
+    (void)sym<fn_destroy>(c, "ncclCommDestroy")(c.nccl_comm);
+    c.nccl_comm = nullptr;
+  }
+  c.nranks = 1;
+  c.rank = 0;
+}
+
+}  // namespace eg

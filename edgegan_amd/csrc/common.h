@@ -1,0 +1,155 @@
+// EdgeGAN MI355X engine -- shared host-side types (context, arena, tensors, tape).
+// gfx950 only; no portability layers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace eg {
+
+// ---------------------------------------------------------------------------------------------
+// errors: C++ exceptions inside the library, translated to int codes at the C ABI (capi.cpp).
+// ---------------------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw Error(code, buf);
+}
+
+#define EG_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      ::eg::fail(2, "HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e),     \
+                 __FILE__, __LINE__, #expr);                                              \
+  } while (0)
+
+#define EG_CHECK(cond, ...)                          \
+  do {                                               \
+    if (!(cond)) ::eg::fail(1, __VA_ARGS__);         \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Arena: chunked bump allocator over HBM.  Sized for 288 GB parts: nothing is freed inside a
+// training iteration, the pointer is reset between iterations, chunks persist, so after the first
+// iteration there is no hipMalloc on the path and every buffer address is replay-stable.
+// ---------------------------------------------------------------------------------------------
+class Arena {
+ public:
+  explicit Arena(size_t chunk_bytes = (size_t)512 << 20) : chunk_bytes_(chunk_bytes) {}
+  ~Arena() { release(); }
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    while (true) {
+      if (cur_ < chunks_.size()) {
+        Chunk& c = chunks_[cur_];
+        if (off_ + bytes <= c.size) {
+          void* p = (char*)c.base + off_;
+          off_ += bytes;
+          used_ += bytes;
+          if (used_ > peak_) peak_ = used_;
+          return p;
+        }
+        ++cur_;
+        off_ = 0;
+        continue;
+      }
+      size_t sz = bytes > chunk_bytes_ ? bytes : chunk_bytes_;
+      void* base = nullptr;
+      EG_HIP(hipMalloc(&base, sz));
+      chunks_.push_back({base, sz});
+      total_ += sz;
+    }
+  }
+  float* allocf(size_t n) { return (float*)alloc(n * sizeof(float)); }
+  void reset() {
+    cur_ = 0;
+    off_ = 0;
+    used_ = 0;
+  }
+  void release() {
+    for (auto& c : chunks_) (void)hipFree(c.base);
+    chunks_.clear();
+    reset();
+    total_ = 0;
+  }
+  size_t peak() const { return peak_; }
+  size_t reserved() const { return total_; }
+
+ private:
+  struct Chunk {
+    void* base;
+    size_t size;
+  };
+  std::vector<Chunk> chunks_;
+  size_t chunk_bytes_, cur_ = 0, off_ = 0, used_ = 0, peak_ = 0, total_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Tensor: NHWC fp32 activation (2-D tensors use n x c with h = w = 1).  `g` is the gradient
+// buffer, allocated on first use; `g_set` says whether it already holds a value (first writer
+// stores, later writers accumulate -- no memsets).
+// ---------------------------------------------------------------------------------------------
+struct Tensor {
+  float* d = nullptr;
+  float* g = nullptr;
+  int n = 0, h = 1, w = 1, c = 0;
+  bool needs_grad = false;
+  bool g_set = false;
+  size_t numel() const { return (size_t)n * h * w * c; }
+  size_t pixels() const { return (size_t)n * h * w; }
+};
+using T = Tensor*;
+
+// A model variable (TF variable of SURVEY Appendix C).  w/g/ms/mom point into the owning
+// network group's flat buffers (one all-reduce + one RMSProp launch per group).
+struct Param {
+  std::string name;
+  std::vector<int> shape;
+  bool trainable = true;
+  bool dead = false;         // trainable in TF but never receives a gradient (quirk N8)
+  int init_kind = 0;         // 0 const, 1 normal, 2 truncated normal, 3 xavier uniform
+  float init_param = 0.f;
+  size_t numel = 0;
+  float* w = nullptr;
+  float* g = nullptr;
+  float* ms = nullptr;
+  float* mom = nullptr;
+  bool want_grad = false;    // set per sub-step for the networks being optimised
+  bool g_set = false;
+};
+
+struct Ctx;
+
+// Tape of backward closures; run in reverse.
+struct Tape {
+  std::vector<std::function<void()>> ops;
+  void push(std::function<void()> f) { ops.push_back(std::move(f)); }
+  void backward() {
+    for (size_t i = ops.size(); i-- > 0;) ops[i]();
+  }
+  void backward_range(size_t lo, size_t hi) {
+    for (size_t i = hi; i-- > lo;) ops[i]();
+  }
+  void clear() { ops.clear(); }
+};
+
+}  // namespace eg

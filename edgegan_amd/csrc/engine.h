@@ -1,0 +1,200 @@
+// EdgeGAN MI355X engine -- context, tape ops and network/sub-step entry points (host side).
+#pragma once
+#include <deque>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace eg {
+
+struct Config {
+  int B = 64, H = 64, W = 128;
+  int num_classes = 14;  // 0 => --nomulticlasses
+  int z_dim = 100, gf = 64, df = 64, c_dim = 3, dis_size = 128;
+  float lambda_gp = 10.f, zl_weight = 10.f, lr = 2e-4f;
+  float joint_dweight = 1.f, image_dweight = 1.f, edge_dweight = 1.f;
+  int device = 0;
+  bool multiclasses() const { return num_classes > 0; }
+  int g_in() const { return z_dim + (multiclasses() ? num_classes : 0); }
+};
+
+enum GroupId { G_G1 = 0, G_G2, G_D2, G_D, G_DP2, G_DP3, G_E, G_COUNT };
+
+// One network's variables in flat HBM buffers: [live trainables | dead trainables | non-trainables].
+// RMSProp and the DP all-reduce run over the live prefix in a single launch / collective.
+struct NetGroup {
+  std::string prefix;
+  std::vector<Param*> params;
+  float *w = nullptr, *g = nullptr, *ms = nullptr, *mom = nullptr;
+  size_t n_live = 0, n_train = 0, n_total = 0;
+};
+
+// Effective weights of one conv/deconv/linear for the current sub-step.
+struct WRef {
+  const float* w = nullptr;  // [T][R][Cc]
+  float* g = nullptr;        // gradient target, same layout
+  bool* g_set = nullptr;
+  bool want_grad = false;
+  const float* wT = nullptr; // per-tap transpose [T][Cc][R] (built lazily, cached per sub-step)
+  int T = 1, R = 0, Cc = 0;
+};
+
+// persistent per-weight spectral-norm buffers (classifier)
+struct SNWeight {
+  Param* W = nullptr;
+  Param* u = nullptr;
+  float *Wbar = nullptr, *WbarT = nullptr, *dWbar = nullptr, *t = nullptr, *sv = nullptr, *dv = nullptr,
+        *scal = nullptr;
+  bool dWbar_set = false;
+  bool wT_valid = false;
+  int K = 0, Co = 0, T = 1;
+};
+
+struct ResizeTab {  // separable resampling taps, forward and transposed
+  int n_in = 0, n_out = 0, fn = 0, bn = 0;
+  int *f_i = nullptr, *b_i = nullptr;    // device
+  float *f_w = nullptr, *b_w = nullptr;  // device
+};
+
+struct ProfRec {
+  const char* name;
+  double flops;
+  hipEvent_t a, b;
+};
+
+struct Ctx {
+  Config cfg;
+  hipStream_t stream = nullptr;
+  Arena arena;
+  Tape tape;
+  std::vector<std::unique_ptr<Param>> params;
+  std::map<std::string, Param*> by_name;
+  NetGroup groups[G_COUNT];
+  std::string last_error;
+
+  // per-step state
+  std::deque<Tensor> tensors;
+  std::deque<WRef> wrefs;
+  std::map<const void*, WRef*> wref_cache;
+  std::deque<bool> flags;   // stable storage for ad-hoc gradient-present flags
+  bool sn_prepared = false;
+  bool param_grad_enabled = true;
+  float* scratch = nullptr;  // persistent reduction scratch
+  size_t scratch_floats = 0;
+
+  // spectral norm
+  std::vector<SNWeight> sn;
+  std::map<Param*, int> sn_index;
+  SNDesc* sn_table = nullptr;
+  int sn_maxK = 0, sn_maxCo = 0;
+
+  std::map<std::pair<int, int>, ResizeTab> resize_tabs;
+
+  // resident batch (device)
+  float *d_images = nullptr, *d_z = nullptr, *d_alpha = nullptr, *d_eps = nullptr;
+  float* d_losses = nullptr;  // [64]
+  int* d_classes = nullptr;
+  long long step_count = 0;
+
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  std::string prof_report;
+
+  // data parallel (RCCL, loaded lazily)
+  void* nccl_lib = nullptr;
+  void* nccl_comm = nullptr;
+  int rank = 0, nranks = 1;
+
+  ~Ctx();
+};
+
+// ---- registry (model.cpp) ----------------------------------------------------------------------
+struct VarInfo {
+  std::string name;
+  std::vector<int> shape;
+  bool trainable, dead;
+  int init_kind;
+  float init_param;
+  int group;
+};
+std::vector<VarInfo> enumerate_variables(const Config& cfg);
+void build_context(Ctx& c);
+Param* P(Ctx& c, const std::string& name);
+
+// ---- tape ops (ops.cpp) --------------------------------------------------------------------------
+T new_tensor(Ctx& c, int n, int h, int w, int ch, bool needs_grad, bool alloc = true);
+T wrap_tensor(Ctx& c, float* data, int n, int h, int w, int ch);
+float* grad_acc(Ctx& c, T t, int* acc);   // returns t->g; *acc = 1 if it already holds a value
+void reset_step(Ctx& c);                  // arena + tape + tensor list (start of a sub-step)
+void reset_grads(Ctx& c);                 // forget every activation / weight gradient (keeps buffers)
+void set_want_grad(Ctx& c, int group, bool on);
+
+WRef* wref_param(Ctx& c, Param* p, int T, int R, int Cc);
+WRef* wref_sn(Ctx& c, Param* p);
+const float* wref_transposed(Ctx& c, WRef* w);
+
+enum PadMode { PAD_SAME = 0, PAD_REFLECT = 1 };
+// y = conv(x, w) (+ bias).  c_off/c_tot: use rows [c_off, c_off + x->c) of a [T][c_tot][N] filter.
+T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into = nullptr,
+         int c_off = 0, int c_tot = -1);
+T deconv2d(Ctx& c, T x, WRef* w /*[25][Cout][Cin]*/, Param* bias, int cout);
+T linear(Ctx& c, T x, WRef* w /*[1][in][out]*/, Param* bias);
+T linear1(Ctx& c, T x, Param* w /*[K][1]*/, Param* bias /*nullable*/);
+T reshape(Ctx& c, T src, int n, int h, int w, int ch);
+WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_, int R, int Cc);
+T in_act(Ctx& c, T x, int act, T* stats_out = nullptr);
+T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int act);
+T act(Ctx& c, T x, int a);
+T act_tangent(Ctx& c, T tx, T out_prim, int a);
+T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times);
+T add(Ctx& c, T a, T b, bool relu);
+T pool2(Ctx& c, T x);
+T gmean(Ctx& c, T x, bool pre_relu);
+T resize(Ctx& c, T x, int size);
+T concat_w(Ctx& c, T a, T b);
+T slice_w(Ctx& c, T x, int w0, int w1);   // no gradient (inputs only)
+T prelu(Ctx& c, T x, Param* leak, float leak_const);
+T minmax(Ctx& c, T x);
+T gate(Ctx& c, T h, T rg, T img);
+T reparam(Ctx& c, T mu, T ls, const float* eps_dev);
+void sn_prepare(Ctx& c);                  // W/sigma for every live SN weight + tape entry for its backward
+void seed_grad(Ctx& c, T t);              // marks t->g as holding a value (after a loss kernel wrote it)
+
+void prof_launch_begin(Ctx& c, const char** name_slot, double** flops_slot);
+struct ProfScope {
+  Ctx& c;
+  int idx = -1;
+  explicit ProfScope(Ctx& c_);
+  void done(const char* name, double flops);
+};
+
+// ---- networks and sub-steps (model.cpp) --------------------------------------------------------
+struct DiscSave {
+  T pre[4] = {nullptr, nullptr, nullptr, nullptr};
+  T out[4] = {nullptr, nullptr, nullptr, nullptr};
+  T stats[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+T generator_forward(Ctx& c, int group, T zin, int bn_times);
+T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_of);
+T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out = nullptr, T* ls_out = nullptr);
+T classifier_forward(Ctx& c, T x);
+
+enum LossSlot {
+  L_JOINT_D = 0, L_JOINT_GP, L_IMAGE_D, L_IMAGE_GP, L_EDGE_D, L_EDGE_GP, L_CLS_D, L_JOINT_G, L_EDGE_G, L_IMAGE_G,
+  L_CLS_G, L_ZL, L_COUNT
+};
+// k in 1..7 (edgegan.py:109-124 order); apply=false computes gradients only (parity tests)
+void run_substep(Ctx& c, int k, bool apply);
+void train_step(Ctx& c);
+void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const float* d_eps2, float* d_edge,
+           float* d_image);
+
+// ---- data parallel (comm.cpp) -----------------------------------------------------------------
+void comm_unique_id(Ctx& c, char* out128);
+void comm_init(Ctx& c, const char* id128, int rank, int nranks);
+void comm_allreduce(Ctx& c, float* buf, size_t n);
+void comm_destroy(Ctx& c);
+
+}  // namespace eg

@@ -1,0 +1,775 @@
+// HBM-bound kernels of the EdgeGAN step: data movement, pooling, legacy-bicubic resize, PReLU,
+// min-max gate, spectral norm, losses, RMSProp.  NHWC fp32.  All reductions are fixed-order
+// (two-stage, no float atomics) so replicas stay bit-identical under data parallelism.
+#include "kernels.h"
+
+namespace eg {
+
+static inline int ew_blocks(size_t n, int cap = 4096) {
+  size_t b = (n + 255) / 256;
+  return (int)(b > (size_t)cap ? cap : (b < 1 ? 1 : b));
+}
+#define GRID_STRIDE(i, n) \
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+// block-wide sum for 256-thread blocks; result valid in thread 0 (and broadcast via LDS)
+__device__ __forceinline__ float block_sum(float v, float* sm /*[4]*/) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void fill_kernel(float* p, float v, size_t n) { GRID_STRIDE(i, n) p[i] = v; }
+__global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) { GRID_STRIDE(i, n) b[i] = a[i]; }
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, float a, int acc, size_t n) {
+  GRID_STRIDE(i, n) y[i] = acc ? y[i] + a * x[i] : a * x[i];
+}
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int relu,
+                           size_t n) {
+  GRID_STRIDE(i, n) {
+    const float v = a[i] + b[i];
+    o[i] = (relu && v < 0.f) ? 0.f : v;
+  }
+}
+void launch_fill(float* p, float v, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, p, v, n);
+}
+void launch_copy(const float* a, float* b, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(copy_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, a, b, n);
+}
+void launch_axpy(const float* x, float* y, float a, int acc, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, a, acc, n);
+}
+void launch_add(const float* a, const float* b, float* o, int relu, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, a, b, o, relu, n);
+}
+
+// narrow [NB][H][Ws][C] <-> column window wo of wide [NB][H][Wd][C]
+__global__ void copy_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int Ws, int Wd, int wo,
+                                 int C, int to_dst, int acc, size_t n) {
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int w = (int)(t % Ws);
+    t /= Ws;  // t = nb*H + h
+    const size_t j = (t * Wd + wo + w) * C + c;
+    if (to_dst) {
+      dst[j] = acc ? dst[j] + src[i] : src[i];
+    } else {
+      float* s2 = const_cast<float*>(src);
+      s2[i] = acc ? s2[i] + dst[j] : dst[j];
+    }
+  }
+}
+void launch_copy_cols(const float* src, float* dst, int NB, int H, int Ws, int Wd, int wo, int C, int to_dst,
+                      int accumulate, hipStream_t s) {
+  const size_t n = (size_t)NB * H * Ws * C;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, src, dst, H, Ws, Wd, wo, C, to_dst,
+                     accumulate, n);
+}
+
+__global__ void blend_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                             const float* __restrict__ alpha, float* __restrict__ out, size_t per, size_t n) {
+  GRID_STRIDE(i, n) {
+    const float a = alpha[i / per];
+    out[i] = real[i] + a * (fake[i] - real[i]);
+  }
+}
+void launch_blend(const float* real, const float* fake, const float* alpha, float* out, int NB, size_t per,
+                  hipStream_t s) {
+  const size_t n = (size_t)NB * per;
+  hipLaunchKernelGGL(blend_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, real, fake, alpha, out, per, n);
+}
+
+// fold the gradient of a REFLECT-padded tensor back onto the unpadded one (tf.pad REFLECT gradient,
+// conv.py:23-26): dx[i] = sum of dpad[P] over every padded index P that mirrors onto i.
+__global__ void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx, int acc, int H, int W,
+                                    int C, int p, size_t n) {
+  const int Hp = H + 2 * p, Wp = W + 2 * p;
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int x_ = (int)(t % W);
+    t /= W;
+    const int y_ = (int)(t % H);
+    const size_t nb = t / H;
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y_ + p;
+    if (y_ >= 1 && y_ <= p) ys[ny++] = p - y_;
+    if (y_ <= H - 2 && y_ >= H - 1 - p) ys[ny++] = 2 * (H - 1) - y_ + p;
+    xs[nx++] = x_ + p;
+    if (x_ >= 1 && x_ <= p) xs[nx++] = p - x_;
+    if (x_ <= W - 2 && x_ >= W - 1 - p) xs[nx++] = 2 * (W - 1) - x_ + p;
+    float s = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) s += dpad[((nb * Hp + ys[a]) * Wp + xs[b]) * C + c];
+    dx[i] = acc ? dx[i] + s : s;
+  }
+}
+void launch_reflect_fold(const float* dpad, float* dx, int accumulate, int NB, int H, int W, int C, int p,
+                         hipStream_t s) {
+  const size_t n = (size_t)NB * H * W * C;
+  hipLaunchKernelGGL(reflect_fold_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dpad, dx, accumulate, H, W, C, p, n);
+}
+
+// ---- column sums (bias gradients): two-stage, fixed order -------------------------------------
+#define CS_RB 128
+__global__ __launch_bounds__(256) void col_sum_stage1(const float* __restrict__ dy, float* __restrict__ part, size_t R,
+                                                      int C) {
+  __shared__ float red[4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const size_t rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const size_t r0 = blockIdx.y * rows_per, r1 = (r0 + rows_per < R) ? r0 + rows_per : R;
+  float s = 0.f;
+  if (c < C)
+    for (size_t r = r0 + py; r < r1; r += 4) s += dy[r * C + c];
+  red[py * 64 + cx] = s;
+  __syncthreads();
+  if (py == 0 && c < C) part[(size_t)blockIdx.y * C + c] = red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx];
+}
+__global__ void col_sum_stage2(const float* __restrict__ part, float* __restrict__ db, int acc, int C, int nrb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nrb; ++b) s += part[(size_t)b * C + c];
+  db[c] = acc ? db[c] + s : s;
+}
+size_t col_sum_scratch_floats(int C) { return (size_t)CS_RB * C; }
+void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C, float* scratch, hipStream_t s) {
+  int nrb = (int)((R + 255) / 256);
+  if (nrb > CS_RB) nrb = CS_RB;
+  if (nrb < 1) nrb = 1;
+  hipLaunchKernelGGL(col_sum_stage1, dim3((C + 63) / 64, nrb), dim3(256), 0, s, dy, scratch, R, C);
+  hipLaunchKernelGGL(col_sum_stage2, dim3((C + 255) / 256), dim3(256), 0, s, scratch, db, accumulate, C, nrb);
+}
+
+__global__ void bias_add_kernel(float* __restrict__ y, const float* __restrict__ b, int C, size_t n) {
+  GRID_STRIDE(i, n) y[i] += b[i % C];
+}
+void launch_bias_add(float* y, const float* b, size_t R, int C, hipStream_t s) {
+  const size_t n = R * C;
+  hipLaunchKernelGGL(bias_add_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, y, b, C, n);
+}
+
+// ---- 2x2 mean pool (pooling.py:4-8; tf.nn.avg_pool 2x2 on even extents, encoder.py:68) ---------
+__global__ void pool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, size_t n) {
+  const int Ho = H / 2, Wo = W / 2;
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const size_t nb = t / Ho;
+    const float* p = x + ((nb * H + 2 * oy) * W + 2 * ox) * C + c;
+    // add_n order of pooling.py: [::2,::2] + [1::2,::2] + [::2,1::2] + [1::2,1::2]
+    y[i] = (p[0] + p[(size_t)W * C] + p[C] + p[(size_t)W * C + C]) * 0.25f;
+  }
+}
+__global__ void pool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int acc, int H, int W, int C,
+                                 size_t n) {
+  const int Ho = H / 2, Wo = W / 2;
+  GRID_STRIDE(i, n) {  // over input elements
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int x_ = (int)(t % W);
+    t /= W;
+    const int y_ = (int)(t % H);
+    const size_t nb = t / H;
+    const float g = 0.25f * dy[((nb * Ho + y_ / 2) * Wo + x_ / 2) * C + c];
+    dx[i] = acc ? dx[i] + g : g;
+  }
+}
+void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hipStream_t s) {
+  const size_t n = (size_t)NB * (H / 2) * (W / 2) * C;
+  hipLaunchKernelGGL(pool2_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, H, W, C, n);
+}
+void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s) {
+  const size_t n = (size_t)NB * H * W * C;
+  hipLaunchKernelGGL(pool2_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, dx, accumulate, H, W, C, n);
+}
+
+// ---- global spatial mean (encoder.py:69-70 relu + avg_pool 8x8 SAME on 2x2; classifier.py:111) --
+__global__ void gmean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int pre_relu,
+                                 size_t n) {
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % C);
+    const size_t nb = i / C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      float v = x[(nb * HW + p) * C + c];
+      if (pre_relu && v < 0.f) v = 0.f;
+      s += v;
+    }
+    y[i] = s / HW;
+  }
+}
+__global__ void gmean_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                 int acc, int HW, int C, int pre_relu, size_t n) {
+  GRID_STRIDE(i, n) {  // over x elements
+    const int c = (int)(i % C);
+    const size_t nb = i / ((size_t)HW * C);
+    float g = dy[nb * C + c] / HW;
+    if (pre_relu && !(x[i] > 0.f)) g = 0.f;
+    dx[i] = acc ? dx[i] + g : g;
+  }
+}
+void launch_gmean_fwd(const float* x, float* y, int NB, int HW, int C, int pre_relu, hipStream_t s) {
+  const size_t n = (size_t)NB * C;
+  hipLaunchKernelGGL(gmean_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, HW, C, pre_relu, n);
+}
+void launch_gmean_bwd(const float* x, const float* dy, float* dx, int accumulate, int NB, int HW, int C,
+                      int pre_relu, hipStream_t s) {
+  const size_t n = (size_t)NB * HW * C;
+  hipLaunchKernelGGL(gmean_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, dy, dx, accumulate, HW, C, pre_relu, n);
+}
+
+// ---- separable resize by host-built tap tables (TF legacy bicubic, edgegan.py:211-213) ---------
+// table row o: `taps` entries (index, weight); rows padded with weight 0.
+__global__ void resize_kernel(const float* __restrict__ x, float* __restrict__ y, int acc, int IH, int IW, int OH,
+                              int OW, int C, const int* __restrict__ ty_i, const float* __restrict__ ty_w, int tyn,
+                              const int* __restrict__ tx_i, const float* __restrict__ tx_w, int txn, size_t n) {
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int ox = (int)(t % OW);
+    t /= OW;
+    const int oy = (int)(t % OH);
+    const size_t nb = t / OH;
+    float s = 0.f;
+    for (int a = 0; a < tyn; ++a) {
+      const float wy = ty_w[oy * tyn + a];
+      if (wy == 0.f) continue;
+      const float* row = x + ((nb * IH + ty_i[oy * tyn + a]) * IW) * C + c;
+      float rs = 0.f;
+      for (int b = 0; b < txn; ++b) {
+        const float wx = tx_w[ox * txn + b];
+        if (wx != 0.f) rs += wx * row[(size_t)tx_i[ox * txn + b] * C];
+      }
+      s += wy * rs;
+    }
+    y[i] = acc ? y[i] + s : s;
+  }
+}
+void launch_resize(const float* x, float* y, int accumulate, int NB, int IH, int IW, int OH, int OW, int C,
+                   const int* ty_i, const float* ty_w, int tyn, const int* tx_i, const float* tx_w, int txn,
+                   hipStream_t s) {
+  const size_t n = (size_t)NB * OH * OW * C;
+  hipLaunchKernelGGL(resize_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, accumulate, IH, IW, OH, OW, C, ty_i,
+                     ty_w, tyn, tx_i, tx_w, txn, n);
+}
+
+// ---- PReLU / fixed-leak lrelu (activation.py:23-32): y = max(leak*x, x) ------------------------
+__global__ void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ leak_p, float leak_c,
+                                 float* __restrict__ y, size_t n) {
+  const float lk = leak_p ? *leak_p : leak_c;
+  GRID_STRIDE(i, n) {
+    const float v = x[i];
+    y[i] = fmaxf(lk * v, v);
+  }
+}
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ leak_p, float leak_c,
+                                                        float* __restrict__ dx, int acc_dx, float* __restrict__ part,
+                                                        size_t n) {
+  __shared__ float sm[4];
+  const float lk = leak_p ? *leak_p : leak_c;
+  float s = 0.f;
+  GRID_STRIDE(i, n) {
+    const float v = x[i], g = dy[i];
+    const bool first = (lk * v >= v);  // tf.maximum sends the gradient to the first argument on ties
+    if (dx) {
+      const float gx = first ? lk * g : g;
+      dx[i] = acc_dx ? dx[i] + gx : gx;
+    }
+    if (first) s += g * v;
+  }
+  if (part) {
+    const float tot = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  }
+}
+__global__ void sum_partials_kernel(const float* __restrict__ part, int np, float* __restrict__ out, int acc,
+                                    float scale) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) s += part[i];
+  const float tot = block_sum(s, sm);
+  if (threadIdx.x == 0) *out = acc ? *out + tot * scale : tot * scale;
+}
+void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, leak_p, leak_c, y, n);
+}
+size_t prelu_scratch_floats() { return 1024; }
+void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, float leak_c, float* dx, int acc_dx,
+                      float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s) {
+  const int nb = ew_blocks(n, 1024);
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, s, x, dy, leak_p, leak_c, dx, acc_dx,
+                     dleak ? scratch : nullptr, n);
+  if (dleak) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, nb, dleak, acc_dleak, 1.0f);
+}
+
+// ---- per-(n,c) spatial min-max normalisation of the MRU update gate (conv.py:197-198) ----------
+__global__ __launch_bounds__(256) void minmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ mm, int HW, int C) {
+  __shared__ float red[2 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int n = blockIdx.x, c = blockIdx.y * 64 + cx;
+  const bool cv = c < C;
+  const size_t base = (size_t)n * HW * C + c;
+  float mn = INFINITY, mx = -INFINITY;
+  if (cv)
+    for (int p = py; p < HW; p += 4) {
+      const float v = x[base + (size_t)p * C];
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+    }
+  red[py * 64 + cx] = mn;
+  red[(4 + py) * 64 + cx] = mx;
+  __syncthreads();
+  mn = fminf(fminf(red[cx], red[64 + cx]), fminf(red[128 + cx], red[192 + cx]));
+  mx = fmaxf(fmaxf(red[256 + cx], red[320 + cx]), fmaxf(red[384 + cx], red[448 + cx]));
+  if (cv) {
+    const float inv = 1.f / (mx - mn);
+    for (int p = py; p < HW; p += 4) y[base + (size_t)p * C] = (x[base + (size_t)p * C] - mn) * inv;
+    if (py == 0) {
+      mm[((size_t)n * C + c) * 2 + 0] = mn;
+      mm[((size_t)n * C + c) * 2 + 1] = mx;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mm,
+                                                         const float* __restrict__ dy, float* __restrict__ dx, int acc,
+                                                         int HW, int C) {
+  __shared__ float red[4 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int n = blockIdx.x, c = blockIdx.y * 64 + cx;
+  const bool cv = c < C;
+  const size_t base = (size_t)n * HW * C + c;
+  const float mn = cv ? mm[((size_t)n * C + c) * 2] : 0.f, mx = cv ? mm[((size_t)n * C + c) * 2 + 1] : 1.f;
+  float s1 = 0.f, s2 = 0.f, cmn = 0.f, cmx = 0.f;
+  if (cv)
+    for (int p = py; p < HW; p += 4) {
+      const float v = x[base + (size_t)p * C], g = dy[base + (size_t)p * C];
+      s1 += g;
+      s2 += g * (v - mn);
+      cmn += (v == mn) ? 1.f : 0.f;
+      cmx += (v == mx) ? 1.f : 0.f;
+    }
+  red[(0 * 4 + py) * 64 + cx] = s1;
+  red[(1 * 4 + py) * 64 + cx] = s2;
+  red[(2 * 4 + py) * 64 + cx] = cmn;
+  red[(3 * 4 + py) * 64 + cx] = cmx;
+  __syncthreads();
+  float v4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    v4[k] = red[(k * 4 + 0) * 64 + cx] + red[(k * 4 + 1) * 64 + cx] + red[(k * 4 + 2) * 64 + cx] +
+            red[(k * 4 + 3) * 64 + cx];
+  if (cv) {
+    const float d = mx - mn;
+    const float dmn = (-v4[0] / d + v4[1] / (d * d)) / v4[2];   // split equally among ties (Appendix B.8)
+    const float dmx = (-v4[1] / (d * d)) / v4[3];
+    for (int p = py; p < HW; p += 4) {
+      const size_t i = base + (size_t)p * C;
+      const float v = x[i];
+      float g = dy[i] / d;
+      if (v == mn) g += dmn;
+      if (v == mx) g += dmx;
+      dx[i] = acc ? dx[i] + g : g;
+    }
+  }
+}
+void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s) {
+  hipLaunchKernelGGL(minmax_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, y, mm, HW, C);
+}
+void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
+                       int HW, int C, hipStream_t s) {
+  hipLaunchKernelGGL(minmax_bwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C);
+}
+
+__global__ void gate_fwd_kernel(const float* __restrict__ h, const float* __restrict__ rg,
+                                const float* __restrict__ img, float* __restrict__ o, size_t n) {
+  GRID_STRIDE(i, n) o[i] = h[i] + rg[i] * img[i];
+}
+__global__ void gate_bwd_kernel(const float* __restrict__ rg, const float* __restrict__ img,
+                                const float* __restrict__ d, float* __restrict__ dh, int acc_h,
+                                float* __restrict__ drg, float* __restrict__ dimg, size_t n) {
+  GRID_STRIDE(i, n) {
+    const float g = d[i];
+    if (dh) dh[i] = acc_h ? dh[i] + g : g;
+    drg[i] = g * img[i];
+    dimg[i] = g * rg[i];
+  }
+}
+void launch_gate_fwd(const float* h, const float* rg, const float* img, float* out, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, h, rg, img, out, n);
+}
+void launch_gate_bwd(const float* rg, const float* img, const float* dout, float* dh, int acc_h, float* drg,
+                     float* dimg, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, rg, img, dout, dh, acc_h, drg, dimg, n);
+}
+
+// ---- N == 1 linear head (d_linear_5, discriminator.py:74) --------------------------------------
+__global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ y, int K) {
+  __shared__ float sm[4];
+  const float* xr = x + (size_t)blockIdx.x * K;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += xr[k] * w[k];
+  const float tot = block_sum(s, sm);
+  if (threadIdx.x == 0) y[blockIdx.x] = tot + (b ? b[0] : 0.f);
+}
+__global__ void gemv_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                  int acc, int K, size_t n) {
+  GRID_STRIDE(i, n) {
+    const float g = dy[i / K] * w[i % K];
+    dx[i] = acc ? dx[i] + g : g;
+  }
+}
+__global__ void gemv_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                  int acc_w, float* __restrict__ db, int acc_b, int R, int K) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += x[(size_t)r * K + k] * dy[r];
+    dw[k] = acc_w ? dw[k] + s : s;
+  }
+  if (db && k == 0) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += dy[r];
+    db[0] = acc_b ? db[0] + s : s;
+  }
+}
+void launch_gemv_fwd(const float* x, const float* w, const float* b, float* y, int R, int K, hipStream_t s) {
+  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(R), dim3(256), 0, s, x, w, b, y, K);
+}
+void launch_gemv_bwd_x(const float* dy, const float* w, float* dx, int accumulate, int R, int K, hipStream_t s) {
+  const size_t n = (size_t)R * K;
+  hipLaunchKernelGGL(gemv_bwd_x_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, w, dx, accumulate, K, n);
+}
+void launch_gemv_bwd_w(const float* x, const float* dy, float* dw, int acc_w, float* db, int acc_b, int R, int K,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(gemv_bwd_w_kernel, dim3((K + 255) / 256), dim3(256), 0, s, x, dy, dw, acc_w, db, acc_b, R, K);
+}
+
+// ---- spectral norm, batched over a device table of weights (normalization.py:38-76) -----------
+#define SN_EPS 1e-12f
+// t[k] = sum_c W[k][c]*vec[c]*coef ; one wave per row
+__global__ __launch_bounds__(256) void sn_rowdot_kernel(const SNDesc* __restrict__ tab, int bwd) {
+  const SNDesc d = tab[blockIdx.y];
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= d.K) return;
+  const float* vec = bwd ? d.sv : d.u;
+  const float coef = bwd ? d.scal[5] : 1.f;
+  const float* wr = d.W + (size_t)k * d.Co;
+  float s = 0.f;
+  for (int c = lane; c < d.Co; c += 64) s += wr[c] * vec[c];
+  s = wave_sum(s);
+  if (lane == 0) (bwd ? d.dv : d.t)[k] = s * coef;
+}
+// nt = |t| ; t <- t/(nt+eps)   (single block per weight)
+__global__ __launch_bounds__(256) void sn_normalize_t_kernel(const SNDesc* __restrict__ tab) {
+  __shared__ float sm[4];
+  const SNDesc d = tab[blockIdx.x];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < d.K; k += 256) s += d.t[k] * d.t[k];
+  const float nt = sqrtf(block_sum(s, sm));
+  const float inv = 1.f / (nt + SN_EPS);
+  for (int k = threadIdx.x; k < d.K; k += 256) d.t[k] *= inv;
+  if (threadIdx.x == 0) d.scal[0] = nt;
+}
+// sv[c] = sum_k v[k]*W[k][c]
+__global__ __launch_bounds__(256) void sn_coldot_kernel(const SNDesc* __restrict__ tab) {
+  __shared__ float red[4 * 64];
+  const SNDesc d = tab[blockIdx.y];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  if (blockIdx.x * 64 >= d.Co) return;
+  float s = 0.f;
+  if (c < d.Co)
+    for (int k = py; k < d.K; k += 4) s += d.t[k] * d.W[(size_t)k * d.Co + c];
+  red[py * 64 + cx] = s;
+  __syncthreads();
+  if (py == 0 && c < d.Co) d.sv[c] = red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx];
+}
+// ns = |sv| ; sigma = ns^2/(ns+eps)  (= v W u'^T with u' = sv/(ns+eps))
+__global__ __launch_bounds__(256) void sn_sigma_kernel(const SNDesc* __restrict__ tab) {
+  __shared__ float sm[4];
+  const SNDesc d = tab[blockIdx.x];
+  float s = 0.f;
+  for (int c = threadIdx.x; c < d.Co; c += 256) s += d.sv[c] * d.sv[c];
+  const float ns = sqrtf(block_sum(s, sm));
+  if (threadIdx.x == 0) {
+    d.scal[1] = ns;
+    d.scal[2] = ns * ns / (ns + SN_EPS);
+  }
+}
+__global__ void sn_scale_kernel(const SNDesc* __restrict__ tab) {
+  const SNDesc d = tab[blockIdx.y];
+  const float inv = 1.f / d.scal[2];
+  const size_t n = (size_t)d.K * d.Co;
+  GRID_STRIDE(i, n) d.Wbar[i] = d.W[i] * inv;
+}
+void launch_sn_fwd(const SNDesc* tab, int count, int maxK, int maxCo, hipStream_t s) {
+  hipLaunchKernelGGL(sn_rowdot_kernel, dim3((maxK + 3) / 4, count), dim3(256), 0, s, tab, 0);
+  hipLaunchKernelGGL(sn_normalize_t_kernel, dim3(count), dim3(256), 0, s, tab);
+  hipLaunchKernelGGL(sn_coldot_kernel, dim3((maxCo + 63) / 64, count), dim3(256), 0, s, tab);
+  hipLaunchKernelGGL(sn_sigma_kernel, dim3(count), dim3(256), 0, s, tab);
+  hipLaunchKernelGGL(sn_scale_kernel, dim3(256, count), dim3(256), 0, s, tab);
+}
+// backward ------------------------------------------------------------------------------------
+// stage 1: partial dots of dWbar.W into dv[0..63] (dv is scratch here, >= 64 floats since K >= 64? no: use scal[8..71])
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const SNDesc* __restrict__ tab) {
+  __shared__ float sm[4];
+  const SNDesc d = tab[blockIdx.y];
+  const size_t n = (size_t)d.K * d.Co;
+  float s = 0.f;
+  GRID_STRIDE(i, n) s += d.dWbar[i] * d.W[i];
+  const float tot = block_sum(s, sm);
+  if (threadIdx.x == 0) d.scal[8 + blockIdx.x] = tot;
+}
+// stage 2: dot, dsigma, coefficient for ds = coef * sv
+__global__ void sn_bwd_coef_kernel(const SNDesc* __restrict__ tab, int nparts) {
+  const SNDesc d = tab[blockIdx.x];
+  if (threadIdx.x != 0) return;
+  float dot = 0.f;
+  for (int i = 0; i < nparts; ++i) dot += d.scal[8 + i];
+  const float sigma = d.scal[2], ns = d.scal[1];
+  const float dsigma = -dot / (sigma * sigma);
+  const float q = ns + SN_EPS;
+  const float dns = dsigma * (ns * ns + 2.f * ns * SN_EPS) / (q * q);
+  d.scal[3] = dot;
+  d.scal[5] = dns / ns;  // ds[c] = scal[5] * sv[c]
+}
+// P = sum_k dv[k]*v[k]
+__global__ __launch_bounds__(256) void sn_bwd_p_kernel(const SNDesc* __restrict__ tab) {
+  __shared__ float sm[4];
+  const SNDesc d = tab[blockIdx.x];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < d.K; k += 256) s += d.dv[k] * d.t[k];
+  const float P = block_sum(s, sm);
+  if (threadIdx.x == 0) d.scal[4] = P;
+}
+// dW = dWbar/sigma + v (x) ds + dt (x) u ,  dt[k] = dv[k]/(nt+eps) - P v[k]/nt
+__global__ void sn_bwd_final_kernel(const SNDesc* __restrict__ tab) {
+  const SNDesc d = tab[blockIdx.y];
+  const float inv_sigma = 1.f / d.scal[2], nt = d.scal[0], P = d.scal[4], coef = d.scal[5];
+  const float invq = 1.f / (nt + SN_EPS);
+  const size_t n = (size_t)d.K * d.Co;
+  GRID_STRIDE(i, n) {
+    const int k = (int)(i / d.Co), c = (int)(i % d.Co);
+    const float v = d.t[k];
+    const float dt = d.dv[k] * invq - P * v / nt;
+    const float g = d.dWbar[i] * inv_sigma + v * coef * d.sv[c] + dt * d.u[c];
+    d.dW[i] = d.acc_dW ? d.dW[i] + g : g;
+  }
+}
+void launch_sn_bwd(const SNDesc* tab, int count, int maxK, int maxCo, hipStream_t s) {
+  const int nparts = 64;
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nparts, count), dim3(256), 0, s, tab);
+  hipLaunchKernelGGL(sn_bwd_coef_kernel, dim3(count), dim3(64), 0, s, tab, nparts);
+  hipLaunchKernelGGL(sn_rowdot_kernel, dim3((maxK + 3) / 4, count), dim3(256), 0, s, tab, 1);
+  hipLaunchKernelGGL(sn_bwd_p_kernel, dim3(count), dim3(256), 0, s, tab);
+  hipLaunchKernelGGL(sn_bwd_final_kernel, dim3(256, count), dim3(256), 0, s, tab);
+}
+
+// ---- losses (edgegan/nn/functional.py) ----------------------------------------------------------
+__global__ void mean_diff_kernel(const float* fake, const float* real, float* out, int B) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += fake[i] - real[i];
+  const float t = block_sum(s, sm);
+  if (threadIdx.x == 0) out[0] = t / B;
+}
+__global__ void mean_neg_kernel(const float* x, float* out, int B) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s -= x[i];
+  const float t = block_sum(s, sm);
+  if (threadIdx.x == 0) out[0] = t / B;
+}
+void launch_mean_diff(const float* fake, const float* real, float* out, int B, hipStream_t s) {
+  hipLaunchKernelGGL(mean_diff_kernel, dim3(1), dim3(256), 0, s, fake, real, out, B);
+}
+void launch_mean_neg(const float* x, float* out, int B, hipStream_t s) {
+  hipLaunchKernelGGL(mean_neg_kernel, dim3(1), dim3(256), 0, s, x, out, B);
+}
+
+// gradient penalty (functional.py:26-29, lambda from train.py:52)
+__global__ __launch_bounds__(256) void gp_norm_kernel(const float* __restrict__ g, float* __restrict__ norms,
+                                                      size_t per) {
+  __shared__ float sm[4];
+  const float* p = g + (size_t)blockIdx.x * per;
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < per; i += 256) s += p[i] * p[i];
+  const float t = block_sum(s, sm);
+  if (threadIdx.x == 0) norms[blockIdx.x] = sqrtf(t);
+}
+__global__ void gp_v_kernel(const float* __restrict__ g, const float* __restrict__ norms, float* __restrict__ v,
+                            size_t per, int B, float lambda, size_t n) {
+  GRID_STRIDE(i, n) {
+    const float nr = norms[i / per];
+    v[i] = lambda * (2.f / B) * (nr - 1.f) / nr * g[i];
+  }
+}
+__global__ void gp_loss_kernel(const float* norms, float* gp, int B, float lambda) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += (norms[i] - 1.f) * (norms[i] - 1.f);
+  const float t = block_sum(s, sm);
+  if (threadIdx.x == 0) gp[0] = lambda * t / B;
+}
+void launch_gp_v(const float* g, float* v, float* norms, float* gp, int B, size_t per, float lambda,
+                 hipStream_t s) {
+  hipLaunchKernelGGL(gp_norm_kernel, dim3(B), dim3(256), 0, s, g, norms, per);
+  const size_t n = (size_t)B * per;
+  if (v) hipLaunchKernelGGL(gp_v_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, g, norms, v, per, B, lambda, n);
+  hipLaunchKernelGGL(gp_loss_kernel, dim3(1), dim3(256), 0, s, norms, gp, B, lambda);
+}
+// quirk N10: the penalised function is sum_b sigmoid(d_b) + d_b
+__global__ void gp_head_kernel(const float* d, const float* td, float* o1, float* o2, int B, int mode) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float sg = 1.f / (1.f + expf(-d[b]));
+  const float sp = sg * (1.f - sg);
+  if (mode == 0) {
+    o1[b] = 1.f + sp;
+  } else {
+    o1[b] = sp * (1.f - 2.f * sg) * td[b];
+    o2[b] = 1.f + sp;
+  }
+}
+void launch_gp_head(const float* d, const float* td, float* o1, float* o2, int B, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(gp_head_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d, td, o1, o2, B, mode);
+}
+
+// focal AC-GAN loss (functional.py:5-16); one thread per sample, NC <= 64
+__global__ void acgan_kernel(const float* __restrict__ logits, const float* __restrict__ zlast, int z_stride,
+                             float* __restrict__ per_loss, float* __restrict__ dlogits, int B, int NC, int mode) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* l = logits + (size_t)b * NC;
+  const int y = (int)zlast[(size_t)b * z_stride];
+  float mx = l[0];
+  for (int j = 1; j < NC; ++j) mx = fmaxf(mx, l[j]);
+  float se = 0.f;
+  for (int j = 0; j < NC; ++j) se += expf(l[j] - mx);
+  const float lse = mx + logf(se);
+  const float ce = lse - l[y];
+  const float py = expf(l[y] - lse);
+  float coef_pj, coef_y;  // dl_j = coef_pj * p_j + (j==y) * coef_y
+  if (mode == 0) {
+    per_loss[b] = (1.f - py) * (1.f - py) * ce;
+    // f = (1-py)^2 * (-log py) ; df/dpy = 2(1-py) log py - (1-py)^2/py ; dpy/dl_j = py (delta - p_j)
+    const float dfdpy = 2.f * (1.f - py) * (-ce) - (1.f - py) * (1.f - py) / py;
+    const float k = dfdpy * py / B;
+    coef_pj = -k;
+    coef_y = k;
+  } else {
+    per_loss[b] = 0.5f * ce;
+    coef_pj = 0.5f / B;
+    coef_y = -0.5f / B;
+  }
+  if (dlogits)
+    for (int j = 0; j < NC; ++j)
+      dlogits[(size_t)b * NC + j] = coef_pj * expf(l[j] - lse) + (j == y ? coef_y : 0.f);
+}
+void launch_acgan_loss(const float* logits, const float* zlast, int z_stride, float* loss, float* dlogits, int B,
+                       int NC, int mode, float* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(acgan_kernel, dim3((B + 255) / 256), dim3(256), 0, s, logits, zlast, z_stride, scratch, dlogits,
+                     B, NC, mode);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, B, loss, 0, 1.0f / B);
+}
+
+// weighted L1 (functional.py:40-41)
+__global__ void l1_kernel(const float* __restrict__ target, int t_stride, const float* __restrict__ recon,
+                          float* __restrict__ loss, float* __restrict__ drecon, int B, int Z, float weight) {
+  __shared__ float sm[4];
+  const int n = B * Z;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int b = i / Z, j = i % Z;
+    const float d = target[(size_t)b * t_stride + j] - recon[i];
+    s += fabsf(d);
+    if (drecon) drecon[i] = -(weight / n) * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+  }
+  const float t = block_sum(s, sm);
+  if (threadIdx.x == 0) loss[0] = weight * t / n;
+}
+void launch_l1(const float* target, int t_stride, const float* recon, float* loss, float* drecon, int B, int Z,
+               float weight, hipStream_t s) {
+  hipLaunchKernelGGL(l1_kernel, dim3(1), dim3(256), 0, s, target, t_stride, recon, loss, drecon, B, Z, weight);
+}
+
+// z = mu + eps*exp(log_sigma) with ONE scalar eps (encoder.py:78-79, quirk N3)
+__global__ void reparam_fwd_kernel(const float* mu, const float* ls, const float* eps_p, float* z, size_t n) {
+  const float e = *eps_p;
+  GRID_STRIDE(i, n) z[i] = mu[i] + e * expf(ls[i]);
+}
+__global__ void reparam_bwd_kernel(const float* ls, const float* eps_p, const float* dz, float* dmu, float* dls,
+                                   size_t n) {
+  const float e = *eps_p;
+  GRID_STRIDE(i, n) {
+    dmu[i] = dz[i];
+    dls[i] = dz[i] * e * expf(ls[i]);
+  }
+}
+void launch_reparam_fwd(const float* mu, const float* ls, const float* eps_p, float* z, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, mu, ls, eps_p, z, n);
+}
+void launch_reparam_bwd(const float* ls, const float* eps_p, const float* dz, float* dmu, float* dls, size_t n,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, ls, eps_p, dz, dmu, dls, n);
+}
+
+// z_onehot (edgegan.py:188-197) / inference concat (edgegan.py:507-514)
+__global__ void z_onehot_kernel(const float* z, const int* classes, int z_stride, float* out, int B, int zd, int NC) {
+  const int W = zd + NC;
+  const size_t n = (size_t)B * W;
+  GRID_STRIDE(i, n) {
+    const int b = (int)(i / W), j = (int)(i % W);
+    if (j < zd) {
+      out[i] = z[(size_t)b * z_stride + j];
+    } else {
+      const int y = classes ? classes[b] : (int)z[(size_t)b * z_stride + zd];
+      out[i] = (j - zd == y) ? 1.f : 0.f;
+    }
+  }
+}
+void launch_z_onehot(const float* z, float* out, int B, int zd, int NC, hipStream_t s) {
+  hipLaunchKernelGGL(z_onehot_kernel, dim3(ew_blocks((size_t)B * (zd + NC))), dim3(256), 0, s, z, (const int*)nullptr,
+                     zd + 1, out, B, zd, NC);
+}
+void launch_class_onehot(const float* zrec, const int* classes, float* out, int B, int zd, int NC, hipStream_t s) {
+  hipLaunchKernelGGL(z_onehot_kernel, dim3(ew_blocks((size_t)B * (zd + NC))), dim3(256), 0, s, zrec, classes, zd, out,
+                     B, zd, NC);
+}
+
+// tf.train.RMSPropOptimizer(lr): decay .9, momentum 0, eps 1e-10
+__global__ void rmsprop_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ ms,
+                               float* __restrict__ mom, size_t n, float lr, float gscale) {
+  GRID_STRIDE(i, n) {
+    const float gi = g[i] * gscale;
+    const float m = ms[i] + (gi * gi - ms[i]) * (1.0f - 0.9f);
+    const float mo = 0.0f * mom[i] + lr * gi / sqrtf(m + 1e-10f);
+    ms[i] = m;
+    mom[i] = mo;
+    w[i] -= mo;
+  }
+}
+void launch_rmsprop(float* w, const float* g, float* ms, float* mom, size_t n, float lr, float gscale,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, w, g, ms, mom, n, lr, gscale);
+}
+
+}  // namespace eg

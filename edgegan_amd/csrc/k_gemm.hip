@@ -1,0 +1,498 @@
+// GEMM-shaped kernels for the EdgeGAN conv / transposed-conv stack on gfx950 (MI355X).
+//
+// All dense contractions of the reference (tf.nn.conv2d, tf.nn.conv2d_transpose and their
+// gradients: edgegan/nn/modules/conv.py:29,49-53,278-285 and the tf.gradients of those ops) are
+// expressed as ONE tap-gather implicit GEMM on the exact-fp32 matrix instruction
+// v_mfma_f32_16x16x4_f32 (157.3 TFLOP/s peak, bitwise an fmaf chain): no im2col buffer, the input
+// tile is gathered straight from NHWC into LDS, stride-2 transposed convolutions are decomposed into
+// their 4 sub-pixel phases so no multiplications by structural zeros are issued.
+//
+//   conv_gemm_kernel : Y[pix_out(m)][n] (+)= b[n] + sum_taps sum_c X[pix_in(m,tap)][c] Wt[tap][c][n]
+//   wgrad_kernel     : dW[tap][c][n]      = sum_m X[pix_in(m,tap)][c] dY[m][n]   (split over m)
+//
+// Tiles: 256 threads = 4 waves; block tile BMxBN, K-step 16; each wave owns a WTMxWTN sub-tile as
+// (WTM/16)x(WTN/16) 16x16 accumulators.  Global->register prefetch of the next K tile overlaps the
+// MFMA work on the current one (register-staged, write-after-barrier).
+#include "kernels.h"
+
+namespace eg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// =============================================================================================
+// conv_gemm_kernel
+// =============================================================================================
+template <int BM, int BN, int WTM, int WTN, bool VEC>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
+  constexpr int BK = 16;
+  constexpr int LDA = BK + 4;
+  constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 32);
+  constexpr int WGN = BN / WTN;
+  constexpr int MI = WTM / 16, NJ = WTN / 16;
+  static_assert((BM / WTM) * (BN / WTN) == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float As[BM * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const ConvPhase ph = a.ph[blockIdx.z];
+  const int M = a.NB * ph.OHp * ph.OWp;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= M) return;
+  const int IH = a.IH, IW = a.IW, C = a.C, N = a.N;
+
+  // ---- per-thread A-row bookkeeping --------------------------------------------------------
+  constexpr int A_ROWS = VEC ? (BM / 64) : (BM / 16);
+  int r_iy0[A_ROWS], r_ix0[A_ROWS], r_base[A_ROWS];
+#pragma unroll
+  for (int i = 0; i < A_ROWS; ++i) {
+    const int r = VEC ? ((tid >> 2) + 64 * i) : ((tid >> 4) + 16 * i);
+    const int m = m0 + r;
+    if (m < M) {
+      const int ox = m % ph.OWp;
+      const int t2 = m / ph.OWp;
+      const int oy = t2 % ph.OHp;
+      const int nb = t2 / ph.OHp;
+      r_iy0[i] = oy * a.S + ph.offy;
+      r_ix0[i] = ox * a.S + ph.offx;
+      r_base[i] = nb * IH * IW;
+    } else {
+      r_iy0[i] = 0;
+      r_ix0[i] = 0;
+      r_base[i] = -1;
+    }
+  }
+
+  const int ntaps = ph.Ty * ph.Tx;
+  const int Kflat = ntaps * C;
+  const int nk = VEC ? ntaps * (C / BK) : (Kflat + BK - 1) / BK;
+
+  constexpr int A_V = BM / 64;                     // float4 per thread (VEC)
+  constexpr int B_V = (4 * BN + 255) / 256;        // float4 per thread (VEC)
+  constexpr int A_S = BM / 16;                     // scalars per thread (FLAT)
+  constexpr int B_S = BN / 16;
+  float4 ra4[VEC ? A_V : 1], rb4[VEC ? B_V : 1];
+  float ras[VEC ? 1 : A_S], rbs[VEC ? 1 : B_S];
+
+  auto gather_ok = [&](int base, int& iy, int& ix) -> bool {
+    if (a.reflect) {
+      iy = reflect_idx(iy, IH);
+      ix = reflect_idx(ix, IW);
+    }
+    return base >= 0 && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+  };
+
+  auto load_tile = [&](int kt) {
+    if constexpr (VEC) {
+      const int cpt = C / BK;
+      const int tap = kt / cpt;
+      const int c0 = (kt - tap * cpt) * BK;
+      const int ty = tap / ph.Tx, tx = tap - ty * ph.Tx;
+      const long long wt = (long long)((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * a.w_ts;
+      const int kq = tid & 3;
+#pragma unroll
+      for (int i = 0; i < A_V; ++i) {
+        int iy = r_iy0[i] + ty * a.D, ix = r_ix0[i] + tx * a.D;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gather_ok(r_base[i], iy, ix))
+          v = *reinterpret_cast<const float4*>(a.x + (size_t)(r_base[i] + iy * IW + ix) * a.x_ps + c0 + kq * 4);
+        ra4[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < B_V; ++i) {
+        const int idx = tid + 256 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < 4 * BN) {
+          const int k = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+          if (n < N) v = *reinterpret_cast<const float4*>(a.wgt + wt + (size_t)(c0 + k) * a.ldw + n);
+        }
+        rb4[i] = v;
+      }
+    } else {
+      {  // A: this thread's k column is fixed inside the tile
+        const int k = kt * BK + (tid & 15);
+        const bool kv = k < Kflat;
+        const int tap = kv ? k / C : 0;
+        const int c = k - tap * C;
+        const int ty = tap / ph.Tx, tx = tap - ty * ph.Tx;
+#pragma unroll
+        for (int i = 0; i < A_S; ++i) {
+          int iy = r_iy0[i] + ty * a.D, ix = r_ix0[i] + tx * a.D;
+          float v = 0.f;
+          if (kv && gather_ok(r_base[i], iy, ix)) v = a.x[(size_t)(r_base[i] + iy * IW + ix) * a.x_ps + c];
+          ras[i] = v;
+        }
+      }
+      {  // B: this thread's k row is fixed inside the tile
+        const int k = kt * BK + (tid >> 4);
+        const bool kv = k < Kflat;
+        const int tap = kv ? k / C : 0;
+        const int c = k - tap * C;
+        const int ty = tap / ph.Tx, tx = tap - ty * ph.Tx;
+        const long long wt = (long long)((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * a.w_ts;
+#pragma unroll
+        for (int j = 0; j < B_S; ++j) {
+          const int n = n0 + (tid & 15) + 16 * j;
+          rbs[j] = (kv && n < N) ? a.wgt[wt + (size_t)c * a.ldw + n] : 0.f;
+        }
+      }
+    }
+  };
+
+  auto store_tile = [&]() {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int i = 0; i < A_V; ++i)
+        *reinterpret_cast<float4*>(&As[((tid >> 2) + 64 * i) * LDA + (tid & 3) * 4]) = ra4[i];
+#pragma unroll
+      for (int i = 0; i < B_V; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < 4 * BN) *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4]) = rb4[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_S; ++i) As[((tid >> 4) + 16 * i) * LDA + (tid & 15)] = ras[i];
+#pragma unroll
+      for (int j = 0; j < B_S; ++j) Bs[(tid >> 4) * LDB + (tid & 15) + 16 * j] = rbs[j];
+    }
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, lq = lane >> 4;
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float af[MI], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = As[(wm * WTM + i * 16 + l15) * LDA + kk * 4 + lq];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = Bs[(kk * 4 + lq) * LDB + wn * WTN + j * 16 + l15];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg --------------------------
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * WTM + i * 16 + lq * 4 + r;
+      if (m >= M) continue;
+      const int ox = m % ph.OWp;
+      const int t2 = m / ph.OWp;
+      const int oy = t2 % ph.OHp;
+      const int nb = t2 / ph.OHp;
+      float* yrow = a.y + ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + l15;
+        if (n < N) {
+          float v = acc[i][j][r];
+          if (a.bias) v += a.bias[n];
+          if (a.accumulate) v += yrow[n];
+          yrow[n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WTM, int WTN, bool VEC>
+static void conv_launch(const ConvArgs& a, int maxM, hipStream_t s) {
+  dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, VEC>), grid, dim3(256), 0, s, a);
+}
+
+double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_name) {
+  int maxM = 0;
+  double flops = 0;
+  for (int p = 0; p < a.nphase; ++p) {
+    const int M = a.NB * a.ph[p].OHp * a.ph[p].OWp;
+    if (M > maxM) maxM = M;
+    flops += 2.0 * M * a.N * (double)(a.ph[p].Ty * a.ph[p].Tx) * a.C;
+  }
+  const bool vec = (a.C % 16 == 0) && (a.N % 4 == 0) && (a.x_ps % 4 == 0) && (a.ldw % 4 == 0) &&
+                   (a.w_ts % 4 == 0) && (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.wgt & 15) == 0);
+  const long long blocks128 = (long long)((maxM + 127) / 128) * ((a.N + 127) / 128) * a.nphase;
+  const char* nm;
+  if (a.N <= 16) {
+    if (vec) { conv_launch<256, 16, 64, 16, true>(a, maxM, s); nm = "conv_gemm<256,16,vec>"; }
+    else { conv_launch<256, 16, 64, 16, false>(a, maxM, s); nm = "conv_gemm<256,16,flat>"; }
+  } else if (a.N >= 128 && blocks128 >= 512) {
+    if (vec) { conv_launch<128, 128, 64, 64, true>(a, maxM, s); nm = "conv_gemm<128,128,vec>"; }
+    else { conv_launch<128, 128, 64, 64, false>(a, maxM, s); nm = "conv_gemm<128,128,flat>"; }
+  } else {
+    if (vec) { conv_launch<64, 64, 32, 32, true>(a, maxM, s); nm = "conv_gemm<64,64,vec>"; }
+    else { conv_launch<64, 64, 32, 32, false>(a, maxM, s); nm = "conv_gemm<64,64,flat>"; }
+  }
+  if (kernel_name) *kernel_name = nm;
+  return flops;
+}
+
+// =============================================================================================
+// wgrad_kernel
+// =============================================================================================
+template <int BM, int BN, int WTM, int WTN, bool VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
+  constexpr int BK = 16;
+  constexpr int LDA = BM + ((BM % 32 == 0) ? 16 : 32);
+  constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 32);
+  constexpr int WGN = BN / WTN;
+  constexpr int MI = WTM / 16, NJ = WTN / 16;
+  __shared__ __attribute__((aligned(16))) float At[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int C = a.C, N = a.N, IH = a.IH, IW = a.IW;
+  const int ntn = (N + BN - 1) / BN;
+  const int c0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+  const int tap = blockIdx.y;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int M = a.NB * a.OH * a.OW;
+  int chunk = (M + a.nsplit - 1) / a.nsplit;
+  chunk = (chunk + BK - 1) / BK * BK;
+  const int p_lo = blockIdx.z * chunk;
+  const int p_hi = min(M, p_lo + chunk);
+
+  constexpr int A_V = (4 * BM + 255) / 256, B_V = (4 * BN + 255) / 256;
+  constexpr int A_S = BM / 16, B_S = BN / 16;
+  float4 ra4[VEC ? A_V : 1], rb4[VEC ? B_V : 1];
+  float ras[VEC ? 1 : A_S], rbs[VEC ? 1 : B_S];
+
+  // pixel m -> offset of the gathered input pixel for this tap (or -1)
+  auto gather_pix = [&](int m) -> long long {
+    if (m >= p_hi) return -1;
+    const int ox = m % a.OW;
+    const int t2 = m / a.OW;
+    const int oy = t2 % a.OH;
+    const int nb = t2 / a.OH;
+    int iy = oy * a.S + kh - a.pad, ix = ox * a.S + kw - a.pad;
+    if (a.reflect) {
+      iy = reflect_idx(iy, IH);
+      ix = reflect_idx(ix, IW);
+    }
+    if (iy < 0 || iy >= IH || ix < 0 || ix >= IW) return -1;
+    return (long long)((nb * IH + iy) * IW + ix) * a.x_ps;
+  };
+
+  auto load_tile = [&](int p) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int i = 0; i < A_V; ++i) {
+        const int idx = tid + 256 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < 4 * BM) {
+          const int k = idx / (BM / 4), c = c0 + (idx % (BM / 4)) * 4;
+          const long long off = gather_pix(p + k);
+          if (off >= 0 && c < C) v = *reinterpret_cast<const float4*>(a.x + off + c);
+        }
+        ra4[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < B_V; ++i) {
+        const int idx = tid + 256 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < 4 * BN) {
+          const int k = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+          const int m = p + k;
+          if (m < p_hi && n < N) v = *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.dy_ps + n);
+        }
+        rb4[i] = v;
+      }
+    } else {
+      const int k = tid >> 4;
+      const int m = p + k;
+      const long long off = gather_pix(m);
+#pragma unroll
+      for (int j = 0; j < A_S; ++j) {
+        const int c = c0 + (tid & 15) + 16 * j;
+        ras[j] = (off >= 0 && c < C) ? a.x[off + c] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < B_S; ++j) {
+        const int n = n0 + (tid & 15) + 16 * j;
+        rbs[j] = (m < p_hi && n < N) ? a.dy[(size_t)m * a.dy_ps + n] : 0.f;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int i = 0; i < A_V; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < 4 * BM) *reinterpret_cast<float4*>(&At[(idx / (BM / 4)) * LDA + (idx % (BM / 4)) * 4]) = ra4[i];
+      }
+#pragma unroll
+      for (int i = 0; i < B_V; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < 4 * BN) *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4]) = rb4[i];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_S; ++j) At[(tid >> 4) * LDA + (tid & 15) + 16 * j] = ras[j];
+#pragma unroll
+      for (int j = 0; j < B_S; ++j) Bs[(tid >> 4) * LDB + (tid & 15) + 16 * j] = rbs[j];
+    }
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, lq = lane >> 4;
+  if (p_lo < p_hi) {
+    load_tile(p_lo);
+    for (int p = p_lo; p < p_hi; p += BK) {
+      store_tile();
+      __syncthreads();
+      if (p + BK < p_hi) load_tile(p + BK);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        float af[MI], bf[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = At[(kk * 4 + lq) * LDA + wm * WTM + i * 16 + l15];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[j] = Bs[(kk * 4 + lq) * LDB + wn * WTN + j * 16 + l15];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+
+  const int T = a.KH * a.KW;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = c0 + wm * WTM + i * 16 + lq * 4 + r;
+      if (c >= C) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + l15;
+        if (n >= N) continue;
+        if (dense_out)  // partial slab [split][T][C][N]
+          out[(((size_t)blockIdx.z * T + tap) * C + c) * N + n] = acc[i][j][r];
+        else
+          out[(size_t)tap * a.w_ts + (size_t)c * a.ldw + n] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int T, int C, int N,
+                                    long long w_ts, int ldw, int nsplit, int accumulate) {
+  const size_t total = (size_t)T * C * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(size_t)z * total + i];
+    const int n = (int)(i % N);
+    const size_t t2 = i / N;
+    const int c = (int)(t2 % C);
+    const int t = (int)(t2 / C);
+    float* p = dw + (size_t)t * w_ts + (size_t)c * ldw + n;
+    *p = accumulate ? (*p + s) : s;
+  }
+}
+
+static bool wgrad_big(const WgradArgs& a) { return a.C >= 128 && a.N >= 128; }
+
+int wgrad_pick_splits(const WgradArgs& a) {
+  const int bm = wgrad_big(a) ? 128 : 64;
+  const long long tiles = (long long)((a.C + bm - 1) / bm) * ((a.N + bm - 1) / bm) * a.KH * a.KW;
+  const long long M = (long long)a.NB * a.OH * a.OW;
+  long long s = (1024 + tiles - 1) / tiles;
+  const long long smax = (M + 255) / 256;
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+
+size_t wgrad_workspace_floats(const WgradArgs& a) {
+  if (a.nsplit == 1 && !a.accumulate) return 0;
+  return (size_t)a.nsplit * a.KH * a.KW * a.C * a.N;
+}
+
+template <int BM, int BN, int WTM, int WTN, bool VEC>
+static void wgrad_launch(const WgradArgs& a, float* out, int dense, hipStream_t s) {
+  dim3 grid(((a.C + BM - 1) / BM) * ((a.N + BN - 1) / BN), a.KH * a.KW, a.nsplit);
+  hipLaunchKernelGGL((wgrad_kernel<BM, BN, WTM, WTN, VEC>), grid, dim3(256), 0, s, a, out, dense);
+}
+
+double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name) {
+  const bool direct = (a.nsplit == 1 && !a.accumulate);
+  float* out = direct ? a.dw : a.ws;
+  const int dense = direct ? 0 : 1;
+  const bool vec = (a.C % 4 == 0) && (a.N % 4 == 0) && (a.x_ps % 4 == 0) && (a.dy_ps % 4 == 0) &&
+                   (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
+  const char* nm;
+  if (wgrad_big(a)) {
+    if (vec) { wgrad_launch<128, 128, 64, 64, true>(a, out, dense, s); nm = "wgrad<128,128,vec>"; }
+    else { wgrad_launch<128, 128, 64, 64, false>(a, out, dense, s); nm = "wgrad<128,128,flat>"; }
+  } else {
+    if (vec) { wgrad_launch<64, 64, 32, 32, true>(a, out, dense, s); nm = "wgrad<64,64,vec>"; }
+    else { wgrad_launch<64, 64, 32, 32, false>(a, out, dense, s); nm = "wgrad<64,64,flat>"; }
+  }
+  if (!direct) {
+    const size_t total = (size_t)a.KH * a.KW * a.C * a.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, a.dw, a.KH * a.KW, a.C, a.N,
+                       a.w_ts, a.ldw, a.nsplit, a.accumulate);
+  }
+  if (kernel_name) *kernel_name = nm;
+  return 2.0 * a.NB * a.OH * a.OW * (double)a.N * a.C * a.KH * a.KW;
+}
+
+// =============================================================================================
+// per-tap transpose [T][R][Cc] -> [T][Cc][R], optional scale 1/(*inv_of)
+// =============================================================================================
+__global__ void tap_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc,
+                                     const float* __restrict__ inv_of) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const float sc = inv_of ? 1.0f / *inv_of : 1.0f;
+  const float* src = in + (size_t)t * R * Cc;
+  float* dst = out + (size_t)t * R * Cc;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < Cc) ? src[(size_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < Cc) dst[(size_t)c * R + r] = tile[threadIdx.x][i] * sc;
+  }
+}
+
+void launch_tap_transpose(const float* in, float* out, int T, int R, int Cc, const float* inv_of, hipStream_t s) {
+  dim3 grid((Cc + 31) / 32, (R + 31) / 32, T);
+  hipLaunchKernelGGL(tap_transpose_kernel, grid, dim3(32, 8), 0, s, in, out, R, Cc, inv_of);
+}
+
+}  // namespace eg

@@ -1,0 +1,320 @@
+// Normalisation + activation kernels (HBM-bound; NHWC fp32).
+//
+// InstanceNorm of the reference (edgegan/nn/modules/normalization.py:13-18):
+//     y = (x - mean) / (sqrt(var) + 1e-5)     mean/var over H*W per (n, c), biased var, no affine
+// fused with the activation that follows it in conv_block / deconv_block / residual
+// (conv.py:61-67,70-85,124-130).  Its Jacobian J = r(I - 11^T/HW) - r^2 xc xc^T/(HW sigma),
+// r = 1/(sigma+eps), is symmetric, so the same "apply J" code serves the backward pass and the
+// forward-mode tangent used for the WGAN-GP term (functional.py:26-29 differentiated once more);
+// in_tangent_bwd is the reverse of that tangent (gradient w.r.t. both the tangent and the primal x).
+//
+// Block = 256 threads = 64 channels x 4 pixel lanes, one block per (sample, 64-channel group):
+// a wave reads 256-byte channel rows (coalesced), reductions over the 4 pixel lanes go through LDS.
+#include "kernels.h"
+
+namespace eg {
+
+#define IN_EPS 1e-5f
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_LRELU: return fmaxf(v, 0.2f * v);
+    case ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+// derivative expressed through the OUTPUT value (tf tie conventions: SURVEY Appendix B.8)
+__device__ __forceinline__ float act_grad_from_out(float o, int act) {
+  switch (act) {
+    case ACT_RELU: return o > 0.f ? 1.f : 0.f;
+    case ACT_LRELU: return o >= 0.f ? 1.f : 0.2f;
+    case ACT_TANH: return 1.f - o * o;
+    default: return 1.f;
+  }
+}
+
+// reduce NV per-thread partials over the 4 pixel lanes; result broadcast to all lanes of a channel
+template <int NV>
+__device__ __forceinline__ void lane4_reduce(float (&v)[NV], float* red /*[NV][4][64]*/, int cx, int py) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) red[(k * 4 + py) * 64 + cx] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    v[k] = red[(k * 4 + 0) * 64 + cx] + red[(k * 4 + 1) * 64 + cx] + red[(k * 4 + 2) * 64 + cx] +
+           red[(k * 4 + 3) * 64 + cx];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void in_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                     float* __restrict__ stats, int HW, int C, int act) {
+  __shared__ float red[2 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int n = blockIdx.x, c = blockIdx.y * 64 + cx;
+  const bool cv = c < C;
+  const float* xp = x + (size_t)n * HW * C + c;
+  float s[1] = {0.f};
+  if (cv)
+    for (int p = py; p < HW; p += 4) s[0] += xp[(size_t)p * C];
+  lane4_reduce<1>(s, red, cx, py);
+  const float mean = s[0] / HW;
+  float q[1] = {0.f};
+  if (cv)
+    for (int p = py; p < HW; p += 4) {
+      const float d = xp[(size_t)p * C] - mean;
+      q[0] += d * d;
+    }
+  lane4_reduce<1>(q, red, cx, py);
+  const float sigma = sqrtf(q[0] / HW);
+  const float r = 1.f / (sigma + IN_EPS);
+  if (cv) {
+    float* op = out + (size_t)n * HW * C + c;
+    for (int p = py; p < HW; p += 4) op[(size_t)p * C] = act_apply((xp[(size_t)p * C] - mean) * r, act);
+    if (py == 0) {
+      stats[((size_t)n * C + c) * 2 + 0] = mean;
+      stats[((size_t)n * C + c) * 2 + 1] = sigma;
+    }
+  }
+}
+
+// MODE 0: backward      res = J (dout * act'(out))                 -> dst (acc)
+// MODE 1: tangent fwd   res = act'(out) * (J tx)                   -> dst
+template <int MODE>
+__global__ __launch_bounds__(256) void in_japply_kernel(const float* __restrict__ x, const float* __restrict__ out,
+                                                        const float* __restrict__ v, const float* __restrict__ stats,
+                                                        float* __restrict__ dst, int accumulate, int HW, int C,
+                                                        int act) {
+  __shared__ float red[2 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int n = blockIdx.x, c = blockIdx.y * 64 + cx;
+  const bool cv = c < C;
+  const size_t base = (size_t)n * HW * C + c;
+  const float mean = cv ? stats[((size_t)n * C + c) * 2 + 0] : 0.f;
+  const float sigma = cv ? stats[((size_t)n * C + c) * 2 + 1] : 1.f;
+  const float r = 1.f / (sigma + IN_EPS);
+  float s[2] = {0.f, 0.f};  // sum(e), sum(e*xc)
+  if (cv)
+    for (int p = py; p < HW; p += 4) {
+      const size_t i = base + (size_t)p * C;
+      float e = v[i];
+      if (MODE == 0) e *= act_grad_from_out(out[i], act);
+      s[0] += e;
+      s[1] += e * (x[i] - mean);
+    }
+  lane4_reduce<2>(s, red, cx, py);
+  const float eb = s[0] / HW;
+  const float k2 = r * r * s[1] / (HW * sigma);
+  if (cv)
+    for (int p = py; p < HW; p += 4) {
+      const size_t i = base + (size_t)p * C;
+      const float o = out[i];
+      float e = v[i];
+      if (MODE == 0) e *= act_grad_from_out(o, act);
+      float res = r * (e - eb) - k2 * (x[i] - mean);
+      if (MODE == 1) res *= act_grad_from_out(o, act);
+      dst[i] = accumulate ? dst[i] + res : res;
+    }
+}
+
+__global__ __launch_bounds__(256) void in_tangent_bwd_kernel(const float* __restrict__ x, const float* __restrict__ out,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ tx,
+                                                             const float* __restrict__ dtout, float* __restrict__ dtx,
+                                                             int acc_dtx, float* __restrict__ dx, int acc_dx, int HW,
+                                                             int C, int act) {
+  __shared__ float red[5 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int n = blockIdx.x, c = blockIdx.y * 64 + cx;
+  const bool cv = c < C;
+  const size_t base = (size_t)n * HW * C + c;
+  const float mean = cv ? stats[((size_t)n * C + c) * 2 + 0] : 0.f;
+  const float sigma = cv ? stats[((size_t)n * C + c) * 2 + 1] : 1.f;
+  const float r = 1.f / (sigma + IN_EPS);
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // sum e, sum tx, sum e*tx, sum xc*tx, sum e*xc
+  if (cv)
+    for (int p = py; p < HW; p += 4) {
+      const size_t i = base + (size_t)p * C;
+      const float e = dtout[i] * act_grad_from_out(out[i], act);
+      const float t = tx[i], xc = x[i] - mean;
+      s[0] += e;
+      s[1] += t;
+      s[2] += e * t;
+      s[3] += xc * t;
+      s[4] += e * xc;
+    }
+  lane4_reduce<5>(s, red, cx, py);
+  const float hw = (float)HW;
+  const float eb = s[0] / hw, ta = s[1] / hw;
+  const float A = s[2] - hw * eb * ta;
+  const float S_xt = s[3], S_ex = s[4];
+  const float B = S_xt * S_ex / hw;
+  const float r2 = r * r;
+  const float c1 = (-A * r2 + 2.f * r2 * r * B / sigma + r2 * B / (sigma * sigma)) / (hw * sigma);
+  const float c2 = -r2 * S_ex / (hw * sigma);
+  const float c3 = -r2 * S_xt / (hw * sigma);
+  const float k2 = r2 * S_ex / (hw * sigma);
+  if (cv)
+    for (int p = py; p < HW; p += 4) {
+      const size_t i = base + (size_t)p * C;
+      const float e = dtout[i] * act_grad_from_out(out[i], act);
+      const float t = tx[i], xc = x[i] - mean;
+      const float gt = r * (e - eb) - k2 * xc;
+      const float gx = c1 * xc + c2 * (t - ta) + c3 * (e - eb);
+      dtx[i] = acc_dtx ? dtx[i] + gt : gt;
+      dx[i] = acc_dx ? dx[i] + gx : gx;
+    }
+}
+
+void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s) {
+  hipLaunchKernelGGL(in_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, stats, HW, C, act);
+}
+void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
+                   int accumulate, int NB, int HW, int C, int act, hipStream_t s) {
+  hipLaunchKernelGGL(in_japply_kernel<0>, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, dout, stats, dx,
+                     accumulate, HW, C, act);
+}
+void launch_in_tangent_fwd(const float* x, const float* out, const float* stats, const float* tx, float* tout,
+                           int NB, int HW, int C, int act, hipStream_t s) {
+  hipLaunchKernelGGL(in_japply_kernel<1>, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, tx, stats, tout, 0, HW,
+                     C, act);
+}
+void launch_in_tangent_bwd(const float* x, const float* out, const float* stats, const float* tx,
+                           const float* dtout, float* dtx, int acc_dtx, float* dx, int acc_dx, int NB, int HW,
+                           int C, int act, hipStream_t s) {
+  hipLaunchKernelGGL(in_tangent_bwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, stats, tx, dtout, dtx,
+                     acc_dtx, dx, acc_dx, HW, C, act);
+}
+
+// ---------------------------------------------------------------------------------------------
+// plain activations
+// ---------------------------------------------------------------------------------------------
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, size_t n, int act) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = act_apply(x[i], act);
+}
+__global__ void act_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ dx,
+                               int accumulate, size_t n, int act) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float g = dout[i] * act_grad_from_out(out[i], act);
+    dx[i] = accumulate ? dx[i] + g : g;
+  }
+}
+static inline int ew_blocks(size_t n) {
+  size_t b = (n + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+void launch_act_fwd(const float* x, float* out, size_t n, int act, hipStream_t s) {
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, out, n, act);
+}
+void launch_act_bwd(const float* out, const float* dout, float* dx, int accumulate, size_t n, int act,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, out, dout, dx, accumulate, n, act);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm (batch statistics, biased variance inside the sqrt) + ReLU over rows [R][C]
+// (generator.py:51-52 via normalization.py:19-25; quirk N1)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ out,
+                                                          float* __restrict__ stats, int R, int C, float eps) {
+  __shared__ float red[4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const bool cv = c < C;
+  float s[1] = {0.f};
+  if (cv)
+    for (int p = py; p < R; p += 4) s[0] += x[(size_t)p * C + c];
+  lane4_reduce<1>(s, red, cx, py);
+  const float mean = s[0] / R;
+  float q[1] = {0.f};
+  if (cv)
+    for (int p = py; p < R; p += 4) {
+      const float d = x[(size_t)p * C + c] - mean;
+      q[0] += d * d;
+    }
+  lane4_reduce<1>(q, red, cx, py);
+  const float var = q[0] / R;
+  if (cv) {
+    const float rs = 1.f / sqrtf(var + eps), g = gamma[c], b = beta[c];
+    for (int p = py; p < R; p += 4) {
+      const float y = (x[(size_t)p * C + c] - mean) * rs * g + b;
+      out[(size_t)p * C + c] = y > 0.f ? y : 0.f;
+    }
+    if (py == 0) {
+      stats[c] = mean;
+      stats[C + c] = var;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ out,
+                                                          const float* __restrict__ dout,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ stats, float* __restrict__ dx,
+                                                          int acc_dx, float* __restrict__ dgamma, int acc_dg,
+                                                          float* __restrict__ dbeta, int acc_db, int R, int C,
+                                                          float eps) {
+  __shared__ float red[2 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const bool cv = c < C;
+  const float mean = cv ? stats[c] : 0.f, var = cv ? stats[C + c] : 1.f;
+  const float rs = 1.f / sqrtf(var + eps);
+  float s[2] = {0.f, 0.f};
+  if (cv)
+    for (int p = py; p < R; p += 4) {
+      const size_t i = (size_t)p * C + c;
+      const float e = out[i] > 0.f ? dout[i] : 0.f;
+      s[0] += e;
+      s[1] += e * (x[i] - mean) * rs;
+    }
+  lane4_reduce<2>(s, red, cx, py);
+  if (cv) {
+    const float g = gamma[c];
+    const float me = s[0] / R, mex = s[1] / R;
+    if (dx)
+      for (int p = py; p < R; p += 4) {
+        const size_t i = (size_t)p * C + c;
+        const float e = out[i] > 0.f ? dout[i] : 0.f;
+        const float xh = (x[i] - mean) * rs;
+        const float v = g * rs * (e - me - xh * mex);
+        dx[i] = acc_dx ? dx[i] + v : v;
+      }
+    if (py == 0) {
+      if (dgamma) dgamma[c] = acc_dg ? dgamma[c] + s[1] : s[1];
+      if (dbeta) dbeta[c] = acc_db ? dbeta[c] + s[0] : s[0];
+    }
+  }
+}
+
+__global__ void bn_moving_kernel(float* mm, float* mv, const float* stats, int C, int R, float decay, int times) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = stats[c], var = stats[C + c] * ((float)R / (float)(R > 1 ? R - 1 : 1));
+  float a = mm[c], b = mv[c];
+  for (int t = 0; t < times; ++t) {
+    a = a * decay + (1.f - decay) * mean;
+    b = b * decay + (1.f - decay) * var;
+  }
+  mm[c] = a;
+  mv[c] = b;
+}
+
+void launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats, int R,
+                        int C, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
+}
+void launch_bn_relu_bwd(const float* x, const float* out, const float* dout, const float* gamma,
+                        const float* stats, float* dx, int acc_dx, float* dgamma, int acc_dg, float* dbeta,
+                        int acc_db, int R, int C, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, out, dout, gamma, stats, dx, acc_dx,
+                     dgamma, acc_dg, dbeta, acc_db, R, C, eps);
+}
+void launch_bn_moving_update(float* mm, float* mv, const float* stats, int C, int R, float decay, int times,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(bn_moving_kernel, dim3((C + 255) / 256), dim3(256), 0, s, mm, mv, stats, C, R, decay, times);
+}
+
+}  // namespace eg

@@ -1,0 +1,206 @@
+// Host-callable launchers for the gfx950 kernels (k_gemm.hip, k_norm.hip, k_elem.hip).
+// Every launcher enqueues on the given stream and returns immediately.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace eg {
+
+// ---------------------------------------------------------------------------------------------
+// Tap-gather implicit GEMM (conv forward, conv input-gradient, transposed conv), NHWC fp32:
+//   Y[pix_out(m)][n] (+)= bias[n] + sum_{tap in phase} sum_c X[pix_in(m,tap)][c] * Wt[wt(tap)][c][n]
+// One launch covers up to 4 output phases (sub-pixel classes of a stride-2 transposed conv).
+// ---------------------------------------------------------------------------------------------
+struct ConvPhase {
+  int OHp, OWp;      // phase sub-grid extents (rows m enumerate (nb, oy, ox) over it)
+  int ophy, ophx;    // output pixel = (oy*os + ophy, ox*os + ophx)
+  int Ty, Tx;        // taps in this phase
+  int kh0, kw0;      // filter tap = (kh0 + ty*kst, kw0 + tx*kst)
+  int offy, offx;    // input pixel = (oy*S + ty*D + offy, ox*S + tx*D + offx)
+};
+
+struct ConvArgs {
+  const float* x;    // [NB][IH][IW] pixels, x_ps floats per pixel, C channels used
+  const float* wgt;  // element (tap wt, c, n) at wgt[wt*w_ts + c*ldw + n]
+  const float* bias; // [N] or null
+  float* y;          // [NB][OHf][OWf] pixels, y_ps floats per pixel
+  int NB, IH, IW, C, x_ps;
+  int OHf, OWf, N, y_ps;
+  int KW, kst, S, D, os;
+  long long w_ts;
+  int ldw;
+  int reflect;       // 1: out-of-range input index is mirrored (tf.pad REFLECT), 0: contributes zero
+  int accumulate;    // 1: y += result
+  int nphase;
+  ConvPhase ph[4];
+};
+
+// flops (2*M*N*K summed over phases) are returned for the profiler.
+double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_name);
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dW[wt(tap)][c][n] = sum_m X[pix_in(m,tap)][c] * dY[m][n], m over NB*OH*OW
+// "output" pixels, pix_in = (oy*S + kh - pad, ox*S + kw - pad) (mirrored when reflect).
+// Split over m with a fixed-order second-stage reduction (deterministic, no float atomics).
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x;    // gathered operand [NB][IH][IW][x_ps], C channels
+  const float* dy;   // dense operand    [NB][OH][OW][dy_ps], N channels
+  float* dw;         // [KH*KW][C][N] with tap stride w_ts, row stride ldw
+  float* ws;         // workspace for split partials: nsplit * (KH*KW*w_ts) floats
+  int NB, IH, IW, C, x_ps;
+  int OH, OW, N, dy_ps;
+  int KH, KW, S, pad;
+  long long w_ts;
+  int ldw;
+  int reflect;
+  int accumulate;    // 1: dw += result
+  int nsplit;
+};
+int wgrad_pick_splits(const WgradArgs& a);
+size_t wgrad_workspace_floats(const WgradArgs& a);
+double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name);
+
+// [T][R][Cc] -> [T][Cc][R] (per-tap transpose), optional scale by 1/(*inv_of) when inv_of != null.
+void launch_tap_transpose(const float* in, float* out, int T, int R, int Cc, const float* inv_of,
+                          hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// norm / activation kernels (k_norm.hip).  act: 0 none, 1 relu, 2 lrelu(max(x,0.2x)), 3 tanh
+// ---------------------------------------------------------------------------------------------
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
+
+// InstanceNorm (x-mean)/(sqrt(var)+1e-5) + act, per (n,c) over H*W. stats[n][c] = {mean, sigma}.
+void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s);
+// dx (+)= J * (dout * act'(out))   (J = IN Jacobian, symmetric)
+void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
+                   int accumulate, int NB, int HW, int C, int act, hipStream_t s);
+// tangent forward: tout = act'(out_primal) * (J * tx)
+void launch_in_tangent_fwd(const float* x, const float* out, const float* stats, const float* tx, float* tout,
+                           int NB, int HW, int C, int act, hipStream_t s);
+// tangent backward: given dtout, produce dtx (+)= ..., dx_primal (+)= ...
+void launch_in_tangent_bwd(const float* x, const float* out, const float* stats, const float* tx,
+                           const float* dtout, float* dtx, int acc_dtx, float* dx, int acc_dx, int NB, int HW,
+                           int C, int act, hipStream_t s);
+// plain activation (no norm): fwd, bwd (dx (+)= dout*act'(out)), tangent (tout = act'(out)*tx)
+void launch_act_fwd(const float* x, float* out, size_t n, int act, hipStream_t s);
+void launch_act_bwd(const float* out, const float* dout, float* dx, int accumulate, size_t n, int act,
+                    hipStream_t s);
+
+// BatchNorm (training statistics) + ReLU over [R][C] rows: y = relu(gamma*(x-mean)/sqrt(var+eps)+beta)
+// stats = {mean[C], var[C]}
+void launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats,
+                        int R, int C, float eps, hipStream_t s);
+void launch_bn_relu_bwd(const float* x, const float* out, const float* dout, const float* gamma,
+                        const float* stats, float* dx, int acc_dx, float* dgamma, int acc_dg, float* dbeta,
+                        int acc_db, int R, int C, float eps, hipStream_t s);
+// moving statistics update: mm = d*mm + (1-d)*mean, mv = d*mv + (1-d)*var*R/(R-1), applied `times` times
+void launch_bn_moving_update(float* mm, float* mv, const float* stats, int C, int R, float decay, int times,
+                             hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// elementwise / data movement / reductions / losses / optimizer (k_elem.hip)
+// ---------------------------------------------------------------------------------------------
+void launch_fill(float* p, float v, size_t n, hipStream_t s);
+void launch_copy(const float* src, float* dst, size_t n, hipStream_t s);
+// y (+)= a*x
+void launch_axpy(const float* x, float* y, float a, int accumulate, size_t n, hipStream_t s);
+// out = a + b ; out = relu(a+b)
+void launch_add(const float* a, const float* b, float* out, int relu, size_t n, hipStream_t s);
+// dst[n][h][wo + w][c] = src[n][h][w][c]  (copy a [NB][H][Ws][C] block into a wider [NB][H][Wd][C] at column wo)
+// to_dst=1: wide[.., wo+w, ..] (+)= narrow ; to_dst=0: narrow (+)= wide[.., wo+w, ..]
+void launch_copy_cols(const float* narrow, float* wide, int NB, int H, int Ws, int Wd, int wo, int C, int to_dst,
+                      int accumulate, hipStream_t s);
+// xhat = real + alpha[n]*(fake-real)
+void launch_blend(const float* real, const float* fake, const float* alpha, float* out, int NB, size_t per,
+                  hipStream_t s);
+// gradient of tf.pad(REFLECT, p): fold [NB][H+2p][W+2p][C] back onto [NB][H][W][C]
+void launch_reflect_fold(const float* dpad, float* dx, int accumulate, int NB, int H, int W, int C, int p,
+                         hipStream_t s);
+// bias gradient: db[c] (+)= sum_rows dy[r][c]
+size_t col_sum_scratch_floats(int C);
+void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C, float* scratch, hipStream_t s);
+// 2x2 mean pool NHWC fwd / bwd
+void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hipStream_t s);
+void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s);
+// global spatial mean: y[n][c] = mean_hw act(x[n][hw][c]) ; pre_relu applies relu first
+void launch_gmean_fwd(const float* x, float* y, int NB, int HW, int C, int pre_relu, hipStream_t s);
+void launch_gmean_bwd(const float* x, const float* dy, float* dx, int accumulate, int NB, int HW, int C,
+                      int pre_relu, hipStream_t s);
+// separable resize driven by host-built tap tables (TF legacy bicubic and its transpose):
+// y[n][oy][ox][c] (+)= sum_a sum_b ty_w[oy][a]*tx_w[ox][b]*x[n][ty_i[oy][a]][tx_i[ox][b]][c]
+void launch_resize(const float* x, float* y, int accumulate, int NB, int IH, int IW, int OH, int OW, int C,
+                   const int* ty_i, const float* ty_w, int tyn, const int* tx_i, const float* tx_w, int txn,
+                   hipStream_t s);
+// prelu / fixed leak: y = max(leak*x, x); leak read from device scalar (leak_p) or constant
+void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s);
+// dx (+)= ..., dleak (+)= sum(dy*x [x<0 or tie]) (when dleak != null)
+size_t prelu_scratch_floats();
+void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, float leak_c, float* dx, int acc_dx,
+                      float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s);
+// per-(n,c) spatial min-max normalisation (conv.py:197-198) fwd/bwd; mm[n][c] = {min,max}
+void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s);
+void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
+                       int HW, int C, hipStream_t s);
+// gate merge: out = h + rg*img ; backward
+void launch_gate_fwd(const float* h, const float* rg, const float* img, float* out, size_t n, hipStream_t s);
+void launch_gate_bwd(const float* rg, const float* img, const float* dout, float* dh, int acc_h, float* drg,
+                     float* dimg, size_t n, hipStream_t s);
+// add bias over last dim in place (y[r][c] += b[c]), optional prelu/lrelu fused variants are separate ops
+void launch_bias_add(float* y, const float* b, size_t R, int C, hipStream_t s);
+
+// N==1 linear head: y[r] = dot(x[r], w) + b ; backward pieces
+void launch_gemv_fwd(const float* x, const float* w, const float* b, float* y, int R, int K, hipStream_t s);
+void launch_gemv_bwd_x(const float* dy, const float* w, float* dx, int accumulate, int R, int K, hipStream_t s);
+void launch_gemv_bwd_w(const float* x, const float* dy, float* dw, int acc_w, float* db, int acc_b, int R,
+                       int K, hipStream_t s);
+
+// ---- spectral norm (normalization.py:38-76), batched over a table of weights -----------------
+struct SNDesc {
+  const float* W;   // [K][Co]
+  const float* u;   // [Co]
+  float* Wbar;      // [K][Co] = W/sigma
+  float* t;         // [K]  scratch: W u^T  (then v)
+  float* sv;        // [Co] scratch: v W
+  float* scal;      // [80]: 0 nt, 1 ns, 2 sigma, 3 dot(dWbar,W), 4 P=dot(dv,v), 5 ds coefficient, 8.. partials
+  const float* dWbar;  // backward input
+  float* dW;        // backward output
+  float* dv;        // [K] scratch
+  int K, Co;
+  int acc_dW;
+};
+void launch_sn_fwd(const SNDesc* d_table, int count, int maxK, int maxCo, hipStream_t s);
+void launch_sn_bwd(const SNDesc* d_table, int count, int maxK, int maxCo, hipStream_t s);
+
+// ---- losses -------------------------------------------------------------------------------------
+// scal layout documented in engine.cpp
+// WGAN: out[0] = mean(fake) - mean(real) over B
+void launch_mean_diff(const float* fake, const float* real, float* out, int B, hipStream_t s);
+void launch_mean_neg(const float* x, float* out, int B, hipStream_t s);
+// GP: per-sample norm of g (per floats each); v = lambda*(2/B)*(|g|-1)*g/|g| ; gp[0] = lambda*mean((|g|-1)^2)
+void launch_gp_v(const float* g, float* v, float* norms, float* gp, int B, size_t per, float lambda,
+                 hipStream_t s);
+// GP head (quirk N10): s = 1 + sig'(d), seeds
+//   mode 0: out[b] = 1 + sig(d)(1-sig(d))                                  (first-order seed)
+//   mode 1: dd[b] = s'(d)*td[b] ; dtd[b] = s(d)                            (reverse seeds)
+void launch_gp_head(const float* d, const float* td, float* o1, float* o2, int B, int mode, hipStream_t s);
+// focal AC loss (functional.py:5-16): logits [B][NC], labels from z last column (float ids)
+// mode 0: d-loss on real logits -> loss[0], dlogits ; mode 1: g-loss 0.5*mean(CE) -> loss[0], dlogits
+void launch_acgan_loss(const float* logits, const float* zlast, int z_stride, float* loss, float* dlogits, int B,
+                       int NC, int mode, float* scratch /*[B]*/, hipStream_t s);
+// L1: loss = w*mean|t - r| ; dr = -w/(n)*sign(t-r)
+void launch_l1(const float* target, int t_stride, const float* recon, float* loss, float* drecon, int B, int Z,
+               float weight, hipStream_t s);
+// reparam: z = mu + eps*exp(ls); backward
+void launch_reparam_fwd(const float* mu, const float* ls, const float* eps_p, float* z, size_t n, hipStream_t s);
+void launch_reparam_bwd(const float* ls, const float* eps_p, const float* dz, float* dmu, float* dls, size_t n,
+                        hipStream_t s);
+// one-hot concat: out[b] = [z[b][:zd], onehot(int(z[b][zd]))]
+void launch_z_onehot(const float* z, float* out, int B, int zd, int NC, hipStream_t s);
+void launch_class_onehot(const float* zrec, const int* classes, float* out, int B, int zd, int NC, hipStream_t s);
+
+// RMSProp over a flat range; gscale multiplies g first (DP averaging)
+void launch_rmsprop(float* w, const float* g, float* ms, float* mom, size_t n, float lr, float gscale,
+                    hipStream_t s);
+
+}  // namespace eg

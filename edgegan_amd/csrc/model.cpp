@@ -1,0 +1,572 @@
+// Variable registry, the seven networks' forward graphs and the seven optimizer sub-steps of
+// EdgeGAN.update_model (edgegan/models/edgegan.py:87-130, 202-342), on the tape ops of ops.cpp.
+#include <cmath>
+
+#include "engine.h"
+
+namespace eg {
+
+static const char* kGroupPrefix[G_COUNT] = {"G1", "G2", "D2", "D", "D_patch2", "D_patch3", "E"};
+static inline int ceil_half(int n) { return (n + 1) / 2; }
+
+// ---------------------------------------------------------------------------------------------
+// registry: names / shapes / initialisers, creation order of
+// edgegan.py:202-275: G1, G2, D2, D, D_patch2, D_patch3, E
+// ---------------------------------------------------------------------------------------------
+static void gen_vars(std::vector<VarInfo>& v, const Config& cfg, int group) {
+  const std::string p = kGroupPrefix[group];
+  int h = cfg.H, w = cfg.W / 2;
+  for (int i = 0; i < 4; ++i) {
+    h = ceil_half(h);
+    w = ceil_half(w);
+  }
+  const int gf = cfg.gf;
+  v.push_back({p + "/g_lin_0/Matrix", {cfg.g_in(), gf * 8 * h * w}, true, false, 1, 0.02f, group});
+  v.push_back({p + "/g_lin_0/bias", {gf * 8 * h * w}, true, false, 0, 0.f, group});
+  v.push_back({p + "/batch_norm/BatchNorm/beta", {gf * 8}, true, false, 0, 0.f, group});
+  v.push_back({p + "/batch_norm/BatchNorm/gamma", {gf * 8}, true, false, 0, 1.f, group});
+  v.push_back({p + "/batch_norm/BatchNorm/moving_mean", {gf * 8}, false, false, 0, 0.f, group});
+  v.push_back({p + "/batch_norm/BatchNorm/moving_variance", {gf * 8}, false, false, 0, 1.f, group});
+  const int ch[5] = {gf * 8, gf * 4, gf * 2, gf, cfg.c_dim};
+  for (int i = 1; i <= 4; ++i) {
+    const std::string b = p + "/g_dconv_" + std::to_string(i) + "/deconv2d/";
+    v.push_back({b + "w", {5, 5, ch[i], ch[i - 1]}, true, false, 1, 0.02f, group});
+    v.push_back({b + "b", {ch[i]}, true, false, 0, 0.f, group});
+  }
+}
+
+static const char* kDiscNames[4] = {"d_conv_0", "d_conv_1", "d_conv_3", "d_conv_4"};
+
+static void disc_vars(std::vector<VarInfo>& v, const Config& cfg, int group, int in_h, int in_w) {
+  const std::string p = kGroupPrefix[group];
+  const int df = cfg.df;
+  const int ch[5] = {cfg.c_dim, df, df * 2, df * 4, df * 8};
+  int h = in_h, w = in_w;
+  for (int i = 0; i < 4; ++i) {
+    v.push_back({p + "/" + kDiscNames[i] + "/conv2d/w", {4, 4, ch[i], ch[i + 1]}, true, false, 2, 0.02f, group});
+    h = ceil_half(h);
+    w = ceil_half(w);
+  }
+  v.push_back({p + "/d_linear_5/Matrix", {h * w * ch[4], 1}, true, false, 1, 0.02f, group});
+  v.push_back({p + "/d_linear_5/bias", {1}, true, false, 0, 0.f, group});
+}
+
+static std::vector<int> encoder_filters(const Config& cfg) {
+  std::vector<int> nf = {128, 256, 512, 512};
+  if (cfg.H == 256) nf.push_back(512);  // encoder.py:57-58
+  return nf;
+}
+
+static void enc_vars(std::vector<VarInfo>& v, const Config& cfg) {
+  v.push_back({"E/e_resnet_64_0/conv2d/w", {4, 4, cfg.c_dim, 64}, true, false, 2, 0.02f, G_E});
+  v.push_back({"E/e_resnet_64_0/conv2d/b", {64}, true, false, 0, 0.f, G_E});
+  int cin = 64, i = 1;
+  for (int n : encoder_filters(cfg)) {
+    const std::string b = "E/e_resnet_" + std::to_string(n) + "_" + std::to_string(i++);
+    v.push_back({b + "/res1/conv2d/w", {3, 3, cin, n}, true, false, 2, 0.02f, G_E});
+    v.push_back({b + "/res1/conv2d/b", {n}, true, false, 0, 0.f, G_E});
+    v.push_back({b + "/res2/conv2d/w", {3, 3, n, n}, true, false, 2, 0.02f, G_E});
+    v.push_back({b + "/res2/conv2d/b", {n}, true, false, 0, 0.f, G_E});
+    v.push_back({b + "/shortcut/conv2d/w", {1, 1, cin, n}, true, false, 2, 0.02f, G_E});
+    v.push_back({b + "/shortcut/conv2d/b", {n}, true, false, 0, 0.f, G_E});
+    cin = n;
+  }
+  for (const char* head : {"FC8_mu", "FC8_sigma"}) {
+    v.push_back({std::string("E/") + head + "/w", {cin, cfg.z_dim}, true, false, 1, 0.02f, G_E});
+    v.push_back({std::string("E/") + head + "/b", {cfg.z_dim}, true, false, 0, 0.f, G_E});
+  }
+}
+
+static std::string sn_u_name(const std::string& scope) { return scope + "/" + scope + "/u"; }
+
+static void cls_conv_vars(std::vector<VarInfo>& v, const std::string& scope, int k, int cin, int cout,
+                          float bias_init, bool prelu_param, bool dead) {
+  v.push_back({scope + "/weights", {k, k, cin, cout}, true, dead, 1, 0.02f, G_D2});
+  v.push_back({sn_u_name(scope), {1, cout}, false, false, 2, 1.0f, G_D2});
+  v.push_back({scope + "/biases", {1, cout, 1, 1}, true, dead, 0, bias_init, G_D2});
+  if (prelu_param) v.push_back({scope + "/prelu/param", {}, true, false, 0, 0.2f, G_D2});
+}
+
+static const int kMruDepth[4] = {128, 256, 512, 768};
+
+static void cls_vars(std::vector<VarInfo>& v, const Config& cfg) {
+  cls_conv_vars(v, "D2/Conv", 7, 3, 8, 0.f, true, false);
+  int hidden = 8;
+  for (int u = 1; u <= 4; ++u) {
+    const std::string b = "D2/mru_conv_unit_t_" + std::to_string(u) + "_layer_0";
+    const int depth = kMruDepth[u - 1];
+    v.push_back({b + "/norm_activation_in/prelu/param", {}, true, false, 0, 0.2f, G_D2});
+    cls_conv_vars(v, b + "/update_gate", 3, hidden + 3, hidden, 0.5f, false, false);
+    cls_conv_vars(v, b + "/Conv", 3, 3, hidden, 0.f, false, false);
+    v.push_back({b + "/norm_activation_merge_1/prelu/param", {}, true, false, 0, 0.2f, G_D2});
+    cls_conv_vars(v, b + "/Conv_1", 3, hidden, depth, 0.f, true, false);
+    cls_conv_vars(v, b + "/Conv_2", 3, depth, depth, 0.f, false, false);
+    cls_conv_vars(v, b + "/Conv_3", 1, hidden, depth, 0.f, false, false);
+    hidden = depth;
+  }
+  v.push_back({"D2/mru_conv_unit_last_norm/prelu/param", {}, true, false, 0, 0.2f, G_D2});
+  cls_conv_vars(v, "D2/Conv_1", 1, hidden, 1, 0.f, false, true);  // dead `disc` head (quirk N8)
+  v.push_back({"D2/fully_connected/weights", {hidden, cfg.num_classes}, true, false, 3, 0.f, G_D2});
+  v.push_back({sn_u_name("D2/fully_connected"), {1, cfg.num_classes}, false, false, 2, 1.0f, G_D2});
+  v.push_back({"D2/fully_connected/biases", {cfg.num_classes}, true, false, 0, 0.f, G_D2});
+}
+
+std::vector<VarInfo> enumerate_variables(const Config& cfg) {
+  std::vector<VarInfo> v;
+  gen_vars(v, cfg, G_G1);
+  gen_vars(v, cfg, G_G2);
+  if (cfg.multiclasses()) cls_vars(v, cfg);
+  disc_vars(v, cfg, G_D, cfg.H, cfg.W);
+  disc_vars(v, cfg, G_DP2, cfg.dis_size, cfg.dis_size);
+  disc_vars(v, cfg, G_DP3, cfg.dis_size, cfg.dis_size);
+  enc_vars(v, cfg);
+  return v;
+}
+
+Param* P(Ctx& c, const std::string& name) {
+  auto it = c.by_name.find(name);
+  if (it == c.by_name.end()) fail(1, "unknown variable '%s'", name.c_str());
+  return it->second;
+}
+
+void build_context(Ctx& c) {
+  const Config& cfg = c.cfg;
+  EG_CHECK(cfg.H % 16 == 0 && (cfg.W / 2) % 16 == 0 && cfg.W % 2 == 0, "H and W/2 must be multiples of 16");
+  EG_CHECK(cfg.B >= 1 && cfg.B <= 1024, "batch size out of range");
+  EG_CHECK(cfg.num_classes <= 64, "num_classes <= 64");
+  EG_HIP(hipSetDevice(cfg.device));
+  EG_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  for (int g = 0; g < G_COUNT; ++g) c.groups[g].prefix = kGroupPrefix[g];
+  for (const VarInfo& vi : enumerate_variables(cfg)) {
+    auto p = std::make_unique<Param>();
+    p->name = vi.name;
+    p->shape = vi.shape;
+    p->trainable = vi.trainable;
+    p->dead = vi.dead;
+    p->init_kind = vi.init_kind;
+    p->init_param = vi.init_param;
+    p->numel = 1;
+    for (int d : vi.shape) p->numel *= (size_t)d;
+    c.by_name[p->name] = p.get();
+    c.groups[vi.group].params.push_back(p.get());
+    c.params.push_back(std::move(p));
+  }
+  // flat layout per group: [live trainables | dead trainables | non-trainables], 64-float aligned slots
+  auto align = [](size_t n) { return (n + 63) & ~(size_t)63; };
+  for (int g = 0; g < G_COUNT; ++g) {
+    NetGroup& ng = c.groups[g];
+    if (ng.params.empty()) continue;
+    size_t off = 0;
+    std::vector<std::pair<Param*, size_t>> place;
+    for (int pass = 0; pass < 3; ++pass) {
+      for (Param* p : ng.params) {
+        const int cls = !p->trainable ? 2 : (p->dead ? 1 : 0);
+        if (cls != pass) continue;
+        place.push_back({p, off});
+        off += align(p->numel);
+      }
+      if (pass == 0) ng.n_live = off;
+      if (pass == 1) ng.n_train = off;
+    }
+    ng.n_total = off;
+    EG_HIP(hipMalloc(&ng.w, ng.n_total * sizeof(float)));
+    EG_HIP(hipMemsetAsync(ng.w, 0, ng.n_total * sizeof(float), c.stream));
+    if (ng.n_train) {
+      EG_HIP(hipMalloc(&ng.g, ng.n_train * sizeof(float)));
+      EG_HIP(hipMalloc(&ng.ms, ng.n_train * sizeof(float)));
+      EG_HIP(hipMalloc(&ng.mom, ng.n_train * sizeof(float)));
+      EG_HIP(hipMemsetAsync(ng.g, 0, ng.n_train * sizeof(float), c.stream));
+      EG_HIP(hipMemsetAsync(ng.mom, 0, ng.n_train * sizeof(float), c.stream));
+      launch_fill(ng.ms, 1.0f, ng.n_train, c.stream);  // RMSProp `rms` slot starts at ones
+    }
+    for (auto& pr : place) {
+      Param* p = pr.first;
+      p->w = ng.w + pr.second;
+      if (p->trainable) {
+        p->g = ng.g + pr.second;
+        p->ms = ng.ms + pr.second;
+        p->mom = ng.mom + pr.second;
+      }
+      if (p->init_kind == 0 && p->init_param != 0.f) launch_fill(p->w, p->init_param, p->numel, c.stream);
+    }
+  }
+  // spectral-norm bookkeeping (classifier): one persistent buffer set per live SN weight
+  if (cfg.multiclasses()) {
+    for (Param* p : c.groups[G_D2].params) {
+      const bool is_w = p->name.size() > 8 && p->name.compare(p->name.size() - 8, 8, "/weights") == 0;
+      if (!is_w || p->dead) continue;
+      const std::string scope = p->name.substr(0, p->name.size() - 8);
+      SNWeight s;
+      s.W = p;
+      s.u = P(c, sn_u_name(scope));
+      s.Co = p->shape.back();
+      s.K = (int)(p->numel / s.Co);
+      s.T = p->shape.size() == 4 ? p->shape[0] * p->shape[1] : 1;
+      EG_HIP(hipMalloc(&s.Wbar, p->numel * 4));
+      EG_HIP(hipMalloc(&s.WbarT, p->numel * 4));
+      EG_HIP(hipMalloc(&s.dWbar, p->numel * 4));
+      EG_HIP(hipMalloc(&s.t, (size_t)s.K * 4));
+      EG_HIP(hipMalloc(&s.dv, (size_t)s.K * 4));
+      EG_HIP(hipMalloc(&s.sv, (size_t)s.Co * 4));
+      EG_HIP(hipMalloc(&s.scal, 80 * 4));
+      c.sn_index[p] = (int)c.sn.size();
+      c.sn.push_back(s);
+      if (s.K > c.sn_maxK) c.sn_maxK = s.K;
+      if (s.Co > c.sn_maxCo) c.sn_maxCo = s.Co;
+    }
+    std::vector<SNDesc> tab(c.sn.size());
+    for (size_t i = 0; i < c.sn.size(); ++i) {
+      const SNWeight& s = c.sn[i];
+      tab[i] = SNDesc{s.W->w, s.u->w, s.Wbar, s.t, s.sv, s.scal, s.dWbar, s.W->g, s.dv, s.K, s.Co, 0};
+    }
+    EG_HIP(hipMalloc(&c.sn_table, tab.size() * sizeof(SNDesc)));
+    EG_HIP(hipMemcpy(c.sn_table, tab.data(), tab.size() * sizeof(SNDesc), hipMemcpyHostToDevice));
+  }
+  c.scratch_floats = (size_t)128 * 16384;
+  EG_HIP(hipMalloc(&c.scratch, c.scratch_floats * 4));
+  const size_t img = (size_t)cfg.B * cfg.H * cfg.W * cfg.c_dim;
+  EG_HIP(hipMalloc(&c.d_images, img * 4));
+  EG_HIP(hipMalloc(&c.d_z, (size_t)cfg.B * (cfg.z_dim + 1) * 4));
+  EG_HIP(hipMalloc(&c.d_alpha, (size_t)3 * cfg.B * 4));
+  EG_HIP(hipMalloc(&c.d_eps, 16 * 4));
+  EG_HIP(hipMalloc(&c.d_losses, 64 * 4));
+  EG_HIP(hipMalloc(&c.d_classes, (size_t)cfg.B * 4));
+  EG_HIP(hipMemsetAsync(c.d_losses, 0, 64 * 4, c.stream));
+  EG_HIP(hipMemsetAsync(c.d_eps, 0, 16 * 4, c.stream));
+  EG_HIP(hipStreamSynchronize(c.stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// networks
+// ---------------------------------------------------------------------------------------------
+// generator.py:35-74 (_convnet): linear -> reshape -> BatchNorm(!) -> ReLU -> 3x[deconv,IN,ReLU] -> deconv -> tanh
+T generator_forward(Ctx& c, int group, T zin, int bn_times) {
+  const Config& cfg = c.cfg;
+  const std::string p = kGroupPrefix[group];
+  const int gf = cfg.gf, h16 = cfg.H / 16, w16 = cfg.W / 2 / 16;
+  const int feat = gf * 8 * h16 * w16;
+  T z_ = linear(c, zin, wref_param(c, P(c, p + "/g_lin_0/Matrix"), 1, zin->c, feat), P(c, p + "/g_lin_0/bias"));
+  T x = reshape(c, z_, zin->n, h16, w16, gf * 8);
+  x = bn_relu(c, x, P(c, p + "/batch_norm/BatchNorm/gamma"), P(c, p + "/batch_norm/BatchNorm/beta"),
+              P(c, p + "/batch_norm/BatchNorm/moving_mean"), P(c, p + "/batch_norm/BatchNorm/moving_variance"),
+              bn_times);
+  const int ch[5] = {gf * 8, gf * 4, gf * 2, gf, cfg.c_dim};
+  for (int i = 1; i <= 4; ++i) {
+    const std::string b = p + "/g_dconv_" + std::to_string(i) + "/deconv2d/";
+    x = deconv2d(c, x, wref_param(c, P(c, b + "w"), 25, ch[i], ch[i - 1]), P(c, b + "b"), ch[i]);
+    if (i < 4) x = in_act(c, x, ACT_RELU);
+  }
+  return act(c, x, ACT_TANH);
+}
+
+// discriminator.py:58-81 (_convnet).  With tangent_of != null this evaluates the forward-mode
+// tangent of the same network at the saved primal activations (convs are linear, so the tangent
+// of a conv is the conv; IN / LeakyReLU are linearised).
+T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_of) {
+  const Config& cfg = c.cfg;
+  const std::string p = kGroupPrefix[group];
+  const int df = cfg.df;
+  const int ch[5] = {cfg.c_dim, df, df * 2, df * 4, df * 8};
+  for (int i = 0; i < 4; ++i) {
+    WRef* w = wref_param(c, P(c, p + "/" + kDiscNames[i] + "/conv2d/w"), 16, ch[i], ch[i + 1]);
+    T pre = conv2d(c, x, w, nullptr, 4, 2, PAD_SAME);
+    T out, st = nullptr;
+    if (!tangent_of) {
+      out = (i == 0) ? act(c, pre, ACT_LRELU) : in_act(c, pre, ACT_LRELU, &st);
+      if (save) {
+        save->pre[i] = pre;
+        save->out[i] = out;
+        save->stats[i] = st;
+      }
+    } else {
+      out = (i == 0) ? act_tangent(c, pre, tangent_of->out[0], ACT_LRELU)
+                     : in_act_tangent(c, pre, tangent_of->pre[i], tangent_of->out[i], tangent_of->stats[i], ACT_LRELU);
+    }
+    x = out;
+  }
+  return linear1(c, x, P(c, p + "/d_linear_5/Matrix"), tangent_of ? nullptr : P(c, p + "/d_linear_5/bias"));
+}
+
+// encoder.py:54-84 (_resnet) with conv.py:70-85 (residual, REFLECT pad, bias=True)
+T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out) {
+  const Config& cfg = c.cfg;
+  T E = conv2d(c, x, wref_param(c, P(c, "E/e_resnet_64_0/conv2d/w"), 16, cfg.c_dim, 64),
+               P(c, "E/e_resnet_64_0/conv2d/b"), 4, 2, PAD_SAME);
+  E = act(c, E, ACT_RELU);
+  int cin = 64, i = 1;
+  for (int n : encoder_filters(cfg)) {
+    const std::string b = "E/e_resnet_" + std::to_string(n) + "_" + std::to_string(i++);
+    T o1 = conv2d(c, E, wref_param(c, P(c, b + "/res1/conv2d/w"), 9, cin, n), P(c, b + "/res1/conv2d/b"), 3, 1,
+                  PAD_REFLECT);
+    o1 = in_act(c, o1, ACT_RELU);
+    T o2 = conv2d(c, o1, wref_param(c, P(c, b + "/res2/conv2d/w"), 9, n, n), P(c, b + "/res2/conv2d/b"), 3, 1,
+                  PAD_REFLECT);
+    o2 = in_act(c, o2, ACT_NONE);
+    T sc = conv2d(c, E, wref_param(c, P(c, b + "/shortcut/conv2d/w"), 1, cin, n), P(c, b + "/shortcut/conv2d/b"),
+                  1, 1, PAD_REFLECT);
+    E = pool2(c, add(c, sc, o2, true));
+    cin = n;
+  }
+  EG_CHECK(E->h <= 8 && E->w <= 8, "encoder tail expects <= 8x8 before the 8x8 SAME average pool");
+  T feat = gmean(c, E, true);  // relu + avg_pool(8x8, SAME) == mean of the valid elements
+  T mu = linear(c, feat, wref_param(c, P(c, "E/FC8_mu/w"), 1, cin, cfg.z_dim), P(c, "E/FC8_mu/b"));
+  T ls = linear(c, feat, wref_param(c, P(c, "E/FC8_sigma/w"), 1, cin, cfg.z_dim), P(c, "E/FC8_sigma/b"));
+  if (mu_out) *mu_out = mu;
+  if (ls_out) *ls_out = ls;
+  return reparam(c, mu, ls, eps_dev);
+}
+
+// classifier.py:12-119 + conv.py:133-357.  The reference runs NCHW; channels-last is the same
+// arithmetic (all spatial reductions are per (n,c)), so the engine stays NHWC end to end.
+T classifier_forward(Ctx& c, T x) {
+  if (!c.sn_prepared) {
+    sn_prepare(c);
+    c.sn_prepared = true;
+  }
+  // input pyramid by 2x2 mean pooling (classifier.py:27-35); levels 64,32,16,8 are used
+  T level[4];
+  level[0] = x;
+  for (int i = 1; i < 4; ++i) level[i] = pool2(c, level[i - 1]);
+  T h = conv2d(c, x, wref_sn(c, P(c, "D2/Conv/weights")), P(c, "D2/Conv/biases"), 7, 1, PAD_SAME);
+  h = prelu(c, h, P(c, "D2/Conv/prelu/param"), 0.f);
+  int hidden = 8;
+  for (int u = 1; u <= 4; ++u) {
+    const std::string b = "D2/mru_conv_unit_t_" + std::to_string(u) + "_layer_0";
+    const int depth = kMruDepth[u - 1];
+    T xin = level[u - 1];
+    T hp = prelu(c, h, P(c, b + "/norm_activation_in/prelu/param"), 0.f);
+    // update gate on concat([prelu(h), x]) (conv.py:185-198) without materialising the concat:
+    // the SN filter is split by input-channel rows into a hidden part and an image part.
+    Param* wg = P(c, b + "/update_gate/weights");
+    WRef* full = wref_sn(c, wg);
+    const int ct = hidden + 3;
+    float* w_h = c.arena.allocf((size_t)9 * hidden * hidden);
+    float* w_x = c.arena.allocf((size_t)9 * 3 * hidden);
+    launch_copy_cols(w_h, const_cast<float*>(full->w), 9, 1, hidden, ct, 0, hidden, 0, 0, c.stream);
+    launch_copy_cols(w_x, const_cast<float*>(full->w), 9, 1, 3, ct, hidden, hidden, 0, 0, c.stream);
+    float *g_h = nullptr, *g_x = nullptr;
+    bool *f_h = nullptr, *f_x = nullptr;
+    c.flags.push_back(false);
+    f_h = &c.flags.back();
+    c.flags.push_back(false);
+    f_x = &c.flags.back();
+    if (full->want_grad) {
+      g_h = c.arena.allocf((size_t)9 * hidden * hidden);
+      g_x = c.arena.allocf((size_t)9 * 3 * hidden);
+      Ctx* cp = &c;
+      c.tape.push([=]() {  // runs after both partial wgrads (pushed before them)
+        Ctx& c = *cp;
+        if (!c.param_grad_enabled || !*f_h || !*f_x) return;
+        launch_copy_cols(g_h, full->g, 9, 1, hidden, ct, 0, hidden, 1, 0, c.stream);
+        launch_copy_cols(g_x, full->g, 9, 1, 3, ct, hidden, hidden, 1, 0, c.stream);
+        *full->g_set = true;
+      });
+    }
+    WRef* wr_h = wref_raw(c, w_h, g_h, f_h, full->want_grad, 9, hidden, hidden);
+    WRef* wr_x = wref_raw(c, w_x, g_x, f_x, full->want_grad, 9, 3, hidden);
+    T rg = conv2d(c, hp, wr_h, P(c, b + "/update_gate/biases"), 3, 1, PAD_SAME);
+    conv2d(c, xin, wr_x, nullptr, 3, 1, PAD_SAME, rg);
+    rg = prelu(c, rg, nullptr, 0.2f);  // lrelu (activation.py:30-32)
+    rg = minmax(c, rg);
+    T img = conv2d(c, xin, wref_sn(c, P(c, b + "/Conv/weights")), P(c, b + "/Conv/biases"), 3, 1, PAD_SAME);
+    T hplus = gate(c, h, rg, img);
+    T hin = prelu(c, hplus, P(c, b + "/norm_activation_merge_1/prelu/param"), 0.f);
+    T c1 = conv2d(c, hin, wref_sn(c, P(c, b + "/Conv_1/weights")), P(c, b + "/Conv_1/biases"), 3, 1, PAD_SAME);
+    c1 = prelu(c, c1, P(c, b + "/Conv_1/prelu/param"), 0.f);
+    T c2 = conv2d(c, c1, wref_sn(c, P(c, b + "/Conv_2/weights")), P(c, b + "/Conv_2/biases"), 3, 1, PAD_SAME);
+    T proj = conv2d(c, h, wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
+    h = pool2(c, add(c, proj, c2, false));
+    hidden = depth;
+  }
+  h = prelu(c, h, P(c, "D2/mru_conv_unit_last_norm/prelu/param"), 0.f);  // conv.py:353-355
+  T feat = gmean(c, h, false);
+  return linear(c, feat, wref_sn(c, P(c, "D2/fully_connected/weights")), P(c, "D2/fully_connected/biases"));
+}
+
+// ---------------------------------------------------------------------------------------------
+// sub-steps
+// ---------------------------------------------------------------------------------------------
+static T make_zin(Ctx& c) {
+  const Config& cfg = c.cfg;
+  if (!cfg.multiclasses()) return wrap_tensor(c, c.d_z, cfg.B, 1, 1, cfg.z_dim);
+  T zin = new_tensor(c, cfg.B, 1, 1, cfg.g_in(), false);
+  launch_z_onehot(c.d_z, zin->d, cfg.B, cfg.z_dim, cfg.num_classes, c.stream);
+  return zin;
+}
+
+static void apply_group(Ctx& c, int group) {
+  NetGroup& g = c.groups[group];
+  for (Param* p : g.params)
+    if (p->trainable && !p->dead) EG_CHECK(p->g_set, "variable %s received no gradient", p->name.c_str());
+  float gscale = 1.f;
+  if (c.nranks > 1) {
+    comm_allreduce(c, g.g, g.n_live);
+    gscale = 1.f / c.nranks;
+  }
+  launch_rmsprop(g.w, g.g, g.ms, g.mom, g.n_live, c.cfg.lr, gscale, c.stream);
+}
+
+// WGAN-GP discriminator step (edgegan.py:278-309, functional.py:26-33, edgegan.py:32-42).
+// The penalty's second-order term is evaluated as reverse-over-forward: with g = d/dx sum_b[sigmoid(D)+D]
+// (quirk N10) and v = dL_gp/dg held constant, dL_gp/dtheta = d/dtheta <g, v> = d/dtheta JVP_v[sigmoid(D)+D],
+// so a tangent pass of D along v at x_hat followed by ONE reverse sweep over (primal, tangent) gives
+// the exact gradient with first-order kernels only.
+static void disc_substep(Ctx& c, int group, T real, T fake, const float* alpha_dev, int slot_d, int slot_gp,
+                         bool apply) {
+  const Config& cfg = c.cfg;
+  const int B = cfg.B;
+  set_want_grad(c, group, true);
+  T xhat = new_tensor(c, real->n, real->h, real->w, real->c, true);
+  const size_t per = xhat->numel() / B;
+  launch_blend(real->d, fake->d, alpha_dev, xhat->d, B, per, c.stream);
+  // --- primal pass on x_hat and first-order gradient g ---
+  DiscSave sv;
+  T d_hat = disc_forward(c, group, xhat, &sv, nullptr);
+  const size_t mark = c.tape.ops.size();
+  seed_grad(c, d_hat);
+  launch_gp_head(d_hat->d, nullptr, d_hat->g, nullptr, B, 0, c.stream);
+  c.param_grad_enabled = false;
+  c.tape.backward_range(0, mark);
+  c.param_grad_enabled = true;
+  const float* g = xhat->g;
+  reset_grads(c);
+  xhat->needs_grad = false;  // the final sweep does not need d/dx_hat again
+  float* v = c.arena.allocf(xhat->numel());
+  float* norms = c.arena.allocf(B);
+  launch_gp_v(g, v, norms, c.d_losses + slot_gp, B, per, cfg.lambda_gp, c.stream);
+  // --- real / fake pass (stacked 2B) ---
+  T rf = new_tensor(c, 2 * B, real->h, real->w, real->c, false);
+  launch_copy(real->d, rf->d, real->numel(), c.stream);
+  launch_copy(fake->d, rf->d + real->numel(), fake->numel(), c.stream);
+  T d_rf = disc_forward(c, group, rf, nullptr, nullptr);
+  launch_mean_diff(d_rf->d + B, d_rf->d, c.d_losses + slot_d, B, c.stream);
+  // --- tangent pass along v ---
+  T tv = wrap_tensor(c, v, B, real->h, real->w, real->c);
+  T td = disc_forward(c, group, tv, nullptr, &sv);
+  // --- seeds and the single reverse sweep ---
+  seed_grad(c, d_rf);
+  launch_fill(d_rf->g, -1.f / B, B, c.stream);
+  launch_fill(d_rf->g + B, 1.f / B, B, c.stream);
+  seed_grad(c, d_hat);
+  seed_grad(c, td);
+  launch_gp_head(d_hat->d, td->d, d_hat->g, td->g, B, 1, c.stream);
+  c.tape.backward();
+  if (apply) apply_group(c, group);
+  set_want_grad(c, group, false);
+}
+
+static T right_half(Ctx& c, T images) { return slice_w(c, images, c.cfg.W / 2, c.cfg.W); }
+static T left_half(Ctx& c, T images) { return slice_w(c, images, 0, c.cfg.W / 2); }
+
+void run_substep(Ctx& c, int k, bool apply) {
+  const Config& cfg = c.cfg;
+  const int B = cfg.B;
+  EG_CHECK(k >= 1 && k <= 7, "sub-step index 1..7");
+  if (k == 4 && !cfg.multiclasses()) return;  // d_optim2 only registered with multiclasses (edgegan.py:115-116)
+  reset_step(c);
+  for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);
+  T images = wrap_tensor(c, c.d_images, B, cfg.H, cfg.W, cfg.c_dim);
+  switch (k) {
+    case 1: {  // d_optim: joint discriminator
+      T zin = make_zin(c);
+      T edge = generator_forward(c, G_G1, zin, 1);
+      T image = generator_forward(c, G_G2, zin, 1);
+      T joint = concat_w(c, edge, image);
+      disc_substep(c, G_D, images, joint, c.d_alpha, L_JOINT_D, L_JOINT_GP, apply);
+    } break;
+    case 2: {  // d_optim_patch2: image discriminator on bicubic-resized right halves
+      T zin = make_zin(c);
+      T image = generator_forward(c, G_G2, zin, 1);
+      T r_real = resize(c, right_half(c, images), cfg.dis_size);
+      T r_fake = resize(c, image, cfg.dis_size);
+      disc_substep(c, G_DP2, r_real, r_fake, c.d_alpha + B, L_IMAGE_D, L_IMAGE_GP, apply);
+    } break;
+    case 3: {  // d_optim_patch3: edge discriminator
+      T zin = make_zin(c);
+      T edge = generator_forward(c, G_G1, zin, 1);
+      T r_real = resize(c, left_half(c, images), cfg.dis_size);
+      T r_fake = resize(c, edge, cfg.dis_size);
+      disc_substep(c, G_DP3, r_real, r_fake, c.d_alpha + 2 * B, L_EDGE_D, L_EDGE_GP, apply);
+    } break;
+    case 4: {  // d_optim2: classifier focal loss on the real right half (edgegan.py:238-239,325-330)
+      set_want_grad(c, G_D2, true);
+      T logits = classifier_forward(c, right_half(c, images));
+      seed_grad(c, logits);
+      launch_acgan_loss(logits->d, c.d_z + cfg.z_dim, cfg.z_dim + 1, c.d_losses + L_CLS_D, logits->g, B,
+                        cfg.num_classes, 0, c.scratch, c.stream);
+      c.tape.backward();
+      if (apply) apply_group(c, G_D2);
+    } break;
+    case 5:
+    case 7: {  // g_optim_u / g_optim_b: both generator minimize ops in one run (quirk N9)
+      set_want_grad(c, G_G1, true);
+      set_want_grad(c, G_G2, true);
+      T zin = make_zin(c);
+      T edge = generator_forward(c, G_G1, zin, 1);
+      T image = generator_forward(c, G_G2, zin, 1);
+      T joint = concat_w(c, edge, image);
+      T dj = disc_forward(c, G_D, joint, nullptr, nullptr);
+      T de = disc_forward(c, G_DP3, resize(c, edge, cfg.dis_size), nullptr, nullptr);
+      T di = disc_forward(c, G_DP2, resize(c, image, cfg.dis_size), nullptr, nullptr);
+      launch_mean_neg(dj->d, c.d_losses + L_JOINT_G, B, c.stream);
+      launch_mean_neg(de->d, c.d_losses + L_EDGE_G, B, c.stream);
+      launch_mean_neg(di->d, c.d_losses + L_IMAGE_G, B, c.stream);
+      seed_grad(c, dj);
+      seed_grad(c, de);
+      seed_grad(c, di);
+      launch_fill(dj->g, -cfg.joint_dweight / B, B, c.stream);
+      launch_fill(de->g, -cfg.edge_dweight / B, B, c.stream);
+      launch_fill(di->g, -cfg.image_dweight / B, B, c.stream);
+      if (cfg.multiclasses()) {
+        T lf = classifier_forward(c, image);
+        seed_grad(c, lf);
+        launch_acgan_loss(lf->d, c.d_z + cfg.z_dim, cfg.z_dim + 1, c.d_losses + L_CLS_G, lf->g, B, cfg.num_classes,
+                          1, c.scratch, c.stream);
+      }
+      c.tape.backward();
+      if (apply) {
+        apply_group(c, G_G1);
+        apply_group(c, G_G2);
+      }
+    } break;
+    case 6: {  // e_optim: L1 latent reconstruction through G1 (edgegan.py:275,337-342)
+      set_want_grad(c, G_E, true);
+      T zin = make_zin(c);
+      T edge = generator_forward(c, G_G1, zin, 1);
+      T zr = encoder_forward(c, edge, c.d_eps);
+      seed_grad(c, zr);
+      launch_l1(c.d_z, cfg.multiclasses() ? cfg.z_dim + 1 : cfg.z_dim, zr->d, c.d_losses + L_ZL, zr->g, B, cfg.z_dim,
+                cfg.zl_weight, c.stream);
+      c.tape.backward();
+      if (apply) apply_group(c, G_E);
+    } break;
+  }
+  if (apply && (k == 4)) c.sn_prepared = false;
+}
+
+void train_step(Ctx& c) {
+  for (int k = 1; k <= 7; ++k) run_substep(c, k, true);
+  ++c.step_count;
+}
+
+// edgegan.py:492-517,606-609: E(left half) -> z (+ one-hot) -> G1 ; second run -> G2 (own eps draw)
+void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const float* d_eps2, float* d_edge,
+           float* d_image) {
+  const Config& cfg = c.cfg;
+  reset_step(c);
+  for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);
+  T images = wrap_tensor(c, const_cast<float*>(d_images), NB, cfg.H, cfg.W, cfg.c_dim);
+  T left = slice_w(c, images, 0, cfg.W / 2);
+  for (int run = 0; run < 2; ++run) {
+    T z = encoder_forward(c, left, d_eps2 + run);
+    T zin = z;
+    if (cfg.multiclasses()) {
+      zin = new_tensor(c, NB, 1, 1, cfg.g_in(), false);
+      launch_class_onehot(z->d, d_classes, zin->d, NB, cfg.z_dim, cfg.num_classes, c.stream);
+    }
+    T out = generator_forward(c, run == 0 ? G_G1 : G_G2, zin, 0);
+    launch_copy(out->d, run == 0 ? d_edge : d_image, out->numel(), c.stream);
+  }
+}
+
+}  // namespace eg

@@ -1,0 +1,893 @@
+// Differentiable ops of the EdgeGAN hot path on a reverse tape.  Each op launches gfx950 kernels
+// for its forward and records a closure that launches the kernels of its backward.
+// Reference semantics are cited per op; TF-1.14 op conventions follow SURVEY.md Appendix B.
+#include <cmath>
+
+#include "engine.h"
+
+namespace eg {
+
+// ---------------------------------------------------------------------------------------------
+// profiling scope: HIP events on the engine's own stream around one launch
+// ---------------------------------------------------------------------------------------------
+static hipEvent_t get_event(Ctx& c) {
+  if (!c.ev_pool.empty()) {
+    hipEvent_t e = c.ev_pool.back();
+    c.ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  EG_HIP(hipEventCreate(&e));
+  return e;
+}
+ProfScope::ProfScope(Ctx& c_) : c(c_) {
+  if (c.prof_on) {
+    ProfRec r{"", 0.0, get_event(c), get_event(c)};
+    EG_HIP(hipEventRecord(r.a, c.stream));
+    c.prof.push_back(r);
+    idx = (int)c.prof.size() - 1;
+  }
+}
+void ProfScope::done(const char* name, double flops) {
+  if (idx >= 0) {
+    c.prof[idx].name = name;
+    c.prof[idx].flops = flops;
+    EG_HIP(hipEventRecord(c.prof[idx].b, c.stream));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tensors / step state
+// ---------------------------------------------------------------------------------------------
+T new_tensor(Ctx& c, int n, int h, int w, int ch, bool needs_grad, bool alloc) {
+  c.tensors.emplace_back();
+  T t = &c.tensors.back();
+  t->n = n;
+  t->h = h;
+  t->w = w;
+  t->c = ch;
+  t->needs_grad = needs_grad;
+  if (alloc) t->d = c.arena.allocf(t->numel());
+  return t;
+}
+T wrap_tensor(Ctx& c, float* data, int n, int h, int w, int ch) {
+  T t = new_tensor(c, n, h, w, ch, false, false);
+  t->d = data;
+  return t;
+}
+float* grad_acc(Ctx& c, T t, int* acc) {
+  if (!t->g) t->g = c.arena.allocf(t->numel());
+  *acc = t->g_set ? 1 : 0;
+  t->g_set = true;
+  return t->g;
+}
+void seed_grad(Ctx& c, T t) {
+  if (!t->g) t->g = c.arena.allocf(t->numel());
+  t->g_set = true;
+}
+void reset_grads(Ctx& c) {
+  for (auto& t : c.tensors) t.g_set = false;
+  for (auto& p : c.params) p->g_set = false;
+  for (auto& s : c.sn) s.dWbar_set = false;
+}
+void reset_step(Ctx& c) {
+  c.arena.reset();
+  c.tape.clear();
+  c.tensors.clear();
+  c.wrefs.clear();
+  c.wref_cache.clear();
+  c.flags.clear();
+  c.sn_prepared = false;
+  c.param_grad_enabled = true;
+  for (auto& p : c.params) p->g_set = false;
+  for (auto& s : c.sn) s.dWbar_set = false;
+}
+void set_want_grad(Ctx& c, int group, bool on) {
+  for (Param* p : c.groups[group].params) p->want_grad = on && p->trainable && !p->dead;
+}
+
+WRef* wref_param(Ctx& c, Param* p, int T_, int R, int Cc) {
+  auto it = c.wref_cache.find(p);
+  if (it != c.wref_cache.end()) return it->second;
+  EG_CHECK((size_t)T_ * R * Cc == p->numel, "wref shape mismatch for %s", p->name.c_str());
+  c.wrefs.emplace_back();
+  WRef* w = &c.wrefs.back();
+  w->w = p->w;
+  w->g = p->g;
+  w->g_set = &p->g_set;
+  w->want_grad = p->want_grad;
+  w->T = T_;
+  w->R = R;
+  w->Cc = Cc;
+  c.wref_cache[p] = w;
+  return w;
+}
+WRef* wref_sn(Ctx& c, Param* p) {
+  auto it = c.wref_cache.find(p);
+  if (it != c.wref_cache.end()) return it->second;
+  SNWeight& s = c.sn[c.sn_index.at(p)];
+  c.wrefs.emplace_back();
+  WRef* w = &c.wrefs.back();
+  w->w = s.Wbar;
+  w->g = s.dWbar;
+  w->g_set = &s.dWbar_set;
+  w->want_grad = p->want_grad;
+  w->T = s.T;
+  w->R = s.K / s.T;
+  w->Cc = s.Co;
+  if (s.wT_valid) w->wT = s.WbarT;
+  c.wref_cache[p] = w;
+  return w;
+}
+// an ad-hoc dense weight (e.g. a channel slice of an SN filter) living in the arena
+WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_, int R, int Cc) {
+  c.wrefs.emplace_back();
+  WRef* w = &c.wrefs.back();
+  w->w = w_;
+  w->g = g;
+  w->g_set = g_set;
+  w->want_grad = want;
+  w->T = T_;
+  w->R = R;
+  w->Cc = Cc;
+  return w;
+}
+const float* wref_transposed(Ctx& c, WRef* w) {
+  if (w->wT) return w->wT;
+  float* buf = nullptr;
+  // SN weights keep their transpose in a persistent buffer
+  for (auto& s : c.sn)
+    if (s.Wbar == w->w) {
+      buf = s.WbarT;
+      s.wT_valid = true;
+      break;
+    }
+  if (!buf) buf = c.arena.allocf((size_t)w->T * w->R * w->Cc);
+  launch_tap_transpose(w->w, buf, w->T, w->R, w->Cc, nullptr, c.stream);
+  w->wT = buf;
+  return buf;
+}
+
+static void same_pad(int n, int k, int s, int* out, int* before) {
+  *out = (n + s - 1) / s;
+  int total = (*out - 1) * s + k - n;
+  if (total < 0) total = 0;
+  *before = total / 2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv2d -- edgegan/nn/modules/conv.py:13-36 (conv2d: SAME / REFLECT+VALID, optional bias) and
+// conv.py:278-285 (conv2d2: SAME stride 1 + biases).  Weights HWIO = [T][Cin][Cout].
+// ---------------------------------------------------------------------------------------------
+static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, int pt, int pl) {
+  const int Cin = x->c, N = y->c;
+  const float* wT = wref_transposed(c, w);  // [T][N][Cin]
+  ConvArgs a{};
+  a.x = y->g;
+  a.wgt = wT;
+  a.bias = nullptr;
+  a.NB = x->n;
+  a.IH = y->h;
+  a.IW = y->w;
+  a.C = N;
+  a.x_ps = N;
+  a.N = Cin;
+  a.y_ps = Cin;
+  a.KW = k;
+  a.w_ts = (long long)N * Cin;
+  a.ldw = Cin;
+  a.reflect = 0;
+  a.S = 1;
+  a.D = -1;
+  if (stride == 1) {
+    a.kst = 1;
+    a.os = 1;
+    a.nphase = 1;
+    if (pad == PAD_REFLECT && pt > 0) {
+      // gradient w.r.t. the padded tensor, then fold the mirrored border back (tf.pad REFLECT grad)
+      const int Hp = x->h + 2 * pt, Wp = x->w + 2 * pl;
+      float* dpad = c.arena.allocf((size_t)x->n * Hp * Wp * Cin);
+      a.y = dpad;
+      a.OHf = Hp;
+      a.OWf = Wp;
+      a.accumulate = 0;
+      a.ph[0] = ConvPhase{Hp, Wp, 0, 0, k, k, 0, 0, 0, 0};
+      const char* nm;
+      ProfScope ps(c);
+      const double fl = launch_conv_gemm(a, c.stream, &nm);
+      ps.done(nm, fl);
+      int acc;
+      float* dx = grad_acc(c, x, &acc);
+      launch_reflect_fold(dpad, dx, acc, x->n, x->h, x->w, Cin, pt, c.stream);
+      return;
+    }
+    int acc;
+    a.y = grad_acc(c, x, &acc);
+    a.accumulate = acc;
+    a.OHf = x->h;
+    a.OWf = x->w;
+    a.ph[0] = ConvPhase{x->h, x->w, 0, 0, k, k, 0, 0, pt, pl};
+  } else {
+    EG_CHECK(stride == 2 && x->h % 2 == 0 && x->w % 2 == 0, "stride-2 dgrad needs even extents");
+    int acc;
+    a.y = grad_acc(c, x, &acc);
+    a.accumulate = acc;
+    a.OHf = x->h;
+    a.OWf = x->w;
+    a.kst = 2;
+    a.os = 2;
+    a.nphase = 4;
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        const int kh0 = (py + pt) % 2, kw0 = (px + pl) % 2;
+        ConvPhase& p = a.ph[py * 2 + px];
+        p.OHp = x->h / 2;
+        p.OWp = x->w / 2;
+        p.ophy = py;
+        p.ophx = px;
+        p.Ty = (k - kh0 + 1) / 2;
+        p.Tx = (k - kw0 + 1) / 2;
+        p.kh0 = kh0;
+        p.kw0 = kw0;
+        p.offy = (py + pt - kh0) / 2;
+        p.offx = (px + pl - kw0) / 2;
+      }
+  }
+  const char* nm;
+  ProfScope ps(c);
+  const double fl = launch_conv_gemm(a, c.stream, &nm);
+  ps.done(nm, fl);
+}
+
+static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, const float* dy, int OH, int OW,
+                       int N, WRef* w, int k, int stride, int pad_before, int reflect) {
+  WgradArgs g{};
+  g.x = xg;
+  g.dy = dy;
+  g.dw = w->g;
+  g.NB = NB;
+  g.IH = IH;
+  g.IW = IW;
+  g.C = C;
+  g.x_ps = C;
+  g.OH = OH;
+  g.OW = OW;
+  g.N = N;
+  g.dy_ps = N;
+  g.KH = k;
+  g.KW = k;
+  g.S = stride;
+  g.pad = pad_before;
+  g.w_ts = (long long)C * N;
+  g.ldw = N;
+  g.reflect = reflect;
+  g.accumulate = *w->g_set ? 1 : 0;
+  g.nsplit = wgrad_pick_splits(g);
+  const size_t wsf = wgrad_workspace_floats(g);
+  g.ws = wsf ? c.arena.allocf(wsf) : nullptr;
+  const char* nm;
+  ProfScope ps(c);
+  const double fl = launch_wgrad(g, c.stream, &nm);
+  ps.done(nm, fl);
+  *w->g_set = true;
+}
+
+static void bias_grad(Ctx& c, Param* b, const float* dy, size_t rows, int C) {
+  if (c.scratch_floats < col_sum_scratch_floats(C)) fail(1, "scratch too small for bias grad");
+  launch_col_sum(dy, b->g, b->g_set ? 1 : 0, rows, C, c.scratch, c.stream);
+  b->g_set = true;
+}
+
+T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into, int, int) {
+  const int Cin = x->c, N = w->Cc;
+  EG_CHECK(w->T == k * k && w->R == Cin, "conv2d weight shape: T=%d R=%d vs k=%d Cin=%d", w->T, w->R, k, Cin);
+  int OH, OW, pt, pl;
+  if (pad == PAD_REFLECT) {
+    EG_CHECK(stride == 1, "REFLECT conv is stride 1");
+    pt = pl = (k - 1) / 2;
+    OH = x->h;
+    OW = x->w;
+  } else {
+    same_pad(x->h, k, stride, &OH, &pt);
+    same_pad(x->w, k, stride, &OW, &pl);
+  }
+  T y = accumulate_into ? accumulate_into : new_tensor(c, x->n, OH, OW, N, false);
+  EG_CHECK(y->n == x->n && y->h == OH && y->w == OW && y->c == N, "conv2d output shape");
+  ConvArgs a{};
+  a.x = x->d;
+  a.wgt = w->w;
+  a.bias = bias ? bias->w : nullptr;
+  a.y = y->d;
+  a.NB = x->n;
+  a.IH = x->h;
+  a.IW = x->w;
+  a.C = Cin;
+  a.x_ps = Cin;
+  a.OHf = OH;
+  a.OWf = OW;
+  a.N = N;
+  a.y_ps = N;
+  a.KW = k;
+  a.kst = 1;
+  a.S = stride;
+  a.D = 1;
+  a.os = 1;
+  a.w_ts = (long long)Cin * N;
+  a.ldw = N;
+  a.reflect = pad == PAD_REFLECT ? 1 : 0;
+  a.accumulate = accumulate_into ? 1 : 0;
+  a.nphase = 1;
+  a.ph[0] = ConvPhase{OH, OW, 0, 0, k, k, 0, 0, -pt, -pl};
+  {
+    const char* nm;
+    ProfScope ps(c);
+    const double fl = launch_conv_gemm(a, c.stream, &nm);
+    ps.done(nm, fl);
+  }
+  const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
+  if (need) {
+    y->needs_grad = true;
+    Ctx* cp = &c;
+    const size_t rows = y->pixels();
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!y->g_set) return;
+      if (c.param_grad_enabled) {
+        if (w->want_grad)
+          conv_wgrad(c, x->d, x->n, x->h, x->w, Cin, y->g, OH, OW, N, w, k, stride, pt, pad == PAD_REFLECT);
+        if (bias && bias->want_grad) bias_grad(c, bias, y->g, rows, N);
+      }
+      if (x->needs_grad) conv_dgrad(c, x, y, w, k, stride, pad, pt, pl);
+    });
+  }
+  return y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// deconv2d -- conv.py:39-58: tf.nn.conv2d_transpose SAME, 5x5 stride 2, filter [kh,kw,Cout,Cin],
+// + bias; y[o] += x[i] w[k] with o = 2i + k - 1 (Appendix B.2), run as 4 sub-pixel phases.
+// ---------------------------------------------------------------------------------------------
+T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
+  const int k = 5, pt = 1, Cin = x->c;
+  EG_CHECK(w->T == 25 && w->R == cout && w->Cc == Cin, "deconv2d weight shape");
+  const int OH = x->h * 2, OW = x->w * 2;
+  T y = new_tensor(c, x->n, OH, OW, cout, false);
+  const float* wT = wref_transposed(c, w);  // [25][Cin][Cout]
+  ConvArgs a{};
+  a.x = x->d;
+  a.wgt = wT;
+  a.bias = bias ? bias->w : nullptr;
+  a.y = y->d;
+  a.NB = x->n;
+  a.IH = x->h;
+  a.IW = x->w;
+  a.C = Cin;
+  a.x_ps = Cin;
+  a.OHf = OH;
+  a.OWf = OW;
+  a.N = cout;
+  a.y_ps = cout;
+  a.KW = k;
+  a.kst = 2;
+  a.S = 1;
+  a.D = -1;
+  a.os = 2;
+  a.w_ts = (long long)Cin * cout;
+  a.ldw = cout;
+  a.nphase = 4;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      const int kh0 = (py + pt) % 2, kw0 = (px + pt) % 2;
+      a.ph[py * 2 + px] = ConvPhase{x->h, x->w, py, px, (k - kh0 + 1) / 2, (k - kw0 + 1) / 2, kh0, kw0,
+                                    (py + pt - kh0) / 2, (px + pt - kw0) / 2};
+    }
+  {
+    const char* nm;
+    ProfScope ps(c);
+    const double fl = launch_conv_gemm(a, c.stream, &nm);
+    ps.done(nm, fl);
+  }
+  const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
+  if (need) {
+    y->needs_grad = true;
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!y->g_set) return;
+      if (c.param_grad_enabled) {
+        // dW[k][co][ci] = sum_i dy[2i+k-1][co] x[i][ci]: wgrad with the roles of x and dy swapped
+        if (w->want_grad) conv_wgrad(c, y->g, x->n, OH, OW, cout, x->d, x->h, x->w, Cin, w, 5, 2, 1, 0);
+        if (bias && bias->want_grad) bias_grad(c, bias, y->g, y->pixels(), cout);
+      }
+      if (x->needs_grad) {
+        // dx[i] = sum_k dy[2i+k-1] w[k]: a stride-2 SAME conv of dy with the filter as stored
+        ConvArgs b{};
+        int acc;
+        b.y = grad_acc(c, x, &acc);
+        b.accumulate = acc;
+        b.x = y->g;
+        b.wgt = w->w;
+        b.NB = x->n;
+        b.IH = OH;
+        b.IW = OW;
+        b.C = cout;
+        b.x_ps = cout;
+        b.OHf = x->h;
+        b.OWf = x->w;
+        b.N = Cin;
+        b.y_ps = Cin;
+        b.KW = 5;
+        b.kst = 1;
+        b.S = 2;
+        b.D = 1;
+        b.os = 1;
+        b.w_ts = (long long)cout * Cin;
+        b.ldw = Cin;
+        b.nphase = 1;
+        b.ph[0] = ConvPhase{x->h, x->w, 0, 0, 5, 5, 0, 0, -1, -1};
+        const char* nm;
+        ProfScope ps(c);
+        const double fl = launch_conv_gemm(b, c.stream, &nm);
+        ps.done(nm, fl);
+      }
+    });
+  }
+  return y;
+}
+
+// linear.py:10-31 / :79-92 / :58-65: y = x W + b as a 1x1 "conv" over B rows
+T linear(Ctx& c, T x, WRef* w, Param* bias) {
+  EG_CHECK(x->h == 1 && x->w == 1, "linear expects [B,1,1,in]");
+  return conv2d(c, x, w, bias, 1, 1, PAD_SAME);
+}
+
+// zero-copy view with shared gradient storage (tf.reshape); src must be single-use
+T reshape(Ctx& c, T src, int n, int h, int w, int ch) {
+  EG_CHECK((size_t)n * h * w * ch == src->numel(), "reshape numel");
+  T v = new_tensor(c, n, h, w, ch, src->needs_grad, false);
+  v->d = src->d;
+  if (src->needs_grad) {
+    if (!src->g) src->g = c.arena.allocf(src->numel());
+    v->g = src->g;
+    c.tape.push([=]() {
+      if (v->g_set) src->g_set = true;
+    });
+  }
+  return v;
+}
+
+// d_linear_5 (discriminator.py:74): N == 1 head on the flattened (h,w,c) activations
+T linear1(Ctx& c, T x, Param* w, Param* bias) {
+  const int K = (int)(x->numel() / x->n);
+  EG_CHECK((size_t)K == w->numel, "linear1 K mismatch %d vs %zu", K, w->numel);
+  T y = new_tensor(c, x->n, 1, 1, 1, false);
+  launch_gemv_fwd(x->d, w->w, bias ? bias->w : nullptr, y->d, x->n, K, c.stream);
+  const bool need = x->needs_grad || w->want_grad;
+  if (need) {
+    y->needs_grad = true;
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!y->g_set) return;
+      if (c.param_grad_enabled && w->want_grad) {
+        const bool wb = bias && bias->want_grad;
+        launch_gemv_bwd_w(x->d, y->g, w->g, w->g_set ? 1 : 0, wb ? bias->g : nullptr, wb && bias->g_set ? 1 : 0,
+                          x->n, K, c.stream);
+        w->g_set = true;
+        if (wb) bias->g_set = true;
+      }
+      if (x->needs_grad) {
+        int acc;
+        float* dx = grad_acc(c, x, &acc);
+        launch_gemv_bwd_x(y->g, w->w, dx, acc, x->n, K, c.stream);
+      }
+    });
+  }
+  return y;
+}
+
+// normalization.py:13-18 + activation.py:4-15 (fused)
+T in_act(Ctx& c, T x, int a, T* stats_out) {
+  T out = new_tensor(c, x->n, x->h, x->w, x->c, x->needs_grad);
+  T st = new_tensor(c, x->n, 1, 1, 2 * x->c, false);
+  const int HW = x->h * x->w;
+  launch_in_fwd(x->d, out->d, st->d, x->n, HW, x->c, a, c.stream);
+  if (stats_out) *stats_out = st;
+  if (x->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      int acc;
+      float* dx = grad_acc(c, x, &acc);
+      launch_in_bwd(x->d, out->d, out->g, st->d, dx, acc, x->n, HW, x->c, a, c.stream);
+    });
+  }
+  return out;
+}
+
+// forward-mode tangent of in_act at the primal (x_prim, out_prim, stats_prim)
+T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int a) {
+  T tout = new_tensor(c, tx->n, tx->h, tx->w, tx->c, true);
+  const int HW = tx->h * tx->w;
+  launch_in_tangent_fwd(x_prim->d, out_prim->d, stats_prim->d, tx->d, tout->d, tx->n, HW, tx->c, a, c.stream);
+  Ctx* cp = &c;
+  c.tape.push([=]() {
+    Ctx& c = *cp;
+    if (!tout->g_set) return;
+    int acc_t, acc_x;
+    float* dtx = grad_acc(c, tx, &acc_t);
+    float* dx = grad_acc(c, x_prim, &acc_x);
+    launch_in_tangent_bwd(x_prim->d, out_prim->d, stats_prim->d, tx->d, tout->g, dtx, acc_t, dx, acc_x, tx->n, HW,
+                          tx->c, a, c.stream);
+  });
+  return tout;
+}
+
+T act(Ctx& c, T x, int a) {
+  T out = new_tensor(c, x->n, x->h, x->w, x->c, x->needs_grad);
+  launch_act_fwd(x->d, out->d, x->numel(), a, c.stream);
+  if (x->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      int acc;
+      float* dx = grad_acc(c, x, &acc);
+      launch_act_bwd(out->d, out->g, dx, acc, x->numel(), a, c.stream);
+    });
+  }
+  return out;
+}
+
+// tangent of a piecewise-linear activation: tout = act'(out_prim) * tx
+T act_tangent(Ctx& c, T tx, T out_prim, int a) {
+  T tout = new_tensor(c, tx->n, tx->h, tx->w, tx->c, true);
+  launch_act_bwd(out_prim->d, tx->d, tout->d, 0, tx->numel(), a, c.stream);
+  Ctx* cp = &c;
+  c.tape.push([=]() {
+    Ctx& c = *cp;
+    if (!tout->g_set) return;
+    int acc;
+    float* dtx = grad_acc(c, tx, &acc);
+    launch_act_bwd(out_prim->d, tout->g, dtx, acc, tx->numel(), a, c.stream);
+  });
+  return tout;
+}
+
+// generator.py:51-52 (quirk N1): contrib batch_norm, batch statistics, then ReLU
+T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times) {
+  const int C = x->c, R = (int)x->pixels();
+  T out = new_tensor(c, x->n, x->h, x->w, C, true);
+  T st = new_tensor(c, 1, 1, 1, 2 * C, false);
+  launch_bn_relu_fwd(x->d, gamma->w, beta->w, out->d, st->d, R, C, 1e-5f, c.stream);
+  if (update_times > 0) launch_bn_moving_update(mm->w, mv->w, st->d, C, R, 0.9f, update_times, c.stream);
+  const bool need = x->needs_grad || gamma->want_grad;
+  out->needs_grad = need;
+  if (need) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      float* dx = nullptr;
+      int acc = 0;
+      if (x->needs_grad) dx = grad_acc(c, x, &acc);
+      const bool pg = c.param_grad_enabled && gamma->want_grad;
+      launch_bn_relu_bwd(x->d, out->d, out->g, gamma->w, st->d, dx, acc, pg ? gamma->g : nullptr,
+                         gamma->g_set ? 1 : 0, pg ? beta->g : nullptr, beta->g_set ? 1 : 0, R, C, 1e-5f, c.stream);
+      if (pg) gamma->g_set = beta->g_set = true;
+    });
+  }
+  return out;
+}
+
+T add(Ctx& c, T a, T b, bool relu) {
+  T out = new_tensor(c, a->n, a->h, a->w, a->c, a->needs_grad || b->needs_grad);
+  launch_add(a->d, b->d, out->d, relu ? 1 : 0, a->numel(), c.stream);
+  if (out->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      for (T in : {a, b}) {
+        if (!in->needs_grad) continue;
+        int acc;
+        float* d = grad_acc(c, in, &acc);
+        if (relu)
+          launch_act_bwd(out->d, out->g, d, acc, in->numel(), ACT_RELU, c.stream);
+        else
+          launch_axpy(out->g, d, 1.f, acc, in->numel(), c.stream);
+      }
+    });
+  }
+  return out;
+}
+
+// pooling.py:4-8 / encoder.py:68
+T pool2(Ctx& c, T x) {
+  EG_CHECK(x->h % 2 == 0 && x->w % 2 == 0, "pool2 needs even extents");
+  T out = new_tensor(c, x->n, x->h / 2, x->w / 2, x->c, x->needs_grad);
+  launch_pool2_fwd(x->d, out->d, x->n, x->h, x->w, x->c, c.stream);
+  if (x->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      int acc;
+      float* dx = grad_acc(c, x, &acc);
+      launch_pool2_bwd(out->g, dx, acc, x->n, x->h, x->w, x->c, c.stream);
+    });
+  }
+  return out;
+}
+
+T gmean(Ctx& c, T x, bool pre_relu) {
+  T out = new_tensor(c, x->n, 1, 1, x->c, x->needs_grad);
+  const int HW = x->h * x->w;
+  launch_gmean_fwd(x->d, out->d, x->n, HW, x->c, pre_relu, c.stream);
+  if (x->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      int acc;
+      float* dx = grad_acc(c, x, &acc);
+      launch_gmean_bwd(x->d, out->g, dx, acc, x->n, HW, x->c, pre_relu, c.stream);
+    });
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tf.image.resize_images(method=2) in TF 1.14 = legacy bicubic (edgegan.py:211-213; Appendix B.3)
+// ---------------------------------------------------------------------------------------------
+static const ResizeTab& resize_tab(Ctx& c, int n_in, int n_out) {
+  auto key = std::make_pair(n_in, n_out);
+  auto it = c.resize_tabs.find(key);
+  if (it != c.resize_tabs.end()) return it->second;
+  // coefficient table exactly as the TF kernel builds it (1024 entries, A = -0.75, float)
+  const double A = -0.75;
+  std::vector<float> tab(1025 * 2);
+  for (int i = 0; i <= 1024; ++i) {
+    double x = i / 1024.0;
+    tab[i * 2] = (float)(((A + 2) * x - (A + 3)) * x * x + 1);
+    x += 1.0;
+    tab[i * 2 + 1] = (float)(((A * x - 5 * A) * x + 8 * A) * x - 4 * A);
+  }
+  std::vector<int> fi((size_t)n_out * 4);
+  std::vector<float> fw((size_t)n_out * 4);
+  std::vector<std::vector<std::pair<int, float>>> back(n_in);
+  const double scale = (double)n_in / n_out;
+  for (int o = 0; o < n_out; ++o) {
+    const double loc = scale * o;
+    const int fl = (int)std::floor(loc);
+    const int off = (int)std::lrint((loc - fl) * 1024);
+    const float wt[4] = {tab[off * 2 + 1], tab[off * 2], tab[(1024 - off) * 2], tab[(1024 - off) * 2 + 1]};
+    for (int t = 0; t < 4; ++t) {
+      int idx = fl - 1 + t;
+      idx = idx < 0 ? 0 : (idx > n_in - 1 ? n_in - 1 : idx);
+      fi[o * 4 + t] = idx;
+      fw[o * 4 + t] = wt[t];
+      if (wt[t] != 0.f) back[idx].push_back({o, wt[t]});
+    }
+  }
+  size_t bn = 1;
+  for (auto& v : back) bn = v.size() > bn ? v.size() : bn;
+  std::vector<int> bi((size_t)n_in * bn, 0);
+  std::vector<float> bw((size_t)n_in * bn, 0.f);
+  for (int i = 0; i < n_in; ++i)
+    for (size_t j = 0; j < back[i].size(); ++j) {
+      bi[i * bn + j] = back[i][j].first;
+      bw[i * bn + j] = back[i][j].second;
+    }
+  ResizeTab r;
+  r.n_in = n_in;
+  r.n_out = n_out;
+  r.fn = 4;
+  r.bn = (int)bn;
+  EG_HIP(hipMalloc(&r.f_i, fi.size() * 4));
+  EG_HIP(hipMalloc(&r.f_w, fw.size() * 4));
+  EG_HIP(hipMalloc(&r.b_i, bi.size() * 4));
+  EG_HIP(hipMalloc(&r.b_w, bw.size() * 4));
+  EG_HIP(hipMemcpy(r.f_i, fi.data(), fi.size() * 4, hipMemcpyHostToDevice));
+  EG_HIP(hipMemcpy(r.f_w, fw.data(), fw.size() * 4, hipMemcpyHostToDevice));
+  EG_HIP(hipMemcpy(r.b_i, bi.data(), bi.size() * 4, hipMemcpyHostToDevice));
+  EG_HIP(hipMemcpy(r.b_w, bw.data(), bw.size() * 4, hipMemcpyHostToDevice));
+  return c.resize_tabs[key] = r;
+}
+
+T resize(Ctx& c, T x, int size) {
+  if (x->h == size && x->w == size) return x;
+  const ResizeTab& ty = resize_tab(c, x->h, size);
+  const ResizeTab& tx = resize_tab(c, x->w, size);
+  T out = new_tensor(c, x->n, size, size, x->c, x->needs_grad);
+  launch_resize(x->d, out->d, 0, x->n, x->h, x->w, size, size, x->c, ty.f_i, ty.f_w, ty.fn, tx.f_i, tx.f_w, tx.fn,
+                c.stream);
+  if (x->needs_grad) {
+    Ctx* cp = &c;
+    const ResizeTab* pty = &ty;
+    const ResizeTab* ptx = &tx;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      int acc;
+      float* dx = grad_acc(c, x, &acc);
+      launch_resize(out->g, dx, acc, x->n, size, size, x->h, x->w, x->c, pty->b_i, pty->b_w, pty->bn, ptx->b_i,
+                    ptx->b_w, ptx->bn, c.stream);
+    });
+  }
+  return out;
+}
+
+// tf.concat([a, b], 2) (edgegan.py:245)
+T concat_w(Ctx& c, T a, T b) {
+  T out = new_tensor(c, a->n, a->h, a->w + b->w, a->c, a->needs_grad || b->needs_grad);
+  launch_copy_cols(a->d, out->d, a->n, a->h, a->w, out->w, 0, a->c, 1, 0, c.stream);
+  launch_copy_cols(b->d, out->d, b->n, b->h, b->w, out->w, a->w, b->c, 1, 0, c.stream);
+  if (out->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      int wo = 0;
+      for (T in : {a, b}) {
+        if (in->needs_grad) {
+          int acc;
+          float* d = grad_acc(c, in, &acc);
+          launch_copy_cols(d, out->g, in->n, in->h, in->w, out->w, wo, in->c, 0, acc, c.stream);
+        }
+        wo += in->w;
+      }
+    });
+  }
+  return out;
+}
+
+T slice_w(Ctx& c, T x, int w0, int w1) {
+  T out = new_tensor(c, x->n, x->h, w1 - w0, x->c, false);
+  launch_copy_cols(out->d, x->d, x->n, x->h, w1 - w0, x->w, w0, x->c, 0, 0, c.stream);
+  return out;
+}
+
+// activation.py:23-32
+T prelu(Ctx& c, T x, Param* leak, float leak_const) {
+  T out = new_tensor(c, x->n, x->h, x->w, x->c, false);
+  launch_prelu_fwd(x->d, leak ? leak->w : nullptr, leak_const, out->d, x->numel(), c.stream);
+  const bool need = x->needs_grad || (leak && leak->want_grad);
+  if (need) {
+    out->needs_grad = true;
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      float* dx = nullptr;
+      int acc = 0;
+      if (x->needs_grad) dx = grad_acc(c, x, &acc);
+      const bool pg = leak && leak->want_grad && c.param_grad_enabled;
+      if (!dx && !pg) return;
+      launch_prelu_bwd(x->d, out->g, leak ? leak->w : nullptr, leak_const, dx, acc, pg ? leak->g : nullptr,
+                       pg && leak->g_set ? 1 : 0, x->numel(), c.scratch, c.stream);
+      if (pg) leak->g_set = true;
+    });
+  }
+  return out;
+}
+
+// conv.py:197-198
+T minmax(Ctx& c, T x) {
+  T out = new_tensor(c, x->n, x->h, x->w, x->c, x->needs_grad);
+  T mm = new_tensor(c, x->n, 1, 1, 2 * x->c, false);
+  const int HW = x->h * x->w;
+  launch_minmax_fwd(x->d, out->d, mm->d, x->n, HW, x->c, c.stream);
+  if (x->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      int acc;
+      float* dx = grad_acc(c, x, &acc);
+      launch_minmax_bwd(x->d, mm->d, out->g, dx, acc, x->n, HW, x->c, c.stream);
+    });
+  }
+  return out;
+}
+
+// conv.py:207: ht_plus = ht + rg * img_new
+T gate(Ctx& c, T h, T rg, T img) {
+  T out = new_tensor(c, h->n, h->h, h->w, h->c, h->needs_grad || rg->needs_grad || img->needs_grad);
+  launch_gate_fwd(h->d, rg->d, img->d, out->d, h->numel(), c.stream);
+  if (out->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      float* dh = nullptr;
+      int acc_h = 0, a1, a2;
+      if (h->needs_grad) dh = grad_acc(c, h, &acc_h);
+      float* drg = grad_acc(c, rg, &a1);
+      float* dimg = grad_acc(c, img, &a2);
+      EG_CHECK(!a1 && !a2, "gate operands are single-use");
+      launch_gate_bwd(rg->d, img->d, out->g, dh, acc_h, drg, dimg, h->numel(), c.stream);
+    });
+  }
+  return out;
+}
+
+// encoder.py:78-79
+T reparam(Ctx& c, T mu, T ls, const float* eps_dev) {
+  T z = new_tensor(c, mu->n, 1, 1, mu->c, mu->needs_grad);
+  launch_reparam_fwd(mu->d, ls->d, eps_dev, z->d, z->numel(), c.stream);
+  if (z->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!z->g_set) return;
+      int a1, a2;
+      float* dmu = grad_acc(c, mu, &a1);
+      float* dls = grad_acc(c, ls, &a2);
+      EG_CHECK(!a1 && !a2, "reparam operands are single-use");
+      launch_reparam_bwd(ls->d, eps_dev, z->g, dmu, dls, z->numel(), c.stream);
+    });
+  }
+  return z;
+}
+
+// normalization.py:38-76 for every live SN weight of the classifier, one batched launch sequence
+void sn_prepare(Ctx& c) {
+  const int count = (int)c.sn.size();
+  if (count == 0) return;
+  launch_sn_fwd(c.sn_table, count, c.sn_maxK, c.sn_maxCo, c.stream);
+  for (auto& s : c.sn) s.wT_valid = false;
+  bool want = false;
+  for (auto& s : c.sn) want |= s.W->want_grad;
+  if (want) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!c.param_grad_enabled) return;
+      for (auto& s : c.sn) EG_CHECK(s.dWbar_set, "SN weight %s received no gradient", s.W->name.c_str());
+      launch_sn_bwd(c.sn_table, (int)c.sn.size(), c.sn_maxK, c.sn_maxCo, c.stream);
+      for (auto& s : c.sn) s.W->g_set = true;
+    });
+  }
+}
+
+Ctx::~Ctx() {
+  for (auto& kv : resize_tabs) {
+    (void)hipFree(kv.second.f_i);
+    (void)hipFree(kv.second.f_w);
+    (void)hipFree(kv.second.b_i);
+    (void)hipFree(kv.second.b_w);
+  }
+  for (auto e : ev_pool) (void)hipEventDestroy(e);
+  for (auto& r : prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (auto& g : groups) {
+    (void)hipFree(g.w);
+    (void)hipFree(g.g);
+    (void)hipFree(g.ms);
+    (void)hipFree(g.mom);
+  }
+  for (auto& s : sn) {
+    (void)hipFree(s.Wbar);
+    (void)hipFree(s.WbarT);
+    (void)hipFree(s.dWbar);
+    (void)hipFree(s.t);
+    (void)hipFree(s.sv);
+    (void)hipFree(s.dv);
+    (void)hipFree(s.scal);
+  }
+  (void)hipFree(sn_table);
+  (void)hipFree(scratch);
+  (void)hipFree(d_images);
+  (void)hipFree(d_z);
+  (void)hipFree(d_alpha);
+  (void)hipFree(d_eps);
+  (void)hipFree(d_losses);
+  (void)hipFree(d_classes);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+}  // namespace eg

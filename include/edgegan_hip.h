@@ -1,0 +1,119 @@
+/* edgegan_hip.h -- C ABI of libedgegan_hip.so, the MI355X (gfx950) engine for the EdgeGAN
+ * training / inference hot path.
+ *
+ * The reference (sysu-imsl/EdgeGAN) has no FFI / plugin interface: its device boundary is
+ * tf.Session.run on a TF-1.14 graph.  Each entry point below names the reference call site it
+ * replaces (paths relative to the reference repository root).  A Python maintainer binds this with
+ * ctypes (INTEGRATION.md shows the stub); nothing here exposes torch / HIP types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; eg_last_error() gives the message;
+ *     no exception ever crosses this boundary;
+ *   - an eg_ctx is bound to ONE HIP device and ONE stream; it is not thread-safe; use one host
+ *     process (or thread) per GPU;
+ *   - host buffers are C-contiguous float32 / int32 and stay owned by the caller; the library
+ *     copies; device memory is owned by the library;
+ *   - calls that return host data synchronise the stream; eg_train_step / eg_substep only enqueue.
+ *   - image tensors are NHWC float32 in [-1,1] (edgegan/models/edgegan.py:185-186);
+ *     z is [B, z_dim] or, with classes, [B, z_dim+1] whose last column is the class id
+ *     (edgegan/models/edgegan.py:188-197, edgegan/utils/data/dataset.py:72-84).
+ */
+#ifndef EDGEGAN_HIP_H
+#define EDGEGAN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct eg_ctx eg_ctx;
+
+/* Flags of edgegan/train.py:14-74 that shape the graph. */
+typedef struct eg_config {
+  int batch_size;      /* train.py:20  (per device)                     */
+  int height;          /* train.py:21-26 input/output_height            */
+  int width;           /* train.py:23-28 input/output_width (edge|image)*/
+  int num_classes;     /* train.py:44-45; 0 == --nomulticlasses         */
+  int z_dim;           /* train.py:74                                   */
+  int gf_dim, df_dim;  /* models/edgegan.py:47                          */
+  int c_dim;           /* models/edgegan.py:48                          */
+  int dis_size;        /* train.py:64,67 image_dis_size/edge_dis_size   */
+  float lambda_gp;     /* train.py:52                                   */
+  float zl_weight;     /* train.py:41 stage1_zl_loss                    */
+  float learning_rate; /* train.py:18                                   */
+  float joint_dweight, image_dweight, edge_dweight; /* train.py:68-73   */
+  int device;          /* train.py:14 --gpu                             */
+} eg_config;
+
+int eg_default_config(eg_config* cfg);
+
+/* ---- variable registry: replaces tf.get_variable creation + tf.train.Saver's view of the graph
+ *      (models/edgegan.py:421; names per SURVEY.md Appendix C).  Usable without a GPU. ---------- */
+int eg_variable_count(const eg_config* cfg);
+/* init_kind: 0 constant(init_param) 1 normal(0,init_param) 2 truncated normal(0,init_param)
+ *            3 xavier/glorot uniform.  shape has up to 4 dims. */
+int eg_variable_info(const eg_config* cfg, int index, char* name, int name_cap, int* shape, int* ndim,
+                     int* trainable, int* init_kind, float* init_param);
+
+/* ---- lifecycle: replaces tf.Session + EdgeGAN.build_train_model (models/edgegan.py:413-423) --- */
+int eg_create(const eg_config* cfg, eg_ctx** out);
+int eg_destroy(eg_ctx* ctx);
+const char* eg_last_error(eg_ctx* ctx); /* ctx may be NULL: last error of a failed eg_create */
+
+/* ---- variables: replaces saver.restore / sess.run(var) (models/edgegan.py:635-657).
+ *      `name` is the TF variable name; suffix "/RMSProp" = rms slot, "/RMSProp_1" = momentum slot,
+ *      "/grad" (get only) = gradient left by the last eg_substep(..., apply=0). ---------------- */
+int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long numel);
+int eg_get_variable(eg_ctx* ctx, const char* name, float* host, long long numel);
+
+/* ---- training: replaces EdgeGAN.update_model (models/edgegan.py:126-130) ----------------------
+ * eg_upload_batch makes one feed resident in HBM (the feed_dict of models/edgegan.py:130):
+ *   images [B,H,W,3]; z [B,z_dim(+1)]; alpha [3,B] ~ U(0,1), the random_blend draws of the joint /
+ *   image / edge discriminator runs (models/edgegan.py:32-35); eps [1] ~ N(0,1), the encoder's
+ *   scalar noise of the e_optim run (models/encoder.py:78-79).
+ * eg_substep runs optimizer sub-step k = 1..7 in the registration order of
+ *   models/edgegan.py:109-124: d_optim, d_optim_patch2, d_optim_patch3, d_optim2, g_optim_u,
+ *   e_optim, g_optim_b; apply=0 leaves the weights untouched and the gradients readable.
+ * eg_train_step = sub-steps 1..7 with apply=1 (one iteration of models/edgegan.py:461). */
+int eg_upload_batch(eg_ctx* ctx, const float* images, const float* z, const float* alpha, const float* eps);
+int eg_substep(eg_ctx* ctx, int k, int apply);
+int eg_train_step(eg_ctx* ctx);
+/* losses of the last sub-steps, replaces the evaluate() read-backs of models/edgegan.py:464-480:
+ * out[0..11] = joint wgan, joint gp, image wgan, image gp, edge wgan, edge gp, loss_d_ac,
+ *              joint_dis_gloss, edge_dis_gloss, image_dis_gloss, loss_g_ac, zl_loss */
+int eg_read_losses(eg_ctx* ctx, float* out12);
+
+/* ---- inference: replaces the two sess.run calls of EdgeGAN.test (models/edgegan.py:606-609) on
+ *      the graph of define_test_input (models/edgegan.py:492-517).  images [nb,H,W,3], classes [nb]
+ *      (ignored without classes), eps2 = the two scalar encoder draws; outputs [nb,H,W/2,3]. ---- */
+int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const float* eps2, float* edge_out,
+             float* image_out);
+
+int eg_sync(eg_ctx* ctx);
+
+/* ---- data parallel (no reference counterpart; the reference is single-GPU, train.py:77) -------
+ * rank 0 calls eg_comm_unique_id and ships the 128 bytes to the other ranks by any host channel;
+ * every rank then calls eg_comm_init.  eg_train_step then all-reduces (RCCL, sum) each optimised
+ * group's flat gradient buffer and averages before RMSProp. */
+int eg_comm_unique_id(eg_ctx* ctx, char* out128);
+int eg_comm_init(eg_ctx* ctx, const char* id128, int rank, int nranks);
+
+/* ---- measurement -------------------------------------------------------------------------------
+ * Between begin/end every GEMM-shaped launch is bracketed by HIP events on the engine's stream;
+ * end writes a JSON object {"kernels":[{"name","launches","ms","flops"}...]} into buf. */
+int eg_profile_begin(eg_ctx* ctx);
+int eg_profile_end(eg_ctx* ctx, char* buf, int cap);
+int eg_memory_stats(eg_ctx* ctx, long long* arena_peak_bytes, long long* arena_reserved_bytes);
+
+/* ---- per-op / per-network test entry points (parity tests against oracle/) ----------------------
+ * eg_test_op runs ONE tape op forward and, if a cotangent is supplied, backward, through exactly
+ * the code the training step uses.  See tests/test_ops_gpu.py for the per-op argument lists.
+ * eg_net_forward runs one network forward: net in {"G1","G2","D","D_patch2","D_patch3","E","D2"}. */
+int eg_test_op(eg_ctx* ctx, const char* op, int n_in, const float* const* inputs, const long long* in_numel,
+               int n_iparam, const int* iparams, int n_out, float* const* outputs, const long long* out_numel);
+int eg_net_forward(eg_ctx* ctx, const char* net, const float* input, int nb, int h, int w, int ch, float eps,
+                   float* out, long long out_numel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDGEGAN_HIP_H */

@@ -1,0 +1,372 @@
+"""Parity checks of the HIP engine against the CPU oracle (oracle/edgegan_oracle.py).
+
+Each check returns rows (name, error, tolerance).  Error metric: max|a-b| / (max|b| + 1e-30) with b the
+fp64 oracle value -- a scale-relative max-norm error.  Tolerances (fp32 arithmetic, different
+summation order than the oracle): forward 2e-4, backward 2e-3 unless a row says otherwise; the
+full-step tolerances are documented in tests/test_substeps_gpu.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import edgegan_oracle as O
+import edgegan_amd as ea
+
+FWD_TOL = 2e-4
+BWD_TOL = 2e-3
+DT = torch.float64
+
+
+def relerr(a, b) -> float:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        return float('inf')
+    if not np.all(np.isfinite(a)):
+        return float('inf')
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def t64(a, grad=False):
+    return torch.tensor(np.asarray(a), dtype=DT, requires_grad=grad)
+
+
+def oracle_config(cfg: ea.Config) -> O.Config:
+    return O.Config(batch_size=cfg.batch_size, height=cfg.height, width=cfg.width, num_classes=cfg.num_classes,
+                    z_dim=cfg.z_dim, gf_dim=cfg.gf_dim, df_dim=cfg.df_dim, c_dim=cfg.c_dim, dis_size=cfg.dis_size,
+                    lambda_gp=cfg.lambda_gp, zl_weight=cfg.zl_weight, learning_rate=cfg.learning_rate,
+                    joint_dweight=cfg.joint_dweight, image_dweight=cfg.image_dweight, edge_dweight=cfg.edge_dweight)
+
+
+# ------------------------------------------------------------------------------------------------
+# per-op checks
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # name, NB,H,W,C,N,k,stride,pad(0 SAME,1 REFLECT), bias
+    ('d_conv_0-like 4x4s2 C3 (flat)', 2, 16, 32, 3, 64, 4, 2, 0, False),
+    ('d_conv_1-like 4x4s2 C64 (vec 64x64)', 2, 16, 16, 64, 128, 4, 2, 0, False),
+    ('big 3x3s1 C16->128 (vec 128x128)', 4, 128, 128, 16, 128, 3, 1, 0, True),
+    ('E res 3x3 REFLECT C64->128 +b', 2, 16, 16, 64, 128, 3, 1, 1, True),
+    ('E res 3x3 REFLECT 4x4 C32->32 +b', 2, 4, 4, 32, 32, 3, 1, 1, True),
+    ('E shortcut 1x1 REFLECT C64->128 +b', 2, 8, 8, 64, 128, 1, 1, 1, True),
+    ('E stem 4x4s2 C3->64 +b', 2, 16, 16, 3, 64, 4, 2, 0, True),
+    ('cls h0 7x7 C3->8 (narrow flat)', 2, 16, 16, 3, 8, 7, 1, 0, True),
+    ('cls Conv_1 3x3 C8->128 (flat)', 2, 16, 16, 8, 128, 3, 1, 0, True),
+    ('cls 3x3 C16->8 (narrow vec)', 2, 16, 16, 16, 8, 3, 1, 0, True),
+    ('cls Conv_3 1x1 C128->256', 2, 8, 8, 128, 256, 1, 1, 0, True),
+    ('g_lin_0-like linear 114->256', 4, 1, 1, 114, 256, 1, 1, 0, True),
+    ('FC8-like linear 512->100', 4, 1, 1, 512, 100, 1, 1, 0, True),
+    ('fc-like linear 768->14 (flat N)', 4, 1, 1, 768, 14, 1, 1, 0, True),
+]
+
+
+def check_conv(net: ea.EdgeGAN, case, seed=0):
+    name, NB, H, W, Cc, N, k, s, pad, bias = case
+    rng = np.random.RandomState(seed)
+    x = rng.normal(size=(NB, H, W, Cc)).astype(np.float32)
+    w = (rng.normal(size=(k, k, Cc, N)) * 0.1).astype(np.float32)
+    b = rng.normal(size=(N,)).astype(np.float32) if bias else None
+    xt, wt = t64(x, True), t64(w, True)
+    bt = t64(b, True) if bias else None
+    yr = O.conv2d(xt, wt, s, 'REFLECT' if pad else 'SAME', bt)
+    dy = rng.normal(size=tuple(yr.shape)).astype(np.float32)
+    gr = torch.autograd.grad((yr * t64(dy)).sum(), [xt, wt] + ([bt] if bias else []))
+    y, dx, dw, db = net.test_op('conv2d', [x, w, b, dy], [NB, H, W, Cc, N, k, s, pad],
+                                [tuple(yr.shape), x.shape, w.shape, (N,) if bias else None])
+    rows = [(f'conv2d[{name}] y', relerr(y, yr.detach().numpy()), FWD_TOL),
+            (f'conv2d[{name}] dx', relerr(dx, gr[0].numpy()), BWD_TOL),
+            (f'conv2d[{name}] dw', relerr(dw, gr[1].numpy()), BWD_TOL)]
+    if bias:
+        rows.append((f'conv2d[{name}] db', relerr(db, gr[2].numpy()), BWD_TOL))
+    return rows
+
+
+DECONV_CASES = [('g_dconv_1-like 512->256', 2, 4, 4, 512, 256), ('g_dconv_3-like 128->64', 2, 8, 8, 128, 64),
+                ('g_dconv_4-like 64->3', 2, 16, 16, 64, 3), ('odd C 24->20', 1, 4, 8, 24, 20)]
+
+
+def check_deconv(net, case, seed=1):
+    name, NB, H, W, Cin, Cout = case
+    rng = np.random.RandomState(seed)
+    x = rng.normal(size=(NB, H, W, Cin)).astype(np.float32)
+    w = (rng.normal(size=(5, 5, Cout, Cin)) * 0.1).astype(np.float32)
+    b = rng.normal(size=(Cout,)).astype(np.float32)
+    xt, wt, bt = t64(x, True), t64(w, True), t64(b, True)
+    yr = O.deconv2d(xt, wt, bt, (2 * H, 2 * W))
+    dy = rng.normal(size=tuple(yr.shape)).astype(np.float32)
+    gr = torch.autograd.grad((yr * t64(dy)).sum(), [xt, wt, bt])
+    y, dx, dw, db = net.test_op('deconv2d', [x, w, b, dy], [NB, H, W, Cin, Cout],
+                                [tuple(yr.shape), x.shape, w.shape, (Cout,)])
+    return [(f'deconv2d[{name}] y', relerr(y, yr.detach().numpy()), FWD_TOL),
+            (f'deconv2d[{name}] dx', relerr(dx, gr[0].numpy()), BWD_TOL),
+            (f'deconv2d[{name}] dw', relerr(dw, gr[1].numpy()), BWD_TOL),
+            (f'deconv2d[{name}] db', relerr(db, gr[2].numpy()), BWD_TOL)]
+
+
+ACTS = {0: None, 1: 'relu', 2: 'lrelu', 3: 'tanh'}
+
+
+def check_in_act(net, act, shape=(3, 8, 16, 128), seed=2):
+    rng = np.random.RandomState(seed)
+    x = (rng.normal(size=shape) * 1.7 + 0.3).astype(np.float32)
+    dy = rng.normal(size=shape).astype(np.float32)
+    xt = t64(x, True)
+    yr = O.activation(O.instance_norm(xt), ACTS[act])
+    gx, = torch.autograd.grad((yr * t64(dy)).sum(), xt)
+    y, dx = net.test_op('in_act', [x, dy], list(shape) + [act], [shape, shape])
+    return [(f'in_act[{ACTS[act]} {shape}] y', relerr(y, yr.detach().numpy()), FWD_TOL),
+            (f'in_act[{ACTS[act]} {shape}] dx', relerr(dx, gx.numpy()), BWD_TOL)]
+
+
+def check_in_tangent(net, act=2, shape=(2, 8, 8, 64), seed=3):
+    """Forward-mode tangent of IN+act and its reverse (used by the WGAN-GP second-order path)."""
+    rng = np.random.RandomState(seed)
+    x = (rng.normal(size=shape) * 1.3).astype(np.float32)
+    tx = rng.normal(size=shape).astype(np.float32)
+    dty = rng.normal(size=shape).astype(np.float32)
+    xt, txt = t64(x, True), t64(tx, True)
+    f = lambda u: O.activation(O.instance_norm(u), ACTS[act])
+    yr, tyr = torch.autograd.functional.jvp(f, (xt,), (txt,), create_graph=True)
+    gx, gtx = torch.autograd.grad((tyr * t64(dty)).sum(), [xt, txt])
+    y, ty, dtx, dx = net.test_op('in_tangent', [x, tx, dty], list(shape) + [act], [shape] * 4)
+    return [(f'in_tangent[{ACTS[act]}] y', relerr(y, yr.detach().numpy()), FWD_TOL),
+            (f'in_tangent[{ACTS[act]}] ty', relerr(ty, tyr.detach().numpy()), FWD_TOL),
+            (f'in_tangent[{ACTS[act]}] dtx', relerr(dtx, gtx.numpy()), BWD_TOL),
+            (f'in_tangent[{ACTS[act]}] dx_primal', relerr(dx, gx.numpy()), BWD_TOL)]
+
+
+def check_simple(net, op, shape, extra, ref_fn, seed=4, positive=False):
+    rng = np.random.RandomState(seed)
+    x = rng.normal(size=shape).astype(np.float32)
+    xt = t64(x, True)
+    yr = ref_fn(xt)
+    dy = rng.normal(size=tuple(yr.shape)).astype(np.float32)
+    gx, = torch.autograd.grad((yr * t64(dy)).sum(), xt)
+    y, dx = net.test_op(op, [x, dy], list(shape) + [extra], [tuple(yr.shape), shape])
+    return [(f'{op}{shape} y', relerr(y, yr.detach().numpy()), FWD_TOL),
+            (f'{op}{shape} dx', relerr(dx, gx.numpy()), BWD_TOL)]
+
+
+def check_bn(net, shape=(4, 4, 4, 128), seed=5):
+    rng = np.random.RandomState(seed)
+    x = rng.normal(size=shape).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, size=(shape[3],)).astype(np.float32)
+    b = rng.normal(size=(shape[3],)).astype(np.float32) * 0.3
+    b = b.astype(np.float32)
+    dy = rng.normal(size=shape).astype(np.float32)
+    xt, gt, bt = t64(x, True), t64(g, True), t64(b, True)
+    yr = torch.relu(O.batch_norm_train(xt, gt, bt)[0])
+    gr = torch.autograd.grad((yr * t64(dy)).sum(), [xt, gt, bt])
+    y, dx, dg, db = net.test_op('bn_relu', [x, g, b, dy], list(shape), [shape, shape, g.shape, b.shape])
+    return [('bn_relu y', relerr(y, yr.detach().numpy()), FWD_TOL), ('bn_relu dx', relerr(dx, gr[0].numpy()), BWD_TOL),
+            ('bn_relu dgamma', relerr(dg, gr[1].numpy()), BWD_TOL), ('bn_relu dbeta', relerr(db, gr[2].numpy()), BWD_TOL)]
+
+
+def check_prelu(net, n=5000, seed=6):
+    rng = np.random.RandomState(seed)
+    x = rng.normal(size=(n,)).astype(np.float32)
+    lk = np.array([0.2], dtype=np.float32)
+    dy = rng.normal(size=(n,)).astype(np.float32)
+    xt, lt = t64(x, True), t64(lk[0], True)
+    yr = O.prelu(xt, lt)
+    gx, gl = torch.autograd.grad((yr * t64(dy)).sum(), [xt, lt])
+    y, dx, dl = net.test_op('prelu', [x, lk, dy], [n], [(n,), (n,), (1,)])
+    return [('prelu y', relerr(y, yr.detach().numpy()), FWD_TOL), ('prelu dx', relerr(dx, gx.numpy()), BWD_TOL),
+            ('prelu dleak', relerr(dl, gl.numpy().reshape(1)), BWD_TOL)]
+
+
+def check_gate(net, n=4096, seed=7):
+    rng = np.random.RandomState(seed)
+    h, rg, im, dy = [rng.normal(size=(n,)).astype(np.float32) for _ in range(4)]
+    y, dh, drg, dim = net.test_op('gate', [h, rg, im, dy], [n], [(n,)] * 4)
+    return [('gate y', relerr(y, h + rg * im), FWD_TOL), ('gate dh', relerr(dh, dy), BWD_TOL),
+            ('gate drg', relerr(drg, dy * im), BWD_TOL), ('gate dimg', relerr(dim, dy * rg), BWD_TOL)]
+
+
+def check_linear1(net, NB=6, K=4096, seed=8):
+    rng = np.random.RandomState(seed)
+    x = rng.normal(size=(NB, K)).astype(np.float32)
+    w = (rng.normal(size=(K, 1)) * 0.05).astype(np.float32)
+    b = np.array([0.3], dtype=np.float32)
+    dy = rng.normal(size=(NB, 1)).astype(np.float32)
+    xt, wt, bt = t64(x, True), t64(w, True), t64(b, True)
+    yr = O.linear(xt, wt, bt)
+    gr = torch.autograd.grad((yr * t64(dy)).sum(), [xt, wt, bt])
+    y, dx, dw, db = net.test_op('linear1', [x, w, b, dy], [NB, K], [(NB, 1), x.shape, w.shape, (1,)])
+    return [('linear1 y', relerr(y, yr.detach().numpy()), FWD_TOL), ('linear1 dx', relerr(dx, gr[0].numpy()), BWD_TOL),
+            ('linear1 dw', relerr(dw, gr[1].numpy()), BWD_TOL), ('linear1 db', relerr(db, gr[2].numpy()), BWD_TOL)]
+
+
+def check_sn(net, K, Co, seed=9):
+    rng = np.random.RandomState(seed)
+    W = (rng.normal(size=(K, Co)) * 0.02).astype(np.float32)
+    u = np.clip(rng.normal(size=(1, Co)), -2, 2).astype(np.float32)
+    dWb = rng.normal(size=(K, Co)).astype(np.float32)
+    Wt = t64(W, True)
+    Wbr = O.spectral_normed_weight(Wt, t64(u))
+    gW, = torch.autograd.grad((Wbr * t64(dWb)).sum(), Wt)
+    Wbar, dW, sigma = net.test_op('sn', [W, u, dWb], [K, Co], [(K, Co), (K, Co), (1,)])
+    return [(f'sn[{K}x{Co}] Wbar', relerr(Wbar, Wbr.detach().numpy()), FWD_TOL),
+            (f'sn[{K}x{Co}] dW', relerr(dW, gW.numpy()), BWD_TOL)]
+
+
+def check_acgan(net, B=16, NC=14, seed=10):
+    rng = np.random.RandomState(seed)
+    lg = (rng.normal(size=(B, NC)) * 2).astype(np.float32)
+    lab = rng.randint(0, NC, size=(B,))
+    rows = []
+    for mode in (0, 1):
+        lt = t64(lg, True)
+        lg_, ld_ = O.acgan_loss_focal(lt, torch.tensor(lab), lt)
+        ref = ld_ if mode == 0 else lg_
+        gl, = torch.autograd.grad(ref, lt)
+        loss, dl = net.test_op('acgan', [lg, lab.astype(np.float32)], [B, NC, mode], [(1,), (B, NC)])
+        rows += [(f'acgan mode{mode} loss', relerr(loss, ref.detach().numpy().reshape(1)), FWD_TOL),
+                 (f'acgan mode{mode} dlogits', relerr(dl, gl.numpy()), BWD_TOL)]
+    return rows
+
+
+def check_gp(net, B=4, per=3000, seed=11):
+    rng = np.random.RandomState(seed)
+    g = rng.normal(size=(B, per)).astype(np.float32) * 0.05
+    gt = t64(g, True)
+    nr = torch.sqrt((gt ** 2).sum(dim=1))
+    gp = net.config.lambda_gp * torch.mean((nr - 1) ** 2)
+    vr, = torch.autograd.grad(gp, gt)
+    v, norms, gpv = net.test_op('gp', [g], [B, per], [(B, per), (B,), (1,)])
+    return [('gp v', relerr(v, vr.numpy()), BWD_TOL), ('gp norms', relerr(norms, nr.detach().numpy()), FWD_TOL),
+            ('gp value', relerr(gpv, gp.detach().numpy().reshape(1)), FWD_TOL)]
+
+
+def check_rmsprop(net, n=10000, seed=12):
+    rng = np.random.RandomState(seed)
+    w, g = rng.normal(size=(n,)).astype(np.float32), rng.normal(size=(n,)).astype(np.float32)
+    ms = rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32)
+    mom = np.zeros(n, dtype=np.float32)
+    wt, gt, mst, momt = t64(w), t64(g), t64(ms), t64(mom)
+    O.rmsprop_apply(wt, gt, mst, momt, 2e-4)
+    w2, ms2, mom2 = net.test_op('rmsprop', [w, g, ms, mom, np.array([2e-4], np.float32)], [n], [(n,)] * 3)
+    return [('rmsprop w', relerr(w2, wt.numpy()), 1e-6), ('rmsprop ms', relerr(ms2, mst.numpy()), 1e-6),
+            ('rmsprop mom', relerr(mom2, momt.numpy()), 1e-5)]
+
+
+def all_op_checks(net):
+    rows = []
+    for c in CONV_CASES:
+        rows += check_conv(net, c)
+    for c in DECONV_CASES:
+        rows += check_deconv(net, c)
+    for a in (0, 1, 2):
+        rows += check_in_act(net, a)
+    rows += check_in_act(net, 2, shape=(2, 4, 8, 512))
+    rows += check_in_tangent(net, 2)
+    rows += check_in_tangent(net, 2, shape=(2, 4, 8, 128), seed=33)
+    rows += check_simple(net, 'act', (2, 4, 4, 32), 3, lambda t: torch.tanh(t))
+    rows += check_simple(net, 'act', (2, 4, 4, 32), 2, lambda t: O.activation(t, 'lrelu'))
+    rows += check_simple(net, 'resize', (2, 64, 64, 3), 128, lambda t: O.resize_bicubic(t, 128))
+    rows += check_simple(net, 'pool2', (2, 8, 8, 24), 0, lambda t: O.avg_pool2(t))
+    rows += check_simple(net, 'gmean', (3, 2, 2, 64), 1, lambda t: O.avg_pool_same(torch.relu(t), 8).reshape(3, 1, 1, 64))
+    rows += check_simple(net, 'gmean', (3, 4, 4, 96), 0, lambda t: t.mean(dim=(1, 2), keepdim=True))
+
+    def mm(t):
+        mn, mx = t.amin(dim=(1, 2), keepdim=True), t.amax(dim=(1, 2), keepdim=True)
+        return (t - mn) / (mx - mn)
+    rows += check_simple(net, 'minmax', (2, 8, 8, 40), 0, mm)
+    rows += check_bn(net)
+    rows += check_prelu(net)
+    rows += check_gate(net)
+    rows += check_linear1(net)
+    rows += check_sn(net, 99, 8)
+    rows += check_sn(net, 1152, 128)
+    rows += check_acgan(net)
+    rows += check_gp(net)
+    rows += check_rmsprop(net)
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------
+# network forward checks (full-size architectures, small batch)
+# ------------------------------------------------------------------------------------------------
+def net_checks(net: ea.EdgeGAN, values, seed=20):
+    cfg = net.config
+    ocfg = oracle_config(cfg)
+    p = {k: t64(v) for k, v in values.items()}
+    rng = np.random.RandomState(seed)
+    NB = cfg.batch_size
+    rows = []
+    g_in = cfg.z_dim + (cfg.num_classes if cfg.multiclasses else 0)
+    zin = rng.normal(size=(NB, g_in)).astype(np.float32)
+    for g in ('G1', 'G2'):
+        ref = O.generator(p, g, t64(zin), ocfg).numpy()
+        out = net.net_forward(g, zin, ref.shape)
+        rows.append((f'net {g} forward', relerr(out, ref), 5e-4))
+    x = rng.uniform(-1, 1, size=(NB, cfg.height, cfg.width, 3)).astype(np.float32)
+    ref = O.discriminator(p, 'D', t64(x))[1].numpy()
+    rows.append(('net D forward', relerr(net.net_forward('D', x, ref.shape), ref), 5e-4))
+    xp = rng.uniform(-1, 1, size=(NB, cfg.dis_size, cfg.dis_size, 3)).astype(np.float32)
+    for d in ('D_patch2', 'D_patch3'):
+        ref = O.discriminator(p, d, t64(xp))[1].numpy()
+        rows.append((f'net {d} forward', relerr(net.net_forward(d, xp, ref.shape), ref), 5e-4))
+    xe = rng.uniform(-1, 1, size=(NB, cfg.height, cfg.width // 2, 3)).astype(np.float32)
+    ref = O.encoder(p, t64(xe), 0.37, ocfg)[0].numpy()
+    rows.append(('net E forward', relerr(net.net_forward('E', xe, (NB, 1, 1, cfg.z_dim), eps=0.37).reshape(ref.shape), ref), 5e-4))
+    if cfg.multiclasses:
+        ref = O.classifier(p, t64(xe), ocfg).numpy()
+        rows.append(('net D2 forward', relerr(net.net_forward('D2', xe, (NB, 1, 1, cfg.num_classes)).reshape(ref.shape), ref), 5e-4))
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------
+# sub-step gradient + update checks
+# ------------------------------------------------------------------------------------------------
+def substep_checks(net: ea.EdgeGAN, values, batch, grad_tol=5e-3, upd_tol=2e-3):
+    """For each sub-step (executed sequentially like update_model): gradient of every optimised
+    variable vs oracle autograd (fp64), then the RMSProp update is applied on both sides."""
+    cfg = net.config
+    ocfg = oracle_config(cfg)
+    om = O.OracleModel(ocfg, values, dtype=DT)
+    inp = O.StepInputs(t64(batch['images']), t64(batch['z']), t64(batch['alpha']), t64(batch['eps']))
+    net.set_variables(values)
+    net.upload_batch(batch['images'], batch['z'], batch['alpha'], batch['eps'])
+    rows = []
+    for k, name in enumerate(O.SUBSTEPS, start=1):
+        if name == 'd_optim2' and not cfg.multiclasses:
+            continue
+        grads, losses = om.compute_grads(name, inp, inp.eps[0])
+        net.substep(k, apply=False)
+        worst = (0.0, '')
+        for vn, g in grads.items():
+            e = relerr(net.get_variable(vn + '/grad'), g.numpy())
+            rows.append((f'substep {k} {name} grad {vn}', e, grad_tol))
+            if e > worst[0]:
+                worst = (e, vn)
+        hl = net.losses()
+        ref_l = {k2: float(v) for k2, v in losses.items()}
+        loss_map = {1: [('joint_dis_dloss', 'joint_dis_dloss')], 2: [('image_dis_dloss', 'image_dis_dloss')],
+                    3: [('edge_dis_dloss', 'edge_dis_dloss')], 4: [('loss_d_ac', 'loss_d_ac')],
+                    5: [('edge_gloss', 'edge_gloss'), ('image_gloss', 'image_gloss')], 6: [('zl_loss', 'zl_loss')],
+                    7: [('edge_gloss', 'edge_gloss'), ('image_gloss', 'image_gloss')]}[k]
+        for hk, rk in loss_map:
+            rows.append((f'substep {k} {name} loss {hk}', abs(hl[hk] - ref_l[rk]) / (abs(ref_l[rk]) + 1e-30), 1e-3))
+        # apply on both sides and compare the updated variables of the group
+        om.apply_grads(grads)
+        om.update_bn_moving(om._GENS[name])
+        net.substep(k, apply=True)
+        for vn in grads:
+            rows.append((f'substep {k} {name} updated {vn}', relerr(net.get_variable(vn), om.p[vn].numpy()), upd_tol))
+    for g in ('G1', 'G2'):
+        for s in ('moving_mean', 'moving_variance'):
+            vn = f'{g}/batch_norm/BatchNorm/{s}'
+            rows.append((f'bn {vn}', relerr(net.get_variable(vn), om.p[vn].numpy()), 1e-3))
+    return rows
+
+
+def format_rows(rows, only_fail=False):
+    out = []
+    for n, e, t in rows:
+        ok = e <= t
+        if only_fail and ok:
+            continue
+        out.append(f"{'ok  ' if ok else 'FAIL'} {e:10.3e} (tol {t:.0e})  {n}")
+    return '\n'.join(out)
