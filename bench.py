@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""Throughput bench of the EdgeGAN training hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one training iteration = the 7 optimizer sub-steps of the reference's
+EdgeGAN.update_model (edgegan/models/edgegan.py:109-130) on one synthetic batch that is already
+resident in HBM.  Workload = BASELINE.json configs[2]: 14-class 64x128 fp32 training, batch 64 per
+GPU; N > 1 is pure data parallel (weak scaling: 64 images per GPU, one RCCL all-reduce per optimised
+network group).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE = 93.55        # algorithmic conv/deconv/linear work, 64x128 14-class
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+
+
+def cpu_baseline(cfg_kwargs, sample_batch=4):
+    """The oracle (torch-CPU fp32 restatement of the reference graph, `kind: port`) timed on this
+    host: one full iteration (7 sub-steps) at a bounded batch.  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch
+    import edgegan_amd as ea
+    import edgegan_oracle as O
+    import parity
+    kw = dict(cfg_kwargs)
+    kw['batch_size'] = sample_batch
+    cfg = ea.Config(**kw)
+    values = ea.init_variables(cfg, 0)
+    b = ea.synthetic_batch(cfg)
+    om = O.OracleModel(parity.oracle_config(cfg), values, dtype=torch.float32)
+    inp = O.StepInputs(*[torch.tensor(b[k]) for k in ('images', 'z', 'alpha', 'eps')])
+    om.run_substep('e_optim', inp)            # untimed: thread pool / allocator warm-up
+    t0 = time.time()
+    om.update_model(inp)
+    dt = time.time() - t0
+    return {'value': sample_batch / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 iteration (7 sub-steps) at batch {sample_batch}, torch-CPU fp32 oracle, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU')
+    ap.add_argument('--classes', type=int, default=14)
+    ap.add_argument('--profile-steps', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f'bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}',
+                  file=sys.stderr)
+            sys.exit(2)
+        args.gpus = world
+
+    import numpy as np
+    import edgegan_amd as ea
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist_mod.init_process_group('gloo', rank=rank, world_size=world)   # host-side rendezvous only
+        dist = dist_mod
+
+    cfg_kwargs = dict(batch_size=args.batch, num_classes=args.classes, device=local)
+    cfg = ea.Config(**cfg_kwargs)
+    values = ea.init_variables(cfg, 0)                 # same weights on every rank
+    net = ea.EdgeGAN(cfg, values)
+    batch = ea.synthetic_batch(cfg, seed=1234, rank=rank)   # each rank its own shard of the global batch
+    if world > 1:
+        import torch
+        uid = [net.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        net.comm_init(uid[0], rank, world)
+    net.upload_batch(batch['images'], batch['z'], batch['alpha'], batch['eps'])
+
+    def barrier_sync():
+        net.sync()
+        if dist is not None:
+            dist.barrier()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+        net.sync()
+
+    for _ in range(args.warmup):
+        net.train_step()
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.train_step()
+    barrier_sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    losses = net.losses()
+    finite = all(np.isfinite(v) for v in losses.values())
+
+    # roofline of the dominant kernel: HIP events around every GEMM-shaped launch on the engine's stream
+    roof = None
+    if rank == 0 and args.profile_steps > 0:
+        net.profile_begin()
+        for _ in range(args.profile_steps):
+            net.train_step()
+        prof = net.profile_end()
+        ks = prof['kernels']
+        if ks:
+            dom = max(ks, key=lambda k: k['ms'])
+            tot_ms = sum(k['ms'] for k in ks)
+            tot_fl = sum(k['flops'] for k in ks)
+            ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None, 'kernel': dom['name'],
+                    'launches_per_step': dom['launches'] / args.profile_steps,
+                    'avg_launch_ms': round(dom['ms'] / dom['launches'], 4),
+                    'flops_per_launch': dom['flops'] / dom['launches'],
+                    'all_gemm_kernels': {'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                         'ms_per_step': round(tot_ms / args.profile_steps, 3),
+                                         'executed_gflop_per_image': round(tot_fl / args.profile_steps / args.batch / 1e9, 2)},
+                    'per_kernel': {k['name']: {'ms_per_step': round(k['ms'] / args.profile_steps, 3),
+                                               'tflops': round(k['flops'] / (k['ms'] * 1e-3) / 1e12, 2)} for k in ks}}
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        out = {
+            'metric': 'training images/sec (G+D step) at 64x128, 14-class',
+            'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[2]: 14-class 64x128 fp32 full G+D+classifier+E training iteration '
+                                   '(7 RMSProp sub-steps), batch 64 per GPU', 'global_batch': args.batch * world,
+                       'per_gpu_batch': args.batch, 'num_classes': args.classes, 'parallelism': f'dp{world}'},
+            'algorithmic_tflops_per_gpu': round(GFLOP_PER_IMAGE * value / world / 1e3, 2),
+            'frac_of_fp32_mfma_peak': round(GFLOP_PER_IMAGE * value / world / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+            'losses_finite': bool(finite), 'memory': net.memory_stats(),
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(dict(num_classes=args.classes))
+            except Exception as e:  # the baseline must never hide the GPU number
+                out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+        print(json.dumps(out))
+    net.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -131,23 +131,31 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_kernel(const float* __rest
   const float mean = cv ? stats[((size_t)n * C + c) * 2 + 0] : 0.f;
   const float sigma = cv ? stats[((size_t)n * C + c) * 2 + 1] : 1.f;
   const float r = 1.f / (sigma + IN_EPS);
-  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // sum e, sum tx, sum e*tx, sum xc*tx, sum e*xc
+  // means first, then centred second moments (the uncentred form sum(e t) - HW mean(e) mean(t) cancels
+  // catastrophically when the tangent / cotangent carry a large per-channel mean)
+  float m[2] = {0.f, 0.f};
+  if (cv)
+    for (int p = py; p < HW; p += 4) {
+      const size_t i = base + (size_t)p * C;
+      m[0] += dtout[i] * act_grad_from_out(out[i], act);
+      m[1] += tx[i];
+    }
+  lane4_reduce<2>(m, red, cx, py);
+  const float hw = (float)HW;
+  const float eb = m[0] / hw, ta = m[1] / hw;
+  float s[3] = {0.f, 0.f, 0.f};  // sum (e-eb)(t-ta), sum xc*t, sum e*xc
   if (cv)
     for (int p = py; p < HW; p += 4) {
       const size_t i = base + (size_t)p * C;
       const float e = dtout[i] * act_grad_from_out(out[i], act);
       const float t = tx[i], xc = x[i] - mean;
-      s[0] += e;
-      s[1] += t;
-      s[2] += e * t;
-      s[3] += xc * t;
-      s[4] += e * xc;
+      s[0] += (e - eb) * (t - ta);
+      s[1] += xc * t;
+      s[2] += e * xc;
     }
-  lane4_reduce<5>(s, red, cx, py);
-  const float hw = (float)HW;
-  const float eb = s[0] / hw, ta = s[1] / hw;
-  const float A = s[2] - hw * eb * ta;
-  const float S_xt = s[3], S_ex = s[4];
+  lane4_reduce<3>(s, red, cx, py);
+  const float A = s[0];
+  const float S_xt = s[1], S_ex = s[2];
   const float B = S_xt * S_ex / hw;
   const float r2 = r * r;
   const float c1 = (-A * r2 + 2.f * r2 * r * B / sigma + r2 * B / (sigma * sigma)) / (hw * sigma);

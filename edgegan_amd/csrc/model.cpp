@@ -466,24 +466,27 @@ void run_substep(Ctx& c, int k, bool apply) {
   reset_step(c);
   for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);
   T images = wrap_tensor(c, c.d_images, B, cfg.H, cfg.W, cfg.c_dim);
+  // contrib batch_norm updates its moving statistics whenever a generator forward is evaluated in a
+  // training run (updates_collections=None); gradient-only probes (apply=false) leave them alone.
+  const int bn_t = apply ? 1 : 0;
   switch (k) {
     case 1: {  // d_optim: joint discriminator
       T zin = make_zin(c);
-      T edge = generator_forward(c, G_G1, zin, 1);
-      T image = generator_forward(c, G_G2, zin, 1);
+      T edge = generator_forward(c, G_G1, zin, bn_t);
+      T image = generator_forward(c, G_G2, zin, bn_t);
       T joint = concat_w(c, edge, image);
       disc_substep(c, G_D, images, joint, c.d_alpha, L_JOINT_D, L_JOINT_GP, apply);
     } break;
     case 2: {  // d_optim_patch2: image discriminator on bicubic-resized right halves
       T zin = make_zin(c);
-      T image = generator_forward(c, G_G2, zin, 1);
+      T image = generator_forward(c, G_G2, zin, bn_t);
       T r_real = resize(c, right_half(c, images), cfg.dis_size);
       T r_fake = resize(c, image, cfg.dis_size);
       disc_substep(c, G_DP2, r_real, r_fake, c.d_alpha + B, L_IMAGE_D, L_IMAGE_GP, apply);
     } break;
     case 3: {  // d_optim_patch3: edge discriminator
       T zin = make_zin(c);
-      T edge = generator_forward(c, G_G1, zin, 1);
+      T edge = generator_forward(c, G_G1, zin, bn_t);
       T r_real = resize(c, left_half(c, images), cfg.dis_size);
       T r_fake = resize(c, edge, cfg.dis_size);
       disc_substep(c, G_DP3, r_real, r_fake, c.d_alpha + 2 * B, L_EDGE_D, L_EDGE_GP, apply);
@@ -502,8 +505,8 @@ void run_substep(Ctx& c, int k, bool apply) {
       set_want_grad(c, G_G1, true);
       set_want_grad(c, G_G2, true);
       T zin = make_zin(c);
-      T edge = generator_forward(c, G_G1, zin, 1);
-      T image = generator_forward(c, G_G2, zin, 1);
+      T edge = generator_forward(c, G_G1, zin, bn_t);
+      T image = generator_forward(c, G_G2, zin, bn_t);
       T joint = concat_w(c, edge, image);
       T dj = disc_forward(c, G_D, joint, nullptr, nullptr);
       T de = disc_forward(c, G_DP3, resize(c, edge, cfg.dis_size), nullptr, nullptr);
@@ -532,7 +535,7 @@ void run_substep(Ctx& c, int k, bool apply) {
     case 6: {  // e_optim: L1 latent reconstruction through G1 (edgegan.py:275,337-342)
       set_want_grad(c, G_E, true);
       T zin = make_zin(c);
-      T edge = generator_forward(c, G_G1, zin, 1);
+      T edge = generator_forward(c, G_G1, zin, bn_t);
       T zr = encoder_forward(c, edge, c.d_eps);
       seed_grad(c, zr);
       launch_l1(c.d_z, cfg.multiclasses() ? cfg.z_dim + 1 : cfg.z_dim, zr->d, c.d_losses + L_ZL, zr->g, B, cfg.z_dim,

@@ -578,56 +578,80 @@ def _vars_with_prefix(p: P, prefix: str, trainable: Dict[str, bool]) -> List[str
     return [n for n in p if n.startswith(prefix + '/') and trainable[n]]
 
 
-def forward_graph(p: P, inp: StepInputs, cfg: Config, eps_val, bn_stats=None) -> Dict[str, Tensor]:
-    """edgegan.py:202-275 (forward) + :277-342 (define_losses).  Returns every loss tensor."""
+ALL_LOSSES = ('joint_dis_dloss', 'image_dis_dloss', 'edge_dis_dloss', 'loss_d_ac', 'edge_gloss', 'image_gloss',
+              'zl_loss')
+
+
+def forward_graph(p: P, inp: StepInputs, cfg: Config, eps_val, bn_stats=None, want=None) -> Dict[str, Tensor]:
+    """edgegan.py:202-275 (forward) + :277-342 (define_losses).  Like sess.run, only the sub-graph that
+    the requested loss tensors (`want`, default: all) depend on is evaluated."""
+    want = set(want or ALL_LOSSES)
     W2 = cfg.width // 2
     zin, labels = z_onehot(inp.z, cfg)
-    st1 = [] if bn_stats is not None else None
-    st2 = [] if bn_stats is not None else None
-    edge = generator(p, 'G1', zin, cfg, st1)
-    image = generator(p, 'G2', zin, cfg, st2)
-    if bn_stats is not None:
-        bn_stats['G1'] = st1[0]
-        bn_stats['G2'] = st2[0]
-    out: Dict[str, Tensor] = {'edge_output': edge, 'image_output': image}
     real = inp.images
     real_edge, real_pic = real[:, :, :W2, :], real[:, :, W2:, :]
+    memo: Dict[str, object] = {}
+    out: Dict[str, Tensor] = {}
 
-    _, d_real = discriminator(p, 'D', real)
-    joint = torch.cat([edge, image], dim=2)
-    _, d_fake = discriminator(p, 'D', joint)
-    out['joint_dis_dloss'] = discriminator_ganloss(d_fake, d_real) + gradient_penalty_term(
-        p, 'D', joint, real, inp.alpha[0], cfg.lambda_gp)
-    out['joint_dis_gloss'] = generator_ganloss(d_fake)
+    def once(key, fn):
+        if key not in memo:
+            memo[key] = fn()
+        return memo[key]
 
-    r_pic = resize_bicubic(real_pic, cfg.dis_size)
-    _, di_real = discriminator(p, 'D_patch2', r_pic)
-    r_img = resize_bicubic(image, cfg.dis_size)
-    _, di_fake = discriminator(p, 'D_patch2', r_img)
-    out['image_dis_dloss'] = discriminator_ganloss(di_fake, di_real) + gradient_penalty_term(
-        p, 'D_patch2', r_img, r_pic, inp.alpha[1], cfg.lambda_gp)
-    out['image_dis_gloss'] = generator_ganloss(di_fake)
+    def gen(name):
+        def make():
+            st = [] if bn_stats is not None else None
+            o = generator(p, name, zin, cfg, st)
+            if bn_stats is not None:
+                bn_stats[name] = st[0]
+            return o
+        return once('gen' + name, make)
 
-    r_edges = resize_bicubic(real_edge, cfg.dis_size)
-    _, de_real = discriminator(p, 'D_patch3', r_edges)
-    r_edge_out = resize_bicubic(edge, cfg.dis_size)
-    _, de_fake = discriminator(p, 'D_patch3', r_edge_out)
-    out['edge_dis_dloss'] = discriminator_ganloss(de_fake, de_real) + gradient_penalty_term(
-        p, 'D_patch3', r_edge_out, r_edges, inp.alpha[2], cfg.lambda_gp)
-    out['edge_dis_gloss'] = generator_ganloss(de_fake)
+    edge = lambda: gen('G1')
+    image = lambda: gen('G2')
+    joint = lambda: once('joint', lambda: torch.cat([edge(), image()], dim=2))
+    d_fake = lambda: once('d_fake', lambda: discriminator(p, 'D', joint())[1])
+    r_pic = lambda: once('r_pic', lambda: resize_bicubic(real_pic, cfg.dis_size))
+    r_img = lambda: once('r_img', lambda: resize_bicubic(image(), cfg.dis_size))
+    di_fake = lambda: once('di_fake', lambda: discriminator(p, 'D_patch2', r_img())[1])
+    r_edges = lambda: once('r_edges', lambda: resize_bicubic(real_edge, cfg.dis_size))
+    r_edge_out = lambda: once('r_edge_out', lambda: resize_bicubic(edge(), cfg.dis_size))
+    de_fake = lambda: once('de_fake', lambda: discriminator(p, 'D_patch3', r_edge_out())[1])
+    joint_g = lambda: once('joint_g', lambda: generator_ganloss(d_fake()))
 
-    out['edge_gloss'] = cfg.joint_dweight * out['joint_dis_gloss'] + cfg.edge_dweight * out['edge_dis_gloss']
-    out['image_gloss'] = cfg.joint_dweight * out['joint_dis_gloss'] + cfg.image_dweight * out['image_dis_gloss']
-    if cfg.multiclasses:
-        lr_ = classifier(p, real_pic, cfg)
-        lf_ = classifier(p, image, cfg)
-        out['real_logits'], out['fake_logits'] = lr_, lf_
-        out['loss_g_ac'], out['loss_d_ac'] = acgan_loss_focal(lr_, labels, lf_)
-        out['image_gloss'] = out['image_gloss'] + out['loss_g_ac']
-    z_recon, _, _ = encoder(p, edge, eps_val, cfg)
-    z_target = inp.z[:, :cfg.z_dim]
-    out['zl_loss'] = l1loss(z_target, z_recon, cfg.zl_weight)
-    out['z_recon'] = z_recon
+    if 'joint_dis_dloss' in want:
+        _, d_real = discriminator(p, 'D', real)
+        out['joint_dis_dloss'] = discriminator_ganloss(d_fake(), d_real) + gradient_penalty_term(
+            p, 'D', joint(), real, inp.alpha[0], cfg.lambda_gp)
+    if 'image_dis_dloss' in want:
+        _, di_real = discriminator(p, 'D_patch2', r_pic())
+        out['image_dis_dloss'] = discriminator_ganloss(di_fake(), di_real) + gradient_penalty_term(
+            p, 'D_patch2', r_img(), r_pic(), inp.alpha[1], cfg.lambda_gp)
+    if 'edge_dis_dloss' in want:
+        _, de_real = discriminator(p, 'D_patch3', r_edges())
+        out['edge_dis_dloss'] = discriminator_ganloss(de_fake(), de_real) + gradient_penalty_term(
+            p, 'D_patch3', r_edge_out(), r_edges(), inp.alpha[2], cfg.lambda_gp)
+    if 'edge_gloss' in want:
+        out['joint_dis_gloss'] = joint_g()
+        out['edge_dis_gloss'] = generator_ganloss(de_fake())
+        out['edge_gloss'] = cfg.joint_dweight * joint_g() + cfg.edge_dweight * out['edge_dis_gloss']
+    if 'image_gloss' in want:
+        out['joint_dis_gloss'] = joint_g()
+        out['image_dis_gloss'] = generator_ganloss(di_fake())
+        out['image_gloss'] = cfg.joint_dweight * joint_g() + cfg.image_dweight * out['image_dis_gloss']
+    if cfg.multiclasses and ('loss_d_ac' in want or 'image_gloss' in want):
+        lr_ = classifier(p, real_pic, cfg) if 'loss_d_ac' in want else None
+        lf_ = classifier(p, image(), cfg) if 'image_gloss' in want else None
+        # functional.py:5-16 computes both terms in one call; each needs only its own logits
+        if lr_ is not None:
+            out['loss_d_ac'] = acgan_loss_focal(lr_, labels, lr_.detach())[1]
+        if lf_ is not None:
+            out['loss_g_ac'] = acgan_loss_focal(lf_.detach(), labels, lf_)[0]
+            out['image_gloss'] = out['image_gloss'] + out['loss_g_ac']
+    if 'zl_loss' in want:
+        z_recon, _, _ = encoder(p, edge(), eps_val, cfg)
+        out['zl_loss'] = l1loss(inp.z[:, :cfg.z_dim], z_recon, cfg.zl_weight)
+        out['z_recon'] = z_recon
     return out
 
 
@@ -679,7 +703,8 @@ class OracleModel:
         pre-update weights of the run, quirk N9).  Returns (grads by var name, losses)."""
         p = self._leaf_params()
         bn = {}
-        losses = forward_graph(p, inp, self.cfg, eps_val, bn_stats=bn)
+        want = [lk for lk, _ in self._substep_targets(name)]
+        losses = forward_graph(p, inp, self.cfg, eps_val, bn_stats=bn, want=want)
         grads: Dict[str, Tensor] = {}
         for loss_key, prefix in self._substep_targets(name):
             names = _vars_with_prefix(p, prefix, self.trainable)

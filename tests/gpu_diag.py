@@ -15,19 +15,19 @@ import parity  # noqa: E402
 def main():
     which = sys.argv[1:] or ['ops', 'nets', 'substeps']
     B = int(os.environ.get('EG_DIAG_B', '2'))
-    cfg = ea.Config(batch_size=B)
-    values = ea.init_variables(cfg, 0)
+    cfg = ea.Config(batch_size=B, num_classes=int(os.environ.get('EG_DIAG_NC', '14')))
+    values = ea.init_variables(cfg, int(os.environ.get('EG_DIAG_SEED', '0')))
     net = ea.EdgeGAN(cfg, values)
     t0 = time.time()
-    for stage, fn in (('ops', lambda: parity.all_op_checks(net)), ('nets', lambda: parity.net_checks(net, values)),
-                      ('substeps', lambda: parity.substep_checks(net, values, ea.synthetic_batch(cfg)))):
+    for stage, fn in (('ops', lambda: parity.all_op_checks(net)), ('sweep', lambda: parity.batch_sweep_checks(net)), ('real', lambda: parity.real_shape_checks(net)), ('nets', lambda: parity.net_checks(net, values)),
+                      ('substeps', lambda: parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=int(os.environ.get('EG_DIAG_BSEED', '1234')))))):
         if stage not in which:
             continue
         try:
             rows = fn()
             nfail = sum(1 for _, e, t in rows if not e <= t)
             print(f'==== {stage}: {len(rows)} checks, {nfail} failed, {time.time() - t0:.1f}s')
-            print(parity.format_rows(rows, only_fail=len(rows) > 150))
+            print(parity.format_rows(rows, only_fail=False))
         except Exception:
             print(f'==== {stage}: EXCEPTION')
             traceback.print_exc()

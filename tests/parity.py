@@ -2,7 +2,7 @@
 
 Each check returns rows (name, error, tolerance).  Error metric: max|a-b| / (max|b| + 1e-30) with b the
 fp64 oracle value -- a scale-relative max-norm error.  Tolerances (fp32 arithmetic, different
-summation order than the oracle): forward 2e-4, backward 2e-3 unless a row says otherwise; the
+summation order than the oracle): forward 2e-5, backward 5e-5 unless a row says otherwise; the
 full-step tolerances are documented in tests/test_substeps_gpu.py.
 """
 from __future__ import annotations
@@ -13,19 +13,30 @@ import torch
 import edgegan_oracle as O
 import edgegan_amd as ea
 
-FWD_TOL = 2e-4
-BWD_TOL = 2e-3
+FWD_TOL = 2e-5
+BWD_TOL = 5e-5
 DT = torch.float64
 
 
-def relerr(a, b) -> float:
+def relerr(a, b, floor: float = 0.0) -> float:
+    """max|a-b| / max(max|b|, floor).  `floor` keeps variables whose true value is (numerically) zero --
+    e.g. the gradient of a bias that feeds an InstanceNorm -- from reporting noise/0."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     if a.shape != b.shape:
         return float('inf')
     if not np.all(np.isfinite(a)):
         return float('inf')
-    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), floor, 1e-30))
+
+
+def rel_l2(a, b, floor: float = 0.0) -> float:
+    """||a-b||_2 / max(||b||_2, floor*sqrt(n))."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    if a.shape != b.shape or not np.all(np.isfinite(a)):
+        return float('inf')
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), floor * np.sqrt(b.size), 1e-300))
 
 
 def t64(a, grad=False):
@@ -320,9 +331,22 @@ def net_checks(net: ea.EdgeGAN, values, seed=20):
 # ------------------------------------------------------------------------------------------------
 # sub-step gradient + update checks
 # ------------------------------------------------------------------------------------------------
-def substep_checks(net: ea.EdgeGAN, values, batch, grad_tol=5e-3, upd_tol=2e-3):
-    """For each sub-step (executed sequentially like update_model): gradient of every optimised
-    variable vs oracle autograd (fp64), then the RMSProp update is applied on both sides."""
+def substep_checks(net: ea.EdgeGAN, values, batch, grad_tol=1e-2, iterations=1):
+    """The 7 sub-steps in update_model order.  Before each sub-step the engine is put on exactly the
+    oracle's state (oracle values are kept fp32-representable), because the GAN trajectory at random
+    init is chaotic: an fp32-vs-fp64 run of the ORACLE ITSELF drifts to 1e-1 relative gradient
+    differences by sub-step 7 (measured; DESIGN.md "conditioning"), which says nothing about kernels.
+    Per sub-step: every optimised variable's gradient vs oracle autograd (fp64, incl. the WGAN-GP
+    double backward), the reported loss, and that RMSProp was applied to the variable and its slot.
+    Gradient metric: relative L2 error, tolerance 1e-2.  Why not the tight max-norm of the op tests:
+    ReLU / LeakyReLU / PReLU derivatives are discontinuous at 0, and among the ~1e6 activations of the
+    small-extent layers (4x4 .. 16x16) one or two pre-activations per sub-step land within fp32
+    rounding (|y| < 1e-6) of the kink; whichever side an fp32 implementation rounds to changes that
+    channel's gradient by ~1/(B*H*W) (percents at B=2..4) -- the fp32 run of the ORACLE ITSELF flips
+    such masks against its fp64 run (measured, DESIGN.md "conditioning").  A flip moves the L2 error
+    of the affected variables to ~1e-3; wiring / formula bugs move it to >= 1e-1.  When no flip
+    occurs the engine agrees with fp64 autograd to ~2e-5 max-norm (the value in each row's name);
+    smooth-regime accuracy is pinned separately by the op tests at 5e-5 max-norm."""
     cfg = net.config
     ocfg = oracle_config(cfg)
     om = O.OracleModel(ocfg, values, dtype=DT)
@@ -330,35 +354,63 @@ def substep_checks(net: ea.EdgeGAN, values, batch, grad_tol=5e-3, upd_tol=2e-3):
     net.set_variables(values)
     net.upload_batch(batch['images'], batch['z'], batch['alpha'], batch['eps'])
     rows = []
-    for k, name in enumerate(O.SUBSTEPS, start=1):
-        if name == 'd_optim2' and not cfg.multiclasses:
-            continue
-        grads, losses = om.compute_grads(name, inp, inp.eps[0])
-        net.substep(k, apply=False)
-        worst = (0.0, '')
-        for vn, g in grads.items():
-            e = relerr(net.get_variable(vn + '/grad'), g.numpy())
-            rows.append((f'substep {k} {name} grad {vn}', e, grad_tol))
-            if e > worst[0]:
-                worst = (e, vn)
-        hl = net.losses()
-        ref_l = {k2: float(v) for k2, v in losses.items()}
-        loss_map = {1: [('joint_dis_dloss', 'joint_dis_dloss')], 2: [('image_dis_dloss', 'image_dis_dloss')],
-                    3: [('edge_dis_dloss', 'edge_dis_dloss')], 4: [('loss_d_ac', 'loss_d_ac')],
-                    5: [('edge_gloss', 'edge_gloss'), ('image_gloss', 'image_gloss')], 6: [('zl_loss', 'zl_loss')],
-                    7: [('edge_gloss', 'edge_gloss'), ('image_gloss', 'image_gloss')]}[k]
-        for hk, rk in loss_map:
-            rows.append((f'substep {k} {name} loss {hk}', abs(hl[hk] - ref_l[rk]) / (abs(ref_l[rk]) + 1e-30), 1e-3))
-        # apply on both sides and compare the updated variables of the group
-        om.apply_grads(grads)
-        om.update_bn_moving(om._GENS[name])
-        net.substep(k, apply=True)
-        for vn in grads:
-            rows.append((f'substep {k} {name} updated {vn}', relerr(net.get_variable(vn), om.p[vn].numpy()), upd_tol))
+
+    def sync(names):
+        for vn in names:
+            for d in (om.p, om.ms, om.mom):
+                d[vn].copy_(d[vn].float().double())
+            net.set_variable(vn, om.p[vn].numpy())
+            net.set_variable(vn + '/RMSProp', om.ms[vn].numpy())
+            net.set_variable(vn + '/RMSProp_1', om.mom[vn].numpy())
+
+    loss_map = {1: ['joint_dis_dloss'], 2: ['image_dis_dloss'], 3: ['edge_dis_dloss'], 4: ['loss_d_ac'],
+                5: ['edge_gloss', 'image_gloss'], 6: ['zl_loss'], 7: ['edge_gloss', 'image_gloss']}
+    for it in range(iterations):
+        for k, name in enumerate(O.SUBSTEPS, start=1):
+            if name == 'd_optim2' and not cfg.multiclasses:
+                continue
+            tag = f'it{it} substep {k} {name}'
+            grads, losses = om.compute_grads(name, inp, inp.eps[0])
+            net.substep(k, apply=False)
+            gmax = max(float(g.abs().max()) for g in grads.values())
+            hip_g = {}
+            for vn, g in grads.items():
+                hip_g[vn] = net.get_variable(vn + '/grad')
+                if float(g.abs().max()) < 1e-9 * gmax:
+                    # structurally zero gradient (a bias in front of an InstanceNorm / min-max gate):
+                    # fp32 may only leave rounding noise, bounded by 1e-5 of the sub-step's largest gradient
+                    rows.append((f'{tag} grad {vn} (structural zero: noise/1e-5*gmax)',
+                                 float(np.abs(hip_g[vn]).max()) / (1e-5 * gmax), 1.0))
+                else:
+                    mx = relerr(hip_g[vn], g.numpy(), 1e-5 * gmax)
+                    rows.append((f'{tag} grad {vn} [L2; max-norm {mx:.1e}]',
+                                 rel_l2(hip_g[vn], g.numpy(), 1e-5 * gmax), grad_tol))
+            hl = net.losses()
+            for lk in loss_map[k]:
+                ref = float(losses[lk])
+                rows.append((f'{tag} loss {lk}', abs(hl[lk] - ref) / (abs(ref) + 1e-30), 1e-4))
+            # the optimizer: the engine must apply tf RMSProp (Appendix B.7) with ITS gradient to exactly
+            # these variables and slots (gradient parity is the rows above; RMSProp's g/sqrt(ms) would
+            # otherwise re-weight element errors by the 1e3 dynamic range of GAN gradients at init)
+            before = {vn: om.p[vn].clone() for vn in grads}
+            ms_before = {vn: om.ms[vn].clone() for vn in grads}
+            om.apply_grads(grads)
+            om.update_bn_moving(om._GENS[name])
+            net.substep(k, apply=True)
+            for vn in grads:
+                gh = torch.tensor(hip_g[vn].astype(np.float64)).reshape(before[vn].shape)
+                ms_new = ms_before[vn] + (gh * gh - ms_before[vn]) * (1.0 - 0.9)
+                w_new = before[vn] - cfg.learning_rate * gh / torch.sqrt(ms_new + 1e-10)
+                got = net.get_variable(vn).astype(np.float64)
+                ulp = float(np.spacing(np.float32(np.abs(w_new.numpy()).max())))
+                e = 0.0 if np.max(np.abs(got - w_new.numpy())) <= 2 * ulp else relerr(got, w_new.numpy())
+                rows.append((f'{tag} rmsprop-applied {vn}', e, 1e-5))
+                rows.append((f'{tag} rms-slot {vn}', relerr(net.get_variable(vn + '/RMSProp'), ms_new.numpy()), 1e-5))
+            sync(list(grads.keys()))
     for g in ('G1', 'G2'):
-        for s in ('moving_mean', 'moving_variance'):
-            vn = f'{g}/batch_norm/BatchNorm/{s}'
-            rows.append((f'bn {vn}', relerr(net.get_variable(vn), om.p[vn].numpy()), 1e-3))
+        for sname in ('moving_mean', 'moving_variance'):
+            vn = f'{g}/batch_norm/BatchNorm/{sname}'
+            rows.append((f'bn {vn}', relerr(net.get_variable(vn), om.p[vn].numpy()), 1e-4))
     return rows
 
 
@@ -370,3 +422,46 @@ def format_rows(rows, only_fail=False):
             continue
         out.append(f"{'ok  ' if ok else 'FAIL'} {e:10.3e} (tol {t:.0e})  {n}")
     return '\n'.join(out)
+
+
+def batch_sweep_checks(net, batches=(1, 3, 4, 5, 8)):
+    """Every batch-dependent op at several batch sizes (shapes of the encoder's top blocks, the
+    discriminator tail and the generator head)."""
+    rows = []
+    for nb in batches:
+        for case in [('E top 3x3 REFLECT 4x4 C256->256', nb, 4, 4, 256, 256, 3, 1, 1, True),
+                     ('E top 1x1 REFLECT 4x4 C128->256', nb, 4, 4, 128, 256, 1, 1, 1, True),
+                     ('E 3x3 REFLECT 8x8 C128->128', nb, 8, 8, 128, 128, 3, 1, 1, True),
+                     ('D tail 4x4s2 8x8 C128->256', nb, 8, 8, 128, 256, 4, 2, 0, False),
+                     ('stem 4x4s2 C3->64', nb, 16, 16, 3, 64, 4, 2, 0, True),
+                     ('FC8 linear 512->100', nb, 1, 1, 512, 100, 1, 1, 0, True),
+                     ('g_lin linear 114->1024', nb, 1, 1, 114, 1024, 1, 1, 0, True)]:
+            rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in check_conv(net, case, seed=nb)]
+        rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in check_deconv(net, ('dconv 4x4 C128->64', nb, 4, 4, 128, 64), seed=nb)]
+        rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in check_in_act(net, 1, shape=(nb, 4, 4, 256), seed=nb)]
+        rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in check_in_tangent(net, 2, shape=(nb, 4, 8, 128), seed=nb)]
+        rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in check_bn(net, shape=(nb, 4, 4, 128), seed=nb)]
+        rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in check_linear1(net, NB=nb, K=2048, seed=nb)]
+        rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in
+                 check_simple(net, 'pool2', (nb, 4, 4, 256), 0, lambda t: O.avg_pool2(t), seed=nb)]
+        rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in
+                 check_simple(net, 'gmean', (nb, 2, 2, 256), 1,
+                              lambda t: O.avg_pool_same(torch.relu(t), 8).reshape(t.shape[0], 1, 1, 256), seed=nb)]
+        rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in
+                 check_simple(net, 'resize', (nb, 16, 16, 3), 32, lambda t: O.resize_bicubic(t, 32), seed=nb)]
+    return rows
+
+
+def real_shape_checks(net, nbs=(4, 8)):
+    rows = []
+    for nb in nbs:
+        for case in [('E 256_2/res1 16x16 C128->256', nb, 16, 16, 128, 256, 3, 1, 1, True),
+                     ('E 512_4/res2 4x4 C512->512', nb, 4, 4, 512, 512, 3, 1, 1, True),
+                     ('E 128_1/res1 32x32 C64->128', nb, 32, 32, 64, 128, 3, 1, 1, True),
+                     ('Dp conv_4 16x16 C256->512', nb, 16, 16, 256, 512, 4, 2, 0, False),
+                     ('Dp conv_3 32x32 C128->256', nb, 32, 32, 128, 256, 4, 2, 0, False)]:
+            rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in check_conv(net, case, seed=nb)]
+        for case in [('g_dconv_1 4x4 512->256', nb, 4, 4, 512, 256), ('g_dconv_2 8x8 256->128', nb, 8, 8, 256, 128),
+                     ('g_dconv_3 16x16 128->64', nb, 16, 16, 128, 64)]:
+            rows += [(f'NB={nb} ' + r[0], r[1], r[2]) for r in check_deconv(net, case, seed=nb)]
+    return rows
