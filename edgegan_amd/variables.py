@@ -40,5 +40,5 @@ def init_variables(cfg: Config, seed: int = 0) -> Dict[str, np.ndarray]:
             a = rng.uniform(-lim, lim, size=shape)
         else:
             raise ValueError(s.init_kind)
-        out[s.name] = np.ascontiguousarray(a, dtype=np.float32)
+        out[s.name] = np.array(a, dtype=np.float32, order='C').reshape(shape)
     return out
