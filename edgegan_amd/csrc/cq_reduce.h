@@ -1,0 +1,69 @@
+// Channel-quad x pixel-lane block layout helpers shared by the per-(n,c) reduction kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace eg {
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+#define F4_OP(dst, expr_x, expr_y, expr_z, expr_w) \
+  do { (dst).x = (expr_x); (dst).y = (expr_y); (dst).z = (expr_z); (dst).w = (expr_w); } while (0)
+
+template <int NV, int CQ>
+__device__ __forceinline__ void cq_reduce(float4 (&v)[NV], float4* red /*[NV][4][CQ]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+#pragma unroll
+    for (int o = CQ; o < 64; o <<= 1) {
+      v[k].x += __shfl_xor(v[k].x, o, 64);
+      v[k].y += __shfl_xor(v[k].y, o, 64);
+      v[k].z += __shfl_xor(v[k].z, o, 64);
+      v[k].w += __shfl_xor(v[k].w, o, 64);
+    }
+  }
+  __syncthreads();
+  if (lane < CQ) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[(k * 4 + wave) * CQ + lane] = v[k];
+  }
+  __syncthreads();
+  const int cq = threadIdx.x % CQ;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const float4 a = red[(k * 4 + 0) * CQ + cq], b = red[(k * 4 + 1) * CQ + cq], c = red[(k * 4 + 2) * CQ + cq],
+                 d = red[(k * 4 + 3) * CQ + cq];
+    F4_OP(v[k], (a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+          (a.w + b.w) + (c.w + d.w));
+  }
+}
+
+
+// same layout, min / max instead of sum
+template <int CQ>
+__device__ __forceinline__ void cq_reduce_minmax(float4& mn, float4& mx, float4* red /*[2][4][CQ]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = CQ; o < 64; o <<= 1) {
+    mn.x = fminf(mn.x, __shfl_xor(mn.x, o, 64)); mn.y = fminf(mn.y, __shfl_xor(mn.y, o, 64));
+    mn.z = fminf(mn.z, __shfl_xor(mn.z, o, 64)); mn.w = fminf(mn.w, __shfl_xor(mn.w, o, 64));
+    mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o, 64));
+    mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o, 64));
+  }
+  __syncthreads();
+  if (lane < CQ) {
+    red[(0 * 4 + wave) * CQ + lane] = mn;
+    red[(1 * 4 + wave) * CQ + lane] = mx;
+  }
+  __syncthreads();
+  const int cq = threadIdx.x % CQ;
+  float4 a = red[cq], b = red[CQ + cq], c = red[2 * CQ + cq], d = red[3 * CQ + cq];
+  mn = make_float4(fminf(fminf(a.x, b.x), fminf(c.x, d.x)), fminf(fminf(a.y, b.y), fminf(c.y, d.y)),
+                   fminf(fminf(a.z, b.z), fminf(c.z, d.z)), fminf(fminf(a.w, b.w), fminf(c.w, d.w)));
+  a = red[4 * CQ + cq]; b = red[5 * CQ + cq]; c = red[6 * CQ + cq]; d = red[7 * CQ + cq];
+  mx = make_float4(fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y)),
+                   fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)), fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w)));
+}
+
+}  // namespace eg

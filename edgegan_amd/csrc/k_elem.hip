@@ -2,6 +2,7 @@
 // min-max gate, spectral norm, losses, RMSProp.  NHWC fp32.  All reductions are fixed-order
 // (two-stage, no float atomics) so replicas stay bit-identical under data parallelism.
 #include "kernels.h"
+#include "cq_reduce.h"
 
 namespace eg {
 
@@ -121,7 +122,7 @@ void launch_reflect_fold(const float* dpad, float* dx, int accumulate, int NB, i
 }
 
 // ---- column sums (bias gradients): two-stage, fixed order -------------------------------------
-#define CS_RB 128
+#define CS_RB 256
 __global__ __launch_bounds__(256) void col_sum_stage1(const float* __restrict__ dy, float* __restrict__ part, size_t R,
                                                       int C) {
   __shared__ float red[4 * 64];
@@ -143,12 +144,31 @@ __global__ void col_sum_stage2(const float* __restrict__ part, float* __restrict
   for (int b = 0; b < nrb; ++b) s += part[(size_t)b * C + c];
   db[c] = acc ? db[c] + s : s;
 }
+// float4 variant: block = 8 channel quads x 32 row lanes, more row blocks
+__global__ __launch_bounds__(256) void col_sum_stage1_v(const float* __restrict__ dy, float* __restrict__ part, size_t R,
+                                                        int C) {
+  __shared__ float4 red[4 * 8];
+  const int cq = threadIdx.x % 8, pl = threadIdx.x / 8;
+  const int c = (blockIdx.x * 8 + cq) * 4;
+  const size_t rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const size_t r0 = blockIdx.y * rows_per, r1 = (r0 + rows_per < R) ? r0 + rows_per : R;
+  float4 s[1] = {f4_zero()};
+  for (size_t r = r0 + pl; r < r1; r += 32) {
+    const float4 v = ld4(dy + r * C + c);
+    s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+  }
+  cq_reduce<1, 8>(s, red);
+  if (pl == 0) st4(part + (size_t)blockIdx.y * C + c, s[0]);
+}
 size_t col_sum_scratch_floats(int C) { return (size_t)CS_RB * C; }
 void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C, float* scratch, hipStream_t s) {
   int nrb = (int)((R + 255) / 256);
   if (nrb > CS_RB) nrb = CS_RB;
   if (nrb < 1) nrb = 1;
-  hipLaunchKernelGGL(col_sum_stage1, dim3((C + 63) / 64, nrb), dim3(256), 0, s, dy, scratch, R, C);
+  if (C % 32 == 0 && (((uintptr_t)dy & 15) == 0))
+    hipLaunchKernelGGL(col_sum_stage1_v, dim3(C / 32, nrb), dim3(256), 0, s, dy, scratch, R, C);
+  else
+    hipLaunchKernelGGL(col_sum_stage1, dim3((C + 63) / 64, nrb), dim3(256), 0, s, dy, scratch, R, C);
   hipLaunchKernelGGL(col_sum_stage2, dim3((C + 255) / 256), dim3(256), 0, s, scratch, db, accumulate, C, nrb);
 }
 
@@ -389,11 +409,101 @@ __global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* __restrict
     }
   }
 }
+template <int CQ>
+__global__ __launch_bounds__(256) void minmax_fwd_v(const float* __restrict__ x, float* __restrict__ y,
+                                                    float* __restrict__ mm, int HW, int C) {
+  constexpr int PL = 256 / CQ;
+  __shared__ float4 red[2 * 4 * CQ];
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+  const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
+  const size_t base = (size_t)n * HW * C + c;
+  float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  for (int p = pl; p < HW; p += PL) {
+    const float4 v = ld4(x + base + (size_t)p * C);
+    mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
+    mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+  }
+  cq_reduce_minmax<CQ>(mn, mx, red);
+  const float4 inv = make_float4(1.f / (mx.x - mn.x), 1.f / (mx.y - mn.y), 1.f / (mx.z - mn.z), 1.f / (mx.w - mn.w));
+  for (int p = pl; p < HW; p += PL) {
+    const size_t i = base + (size_t)p * C;
+    const float4 v = ld4(x + i);
+    st4(y + i, make_float4((v.x - mn.x) * inv.x, (v.y - mn.y) * inv.y, (v.z - mn.z) * inv.z, (v.w - mn.w) * inv.w));
+  }
+  if (pl == 0) {
+    float* mp = mm + ((size_t)n * C + c) * 2;
+    mp[0] = mn.x; mp[1] = mx.x; mp[2] = mn.y; mp[3] = mx.y; mp[4] = mn.z; mp[5] = mx.z; mp[6] = mn.w; mp[7] = mx.w;
+  }
+}
+
+template <int CQ>
+__global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x, const float* __restrict__ mm,
+                                                    const float* __restrict__ dy, float* __restrict__ dx, int acc,
+                                                    int HW, int C) {
+  constexpr int PL = 256 / CQ;
+  __shared__ float4 red[4 * 4 * CQ];
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+  const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
+  const size_t base = (size_t)n * HW * C + c;
+  const float4 a = ld4(mm + ((size_t)n * C + c) * 2), b = ld4(mm + ((size_t)n * C + c) * 2 + 4);
+  const float mn[4] = {a.x, a.z, b.x, b.z}, mx[4] = {a.y, a.w, b.y, b.w};
+  float4 s[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};  // sum g, sum g*(x-mn), count==mn, count==mx
+  for (int p = pl; p < HW; p += PL) {
+    const size_t i = base + (size_t)p * C;
+    const float4 v = ld4(x + i), g = ld4(dy + i);
+    s[0].x += g.x; s[0].y += g.y; s[0].z += g.z; s[0].w += g.w;
+    s[1].x += g.x * (v.x - mn[0]); s[1].y += g.y * (v.y - mn[1]); s[1].z += g.z * (v.z - mn[2]); s[1].w += g.w * (v.w - mn[3]);
+    s[2].x += v.x == mn[0] ? 1.f : 0.f; s[2].y += v.y == mn[1] ? 1.f : 0.f; s[2].z += v.z == mn[2] ? 1.f : 0.f; s[2].w += v.w == mn[3] ? 1.f : 0.f;
+    s[3].x += v.x == mx[0] ? 1.f : 0.f; s[3].y += v.y == mx[1] ? 1.f : 0.f; s[3].z += v.z == mx[2] ? 1.f : 0.f; s[3].w += v.w == mx[3] ? 1.f : 0.f;
+  }
+  cq_reduce<4, CQ>(s, red);
+  const float S1[4] = {s[0].x, s[0].y, s[0].z, s[0].w}, S2[4] = {s[1].x, s[1].y, s[1].z, s[1].w},
+              Cn[4] = {s[2].x, s[2].y, s[2].z, s[2].w}, Cx[4] = {s[3].x, s[3].y, s[3].z, s[3].w};
+  float d[4], dmn[4], dmx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    d[j] = mx[j] - mn[j];
+    dmn[j] = (-S1[j] / d[j] + S2[j] / (d[j] * d[j])) / Cn[j];
+    dmx[j] = (-S2[j] / (d[j] * d[j])) / Cx[j];
+  }
+  for (int p = pl; p < HW; p += PL) {
+    const size_t i = base + (size_t)p * C;
+    const float4 v = ld4(x + i), g = ld4(dy + i);
+    const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[j] = gg[j] / d[j];
+      if (vv[j] == mn[j]) r[j] += dmn[j];
+      if (vv[j] == mx[j]) r[j] += dmx[j];
+    }
+    float4 o = make_float4(r[0], r[1], r[2], r[3]);
+    if (acc) { const float4 t = ld4(dx + i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+    st4(dx + i, o);
+  }
+}
+
 void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s) {
+  if (C % 32 == 0) {
+    hipLaunchKernelGGL(minmax_fwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, y, mm, HW, C);
+    return;
+  }
+  if (C % 8 == 0) {
+    hipLaunchKernelGGL(minmax_fwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, y, mm, HW, C);
+    return;
+  }
   hipLaunchKernelGGL(minmax_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, y, mm, HW, C);
 }
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
                        int HW, int C, hipStream_t s) {
+  if (C % 32 == 0) {
+    hipLaunchKernelGGL(minmax_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C);
+    return;
+  }
+  if (C % 8 == 0) {
+    hipLaunchKernelGGL(minmax_bwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C);
+    return;
+  }
   hipLaunchKernelGGL(minmax_bwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C);
 }
 

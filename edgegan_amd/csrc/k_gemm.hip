@@ -27,7 +27,7 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // =============================================================================================
 // conv_gemm_kernel
 // =============================================================================================
-template <int BM, int BN, int WTM, int WTN, bool VEC>
+template <int BM, int BN, int WTM, int WTN, bool VEC, bool BVEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
   constexpr int BK = 16;
   constexpr int LDA = BK + 4;
@@ -76,8 +76,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
   constexpr int B_V = (4 * BN + 255) / 256;        // float4 per thread (VEC)
   constexpr int A_S = BM / 16;                     // scalars per thread (FLAT)
   constexpr int B_S = BN / 16;
-  float4 ra4[VEC ? A_V : 1], rb4[VEC ? B_V : 1];
-  float ras[VEC ? 1 : A_S], rbs[VEC ? 1 : B_S];
+  float4 ra4[VEC ? A_V : 1], rb4[BVEC ? B_V : 1];
+  float ras[VEC ? 1 : A_S], rbs[BVEC ? 1 : B_S];
+  static_assert(VEC || !BVEC, "BVEC needs the tap-tiled K order");
 
   auto gather_ok = [&](int base, int& iy, int& ix) -> bool {
     if (a.reflect) {
@@ -103,15 +104,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
           v = *reinterpret_cast<const float4*>(a.x + (size_t)(r_base[i] + iy * IW + ix) * a.x_ps + c0 + kq * 4);
         ra4[i] = v;
       }
+      if constexpr (BVEC) {
 #pragma unroll
-      for (int i = 0; i < B_V; ++i) {
-        const int idx = tid + 256 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < 4 * BN) {
-          const int k = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
-          if (n < N) v = *reinterpret_cast<const float4*>(a.wgt + wt + (size_t)(c0 + k) * a.ldw + n);
+        for (int i = 0; i < B_V; ++i) {
+          const int idx = tid + 256 * i;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (idx < 4 * BN) {
+            const int k = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+            if (n < N) v = *reinterpret_cast<const float4*>(a.wgt + wt + (size_t)(c0 + k) * a.ldw + n);
+          }
+          rb4[i] = v;
         }
-        rb4[i] = v;
+      } else {  // 16-byte A gathers, scalar filter loads (Cout not a multiple of 4, e.g. the 3-channel image)
+        const float* wrow = a.wgt + wt + (size_t)(c0 + (tid >> 4)) * a.ldw;
+#pragma unroll
+        for (int j = 0; j < B_S; ++j) {
+          const int n = n0 + (tid & 15) + 16 * j;
+          rbs[j] = n < N ? wrow[n] : 0.f;
+        }
       }
     } else {
       {  // A: this thread's k column is fixed inside the tile
@@ -149,14 +159,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < A_V; ++i)
         *reinterpret_cast<float4*>(&As[((tid >> 2) + 64 * i) * LDA + (tid & 3) * 4]) = ra4[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_S; ++i) As[((tid >> 4) + 16 * i) * LDA + (tid & 15)] = ras[i];
+    }
+    if constexpr (BVEC) {
 #pragma unroll
       for (int i = 0; i < B_V; ++i) {
         const int idx = tid + 256 * i;
         if (idx < 4 * BN) *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4]) = rb4[i];
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < A_S; ++i) As[((tid >> 4) + 16 * i) * LDA + (tid & 15)] = ras[i];
 #pragma unroll
       for (int j = 0; j < B_S; ++j) Bs[(tid >> 4) * LDB + (tid & 15) + 16 * j] = rbs[j];
     }
@@ -215,10 +228,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
   }
 }
 
-template <int BM, int BN, int WTM, int WTN, bool VEC>
+template <int BM, int BN, int WTM, int WTN, bool VEC, bool BVEC>
 static void conv_launch(const ConvArgs& a, int maxM, hipStream_t s) {
   dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, VEC>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, VEC, BVEC>), grid, dim3(256), 0, s, a);
+}
+
+template <int BM, int BN, int WTM, int WTN>
+static const char* conv_dispatch(const ConvArgs& a, int maxM, bool avec, bool bvec, hipStream_t s, const char* nv,
+                                 const char* nav, const char* nf) {
+  if (avec && bvec) { conv_launch<BM, BN, WTM, WTN, true, true>(a, maxM, s); return nv; }
+  if (avec) { conv_launch<BM, BN, WTM, WTN, true, false>(a, maxM, s); return nav; }
+  conv_launch<BM, BN, WTM, WTN, false, false>(a, maxM, s);
+  return nf;
 }
 
 double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_name) {
@@ -229,19 +251,23 @@ double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_na
     if (M > maxM) maxM = M;
     flops += 2.0 * M * a.N * (double)(a.ph[p].Ty * a.ph[p].Tx) * a.C;
   }
-  const bool vec = (a.C % 16 == 0) && (a.N % 4 == 0) && (a.x_ps % 4 == 0) && (a.ldw % 4 == 0) &&
-                   (a.w_ts % 4 == 0) && (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.wgt & 15) == 0);
+  const bool avec = (a.C % 16 == 0) && (a.x_ps % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
+  const bool bvec = (a.N % 4 == 0) && (a.ldw % 4 == 0) && (a.w_ts % 4 == 0) && (((uintptr_t)a.wgt & 15) == 0);
   const long long blocks128 = (long long)((maxM + 127) / 128) * ((a.N + 127) / 128) * a.nphase;
   const char* nm;
   if (a.N <= 16) {
-    if (vec) { conv_launch<256, 16, 64, 16, true>(a, maxM, s); nm = "conv_gemm<256,16,vec>"; }
-    else { conv_launch<256, 16, 64, 16, false>(a, maxM, s); nm = "conv_gemm<256,16,flat>"; }
+    if ((long long)((maxM + 255) / 256) * a.nphase >= 256)
+      nm = conv_dispatch<256, 16, 64, 16>(a, maxM, avec, bvec, s, "conv_gemm<256,16,vec>", "conv_gemm<256,16,avec>",
+                                          "conv_gemm<256,16,flat>");
+    else
+      nm = conv_dispatch<64, 16, 16, 16>(a, maxM, avec, bvec, s, "conv_gemm<64,16,vec>", "conv_gemm<64,16,avec>",
+                                         "conv_gemm<64,16,flat>");
   } else if (a.N >= 128 && blocks128 >= 512) {
-    if (vec) { conv_launch<128, 128, 64, 64, true>(a, maxM, s); nm = "conv_gemm<128,128,vec>"; }
-    else { conv_launch<128, 128, 64, 64, false>(a, maxM, s); nm = "conv_gemm<128,128,flat>"; }
+    nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s, "conv_gemm<128,128,vec>", "conv_gemm<128,128,avec>",
+                                         "conv_gemm<128,128,flat>");
   } else {
-    if (vec) { conv_launch<64, 64, 32, 32, true>(a, maxM, s); nm = "conv_gemm<64,64,vec>"; }
-    else { conv_launch<64, 64, 32, 32, false>(a, maxM, s); nm = "conv_gemm<64,64,flat>"; }
+    nm = conv_dispatch<64, 64, 32, 32>(a, maxM, avec, bvec, s, "conv_gemm<64,64,vec>", "conv_gemm<64,64,avec>",
+                                       "conv_gemm<64,64,flat>");
   }
   if (kernel_name) *kernel_name = nm;
   return flops;
@@ -403,6 +429,139 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad for small gathered-channel counts (C <= 16: the 3-channel image layers, the 8-channel first
+// MRU unit, the generator's 3-channel output): the GEMM M dimension is the FLATTENED (tap, c) index,
+// so dY is streamed once instead of once per tap.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_flatm_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
+  constexpr int BM = 64, BN = 64, BK = 16, LD = 64 + 16;
+  __shared__ __attribute__((aligned(16))) float At[BK * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
+  __shared__ int pinfo[2][BK][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int C = a.C, N = a.N, IH = a.IH, IW = a.IW;
+  const int TC = a.KH * a.KW * C;
+  const int ntn = (N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+  const int M = a.NB * a.OH * a.OW;
+  int chunk = (M + a.nsplit - 1) / a.nsplit;
+  chunk = (chunk + BK - 1) / BK * BK;
+  const int p_lo = blockIdx.y * chunk;
+  const int p_hi = min(M, p_lo + chunk);
+  // this thread's flattened (tap, c) column of A
+  const int mcol = m0 + (tid & 63);
+  const bool mv = mcol < TC;
+  const int tap = mv ? mcol / C : 0;
+  const int cch = mcol - tap * C;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const bool nvec = (N % 4 == 0) && (a.dy_ps % 4 == 0) && (((uintptr_t)a.dy & 15) == 0);
+
+  auto decode = [&](int p, int buf) {
+    if (tid < BK) {
+      const int m = p + tid;
+      int b = -1, iy0 = 0, ix0 = 0;
+      if (m < p_hi) {
+        const int ox = m % a.OW;
+        const int t2 = m / a.OW;
+        const int oy = t2 % a.OH;
+        b = (t2 / a.OH) * IH * IW;
+        iy0 = oy * a.S - a.pad;
+        ix0 = ox * a.S - a.pad;
+      }
+      pinfo[buf][tid][0] = b;
+      pinfo[buf][tid][1] = iy0;
+      pinfo[buf][tid][2] = ix0;
+    }
+  };
+  float ra[4];
+  float4 rb;
+  auto load_tile = [&](int p, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = (tid >> 6) + 4 * i;
+      const int b = pinfo[buf][k][0];
+      int iy = pinfo[buf][k][1] + kh, ix = pinfo[buf][k][2] + kw;
+      if (a.reflect) {
+        iy = reflect_idx(iy, IH);
+        ix = reflect_idx(ix, IW);
+      }
+      float v = 0.f;
+      if (mv && b >= 0 && iy >= 0 && iy < IH && ix >= 0 && ix < IW) v = a.x[(size_t)(b + iy * IW + ix) * a.x_ps + cch];
+      ra[i] = v;
+    }
+    const int k = tid >> 4, n = n0 + (tid & 15) * 4, m = p + k;
+    rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < p_hi) {
+      const float* row = a.dy + (size_t)m * a.dy_ps;
+      if (nvec && n + 3 < N) {
+        rb = *reinterpret_cast<const float4*>(row + n);
+      } else {
+        if (n < N) rb.x = row[n];
+        if (n + 1 < N) rb.y = row[n + 1];
+        if (n + 2 < N) rb.z = row[n + 2];
+        if (n + 3 < N) rb.w = row[n + 3];
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) At[((tid >> 6) + 4 * i) * LD + (tid & 63)] = ra[i];
+    *reinterpret_cast<float4*>(&Bs[(tid >> 4) * LD + (tid & 15) * 4]) = rb;
+  };
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, lq = lane >> 4;
+  if (p_lo < p_hi) {
+    decode(p_lo, 0);
+    __syncthreads();
+    load_tile(p_lo, 0);
+    int it = 0;
+    for (int p = p_lo; p < p_hi; p += BK, ++it) {
+      store_tile();
+      const bool more = p + BK < p_hi;
+      if (more) decode(p + BK, (it + 1) & 1);
+      __syncthreads();
+      if (more) load_tile(p + BK, (it + 1) & 1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        float af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = At[(kk * 4 + lq) * LD + wm * 32 + i * 16 + l15];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = Bs[(kk * 4 + lq) * LD + wn * 32 + j * 16 + l15];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 32 + i * 16 + lq * 4 + r;
+      if (m >= TC) continue;
+      const int t = m / C, c = m - t * C;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 32 + j * 16 + l15;
+        if (n >= N) continue;
+        if (dense_out)
+          out[((size_t)blockIdx.y * TC + m) * N + n] = acc[i][j][r];
+        else
+          out[(size_t)t * a.w_ts + (size_t)c * a.ldw + n] = acc[i][j][r];
+      }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int T, int C, int N,
                                     long long w_ts, int ldw, int nsplit, int accumulate) {
   const size_t total = (size_t)T * C * N;
@@ -419,8 +578,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 }
 
 static bool wgrad_big(const WgradArgs& a) { return a.C >= 128 && a.N >= 128; }
+static bool wgrad_flatm(const WgradArgs& a) { return a.C <= 16; }
 
 int wgrad_pick_splits(const WgradArgs& a) {
+  if (wgrad_flatm(a)) {
+    const long long tiles = (long long)((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64);
+    const long long M = (long long)a.NB * a.OH * a.OW;
+    long long s = (2048 + tiles - 1) / tiles;
+    const long long smax = (M + 511) / 512;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return (int)s;
+  }
   const int bm = wgrad_big(a) ? 128 : 64;
   const long long tiles = (long long)((a.C + bm - 1) / bm) * ((a.N + bm - 1) / bm) * a.KH * a.KW;
   const long long M = (long long)a.NB * a.OH * a.OW;
@@ -450,7 +620,11 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
   const bool vec = (a.C % 4 == 0) && (a.N % 4 == 0) && (a.x_ps % 4 == 0) && (a.dy_ps % 4 == 0) &&
                    (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
   const char* nm;
-  if (wgrad_big(a)) {
+  if (wgrad_flatm(a)) {
+    dim3 grid(((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64), a.nsplit);
+    hipLaunchKernelGGL(wgrad_flatm_kernel, grid, dim3(256), 0, s, a, out, dense);
+    nm = "wgrad_flatm<64,64>";
+  } else if (wgrad_big(a)) {
     if (vec) { wgrad_launch<128, 128, 64, 64, true>(a, out, dense, s); nm = "wgrad<128,128,vec>"; }
     else { wgrad_launch<128, 128, 64, 64, false>(a, out, dense, s); nm = "wgrad<128,128,flat>"; }
   } else {

@@ -11,6 +11,7 @@
 // Block = 256 threads = 64 channels x 4 pixel lanes, one block per (sample, 64-channel group):
 // a wave reads 256-byte channel rows (coalesced), reductions over the 4 pixel lanes go through LDS.
 #include "kernels.h"
+#include "cq_reduce.h"
 
 namespace eg {
 
@@ -174,22 +175,222 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_kernel(const float* __rest
     }
 }
 
+
+// =============================================================================================
+// Vectorised per-(n,c) kernels: block = CQ channel quads (float4 = 4 channels) x 256/CQ pixel
+// lanes; a wave reads CQ*16-byte contiguous channel runs of 64/CQ consecutive pixels; pixel-lane
+// reduction by xor-shuffles inside the wave, then across the 4 waves through LDS.  Used when
+// C % (4*CQ) == 0 (every IN / BN site of the model); the scalar kernels above remain the fallback.
+// =============================================================================================
+__device__ __forceinline__ float4 act4(float4 v, int act) {
+  return make_float4(act_apply(v.x, act), act_apply(v.y, act), act_apply(v.z, act), act_apply(v.w, act));
+}
+__device__ __forceinline__ float4 actg4(float4 o, int act) {
+  return make_float4(act_grad_from_out(o.x, act), act_grad_from_out(o.y, act), act_grad_from_out(o.z, act),
+                     act_grad_from_out(o.w, act));
+}
+
+template <int CQ>
+__global__ __launch_bounds__(256) void in_fwd_v(const float* __restrict__ x, float* __restrict__ out,
+                                                float* __restrict__ stats, int HW, int C, int act) {
+  constexpr int PL = 256 / CQ;
+  __shared__ float4 red[4 * CQ];
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+  const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
+  const float* xp = x + (size_t)n * HW * C + c;
+  float4 s[1] = {f4_zero()};
+  for (int p = pl; p < HW; p += PL) {
+    const float4 v = ld4(xp + (size_t)p * C);
+    s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+  }
+  cq_reduce<1, CQ>(s, red);
+  const float inv = 1.f / HW;
+  const float4 mean = make_float4(s[0].x * inv, s[0].y * inv, s[0].z * inv, s[0].w * inv);
+  float4 q[1] = {f4_zero()};
+  for (int p = pl; p < HW; p += PL) {
+    const float4 v = ld4(xp + (size_t)p * C);
+    const float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
+    q[0].x += dx * dx; q[0].y += dy * dy; q[0].z += dz * dz; q[0].w += dw * dw;
+  }
+  cq_reduce<1, CQ>(q, red);
+  const float4 sigma = make_float4(sqrtf(q[0].x * inv), sqrtf(q[0].y * inv), sqrtf(q[0].z * inv), sqrtf(q[0].w * inv));
+  const float4 r = make_float4(1.f / (sigma.x + IN_EPS), 1.f / (sigma.y + IN_EPS), 1.f / (sigma.z + IN_EPS),
+                               1.f / (sigma.w + IN_EPS));
+  float* op = out + (size_t)n * HW * C + c;
+  for (int p = pl; p < HW; p += PL) {
+    const float4 v = ld4(xp + (size_t)p * C);
+    st4(op + (size_t)p * C, act4(make_float4((v.x - mean.x) * r.x, (v.y - mean.y) * r.y, (v.z - mean.z) * r.z,
+                                             (v.w - mean.w) * r.w), act));
+  }
+  if (pl == 0) {
+    float* sp = stats + ((size_t)n * C + c) * 2;
+    sp[0] = mean.x; sp[1] = sigma.x; sp[2] = mean.y; sp[3] = sigma.y;
+    sp[4] = mean.z; sp[5] = sigma.z; sp[6] = mean.w; sp[7] = sigma.w;
+  }
+}
+
+struct Stat4 { float4 mean, sigma, r; };
+__device__ __forceinline__ Stat4 load_stats4(const float* stats, size_t nc) {
+  const float4 a = ld4(stats + nc * 2), b = ld4(stats + nc * 2 + 4);
+  Stat4 s;
+  s.mean = make_float4(a.x, a.z, b.x, b.z);
+  s.sigma = make_float4(a.y, a.w, b.y, b.w);
+  s.r = make_float4(1.f / (s.sigma.x + IN_EPS), 1.f / (s.sigma.y + IN_EPS), 1.f / (s.sigma.z + IN_EPS),
+                    1.f / (s.sigma.w + IN_EPS));
+  return s;
+}
+
+template <int MODE, int CQ>
+__global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, const float* __restrict__ out,
+                                                   const float* __restrict__ v, const float* __restrict__ stats,
+                                                   float* __restrict__ dst, int accumulate, int HW, int C, int act) {
+  constexpr int PL = 256 / CQ;
+  __shared__ float4 red[2 * 4 * CQ];
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+  const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
+  const size_t base = (size_t)n * HW * C + c;
+  const Stat4 st = load_stats4(stats, (size_t)n * C + c);
+  float4 s[2] = {f4_zero(), f4_zero()};
+  for (int p = pl; p < HW; p += PL) {
+    const size_t i = base + (size_t)p * C;
+    float4 e = ld4(v + i);
+    if (MODE == 0) {
+      const float4 g = actg4(ld4(out + i), act);
+      e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w;
+    }
+    const float4 xv = ld4(x + i);
+    s[0].x += e.x; s[0].y += e.y; s[0].z += e.z; s[0].w += e.w;
+    s[1].x += e.x * (xv.x - st.mean.x); s[1].y += e.y * (xv.y - st.mean.y);
+    s[1].z += e.z * (xv.z - st.mean.z); s[1].w += e.w * (xv.w - st.mean.w);
+  }
+  cq_reduce<2, CQ>(s, red);
+  const float hw = (float)HW;
+  const float4 eb = make_float4(s[0].x / hw, s[0].y / hw, s[0].z / hw, s[0].w / hw);
+  const float4 k2 = make_float4(st.r.x * st.r.x * s[1].x / (hw * st.sigma.x), st.r.y * st.r.y * s[1].y / (hw * st.sigma.y),
+                                st.r.z * st.r.z * s[1].z / (hw * st.sigma.z), st.r.w * st.r.w * s[1].w / (hw * st.sigma.w));
+  for (int p = pl; p < HW; p += PL) {
+    const size_t i = base + (size_t)p * C;
+    const float4 o = ld4(out + i);
+    const float4 g = actg4(o, act);
+    float4 e = ld4(v + i);
+    if (MODE == 0) { e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w; }
+    const float4 xv = ld4(x + i);
+    float4 res = make_float4(st.r.x * (e.x - eb.x) - k2.x * (xv.x - st.mean.x), st.r.y * (e.y - eb.y) - k2.y * (xv.y - st.mean.y),
+                             st.r.z * (e.z - eb.z) - k2.z * (xv.z - st.mean.z), st.r.w * (e.w - eb.w) - k2.w * (xv.w - st.mean.w));
+    if (MODE == 1) { res.x *= g.x; res.y *= g.y; res.z *= g.z; res.w *= g.w; }
+    if (accumulate) {
+      const float4 d = ld4(dst + i);
+      res.x += d.x; res.y += d.y; res.z += d.z; res.w += d.w;
+    }
+    st4(dst + i, res);
+  }
+}
+
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s) {
+  if (C % 32 == 0) {
+    hipLaunchKernelGGL(in_fwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, out, stats, HW, C, act);
+    return;
+  }
+
   hipLaunchKernelGGL(in_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, stats, HW, C, act);
 }
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
                    int accumulate, int NB, int HW, int C, int act, hipStream_t s) {
+  if (C % 32 == 0) {
+    hipLaunchKernelGGL((in_japply_v<0, 8>), dim3(NB, C / 32), dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW,
+                       C, act);
+    return;
+  }
   hipLaunchKernelGGL(in_japply_kernel<0>, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, dout, stats, dx,
                      accumulate, HW, C, act);
 }
 void launch_in_tangent_fwd(const float* x, const float* out, const float* stats, const float* tx, float* tout,
                            int NB, int HW, int C, int act, hipStream_t s) {
+  if (C % 32 == 0) {
+    hipLaunchKernelGGL((in_japply_v<1, 8>), dim3(NB, C / 32), dim3(256), 0, s, x, out, tx, stats, tout, 0, HW, C, act);
+    return;
+  }
   hipLaunchKernelGGL(in_japply_kernel<1>, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, tx, stats, tout, 0, HW,
                      C, act);
 }
+template <int CQ>
+__global__ __launch_bounds__(256) void in_tangent_bwd_v(const float* __restrict__ x, const float* __restrict__ out,
+                                                        const float* __restrict__ stats, const float* __restrict__ tx,
+                                                        const float* __restrict__ dtout, float* __restrict__ dtx,
+                                                        int acc_dtx, float* __restrict__ dx, int acc_dx, int HW, int C,
+                                                        int act) {
+  constexpr int PL = 256 / CQ;
+  __shared__ float4 red[3 * 4 * CQ];
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+  const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
+  const size_t base = (size_t)n * HW * C + c;
+  const Stat4 st = load_stats4(stats, (size_t)n * C + c);
+  float4 m[2] = {f4_zero(), f4_zero()};
+  for (int p = pl; p < HW; p += PL) {
+    const size_t i = base + (size_t)p * C;
+    const float4 g = actg4(ld4(out + i), act), d = ld4(dtout + i), t = ld4(tx + i);
+    m[0].x += d.x * g.x; m[0].y += d.y * g.y; m[0].z += d.z * g.z; m[0].w += d.w * g.w;
+    m[1].x += t.x; m[1].y += t.y; m[1].z += t.z; m[1].w += t.w;
+  }
+  cq_reduce<2, CQ>(m, red);
+  const float hw = (float)HW;
+  const float4 eb = make_float4(m[0].x / hw, m[0].y / hw, m[0].z / hw, m[0].w / hw);
+  const float4 ta = make_float4(m[1].x / hw, m[1].y / hw, m[1].z / hw, m[1].w / hw);
+  float4 s[3] = {f4_zero(), f4_zero(), f4_zero()};  // sum (e-eb)(t-ta), sum xc*t, sum e*xc
+  for (int p = pl; p < HW; p += PL) {
+    const size_t i = base + (size_t)p * C;
+    const float4 g = actg4(ld4(out + i), act), d = ld4(dtout + i), t = ld4(tx + i), xv = ld4(x + i);
+    const float ex = d.x * g.x, ey = d.y * g.y, ez = d.z * g.z, ew = d.w * g.w;
+    const float cx = xv.x - st.mean.x, cy = xv.y - st.mean.y, cz = xv.z - st.mean.z, cw = xv.w - st.mean.w;
+    s[0].x += (ex - eb.x) * (t.x - ta.x); s[0].y += (ey - eb.y) * (t.y - ta.y);
+    s[0].z += (ez - eb.z) * (t.z - ta.z); s[0].w += (ew - eb.w) * (t.w - ta.w);
+    s[1].x += cx * t.x; s[1].y += cy * t.y; s[1].z += cz * t.z; s[1].w += cw * t.w;
+    s[2].x += ex * cx; s[2].y += ey * cy; s[2].z += ez * cz; s[2].w += ew * cw;
+  }
+  cq_reduce<3, CQ>(s, red);
+  float c1[4], c2[4], c3[4], k2[4];
+  {
+    const float A_[4] = {s[0].x, s[0].y, s[0].z, s[0].w}, Sxt[4] = {s[1].x, s[1].y, s[1].z, s[1].w},
+                Sex[4] = {s[2].x, s[2].y, s[2].z, s[2].w}, sg[4] = {st.sigma.x, st.sigma.y, st.sigma.z, st.sigma.w},
+                rr[4] = {st.r.x, st.r.y, st.r.z, st.r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float B = Sxt[j] * Sex[j] / hw, r2 = rr[j] * rr[j];
+      c1[j] = (-A_[j] * r2 + 2.f * r2 * rr[j] * B / sg[j] + r2 * B / (sg[j] * sg[j])) / (hw * sg[j]);
+      c2[j] = -r2 * Sex[j] / (hw * sg[j]);
+      c3[j] = -r2 * Sxt[j] / (hw * sg[j]);
+      k2[j] = r2 * Sex[j] / (hw * sg[j]);
+    }
+  }
+  for (int p = pl; p < HW; p += PL) {
+    const size_t i = base + (size_t)p * C;
+    const float4 g = actg4(ld4(out + i), act), d = ld4(dtout + i), t = ld4(tx + i), xv = ld4(x + i);
+    const float e[4] = {d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w};
+    const float xc[4] = {xv.x - st.mean.x, xv.y - st.mean.y, xv.z - st.mean.z, xv.w - st.mean.w};
+    const float tt[4] = {t.x, t.y, t.z, t.w}, ebv[4] = {eb.x, eb.y, eb.z, eb.w}, tav[4] = {ta.x, ta.y, ta.z, ta.w},
+                rr[4] = {st.r.x, st.r.y, st.r.z, st.r.w};
+    float gt[4], gx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gt[j] = rr[j] * (e[j] - ebv[j]) - k2[j] * xc[j];
+      gx[j] = c1[j] * xc[j] + c2[j] * (tt[j] - tav[j]) + c3[j] * (e[j] - ebv[j]);
+    }
+    float4 o1 = make_float4(gt[0], gt[1], gt[2], gt[3]), o2 = make_float4(gx[0], gx[1], gx[2], gx[3]);
+    if (acc_dtx) { const float4 a = ld4(dtx + i); o1.x += a.x; o1.y += a.y; o1.z += a.z; o1.w += a.w; }
+    if (acc_dx) { const float4 a = ld4(dx + i); o2.x += a.x; o2.y += a.y; o2.z += a.z; o2.w += a.w; }
+    st4(dtx + i, o1);
+    st4(dx + i, o2);
+  }
+}
+
 void launch_in_tangent_bwd(const float* x, const float* out, const float* stats, const float* tx,
                            const float* dtout, float* dtx, int acc_dtx, float* dx, int acc_dx, int NB, int HW,
                            int C, int act, hipStream_t s) {
+  if (C % 32 == 0) {
+    hipLaunchKernelGGL(in_tangent_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, out, stats, tx, dtout, dtx, acc_dtx,
+                       dx, acc_dx, HW, C, act);
+    return;
+  }
   hipLaunchKernelGGL(in_tangent_bwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, stats, tx, dtout, dtx,
                      acc_dtx, dx, acc_dx, HW, C, act);
 }

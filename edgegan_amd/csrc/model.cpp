@@ -222,7 +222,7 @@ void build_context(Ctx& c) {
     EG_HIP(hipMalloc(&c.sn_table, tab.size() * sizeof(SNDesc)));
     EG_HIP(hipMemcpy(c.sn_table, tab.data(), tab.size() * sizeof(SNDesc), hipMemcpyHostToDevice));
   }
-  c.scratch_floats = (size_t)128 * 16384;
+  c.scratch_floats = (size_t)256 * 16384;
   EG_HIP(hipMalloc(&c.scratch, c.scratch_floats * 4));
   const size_t img = (size_t)cfg.B * cfg.H * cfg.W * cfg.c_dim;
   EG_HIP(hipMalloc(&c.d_images, img * 4));
