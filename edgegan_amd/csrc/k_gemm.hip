@@ -27,14 +27,14 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // =============================================================================================
 // conv_gemm_kernel
 // =============================================================================================
-template <int BM, int BN, int WTM, int WTN, bool VEC, bool BVEC>
+template <int BM, int BN, int WTM, int WTN, int BK, bool VEC, bool BVEC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
-  constexpr int BK = 16;
   constexpr int LDA = BK + 4;
   constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 32);
   constexpr int WGN = BN / WTN;
   constexpr int MI = WTM / 16, NJ = WTN / 16;
   static_assert((BM / WTM) * (BN / WTN) == 4, "4 waves");
+  static_assert(VEC || (!BVEC && BK == 16), "flat-K path: scalar loads, K step 16");
   __shared__ __attribute__((aligned(16))) float As[BM * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
 
@@ -47,11 +47,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
   const int IH = a.IH, IW = a.IW, C = a.C, N = a.N;
 
   // ---- per-thread A-row bookkeeping --------------------------------------------------------
-  constexpr int A_ROWS = VEC ? (BM / 64) : (BM / 16);
+  constexpr int Q = BK / 4;                        // float4 per A row (VEC)
+  constexpr int A_V = (BM * Q) / 256;              // float4 per thread (VEC)
+  constexpr int B_V = (BK * BN / 4 + 255) / 256;   // float4 per thread (BVEC)
+  constexpr int A_S = BM / 16;                     // scalars per thread (FLAT)
+  constexpr int B_S = (BK / 16) * (BN / 16);       // scalars per thread (!BVEC)
+  constexpr int A_ROWS = VEC ? A_V : A_S;
   int r_iy0[A_ROWS], r_ix0[A_ROWS], r_base[A_ROWS];
 #pragma unroll
   for (int i = 0; i < A_ROWS; ++i) {
-    const int r = VEC ? ((tid >> 2) + 64 * i) : ((tid >> 4) + 16 * i);
+    const int r = VEC ? (tid / Q + (256 / Q) * i) : ((tid >> 4) + 16 * i);
     const int m = m0 + r;
     if (m < M) {
       const int ox = m % ph.OWp;
@@ -72,13 +77,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
   const int Kflat = ntaps * C;
   const int nk = VEC ? ntaps * (C / BK) : (Kflat + BK - 1) / BK;
 
-  constexpr int A_V = BM / 64;                     // float4 per thread (VEC)
-  constexpr int B_V = (4 * BN + 255) / 256;        // float4 per thread (VEC)
-  constexpr int A_S = BM / 16;                     // scalars per thread (FLAT)
-  constexpr int B_S = BN / 16;
   float4 ra4[VEC ? A_V : 1], rb4[BVEC ? B_V : 1];
   float ras[VEC ? 1 : A_S], rbs[BVEC ? 1 : B_S];
-  static_assert(VEC || !BVEC, "BVEC needs the tap-tiled K order");
 
   auto gather_ok = [&](int base, int& iy, int& ix) -> bool {
     if (a.reflect) {
@@ -88,14 +88,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     return base >= 0 && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
   };
 
+  // position of the NEXT tile to load in the tap-tiled K order (no divisions in the loop)
+  int nx_ty = 0, nx_tx = 0, nx_c0 = 0;
+
   auto load_tile = [&](int kt) {
     if constexpr (VEC) {
-      const int cpt = C / BK;
-      const int tap = kt / cpt;
-      const int c0 = (kt - tap * cpt) * BK;
-      const int ty = tap / ph.Tx, tx = tap - ty * ph.Tx;
+      const int ty = nx_ty, tx = nx_tx, c0 = nx_c0;
       const long long wt = (long long)((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * a.w_ts;
-      const int kq = tid & 3;
+      const int kq = tid % Q;
 #pragma unroll
       for (int i = 0; i < A_V; ++i) {
         int iy = r_iy0[i] + ty * a.D, ix = r_ix0[i] + tx * a.D;
@@ -109,18 +109,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
         for (int i = 0; i < B_V; ++i) {
           const int idx = tid + 256 * i;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (idx < 4 * BN) {
+          if (idx < BK * BN / 4) {
             const int k = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
             if (n < N) v = *reinterpret_cast<const float4*>(a.wgt + wt + (size_t)(c0 + k) * a.ldw + n);
           }
           rb4[i] = v;
         }
       } else {  // 16-byte A gathers, scalar filter loads (Cout not a multiple of 4, e.g. the 3-channel image)
-        const float* wrow = a.wgt + wt + (size_t)(c0 + (tid >> 4)) * a.ldw;
 #pragma unroll
         for (int j = 0; j < B_S; ++j) {
-          const int n = n0 + (tid & 15) + 16 * j;
-          rbs[j] = n < N ? wrow[n] : 0.f;
+          const int kk = (tid >> 4) + 16 * (j / (BN / 16));
+          const int n = n0 + (tid & 15) + 16 * (j % (BN / 16));
+          rbs[j] = n < N ? a.wgt[wt + (size_t)(c0 + kk) * a.ldw + n] : 0.f;
+        }
+      }
+      nx_c0 += BK;
+      if (nx_c0 >= C) {
+        nx_c0 = 0;
+        if (++nx_tx == ph.Tx) {
+          nx_tx = 0;
+          ++nx_ty;
         }
       }
     } else {
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     if constexpr (VEC) {
 #pragma unroll
       for (int i = 0; i < A_V; ++i)
-        *reinterpret_cast<float4*>(&As[((tid >> 2) + 64 * i) * LDA + (tid & 3) * 4]) = ra4[i];
+        *reinterpret_cast<float4*>(&As[(tid / Q + (256 / Q) * i) * LDA + (tid % Q) * 4]) = ra4[i];
     } else {
 #pragma unroll
       for (int i = 0; i < A_S; ++i) As[((tid >> 4) + 16 * i) * LDA + (tid & 15)] = ras[i];
@@ -167,11 +175,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < B_V; ++i) {
         const int idx = tid + 256 * i;
-        if (idx < 4 * BN) *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4]) = rb4[i];
+        if (idx < BK * BN / 4) *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4]) = rb4[i];
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < B_S; ++j) Bs[(tid >> 4) * LDB + (tid & 15) + 16 * j] = rbs[j];
+      for (int j = 0; j < B_S; ++j)
+        Bs[((tid >> 4) + 16 * (j / (BN / 16))) * LDB + (tid & 15) + 16 * (j % (BN / 16))] = rbs[j];
     }
   };
 
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     __syncthreads();
     if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < BK / 4; ++kk) {
       float af[MI], bf[NJ];
 #pragma unroll
       for (int i = 0; i < MI; ++i) af[i] = As[(wm * WTM + i * 16 + l15) * LDA + kk * 4 + lq];
@@ -228,18 +237,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
   }
 }
 
-template <int BM, int BN, int WTM, int WTN, bool VEC, bool BVEC>
+template <int BM, int BN, int WTM, int WTN, int BK, bool VEC, bool BVEC>
 static void conv_launch(const ConvArgs& a, int maxM, hipStream_t s) {
   dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, VEC, BVEC>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, BK, VEC, BVEC>), grid, dim3(256), 0, s, a);
 }
 
+// k32: C % 32 == 0 -> K step 32 (half the barriers / address arithmetic per MFMA)
 template <int BM, int BN, int WTM, int WTN>
 static const char* conv_dispatch(const ConvArgs& a, int maxM, bool avec, bool bvec, hipStream_t s, const char* nv,
                                  const char* nav, const char* nf) {
-  if (avec && bvec) { conv_launch<BM, BN, WTM, WTN, true, true>(a, maxM, s); return nv; }
-  if (avec) { conv_launch<BM, BN, WTM, WTN, true, false>(a, maxM, s); return nav; }
-  conv_launch<BM, BN, WTM, WTN, false, false>(a, maxM, s);
+  const bool k32 = (a.C % 32 == 0);
+  if (avec && bvec) {
+    if (k32) conv_launch<BM, BN, WTM, WTN, 32, true, true>(a, maxM, s);
+    else conv_launch<BM, BN, WTM, WTN, 16, true, true>(a, maxM, s);
+    return nv;
+  }
+  if (avec) {
+    if (k32) conv_launch<BM, BN, WTM, WTN, 32, true, false>(a, maxM, s);
+    else conv_launch<BM, BN, WTM, WTN, 16, true, false>(a, maxM, s);
+    return nav;
+  }
+  conv_launch<BM, BN, WTM, WTN, 16, false, false>(a, maxM, s);
   return nf;
 }
 
@@ -262,7 +281,7 @@ double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_na
     else
       nm = conv_dispatch<64, 16, 16, 16>(a, maxM, avec, bvec, s, "conv_gemm<64,16,vec>", "conv_gemm<64,16,avec>",
                                          "conv_gemm<64,16,flat>");
-  } else if (a.N >= 128 && blocks128 >= 512) {
+  } else if (a.N >= 128 && blocks128 >= 240) {
     nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s, "conv_gemm<128,128,vec>", "conv_gemm<128,128,avec>",
                                          "conv_gemm<128,128,flat>");
   } else {
@@ -276,15 +295,16 @@ double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_na
 // =============================================================================================
 // wgrad_kernel
 // =============================================================================================
-template <int BM, int BN, int WTM, int WTN, bool VEC>
+template <int BM, int BN, int WTM, int WTN, int BK, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
-  constexpr int BK = 16;
   constexpr int LDA = BM + ((BM % 32 == 0) ? 16 : 32);
   constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 32);
   constexpr int WGN = BN / WTN;
   constexpr int MI = WTM / 16, NJ = WTN / 16;
+  static_assert(VEC || BK == 16, "scalar path uses K step 16");
   __shared__ __attribute__((aligned(16))) float At[BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  __shared__ long long poff[2][BK];   // gathered-pixel offset (floats) of each K row, -1 if outside
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -299,36 +319,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __
   const int p_lo = blockIdx.z * chunk;
   const int p_hi = min(M, p_lo + chunk);
 
-  constexpr int A_V = (4 * BM + 255) / 256, B_V = (4 * BN + 255) / 256;
+  constexpr int A_V = (BK * BM / 4 + 255) / 256, B_V = (BK * BN / 4 + 255) / 256;
   constexpr int A_S = BM / 16, B_S = BN / 16;
   float4 ra4[VEC ? A_V : 1], rb4[VEC ? B_V : 1];
   float ras[VEC ? 1 : A_S], rbs[VEC ? 1 : B_S];
 
-  // pixel m -> offset of the gathered input pixel for this tap (or -1)
-  auto gather_pix = [&](int m) -> long long {
-    if (m >= p_hi) return -1;
-    const int ox = m % a.OW;
-    const int t2 = m / a.OW;
-    const int oy = t2 % a.OH;
-    const int nb = t2 / a.OH;
-    int iy = oy * a.S + kh - a.pad, ix = ox * a.S + kw - a.pad;
-    if (a.reflect) {
-      iy = reflect_idx(iy, IH);
-      ix = reflect_idx(ix, IW);
+  // one thread per K row decodes the pixel once for the whole block
+  auto decode = [&](int p, int buf) {
+    if (tid < BK) {
+      const int m = p + tid;
+      long long off = -1;
+      if (m < p_hi) {
+        const int ox = m % a.OW;
+        const int t2 = m / a.OW;
+        const int oy = t2 % a.OH;
+        const int nb = t2 / a.OH;
+        int iy = oy * a.S + kh - a.pad, ix = ox * a.S + kw - a.pad;
+        if (a.reflect) {
+          iy = reflect_idx(iy, IH);
+          ix = reflect_idx(ix, IW);
+        }
+        if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) off = (long long)((nb * IH + iy) * IW + ix) * a.x_ps;
+      }
+      poff[buf][tid] = off;
     }
-    if (iy < 0 || iy >= IH || ix < 0 || ix >= IW) return -1;
-    return (long long)((nb * IH + iy) * IW + ix) * a.x_ps;
   };
 
-  auto load_tile = [&](int p) {
+  auto load_tile = [&](int p, int buf) {
     if constexpr (VEC) {
 #pragma unroll
       for (int i = 0; i < A_V; ++i) {
         const int idx = tid + 256 * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < 4 * BM) {
+        if (idx < BK * BM / 4) {
           const int k = idx / (BM / 4), c = c0 + (idx % (BM / 4)) * 4;
-          const long long off = gather_pix(p + k);
+          const long long off = poff[buf][k];
           if (off >= 0 && c < C) v = *reinterpret_cast<const float4*>(a.x + off + c);
         }
         ra4[i] = v;
@@ -337,7 +362,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __
       for (int i = 0; i < B_V; ++i) {
         const int idx = tid + 256 * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < 4 * BN) {
+        if (idx < BK * BN / 4) {
           const int k = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
           const int m = p + k;
           if (m < p_hi && n < N) v = *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.dy_ps + n);
@@ -347,7 +372,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __
     } else {
       const int k = tid >> 4;
       const int m = p + k;
-      const long long off = gather_pix(m);
+      const long long off = poff[buf][k];
 #pragma unroll
       for (int j = 0; j < A_S; ++j) {
         const int c = c0 + (tid & 15) + 16 * j;
@@ -365,12 +390,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __
 #pragma unroll
       for (int i = 0; i < A_V; ++i) {
         const int idx = tid + 256 * i;
-        if (idx < 4 * BM) *reinterpret_cast<float4*>(&At[(idx / (BM / 4)) * LDA + (idx % (BM / 4)) * 4]) = ra4[i];
+        if (idx < BK * BM / 4) *reinterpret_cast<float4*>(&At[(idx / (BM / 4)) * LDA + (idx % (BM / 4)) * 4]) = ra4[i];
       }
 #pragma unroll
       for (int i = 0; i < B_V; ++i) {
         const int idx = tid + 256 * i;
-        if (idx < 4 * BN) *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4]) = rb4[i];
+        if (idx < BK * BN / 4) *reinterpret_cast<float4*>(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4]) = rb4[i];
       }
     } else {
 #pragma unroll
@@ -388,13 +413,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __
 
   const int l15 = lane & 15, lq = lane >> 4;
   if (p_lo < p_hi) {
-    load_tile(p_lo);
-    for (int p = p_lo; p < p_hi; p += BK) {
+    decode(p_lo, 0);
+    __syncthreads();
+    load_tile(p_lo, 0);
+    int it = 0;
+    for (int p = p_lo; p < p_hi; p += BK, ++it) {
       store_tile();
+      const bool more = p + BK < p_hi;
+      if (more) decode(p + BK, (it + 1) & 1);
       __syncthreads();
-      if (p + BK < p_hi) load_tile(p + BK);
+      if (more) load_tile(p + BK, (it + 1) & 1);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < BK / 4; ++kk) {
         float af[MI], bf[NJ];
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = At[(kk * 4 + lq) * LDA + wm * WTM + i * 16 + l15];
@@ -610,7 +640,10 @@ size_t wgrad_workspace_floats(const WgradArgs& a) {
 template <int BM, int BN, int WTM, int WTN, bool VEC>
 static void wgrad_launch(const WgradArgs& a, float* out, int dense, hipStream_t s) {
   dim3 grid(((a.C + BM - 1) / BM) * ((a.N + BN - 1) / BN), a.KH * a.KW, a.nsplit);
-  hipLaunchKernelGGL((wgrad_kernel<BM, BN, WTM, WTN, VEC>), grid, dim3(256), 0, s, a, out, dense);
+  if constexpr (VEC)
+    hipLaunchKernelGGL((wgrad_kernel<BM, BN, WTM, WTN, 32, true>), grid, dim3(256), 0, s, a, out, dense);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<BM, BN, WTM, WTN, 16, false>), grid, dim3(256), 0, s, a, out, dense);
 }
 
 double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name) {
