@@ -158,7 +158,7 @@ int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long 
   EG_CHECK((size_t)numel == n, "size mismatch for %s: got %lld, want %zu", name, numel, n);
   EG_HIP(hipMemcpyAsync(d, host, n * 4, hipMemcpyHostToDevice, ctx->c.stream));
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
-  ctx->c.sn_prepared = false;
+  ctx->c.sn_valid = false;
   EG_API_END(ctx)
 }
 

@@ -77,7 +77,8 @@ struct Ctx {
   std::deque<WRef> wrefs;
   std::map<const void*, WRef*> wref_cache;
   std::deque<bool> flags;   // stable storage for ad-hoc gradient-present flags
-  bool sn_prepared = false;
+  bool sn_prepared = false;   // tape entry for the SN backward pushed in this sub-step
+  bool sn_valid = false;      // Wbar buffers match the current D2 weights (persists across sub-steps)
   bool param_grad_enabled = true;
   float* scratch = nullptr;  // persistent reduction scratch
   size_t scratch_floats = 0;

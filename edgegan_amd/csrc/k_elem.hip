@@ -137,12 +137,20 @@ __global__ __launch_bounds__(256) void col_sum_stage1(const float* __restrict__ 
   __syncthreads();
   if (py == 0 && c < C) part[(size_t)blockIdx.y * C + c] = red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx];
 }
-__global__ void col_sum_stage2(const float* __restrict__ part, float* __restrict__ db, int acc, int C, int nrb) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void col_sum_stage2(const float* __restrict__ part, float* __restrict__ db, int acc,
+                                                      int C, int nrb) {
+  __shared__ float red[4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int b = 0; b < nrb; ++b) s += part[(size_t)b * C + c];
-  db[c] = acc ? db[c] + s : s;
+  if (c < C)
+    for (int b = py; b < nrb; b += 4) s += part[(size_t)b * C + c];
+  red[py * 64 + cx] = s;
+  __syncthreads();
+  if (py == 0 && c < C) {
+    const float t = (red[cx] + red[64 + cx]) + (red[128 + cx] + red[192 + cx]);
+    db[c] = acc ? db[c] + t : t;
+  }
 }
 // float4 variant: block = 8 channel quads x 32 row lanes, more row blocks
 __global__ __launch_bounds__(256) void col_sum_stage1_v(const float* __restrict__ dy, float* __restrict__ part, size_t R,
@@ -169,7 +177,7 @@ void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C,
     hipLaunchKernelGGL(col_sum_stage1_v, dim3(C / 32, nrb), dim3(256), 0, s, dy, scratch, R, C);
   else
     hipLaunchKernelGGL(col_sum_stage1, dim3((C + 63) / 64, nrb), dim3(256), 0, s, dy, scratch, R, C);
-  hipLaunchKernelGGL(col_sum_stage2, dim3((C + 255) / 256), dim3(256), 0, s, scratch, db, accumulate, C, nrb);
+  hipLaunchKernelGGL(col_sum_stage2, dim3((C + 63) / 64), dim3(256), 0, s, scratch, db, accumulate, C, nrb);
 }
 
 __global__ void bias_add_kernel(float* __restrict__ y, const float* __restrict__ b, int C, size_t n) {

@@ -281,12 +281,24 @@ double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_na
     else
       nm = conv_dispatch<64, 16, 16, 16>(a, maxM, avec, bvec, s, "conv_gemm<64,16,vec>", "conv_gemm<64,16,avec>",
                                          "conv_gemm<64,16,flat>");
-  } else if (a.N >= 128 && blocks128 >= 240) {
-    nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s, "conv_gemm<128,128,vec>", "conv_gemm<128,128,avec>",
-                                         "conv_gemm<128,128,flat>");
   } else {
-    nm = conv_dispatch<64, 64, 32, 32>(a, maxM, avec, bvec, s, "conv_gemm<64,64,vec>", "conv_gemm<64,64,avec>",
-                                       "conv_gemm<64,64,flat>");
+    // pick the tile by block-round quantisation: 128x128 runs 3 blocks/CU (768 slots), 64x64 8 blocks/CU
+    // (2048 slots) at ~0.78 of the big tile's per-block efficiency
+    const long long t128 = blocks128;
+    const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase;
+    auto rounds_eff = [](long long tiles, long long slots, double fill_at) {
+      if (tiles <= slots) return tiles >= fill_at ? 1.0 : (double)tiles / fill_at;
+      const long long r = (tiles + slots - 1) / slots;
+      return (double)tiles / (double)(r * slots);
+    };
+    const double e128 = a.N >= 128 ? 0.95 * rounds_eff(t128, 768, 256.0) : 0.0;
+    const double e64 = 0.78 * rounds_eff(t64, 2048, 512.0);
+    if (e128 >= e64)
+      nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s, "conv_gemm<128,128,vec>", "conv_gemm<128,128,avec>",
+                                           "conv_gemm<128,128,flat>");
+    else
+      nm = conv_dispatch<64, 64, 32, 32>(a, maxM, avec, bvec, s, "conv_gemm<64,64,vec>", "conv_gemm<64,64,avec>",
+                                         "conv_gemm<64,64,flat>");
   }
   if (kernel_name) *kernel_name = nm;
   return flops;
@@ -451,10 +463,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __
       for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wn * WTN + j * 16 + l15;
         if (n >= N) continue;
-        if (dense_out)  // partial slab [split][T][C][N]
+        if (dense_out) {  // partial slab [split][T][C][N]
           out[(((size_t)blockIdx.z * T + tap) * C + c) * N + n] = acc[i][j][r];
-        else
-          out[(size_t)tap * a.w_ts + (size_t)c * a.ldw + n] = acc[i][j][r];
+        } else {
+          float* q = out + (size_t)tap * a.w_ts + (size_t)c * a.ldw + n;
+          *q = a.accumulate ? *q + acc[i][j][r] : acc[i][j][r];
+        }
       }
     }
 }
@@ -584,10 +598,12 @@ __global__ __launch_bounds__(256) void wgrad_flatm_kernel(const WgradArgs a, flo
       for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 32 + j * 16 + l15;
         if (n >= N) continue;
-        if (dense_out)
+        if (dense_out) {
           out[((size_t)blockIdx.y * TC + m) * N + n] = acc[i][j][r];
-        else
-          out[(size_t)t * a.w_ts + (size_t)c * a.ldw + n] = acc[i][j][r];
+        } else {
+          float* q = out + (size_t)t * a.w_ts + (size_t)c * a.ldw + n;
+          *q = a.accumulate ? *q + acc[i][j][r] : acc[i][j][r];
+        }
       }
     }
 }
@@ -624,7 +640,7 @@ int wgrad_pick_splits(const WgradArgs& a) {
   const int bm = wgrad_big(a) ? 128 : 64;
   const long long tiles = (long long)((a.C + bm - 1) / bm) * ((a.N + bm - 1) / bm) * a.KH * a.KW;
   const long long M = (long long)a.NB * a.OH * a.OW;
-  long long s = (1024 + tiles - 1) / tiles;
+  long long s = (768 + tiles - 1) / tiles;
   const long long smax = (M + 255) / 256;
   if (s > smax) s = smax;
   if (s < 1) s = 1;
@@ -633,7 +649,7 @@ int wgrad_pick_splits(const WgradArgs& a) {
 }
 
 size_t wgrad_workspace_floats(const WgradArgs& a) {
-  if (a.nsplit == 1 && !a.accumulate) return 0;
+  if (a.nsplit == 1) return 0;
   return (size_t)a.nsplit * a.KH * a.KW * a.C * a.N;
 }
 
@@ -647,7 +663,7 @@ static void wgrad_launch(const WgradArgs& a, float* out, int dense, hipStream_t 
 }
 
 double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name) {
-  const bool direct = (a.nsplit == 1 && !a.accumulate);
+  const bool direct = (a.nsplit == 1);
   float* out = direct ? a.dw : a.ws;
   const int dense = direct ? 0 : 1;
   const bool vec = (a.C % 4 == 0) && (a.N % 4 == 0) && (a.x_ps % 4 == 0) && (a.dy_ps % 4 == 0) &&

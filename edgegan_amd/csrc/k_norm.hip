@@ -511,13 +511,111 @@ __global__ void bn_moving_kernel(float* mm, float* mv, const float* stats, int C
   mv[c] = b;
 }
 
+// float4 variants (C % 32 == 0): 8 channel quads x 32 row lanes per block
+__global__ __launch_bounds__(256) void bn_relu_fwd_v(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ out,
+                                                     float* __restrict__ stats, int R, int C, float eps) {
+  __shared__ float4 red[4 * 8];
+  const int cq = threadIdx.x % 8, pl = threadIdx.x / 8;
+  const int c = (blockIdx.x * 8 + cq) * 4;
+  float4 s[1] = {f4_zero()};
+  for (int p = pl; p < R; p += 32) {
+    const float4 v = ld4(x + (size_t)p * C + c);
+    s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+  }
+  cq_reduce<1, 8>(s, red);
+  const float4 mean = make_float4(s[0].x / R, s[0].y / R, s[0].z / R, s[0].w / R);
+  float4 q[1] = {f4_zero()};
+  for (int p = pl; p < R; p += 32) {
+    const float4 v = ld4(x + (size_t)p * C + c);
+    const float a = v.x - mean.x, b = v.y - mean.y, d = v.z - mean.z, e = v.w - mean.w;
+    q[0].x += a * a; q[0].y += b * b; q[0].z += d * d; q[0].w += e * e;
+  }
+  cq_reduce<1, 8>(q, red);
+  const float4 var = make_float4(q[0].x / R, q[0].y / R, q[0].z / R, q[0].w / R);
+  const float4 g = ld4(gamma + c), b = ld4(beta + c);
+  const float4 sc = make_float4(g.x / sqrtf(var.x + eps), g.y / sqrtf(var.y + eps), g.z / sqrtf(var.z + eps),
+                                g.w / sqrtf(var.w + eps));
+  for (int p = pl; p < R; p += 32) {
+    const float4 v = ld4(x + (size_t)p * C + c);
+    st4(out + (size_t)p * C + c,
+        make_float4(fmaxf((v.x - mean.x) * sc.x + b.x, 0.f), fmaxf((v.y - mean.y) * sc.y + b.y, 0.f),
+                    fmaxf((v.z - mean.z) * sc.z + b.z, 0.f), fmaxf((v.w - mean.w) * sc.w + b.w, 0.f)));
+  }
+  if (pl == 0) {
+    st4(stats + c, mean);
+    st4(stats + C + c, var);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_v(const float* __restrict__ x, const float* __restrict__ out,
+                                                     const float* __restrict__ dout, const float* __restrict__ gamma,
+                                                     const float* __restrict__ stats, float* __restrict__ dx, int acc_dx,
+                                                     float* __restrict__ dgamma, int acc_dg, float* __restrict__ dbeta,
+                                                     int acc_db, int R, int C, float eps) {
+  __shared__ float4 red[2 * 4 * 8];
+  const int cq = threadIdx.x % 8, pl = threadIdx.x / 8;
+  const int c = (blockIdx.x * 8 + cq) * 4;
+  const float4 mean = ld4(stats + c), var = ld4(stats + C + c);
+  const float4 rs = make_float4(1.f / sqrtf(var.x + eps), 1.f / sqrtf(var.y + eps), 1.f / sqrtf(var.z + eps),
+                                1.f / sqrtf(var.w + eps));
+  float4 s[2] = {f4_zero(), f4_zero()};
+  for (int p = pl; p < R; p += 32) {
+    const size_t i = (size_t)p * C + c;
+    const float4 o = ld4(out + i), d = ld4(dout + i), v = ld4(x + i);
+    const float e0 = o.x > 0.f ? d.x : 0.f, e1 = o.y > 0.f ? d.y : 0.f, e2 = o.z > 0.f ? d.z : 0.f,
+                e3 = o.w > 0.f ? d.w : 0.f;
+    s[0].x += e0; s[0].y += e1; s[0].z += e2; s[0].w += e3;
+    s[1].x += e0 * (v.x - mean.x) * rs.x; s[1].y += e1 * (v.y - mean.y) * rs.y;
+    s[1].z += e2 * (v.z - mean.z) * rs.z; s[1].w += e3 * (v.w - mean.w) * rs.w;
+  }
+  cq_reduce<2, 8>(s, red);
+  const float4 g = ld4(gamma + c);
+  const float4 me = make_float4(s[0].x / R, s[0].y / R, s[0].z / R, s[0].w / R);
+  const float4 mex = make_float4(s[1].x / R, s[1].y / R, s[1].z / R, s[1].w / R);
+  if (dx)
+    for (int p = pl; p < R; p += 32) {
+      const size_t i = (size_t)p * C + c;
+      const float4 o = ld4(out + i), d = ld4(dout + i), v = ld4(x + i);
+      const float e0 = o.x > 0.f ? d.x : 0.f, e1 = o.y > 0.f ? d.y : 0.f, e2 = o.z > 0.f ? d.z : 0.f,
+                  e3 = o.w > 0.f ? d.w : 0.f;
+      float4 r = make_float4(g.x * rs.x * (e0 - me.x - (v.x - mean.x) * rs.x * mex.x),
+                             g.y * rs.y * (e1 - me.y - (v.y - mean.y) * rs.y * mex.y),
+                             g.z * rs.z * (e2 - me.z - (v.z - mean.z) * rs.z * mex.z),
+                             g.w * rs.w * (e3 - me.w - (v.w - mean.w) * rs.w * mex.w));
+      if (acc_dx) { const float4 t = ld4(dx + i); r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+      st4(dx + i, r);
+    }
+  if (pl == 0) {
+    if (dgamma) {
+      float4 t = s[1];
+      if (acc_dg) { const float4 u = ld4(dgamma + c); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      st4(dgamma + c, t);
+    }
+    if (dbeta) {
+      float4 t = s[0];
+      if (acc_db) { const float4 u = ld4(dbeta + c); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      st4(dbeta + c, t);
+    }
+  }
+}
+
 void launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats, int R,
                         int C, float eps, hipStream_t s) {
+  if (C % 32 == 0) {
+    hipLaunchKernelGGL(bn_relu_fwd_v, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
+    return;
+  }
   hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
 }
 void launch_bn_relu_bwd(const float* x, const float* out, const float* dout, const float* gamma,
                         const float* stats, float* dx, int acc_dx, float* dgamma, int acc_dg, float* dbeta,
                         int acc_db, int R, int C, float eps, hipStream_t s) {
+  if (C % 32 == 0) {
+    hipLaunchKernelGGL(bn_relu_bwd_v, dim3(C / 32), dim3(256), 0, s, x, out, dout, gamma, stats, dx, acc_dx, dgamma,
+                       acc_dg, dbeta, acc_db, R, C, eps);
+    return;
+  }
   hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, out, dout, gamma, stats, dx, acc_dx,
                      dgamma, acc_dg, dbeta, acc_db, R, C, eps);
 }

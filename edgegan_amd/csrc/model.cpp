@@ -544,7 +544,7 @@ void run_substep(Ctx& c, int k, bool apply) {
       if (apply) apply_group(c, G_E);
     } break;
   }
-  if (apply && (k == 4)) c.sn_prepared = false;
+  if (apply && (k == 4)) c.sn_valid = false;
 }
 
 void train_step(Ctx& c) {

@@ -836,8 +836,11 @@ T reparam(Ctx& c, T mu, T ls, const float* eps_dev) {
 void sn_prepare(Ctx& c) {
   const int count = (int)c.sn.size();
   if (count == 0) return;
-  launch_sn_fwd(c.sn_table, count, c.sn_maxK, c.sn_maxCo, c.stream);
-  for (auto& s : c.sn) s.wT_valid = false;
+  if (!c.sn_valid) {  // the classifier's weights only change in sub-step 4: sub-steps 5 and 7 share one W/sigma
+    launch_sn_fwd(c.sn_table, count, c.sn_maxK, c.sn_maxCo, c.stream);
+    for (auto& s : c.sn) s.wT_valid = false;
+    c.sn_valid = true;
+  }
   bool want = false;
   for (auto& s : c.sn) want |= s.W->want_grad;
   if (want) {
