@@ -24,6 +24,36 @@ GFLOP_PER_IMAGE = 93.55        # algorithmic conv/deconv
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of `kernel_label` (e.g. 'conv_gemm<128,128,vec>') from the committed rocprofv3 PMC
+    summary (profiles/pmc_hbm_traffic_latest.csv: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read
+    correction -- tools/pmc_summary.py).  None if there is no matching row."""
+    import csv
+    import re
+    path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic_latest.csv')
+    m = re.match(r'(\w+)<(\d+),(\d+)(?:,(\w+))?>', kernel_label)
+    if not m or not os.path.exists(path):
+        return None
+    base, bm, bn, mode = m.group(1), m.group(2), m.group(3), m.group(4)
+    best = None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = r['Kernel']
+            if f'{base}_kernel<{bm}, {bn},' not in k and f'{base}_kernel<' not in k:
+                continue
+            if f'<{bm}, {bn},' not in k:
+                continue
+            flags = re.findall(r'(true|false)', k)
+            want = {'vec': ['true', 'true'], 'avec': ['true', 'false'], 'flat': ['false', 'false']}.get(mode)
+            if base == 'conv_gemm' and want and flags[-2:] != want:
+                continue
+            if base == 'wgrad' and mode and flags[-1:] != (['true'] if mode == 'vec' else ['false']):
+                continue
+            if best is None or int(r['Launches']) > int(best['Launches']):
+                best = r
+    return float(best['HbmBytesPerLaunch']) if best else None
+
+
 def cpu_baseline(cfg_kwargs, sample_batch=4):
     """The oracle (torch-CPU fp32 restatement of the reference graph, `kind: port`) timed on this
     host: one full iteration (7 sub-steps) at a bounded batch.  Reported, never the target."""
@@ -133,7 +163,9 @@ def main():
             tot_fl = sum(k['flops'] for k in ks)
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None, 'kernel': dom['name'],
+                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(dom['name']),
+                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.csv)',
+                    'kernel': dom['name'],
                     'launches_per_step': dom['launches'] / args.profile_steps,
                     'avg_launch_ms': round(dom['ms'] / dom['launches'], 4),
                     'flops_per_launch': dom['flops'] / dom['launches'],

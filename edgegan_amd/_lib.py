@@ -61,7 +61,7 @@ class Config:
 EXPORTS = ['eg_default_config', 'eg_variable_count', 'eg_variable_info', 'eg_create', 'eg_destroy',
            'eg_last_error', 'eg_set_variable', 'eg_get_variable', 'eg_upload_batch', 'eg_substep',
            'eg_train_step', 'eg_read_losses', 'eg_infer', 'eg_sync', 'eg_comm_unique_id', 'eg_comm_init',
-           'eg_profile_begin', 'eg_profile_end', 'eg_memory_stats', 'eg_test_op', 'eg_net_forward']
+           'eg_profile_begin', 'eg_profile_end', 'eg_memory_stats', 'eg_test_op', 'eg_net_forward', 'eg_crc32c']
 
 _lib = None
 
@@ -99,6 +99,8 @@ def load_library() -> C.CDLL:
                                C.c_int, C.POINTER(fp), C.POINTER(C.c_longlong)]
     lib.eg_net_forward.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fp,
                                    C.c_longlong]
+    lib.eg_crc32c.restype = C.c_uint
+    lib.eg_crc32c.argtypes = [C.c_uint, C.c_void_p, C.c_ulonglong]
     _lib = lib
     return lib
 

@@ -1,0 +1,97 @@
+"""``python -m edgegan_amd.train`` -- flag-compatible stand-in for ``python -m edgegan.train``
+(edgegan/train.py:109-138 + the loop of edgegan/models/edgegan.py:425-489) on the HIP engine.
+
+Under a multi-process launcher (RANK / WORLD_SIZE / LOCAL_RANK) the batches are sharded data-parallel: rank r
+trains on batch idx*world+r of every epoch, gradients are all-reduced inside the engine, rank 0 prints and saves."""
+from __future__ import annotations
+
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import checkpoint, flags as F
+from ._lib import Config
+from .data import Dataset, Prefetcher
+from .engine import EdgeGAN
+
+
+def update_flags(fl):
+    """train.py:85-98."""
+    if fl.input_width is None:
+        fl.input_width = fl.input_height
+    if fl.output_width is None:
+        fl.output_width = fl.output_height
+    if not fl.multiclasses:
+        fl.num_classes = None
+    path = os.path.join(fl.outputsroot, fl.name)
+    fl.checkpoint_dir = os.path.join(path, 'checkpoints')
+    fl.logdir = os.path.join(path, 'logs')
+    return fl
+
+
+def engine_config(fl, device: int) -> Config:
+    h, w = (fl.output_height, fl.output_width) if fl.crop else (fl.input_height, fl.input_width)
+    return Config(batch_size=fl.batch_size, height=h, width=w, num_classes=fl.num_classes or 0,
+                  z_dim=getattr(fl, 'z_dim', 100), dis_size=getattr(fl, 'image_dis_size', 128),
+                  lambda_gp=getattr(fl, 'lambda_gp', 10.0), zl_weight=getattr(fl, 'stage1_zl_loss', 10.0),
+                  learning_rate=fl.learning_rate, joint_dweight=getattr(fl, 'joint_dweight', 1.0),
+                  image_dweight=getattr(fl, 'image_dweight', 1.0), edge_dweight=getattr(fl, 'edge_dweight', 1.0),
+                  device=device)
+
+
+def main(argv=None):
+    fl = update_flags(F.parse(sys.argv[1:] if argv is None else argv, F.TRAIN_FLAGS))
+    F.check_supported(fl)
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', fl.gpu if world == 1 else rank))
+    if rank == 0:
+        print({k: v for k, v in vars(fl).items()})
+        for d in (fl.outputsroot, fl.checkpoint_dir, fl.logdir):
+            os.makedirs(d, exist_ok=True)
+        with open(os.path.join(fl.outputsroot, fl.name, 'flags.json'), 'w') as f:      # train.py:100-107
+            json.dump({k: (v if v != math.inf else 'Infinity') for k, v in vars(fl).items()}, f, indent=4)
+    dataset_config = {'input_height': fl.input_height, 'input_width': fl.input_width,
+                      'output_height': fl.output_height, 'output_width': fl.output_width, 'crop': fl.crop,
+                      'grayscale': False, 'z_dim': fl.z_dim}
+    dataset = Dataset(fl.dataroot, fl.dataset, fl.train_size, fl.batch_size, dataset_config, fl.num_classes, 'train')
+    from .variables import init_variables
+    cfg = engine_config(fl, local)
+    net = EdgeGAN(cfg, init_variables(cfg, seed=0))        # tf.global_variables_initializer (edgegan.py:437-440)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        uid = [net.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        net.comm_init(uid[0], rank, world)
+    counter = 1
+    start_time = time.time()
+    loaded, ckpt_counter = checkpoint.load(net, fl.checkpoint_dir)               # edgegan.py:447-453
+    if loaded:
+        counter = ckpt_counter
+        print(' [*] Load SUCCESS')
+    else:
+        print(' [!] Load failed...')
+    for epoch in range(fl.epoch):
+        dataset.shuffle()
+        steps = len(dataset) // world
+        for it, (idx, images, z, _) in enumerate(Prefetcher(dataset, [i * world + rank for i in range(steps)])):
+            net.update_model(images, z)                                              # edgegan.py:461
+            l = net.losses()                                                         # edgegan.py:464-481
+            discriminator_err = l['joint_dis_dloss'] + l['image_dis_dloss'] + l['edge_dis_dloss']
+            generator_err = l['edge_gloss'] + l['image_gloss']
+            counter += 1
+            if rank == 0:
+                print('Epoch: [%2d/%2d] [%4d/%4d] time: %4.4f, joint_dis_dloss: %.8f, joint_dis_gloss: %.8f'
+                      % (epoch, fl.epoch, it, steps, time.time() - start_time, 2 * discriminator_err, generator_err))
+                if np.mod(counter, fl.save_checkpoint_frequency) == 2:               # edgegan.py:487-489
+                    checkpoint.save(net, fl.checkpoint_dir, counter)
+    net.close()
+
+
+if __name__ == '__main__':
+    main()

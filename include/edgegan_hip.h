@@ -113,6 +113,10 @@ int eg_test_op(eg_ctx* ctx, const char* op, int n_in, const float* const* inputs
 int eg_net_forward(eg_ctx* ctx, const char* net, const float* input, int nb, int h, int w, int ch, float eps,
                    float* out, long long out_numel);
 
+/* ---- checkpoint IO helper: CRC-32C (Castagnoli) as used by TensorFlow's tensor-bundle files that
+ *      tf.train.Saver writes (models/edgegan.py:635-639); needs no GPU. -------------------------------- */
+unsigned int eg_crc32c(unsigned int crc, const void* data, unsigned long long n);
+
 #ifdef __cplusplus
 }
 #endif

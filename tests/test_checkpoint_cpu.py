@@ -1,0 +1,124 @@
+"""TF tensor-bundle reader/writer (edgegan_amd/tf_bundle.py) and the checkpoint layout
+(edgegan/models/edgegan.py:635-661), without TensorFlow: format invariants + round trips."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from edgegan_amd import tf_bundle as B
+from edgegan_amd import checkpoint as CK
+
+
+def test_crc32c_known_answers(built_lib):
+    # RFC 3720 B.4 / the vectors tensorflow/core/lib/hash/crc32c_test.cc uses
+    assert B.crc32c(b'123456789') == 0xe3069283
+    assert B.crc32c(bytes(32)) == 0x8a9136aa
+    assert B.crc32c(bytes([0xff] * 32)) == 0x62a8ab43
+    assert B.crc32c(bytes(range(32))) == 0x46dd794e
+    # incremental == one-shot, array path == bytes path
+    data = np.random.RandomState(0).bytes(100003)
+    assert B.crc32c(data[5000:], B.crc32c(data[:5000])) == B.crc32c(data)
+    arr = np.frombuffer(data[:100000], dtype=np.float32)
+    assert B.crc32c(arr) == B.crc32c(data[:100000])
+    # mask / unmask (crc32c.h) are inverse and not the identity
+    c = B.crc32c(b'foo')
+    assert B.unmask_crc(B.mask_crc(c)) == c and B.mask_crc(c) != c and B.mask_crc(B.mask_crc(c)) != c
+
+
+def test_table_format_invariants(tmp_path):
+    items = [(('var_%05d/w' % i).encode(), os.urandom(i % 50 + 1)) for i in range(3000)] + [(b'', b'hdr')]
+    p = str(tmp_path / 't.index')
+    B.write_table(p, items)
+    raw = open(p, 'rb').read()
+    assert struct.unpack('<Q', raw[-8:])[0] == 0xdb4775248b80fb57 and len(raw) > 48
+    got = B.read_table(p)
+    assert got == sorted(items)                        # sorted bytewise, "" first, prefix compression undone
+    # a flipped payload bit must be caught by the block checksum
+    bad = bytearray(raw)
+    bad[100] ^= 1
+    open(p, 'wb').write(bytes(bad))
+    with pytest.raises(ValueError, match='checksum'):
+        B.read_table(p)
+
+
+def test_table_splits_into_blocks(tmp_path):
+    items = [(('k%06d' % i).encode(), bytes(1000)) for i in range(1000)]       # ~1 MB > 256 KiB blocks
+    p = str(tmp_path / 'big.index')
+    B.write_table(p, items)
+    assert B.read_table(p) == items
+
+
+def test_bundle_round_trip_and_entry_encoding(tmp_path):
+    rng = np.random.RandomState(1)
+    t = {'G1/g_lin_0/Matrix': rng.normal(size=(114, 64)).astype(np.float32),
+         'D2/Conv/prelu/param': np.float32(0.2),
+         'D2/Conv/D2/Conv/u': rng.normal(size=(1, 8)).astype(np.float32),
+         'G1/g_lin_0/Matrix/RMSProp': np.ones((114, 64), np.float32),
+         'counter': np.array([7, 8], dtype=np.int64)}
+    prefix = str(tmp_path / 'EdgeGAN-Model-502')
+    B.write_bundle(prefix, t)
+    assert os.path.exists(prefix + '.index') and os.path.exists(prefix + '.data-00000-of-00001')
+    assert os.path.getsize(prefix + '.data-00000-of-00001') == sum(np.asarray(v).nbytes for v in t.values())
+    got = B.read_bundle(prefix)
+    assert set(got) == set(t)
+    for k in t:
+        assert got[k].shape == np.asarray(t[k]).shape and np.array_equal(got[k], t[k]), k
+    assert B.list_bundle(prefix)['D2/Conv/prelu/param'] == ((), B.DT_FLOAT)
+    # BundleEntryProto wire format: dtype=1, shape dims, offset, size, masked crc as fixed32 (field 6)
+    e = B.encode_entry(B.DT_FLOAT, (3, 4), 0, 48, 48, 0x12345678)
+    assert e == bytes([0x08, 1, 0x12, 8, 0x12, 2, 0x08, 3, 0x12, 2, 0x08, 4, 0x20, 48, 0x28, 48, 0x35]) + \
+        struct.pack('<I', 0x12345678)
+    assert B.decode_entry(e) == {'dtype': 1, 'shape': (3, 4), 'shard_id': 0, 'offset': 48, 'size': 48,
+                                 'crc32c': 0x12345678, 'slices': 0}
+    assert B.encode_header() == bytes([0x08, 1, 0x1a, 2, 0x08, 1])
+    # corrupt tensor bytes -> per-tensor crc mismatch
+    with open(prefix + '.data-00000-of-00001', 'r+b') as f:
+        f.seek(10)
+        f.write(b'\xff')
+    with pytest.raises(ValueError, match='tensor checksum'):
+        B.read_bundle(prefix)
+
+
+class _FakeNet:
+    """Host-only stand-in for edgegan_amd.EdgeGAN's variable interface."""
+    def __init__(self, specs, values):
+        self.specs, self.v = specs, dict(values)
+
+    def get_variable(self, name, shape=None):
+        return self.v[name]
+
+    def set_variable(self, name, value):
+        self.v[name] = np.array(value, dtype=np.float32)
+
+
+def test_checkpoint_layout_and_resume_rule(tmp_path, built_lib):
+    import edgegan_amd as ea
+    cfg = ea.Config(batch_size=2, gf_dim=8, df_dim=8)
+    specs = ea.variable_specs(cfg)
+    vals = ea.init_variables(cfg, 0)
+    for s in specs:
+        if s.trainable:
+            vals[s.name + '/RMSProp'] = np.full(s.shape, 0.9, np.float32)
+            vals[s.name + '/RMSProp_1'] = np.full(s.shape, 0.1, np.float32)
+    net = _FakeNet(specs, vals)
+    d = str(tmp_path / 'checkpoints')
+    CK.save(net, d, 2)
+    CK.save(net, d, 502)
+    assert sorted(os.listdir(d)) == ['EdgeGAN-Model-2.data-00000-of-00001', 'EdgeGAN-Model-2.index',
+                                     'EdgeGAN-Model-502.data-00000-of-00001', 'EdgeGAN-Model-502.index', 'checkpoint']
+    assert open(os.path.join(d, 'checkpoint')).read() == ('model_checkpoint_path: "EdgeGAN-Model-502"\n'
+                                                           'all_model_checkpoint_paths: "EdgeGAN-Model-2"\n'
+                                                           'all_model_checkpoint_paths: "EdgeGAN-Model-502"\n')
+    keys = B.list_bundle(os.path.join(d, 'EdgeGAN-Model-502'))
+    assert 'G1/batch_norm/BatchNorm/moving_variance' in keys and 'D2/Conv/D2/Conv/u' in keys
+    assert 'E/FC8_mu/w/RMSProp' in keys and 'E/FC8_mu/w/RMSProp_1' in keys
+    assert 'D2/Conv_1/weights' in keys and 'D2/Conv_1/weights/RMSProp' not in keys     # quirk N8: no slots
+    assert 'G1/batch_norm/BatchNorm/moving_mean/RMSProp' not in keys                    # non-trainable
+    fresh = _FakeNet(specs, {k: np.zeros_like(v) for k, v in vals.items()})
+    ok, counter = CK.load(fresh, d)
+    assert ok and counter == 502                                                        # trailing integer
+    for s in specs:
+        assert np.array_equal(fresh.v[s.name], vals[s.name]), s.name
+    assert np.all(fresh.v['E/FC8_mu/w/RMSProp'] == np.float32(0.9))
+    assert CK.load(fresh, str(tmp_path / 'nothing')) == (False, 0)

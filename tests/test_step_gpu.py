@@ -1,5 +1,7 @@
 """GPU parity of the networks, the 7 optimizer sub-steps (gradients incl. the WGAN-GP double
 backward, losses, RMSProp application, BatchNorm moving statistics) and inference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -98,3 +100,54 @@ def test_rccl_single_rank_allreduce_path():
     net.substep(6, True)
     assert np.array_equal(net.get_variable('E/FC8_mu/w'), want)
     net.close()
+
+
+def test_checkpoint_round_trip_on_device(tmp_path):
+    """save -> fresh engine -> load: every variable and RMSProp slot identical; resume counter from the name."""
+    from edgegan_amd import checkpoint, tf_bundle
+    cfg = ea.Config(batch_size=2)
+    net = ea.EdgeGAN(cfg, ea.init_variables(cfg, 3))
+    net.upload_batch(**ea.synthetic_batch(cfg))
+    net.train_step()
+    d = str(tmp_path / 'checkpoints')
+    checkpoint.save(net, d, 502)
+    want = net.get_variables(slots=True)
+    net.close()
+    keys = tf_bundle.list_bundle(d + '/EdgeGAN-Model-502')
+    assert len(keys) == 159 + 2 * (sum(1 for s in ea.variable_specs(cfg) if s.trainable) - 2)
+    fresh = ea.EdgeGAN(cfg)
+    ok, counter = checkpoint.load(fresh, d, strict=True)
+    assert ok and counter == 502
+    got = fresh.get_variables(slots=True)
+    for k, v in want.items():
+        if k.startswith('D2/Conv_1/') and 'RMSProp' in k:
+            continue
+        assert np.array_equal(got[k], v), k
+    fresh.close()
+
+
+def test_train_and_test_command_lines_end_to_end(tmp_path, monkeypatch):
+    """python -m edgegan_amd.train / .test on a tiny generated dataset: output tree, flags.json, checkpoint at
+    counter % frequency == 2, resume, generated PNGs (edgegan/train.py, edgegan/test.py, edgegan.py:425-633)."""
+    from PIL import Image
+    from edgegan_amd import train as TR, test as TE, tf_bundle
+    rng = np.random.RandomState(0)
+    root = tmp_path / 'data'
+    for c in (0, 5):
+        for phase in ('train', 'test'):
+            os.makedirs(root / 'class14' / phase / str(c))
+            for i in range(2):
+                Image.fromarray(rng.randint(0, 256, size=(64, 128, 3)).astype(np.uint8)).save(
+                    root / 'class14' / phase / str(c) / f'{i}.png')
+    monkeypatch.chdir(tmp_path)
+    args = ['--name=t1', f'--dataroot={root}', '--batch_size=2', '--epoch=1', '--save_checkpoint_frequency=3']
+    TR.main(args)
+    out = tmp_path / 'outputs' / 't1'
+    assert (out / 'flags.json').exists() and (out / 'logs').is_dir()
+    # counter starts at 1, +1 per iteration; saved when counter % 3 == 2 -> after the 1st iteration (counter 2)
+    assert (out / 'checkpoints' / 'EdgeGAN-Model-2.index').exists()
+    assert tf_bundle.read_checkpoint_state(str(out / 'checkpoints'))[0] == 'EdgeGAN-Model-2'
+    TE.main(['--name=t1', f'--dataroot={root}'])
+    pngs = sorted((out / 'test_output' / 'class14').rglob('*.png'))
+    assert len(pngs) == 4
+    assert Image.open(pngs[0]).size == (256, 64)          # 'full': input | edge | image  (edgegan.py:617-619)
