@@ -608,18 +608,30 @@ __global__ __launch_bounds__(256) void wgrad_flatm_kernel(const WgradArgs a, flo
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int T, int C, int N,
-                                    long long w_ts, int ldw, int nsplit, int accumulate) {
+// second stage of the split reduction: 16 elements x 16 split-lanes per block, fixed summation order
+// (lane l sums splits l, l+16, ...; the 16 lane totals are added in lane order) -> deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           int T, int C, int N, long long w_ts, int ldw, int nsplit,
+                                                           int accumulate) {
+  __shared__ float red[16][17];
   const size_t total = (size_t)T * C * N;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += ws[(size_t)z * total + i];
+  const int e = threadIdx.x & 15, l = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + e;
+  float s = 0.f;
+  if (i < total)
+    for (int z = l; z < nsplit; z += 16) s += ws[(size_t)z * total + i];
+  red[l][e] = s;
+  __syncthreads();
+  if (l == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][e];
     const int n = (int)(i % N);
     const size_t t2 = i / N;
     const int c = (int)(t2 % C);
-    const int t = (int)(t2 / C);
-    float* p = dw + (size_t)t * w_ts + (size_t)c * ldw + n;
-    *p = accumulate ? (*p + s) : s;
+    const int tp = (int)(t2 / C);
+    float* p = dw + (size_t)tp * w_ts + (size_t)c * ldw + n;
+    *p = accumulate ? (*p + t) : t;
   }
 }
 
@@ -682,10 +694,8 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
   }
   if (!direct) {
     const size_t total = (size_t)a.KH * a.KW * a.C * a.N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, a.dw, a.KH * a.KW, a.C, a.N,
-                       a.w_ts, a.ldw, a.nsplit, a.accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, a.ws, a.dw,
+                       a.KH * a.KW, a.C, a.N, a.w_ts, a.ldw, a.nsplit, a.accumulate);
   }
   if (kernel_name) *kernel_name = nm;
   return 2.0 * a.NB * a.OH * a.OW * (double)a.N * a.C * a.KH * a.KW;
