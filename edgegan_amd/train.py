@@ -17,6 +17,7 @@ from . import checkpoint, flags as F
 from ._lib import Config
 from .data import Dataset, Prefetcher
 from .engine import EdgeGAN
+from .summary import SCALAR_TAGS, SummaryWriter
 
 
 def update_flags(fl):
@@ -68,6 +69,7 @@ def main(argv=None):
         uid = [net.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         net.comm_init(uid[0], rank, world)
+    writer = SummaryWriter(fl.logdir) if rank == 0 else None                      # edgegan.py:443
     counter = 1
     start_time = time.time()
     loaded, ckpt_counter = checkpoint.load(net, fl.checkpoint_dir)               # edgegan.py:447-453
@@ -84,12 +86,17 @@ def main(argv=None):
             l = net.losses()                                                         # edgegan.py:464-481
             discriminator_err = l['joint_dis_dloss'] + l['image_dis_dloss'] + l['edge_dis_dloss']
             generator_err = l['edge_gloss'] + l['image_gloss']
+            if writer is not None:                                                   # edgegan.py:427-433,462
+                writer.add_scalars({t: l[t] for t in SCALAR_TAGS if t in l and (cfg.multiclasses or 'ac' not in t)},
+                                   counter)
             counter += 1
             if rank == 0:
                 print('Epoch: [%2d/%2d] [%4d/%4d] time: %4.4f, joint_dis_dloss: %.8f, joint_dis_gloss: %.8f'
                       % (epoch, fl.epoch, it, steps, time.time() - start_time, 2 * discriminator_err, generator_err))
                 if np.mod(counter, fl.save_checkpoint_frequency) == 2:               # edgegan.py:487-489
                     checkpoint.save(net, fl.checkpoint_dir, counter)
+    if writer is not None:
+        writer.close()
     net.close()
 
 

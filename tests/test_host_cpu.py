@@ -121,3 +121,25 @@ def test_save_images_and_output_composition(tmp_path):
     assert T.compose(b, L, R, 'full', 64).shape == (1, 64, 256, 3)
     assert T.compose(b, L, R, 'inputL_outputR', 64).shape == (1, 64, 128, 3)
     assert T.compose(b, L, R, 'outputR', 64) is R
+
+
+def test_tensorboard_event_file_round_trip(tmp_path, built_lib):
+    import struct
+    from edgegan_amd import summary as S
+    w = S.SummaryWriter(str(tmp_path / 'logs'))
+    w.add_scalars({'joint_dis_dloss': 12.5, 'zl_loss': 0.25}, 1)
+    w.add_scalars({'edge_gloss': -3.0}, 2)
+    w.close()
+    name = os.path.basename(w.path)
+    assert name.startswith('events.out.tfevents.')
+    ev = S.read_events(w.path)
+    assert ev[0] == (0, {}) and ev[1] == (1, {'joint_dis_dloss': 12.5, 'zl_loss': 0.25}) and ev[2] == (2, {'edge_gloss': -3.0})
+    raw = open(w.path, 'rb').read()
+    n0 = struct.unpack_from('<Q', raw, 0)[0]
+    assert b'brain.Event:2' in raw[12:12 + n0]                      # first record = file version event
+    bad = bytearray(raw)
+    bad[14] ^= 0xff
+    open(w.path, 'wb').write(bytes(bad))
+    with pytest.raises(ValueError, match='checksum'):
+        S.read_events(w.path)
+    assert set(S.SCALAR_TAGS) >= {'joint_dis_dloss', 'image_dis_dloss', 'edge_dis_dloss', 'loss_d_ac', 'zl_loss'}

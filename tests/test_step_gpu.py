@@ -147,7 +147,26 @@ def test_train_and_test_command_lines_end_to_end(tmp_path, monkeypatch):
     # counter starts at 1, +1 per iteration; saved when counter % 3 == 2 -> after the 1st iteration (counter 2)
     assert (out / 'checkpoints' / 'EdgeGAN-Model-2.index').exists()
     assert tf_bundle.read_checkpoint_state(str(out / 'checkpoints'))[0] == 'EdgeGAN-Model-2'
+    from edgegan_amd import summary
+    ev = summary.read_events(str(next((out / 'logs').glob('events.out.tfevents.*'))))
+    assert len(ev) == 1 + 2 and set(ev[1][1]) == set(summary.SCALAR_TAGS) and ev[1][0] == 1 and ev[2][0] == 2
     TE.main(['--name=t1', f'--dataroot={root}'])
     pngs = sorted((out / 'test_output' / 'class14').rglob('*.png'))
     assert len(pngs) == 4
     assert Image.open(pngs[0]).size == (256, 64)          # 'full': input | edge | image  (edgegan.py:617-619)
+
+
+def test_high_resolution_config_forwards():
+    """configs[4] geometry (256x512, 14 classes): 5-block encoder (encoder.py:57-58), 256->128 legacy-bicubic
+    (= 2x subsampling) into the patch discriminators, 131072-wide generator projection."""
+    cfg = ea.Config(batch_size=1, height=256, width=512)
+    values = ea.init_variables(cfg, 4)
+    net = ea.EdgeGAN(cfg, values)
+    rows = parity.net_checks(net, values)
+    _assert(rows)
+    om = O.OracleModel(parity.oracle_config(cfg), values, dtype=torch.float64)
+    imgs = np.random.RandomState(0).uniform(-1, 1, size=(1, 256, 512, 3)).astype(np.float32)
+    e_ref, i_ref = om.infer(parity.t64(imgs), torch.tensor([5]), 0.1, 0.2)
+    e, i = net.infer(imgs, np.array([5], np.int32), eps2=[0.1, 0.2])
+    assert parity.relerr(e, e_ref.numpy()) < 1e-4 and parity.relerr(i, i_ref.numpy()) < 1e-4
+    net.close()
