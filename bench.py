@@ -128,6 +128,7 @@ def main():
         try:
             import torch
             if torch.cuda.is_available():
+                torch.cuda.set_device(local)
                 torch.cuda.synchronize()
         except Exception:
             pass

@@ -137,9 +137,8 @@ WRef* wref_sn(Ctx& c, Param* p);
 const float* wref_transposed(Ctx& c, WRef* w);
 
 enum PadMode { PAD_SAME = 0, PAD_REFLECT = 1 };
-// y = conv(x, w) (+ bias).  c_off/c_tot: use rows [c_off, c_off + x->c) of a [T][c_tot][N] filter.
-T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into = nullptr,
-         int c_off = 0, int c_tot = -1);
+// y = conv(x, w) (+ bias); with accumulate_into the result is added to an existing output (split-input convs)
+T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into = nullptr);
 T deconv2d(Ctx& c, T x, WRef* w /*[25][Cout][Cin]*/, Param* bias, int cout);
 T linear(Ctx& c, T x, WRef* w /*[1][in][out]*/, Param* bias);
 T linear1(Ctx& c, T x, Param* w /*[K][1]*/, Param* bias /*nullable*/);
@@ -163,7 +162,6 @@ T reparam(Ctx& c, T mu, T ls, const float* eps_dev);
 void sn_prepare(Ctx& c);                  // W/sigma for every live SN weight + tape entry for its backward
 void seed_grad(Ctx& c, T t);              // marks t->g as holding a value (after a loss kernel wrote it)
 
-void prof_launch_begin(Ctx& c, const char** name_slot, double** flops_slot);
 struct ProfScope {
   Ctx& c;
   int idx = -1;

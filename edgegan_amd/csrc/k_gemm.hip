@@ -27,8 +27,8 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // =============================================================================================
 // conv_gemm_kernel
 // =============================================================================================
-template <int BM, int BN, int WTM, int WTN, int BK, bool VEC, bool BVEC>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
+template <int BM, int BN, int WTM, int WTN, int BK, bool VEC, bool BVEC, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvArgs a) {
   constexpr int LDA = BK + 4;
   constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 32);
   constexpr int WGN = BN / WTN;
@@ -237,10 +237,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
   }
 }
 
-template <int BM, int BN, int WTM, int WTN, int BK, bool VEC, bool BVEC>
+template <int BM, int BN, int WTM, int WTN, int BK, bool VEC, bool BVEC, int MINW = 1>
 static void conv_launch(const ConvArgs& a, int maxM, hipStream_t s) {
   dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, BK, VEC, BVEC>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, BK, VEC, BVEC, MINW>), grid, dim3(256), 0, s, a);
 }
 
 // k32: C % 32 == 0 -> K step 32 (half the barriers / address arithmetic per MFMA)

@@ -278,7 +278,7 @@ static void bias_grad(Ctx& c, Param* b, const float* dy, size_t rows, int C) {
   b->g_set = true;
 }
 
-T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into, int, int) {
+T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into) {
   const int Cin = x->c, N = w->Cc;
   EG_CHECK(w->T == k * k && w->R == Cin, "conv2d weight shape: T=%d R=%d vs k=%d Cin=%d", w->T, w->R, k, Cin);
   int OH, OW, pt, pl;

@@ -170,3 +170,37 @@ def test_high_resolution_config_forwards():
     e, i = net.infer(imgs, np.array([5], np.int32), eps2=[0.1, 0.2])
     assert parity.relerr(e, e_ref.numpy()) < 1e-4 and parity.relerr(i, i_ref.numpy()) < 1e-4
     net.close()
+
+
+def test_full_size_classifier_step_equals_mean_of_small_shards():
+    """Size-independent property at BASELINE's full size (batch 64, 14 classes): sub-step 4's loss is a batch
+    mean over per-sample-independent computations (no BatchNorm on this path), so its gradient at B=64 must equal
+    the mean of the gradients of 32 shards of 2 -- the small-batch path is the one pinned against the oracle, the
+    B=64 path exercises the 128x128 tiles, split wgrads and the flattened-(tap,c) kernels at production shapes."""
+    names = ['D2/Conv/weights', 'D2/mru_conv_unit_t_1_layer_0/Conv_2/weights', 'D2/mru_conv_unit_t_1_layer_0/update_gate/weights',
+             'D2/mru_conv_unit_t_2_layer_0/Conv_1/weights', 'D2/mru_conv_unit_t_4_layer_0/Conv_2/weights',
+             'D2/mru_conv_unit_t_3_layer_0/Conv_3/biases', 'D2/mru_conv_unit_t_2_layer_0/norm_activation_in/prelu/param',
+             'D2/fully_connected/weights']
+    big_cfg, small_cfg = ea.Config(batch_size=64), ea.Config(batch_size=2)
+    values = ea.init_variables(big_cfg, 0)
+    batch = ea.synthetic_batch(big_cfg)
+    big = ea.EdgeGAN(big_cfg, values)
+    big.upload_batch(**batch)
+    big.substep(4, apply=False)
+    want = {n: big.get_variable(n + '/grad').astype(np.float64) for n in names}
+    loss_big = big.losses()['loss_d_ac']
+    big.close()
+    small = ea.EdgeGAN(small_cfg, values)
+    acc = {n: 0.0 for n in names}
+    loss = 0.0
+    for s in range(32):
+        sl = slice(2 * s, 2 * s + 2)
+        small.upload_batch(batch['images'][sl], batch['z'][sl], batch['alpha'][:, sl].copy(), batch['eps'])
+        small.substep(4, apply=False)
+        for n in names:
+            acc[n] = acc[n] + small.get_variable(n + '/grad').astype(np.float64) / 32
+        loss += small.losses()['loss_d_ac'] / 32
+    small.close()
+    assert abs(loss - loss_big) / abs(loss_big) < 1e-5
+    for n in names:
+        assert parity.rel_l2(want[n], acc[n]) < 1e-3, (n, parity.rel_l2(want[n], acc[n]))
