@@ -282,17 +282,17 @@ double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_na
       nm = conv_dispatch<64, 16, 16, 16>(a, maxM, avec, bvec, s, "conv_gemm<64,16,vec>", "conv_gemm<64,16,avec>",
                                          "conv_gemm<64,16,flat>");
   } else {
-    // pick the tile by block-round quantisation: 128x128 runs 3 blocks/CU (768 slots), 64x64 8 blocks/CU
-    // (2048 slots) at ~0.78 of the big tile's per-block efficiency
+    // pick the tile by CU load balance: the MFMA pipe is the bottleneck, so what matters is how evenly the
+    // tiles divide over the 256 CUs (measured: 4 vs 3 resident blocks per CU changes nothing), times the
+    // per-tile efficiency of each configuration (64x64 runs at ~0.8 of the 128x128 tile's rate)
     const long long t128 = blocks128;
     const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase;
-    auto rounds_eff = [](long long tiles, long long slots, double fill_at) {
-      if (tiles <= slots) return tiles >= fill_at ? 1.0 : (double)tiles / fill_at;
-      const long long r = (tiles + slots - 1) / slots;
-      return (double)tiles / (double)(r * slots);
+    auto balance = [](long long tiles) {
+      const long long per_cu = (tiles + 255) / 256;
+      return (double)tiles / (double)(per_cu * 256);
     };
-    const double e128 = a.N >= 128 ? 0.95 * rounds_eff(t128, 768, 256.0) : 0.0;
-    const double e64 = 0.78 * rounds_eff(t64, 2048, 512.0);
+    const double e128 = a.N >= 128 ? 0.95 * balance(t128) : 0.0;
+    const double e64 = 0.80 * balance(t64);
     if (e128 >= e64)
       nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s, "conv_gemm<128,128,vec>", "conv_gemm<128,128,avec>",
                                            "conv_gemm<128,128,flat>");
