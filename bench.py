@@ -92,6 +92,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if 'EG_FORCE_DEVICE' in os.environ:      # test hook: several ranks on one GPU (1-GPU dev boxes)
+        local = int(os.environ['EG_FORCE_DEVICE'])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             print(f'bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}',
