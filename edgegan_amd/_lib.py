@@ -9,7 +9,7 @@ from typing import List, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libedgegan_hip.so')
+LIB_PATH = os.environ.get('EG_LIB_PATH') or os.path.join(_HERE, 'libedgegan_hip.so')   # override: A/B builds
 
 
 class EdgeGANLibError(RuntimeError):

@@ -153,6 +153,7 @@ static float* resolve_var(Ctx& c, const std::string& name, size_t* numel, bool f
 
 int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long numel) {
   EG_API_BEGIN
+  comm_wait_all(ctx->c);
   size_t n;
   float* d = resolve_var(ctx->c, name, &n, true);
   EG_CHECK((size_t)numel == n, "size mismatch for %s: got %lld, want %zu", name, numel, n);
@@ -164,6 +165,7 @@ int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long 
 
 int eg_get_variable(eg_ctx* ctx, const char* name, float* host, long long numel) {
   EG_API_BEGIN
+  comm_wait_all(ctx->c);
   size_t n;
   float* d = resolve_var(ctx->c, name, &n, false);
   EG_CHECK((size_t)numel == n, "size mismatch for %s: got %lld, want %zu", name, numel, n);
@@ -174,6 +176,7 @@ int eg_get_variable(eg_ctx* ctx, const char* name, float* host, long long numel)
 
 int eg_upload_batch(eg_ctx* ctx, const float* images, const float* z, const float* alpha, const float* eps) {
   EG_API_BEGIN
+  comm_wait_all(ctx->c);
   Ctx& c = ctx->c;
   const Config& cfg = c.cfg;
   EG_CHECK(images && z && alpha && eps, "null batch pointer");
@@ -201,6 +204,7 @@ int eg_train_step(eg_ctx* ctx) {
 
 int eg_read_losses(eg_ctx* ctx, float* out12) {
   EG_API_BEGIN
+  comm_wait_all(ctx->c);
   EG_HIP(hipMemcpyAsync(out12, ctx->c.d_losses, L_COUNT * 4, hipMemcpyDeviceToHost, ctx->c.stream));
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
   EG_API_END(ctx)
@@ -238,6 +242,7 @@ int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const
 
 int eg_sync(eg_ctx* ctx) {
   EG_API_BEGIN
+  comm_wait_all(ctx->c);
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
   EG_API_END(ctx)
 }
@@ -370,6 +375,7 @@ struct OpIO {
 int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* inputs, const long long* in_numel,
                int n_ip, const int* ip, int n_out, float* const* outputs, const long long* out_numel) {
   EG_API_BEGIN
+  comm_wait_all(ctx->c);
   Ctx& c = ctx->c;
   reset_step(c);
   ctx->tmp_params.clear();
@@ -562,6 +568,7 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
 int eg_net_forward(eg_ctx* ctx, const char* net_, const float* input, int nb, int h, int w, int ch, float eps,
                    float* out, long long out_numel) {
   EG_API_BEGIN
+  comm_wait_all(ctx->c);
   Ctx& c = ctx->c;
   reset_step(c);
   for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);

@@ -56,16 +56,42 @@ void comm_init(Ctx& c, const char* id128, int rank, int nranks) {
   check(c, sym<fn_init_rank>(c, "ncclCommInitRank")(&c.nccl_comm, nranks, id, rank), "ncclCommInitRank");
   c.rank = rank;
   c.nranks = nranks;
+  if (!c.comm_stream) {
+    EG_HIP(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
+    for (int g = 0; g < G_COUNT; ++g) {
+      EG_HIP(hipEventCreateWithFlags(&c.ev_ready[g], hipEventDisableTiming));
+      EG_HIP(hipEventCreateWithFlags(&c.ev_applied[g], hipEventDisableTiming));
+    }
+  }
 }
 
-void comm_allreduce(Ctx& c, float* buf, size_t n) {
-  if (c.nranks <= 1) return;
+void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream) {
   EG_CHECK(c.nccl_comm, "comm_allreduce without comm_init");
   // ncclFloat32 = 7, ncclSum = 0
-  check(c, sym<fn_allreduce>(c, "ncclAllReduce")(buf, buf, n, 7, 0, c.nccl_comm, c.stream), "ncclAllReduce");
+  check(c, sym<fn_allreduce>(c, "ncclAllReduce")(buf, buf, n, 7, 0, c.nccl_comm, stream), "ncclAllReduce");
 }
 
+void comm_wait_groups(Ctx& c, unsigned mask) {
+  for (int g = 0; g < G_COUNT; ++g)
+    if ((mask >> g & 1u) && c.pending[g]) {
+      EG_HIP(hipStreamWaitEvent(c.stream, c.ev_applied[g], 0));
+      c.pending[g] = false;
+    }
+}
+
+void comm_wait_all(Ctx& c) { comm_wait_groups(c, ~0u); }
+
 void comm_destroy(Ctx& c) {
+  if (c.comm_stream) {
+    (void)hipStreamSynchronize(c.comm_stream);
+    for (int g = 0; g < G_COUNT; ++g) {
+      (void)hipEventDestroy(c.ev_ready[g]);
+      (void)hipEventDestroy(c.ev_applied[g]);
+      c.pending[g] = false;
+    }
+    (void)hipStreamDestroy(c.comm_stream);
+    c.comm_stream = nullptr;
+  }
   if (c.nccl_comm) {
     (void)sym<fn_destroy>(c, "ncclCommDestroy")(c.nccl_comm);
     c.nccl_comm = nullptr;

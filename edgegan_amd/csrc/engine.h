@@ -107,6 +107,10 @@ struct Ctx {
   void* nccl_lib = nullptr;
   void* nccl_comm = nullptr;
   int rank = 0, nranks = 1;
+  // gradient exchange + optimizer of a group run on a side stream so they overlap the next sub-step's compute
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_ready[G_COUNT] = {}, ev_applied[G_COUNT] = {};
+  bool pending[G_COUNT] = {};
 
   ~Ctx();
 };
@@ -193,7 +197,9 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
 // ---- data parallel (comm.cpp) -----------------------------------------------------------------
 void comm_unique_id(Ctx& c, char* out128);
 void comm_init(Ctx& c, const char* id128, int rank, int nranks);
-void comm_allreduce(Ctx& c, float* buf, size_t n);
+void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream);
+void comm_wait_groups(Ctx& c, unsigned mask);   // main stream waits for the pending updates of these groups
+void comm_wait_all(Ctx& c);
 void comm_destroy(Ctx& c);
 
 }  // namespace eg

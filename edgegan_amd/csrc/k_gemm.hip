@@ -123,22 +123,12 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvArgs a) 
           rbs[j] = n < N ? a.wgt[wt + (size_t)(c0 + kk) * a.ldw + n] : 0.f;
         }
       }
-      if (a.tap_inner) {  // channel chunk outer, taps inner: neighbouring taps re-read the same pixels while hot
+      nx_c0 += BK;
+      if (nx_c0 >= C) {
+        nx_c0 = 0;
         if (++nx_tx == ph.Tx) {
           nx_tx = 0;
-          if (++nx_ty == ph.Ty) {
-            nx_ty = 0;
-            nx_c0 += BK;
-          }
-        }
-      } else {
-        nx_c0 += BK;
-        if (nx_c0 >= C) {
-          nx_c0 = 0;
-          if (++nx_tx == ph.Tx) {
-            nx_tx = 0;
-            ++nx_ty;
-          }
+          ++nx_ty;
         }
       }
     } else {
@@ -272,8 +262,7 @@ static const char* conv_dispatch(const ConvArgs& a, int maxM, bool avec, bool bv
   return nf;
 }
 
-double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel_name) {
-  ConvArgs a = a_in;
+double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_name) {
   int maxM = 0;
   double flops = 0;
   for (int p = 0; p < a.nphase; ++p) {
@@ -285,9 +274,6 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
   const bool bvec = (a.N % 4 == 0) && (a.ldw % 4 == 0) && (a.w_ts % 4 == 0) && (((uintptr_t)a.wgt & 15) == 0);
   const long long blocks128 = (long long)((maxM + 127) / 128) * ((a.N + 127) / 128) * a.nphase;
   const char* nm;
-  // K order: (tap, channel chunk) by default; the (channel chunk, tap) order was measured neutral on the thin
-  // layers (they are VALU/issue-bound on the gather address arithmetic, not L2-bound)
-  if (a.tap_inner < 0) a.tap_inner = 0;
   if (a.N <= 16) {
     if ((long long)((maxM + 255) / 256) * a.nphase >= 256)
       nm = conv_dispatch<256, 16, 64, 16>(a, maxM, avec, bvec, s, "conv_gemm<256,16,vec>", "conv_gemm<256,16,avec>",

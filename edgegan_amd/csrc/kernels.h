@@ -31,7 +31,6 @@ struct ConvArgs {
   int ldw;
   int reflect;       // 1: out-of-range input index is mirrored (tf.pad REFLECT), 0: contributes zero
   int accumulate;    // 1: y += result
-  int tap_inner;     // K order: 1 = (channel chunk, tap), 0 = (tap, channel chunk), -1 = let the launcher choose
   int nphase;
   ConvPhase ph[4];
 };

@@ -394,16 +394,24 @@ static T make_zin(Ctx& c) {
   return zin;
 }
 
+// Data parallel: sum the group's flat gradient over the ranks (RCCL) and average inside RMSProp.  Both run on
+// the side stream behind an event, so the exchange of sub-step k overlaps the compute of sub-step k+1 whenever
+// that one does not read this group's weights (sub-steps 1-4 touch disjoint groups and G is frozen until 5;
+// E's update overlaps sub-step 7) -- run_substep() waits for exactly the groups it reads.
 static void apply_group(Ctx& c, int group) {
   NetGroup& g = c.groups[group];
   for (Param* p : g.params)
     if (p->trainable && !p->dead) EG_CHECK(p->g_set, "variable %s received no gradient", p->name.c_str());
-  float gscale = 1.f;
-  if (c.nranks > 1) {
-    comm_allreduce(c, g.g, g.n_live);
-    gscale = 1.f / c.nranks;
+  if (c.nccl_comm) {
+    EG_HIP(hipEventRecord(c.ev_ready[group], c.stream));
+    EG_HIP(hipStreamWaitEvent(c.comm_stream, c.ev_ready[group], 0));
+    comm_allreduce(c, g.g, g.n_live, c.comm_stream);
+    launch_rmsprop(g.w, g.g, g.ms, g.mom, g.n_live, c.cfg.lr, 1.f / c.nranks, c.comm_stream);
+    EG_HIP(hipEventRecord(c.ev_applied[group], c.comm_stream));
+    c.pending[group] = true;
+    return;
   }
-  launch_rmsprop(g.w, g.g, g.ms, g.mom, g.n_live, c.cfg.lr, gscale, c.stream);
+  launch_rmsprop(g.w, g.g, g.ms, g.mom, g.n_live, c.cfg.lr, 1.f, c.stream);
 }
 
 // WGAN-GP discriminator step (edgegan.py:278-309, functional.py:26-33, edgegan.py:32-42).
@@ -463,6 +471,17 @@ void run_substep(Ctx& c, int k, bool apply) {
   const int B = cfg.B;
   EG_CHECK(k >= 1 && k <= 7, "sub-step index 1..7");
   if (k == 4 && !cfg.multiclasses()) return;  // d_optim2 only registered with multiclasses (edgegan.py:115-116)
+  {  // weights (and flat gradient buffers) this sub-step touches must have their pending update applied
+    static const unsigned reads[8] = {0,
+                                      1u << G_G1 | 1u << G_G2 | 1u << G_D,
+                                      1u << G_G2 | 1u << G_DP2,
+                                      1u << G_G1 | 1u << G_DP3,
+                                      1u << G_D2,
+                                      1u << G_G1 | 1u << G_G2 | 1u << G_D | 1u << G_DP2 | 1u << G_DP3 | 1u << G_D2,
+                                      1u << G_G1 | 1u << G_E,
+                                      1u << G_G1 | 1u << G_G2 | 1u << G_D | 1u << G_DP2 | 1u << G_DP3 | 1u << G_D2};
+    comm_wait_groups(c, reads[k]);
+  }
   reset_step(c);
   for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);
   T images = wrap_tensor(c, c.d_images, B, cfg.H, cfg.W, cfg.c_dim);
@@ -556,6 +575,7 @@ void train_step(Ctx& c) {
 void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const float* d_eps2, float* d_edge,
            float* d_image) {
   const Config& cfg = c.cfg;
+  comm_wait_all(c);
   reset_step(c);
   for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);
   T images = wrap_tensor(c, const_cast<float*>(d_images), NB, cfg.H, cfg.W, cfg.c_dim);

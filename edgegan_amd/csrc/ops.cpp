@@ -163,7 +163,6 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
   const int Cin = x->c, N = y->c;
   const float* wT = wref_transposed(c, w);  // [T][N][Cin]
   ConvArgs a{};
-  a.tap_inner = -1;
   a.x = y->g;
   a.wgt = wT;
   a.bias = nullptr;
@@ -295,7 +294,6 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   T y = accumulate_into ? accumulate_into : new_tensor(c, x->n, OH, OW, N, false);
   EG_CHECK(y->n == x->n && y->h == OH && y->w == OW && y->c == N, "conv2d output shape");
   ConvArgs a{};
-  a.tap_inner = -1;
   a.x = x->d;
   a.wgt = w->w;
   a.bias = bias ? bias->w : nullptr;
@@ -356,7 +354,6 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
   T y = new_tensor(c, x->n, OH, OW, cout, false);
   const float* wT = wref_transposed(c, w);  // [25][Cin][Cout]
   ConvArgs a{};
-  a.tap_inner = -1;
   a.x = x->d;
   a.wgt = wT;
   a.bias = bias ? bias->w : nullptr;
@@ -405,7 +402,6 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
       if (x->needs_grad) {
         // dx[i] = sum_k dy[2i+k-1] w[k]: a stride-2 SAME conv of dy with the filter as stored
         ConvArgs b{};
-        b.tap_inner = -1;
         int acc;
         b.y = grad_acc(c, x, &acc);
         b.accumulate = acc;

@@ -84,22 +84,26 @@ def test_train_step_equals_sequential_substeps_and_is_deterministic():
     assert np.all(outs[0]['D2/Conv_1/weights/RMSProp'] == 1)
 
 
-def test_rccl_single_rank_allreduce_path():
-    """nranks=1 communicator: exercises RCCL binding + the all-reduce call on the real library."""
+def test_rccl_single_rank_allreduce_and_overlap_path():
+    """nranks=1 communicator: exercises the RCCL binding, the all-reduce on the real library and the side-stream
+    overlap of (all-reduce + RMSProp) with the next sub-step's compute.  With one rank the exchange is the
+    identity, so two full iterations must reproduce the communicator-free run bit for bit."""
     cfg = ea.Config(batch_size=2)
     values = ea.init_variables(cfg, 0)
     batch = ea.synthetic_batch(cfg)
-    ref = ea.EdgeGAN(cfg, values)
-    ref.upload_batch(**batch)
-    ref.substep(6, True)
-    want = ref.get_variable('E/FC8_mu/w')
-    ref.close()
-    net = ea.EdgeGAN(cfg, values)
-    net.comm_init(net.comm_unique_id(), 0, 1)
-    net.upload_batch(**batch)
-    net.substep(6, True)
-    assert np.array_equal(net.get_variable('E/FC8_mu/w'), want)
-    net.close()
+    outs = []
+    for use_comm in (False, True):
+        net = ea.EdgeGAN(cfg, values)
+        if use_comm:
+            net.comm_init(net.comm_unique_id(), 0, 1)
+        net.upload_batch(**batch)
+        net.train_step()
+        net.train_step()
+        outs.append((net.get_variables(slots=True), net.losses()))
+        net.close()
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+    assert outs[0][1] == outs[1][1]
 
 
 def test_checkpoint_round_trip_on_device(tmp_path):
