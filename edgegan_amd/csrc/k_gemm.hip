@@ -13,6 +13,8 @@
 // Tiles: 256 threads = 4 waves; block tile BMxBN, K-step 16; each wave owns a WTMxWTN sub-tile as
 // (WTM/16)x(WTN/16) 16x16 accumulators.  Global->register prefetch of the next K tile overlaps the
 // MFMA work on the current one (register-staged, write-after-barrier).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace eg {
@@ -27,8 +29,8 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // =============================================================================================
 // conv_gemm_kernel
 // =============================================================================================
-template <int BM, int BN, int WTM, int WTN, int BK, bool VEC, bool BVEC, int MINW = 1>
-__global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvArgs a) {
+template <int BM, int BN, int WTM, int WTN, int BK, bool VEC, bool BVEC, bool SPLITK = false>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
   constexpr int LDA = BK + 4;
   constexpr int LDB = BN + ((BN % 32 == 0) ? 16 : 32);
   constexpr int WGN = BN / WTN;
@@ -40,7 +42,9 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvArgs a) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const ConvPhase ph = a.ph[blockIdx.z];
+  const int zphase = SPLITK ? (int)blockIdx.z / a.ksplit : (int)blockIdx.z;
+  const int zsplit = SPLITK ? (int)blockIdx.z - zphase * a.ksplit : 0;
+  const ConvPhase ph = a.ph[zphase];
   const int M = a.NB * ph.OHp * ph.OWp;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   if (m0 >= M) return;
@@ -90,6 +94,17 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvArgs a) 
 
   // position of the NEXT tile to load in the tap-tiled K order (no divisions in the loop)
   int nx_ty = 0, nx_tx = 0, nx_c0 = 0;
+  int kt_lo = 0, kt_hi = nk;
+  if constexpr (SPLITK) {  // this block owns K tiles [kt_lo, kt_hi) and writes a partial slab
+    const int per = (nk + a.ksplit - 1) / a.ksplit;
+    kt_lo = zsplit * per;
+    kt_hi = min(nk, kt_lo + per);
+    const int cpt = C / BK;
+    const int tap0 = kt_lo / cpt;
+    nx_c0 = (kt_lo - tap0 * cpt) * BK;
+    nx_ty = tap0 / ph.Tx;
+    nx_tx = tap0 - nx_ty * ph.Tx;
+  }
 
   auto load_tile = [&](int kt) {
     if constexpr (VEC) {
@@ -191,11 +206,11 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvArgs a) 
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int l15 = lane & 15, lq = lane >> 4;
-  load_tile(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  if (kt_lo < kt_hi) load_tile(kt_lo);
+  for (int kt = kt_lo; kt < kt_hi; ++kt) {
     store_tile();
     __syncthreads();
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < kt_hi) load_tile(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       float af[MI], bf[NJ];
@@ -222,14 +237,17 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvArgs a) 
       const int t2 = m / ph.OWp;
       const int oy = t2 % ph.OHp;
       const int nb = t2 / ph.OHp;
-      float* yrow = a.y + ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
+      float* yrow = (SPLITK ? a.ws + (size_t)zsplit * a.y_total : a.y) +
+                    ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wn * WTN + j * 16 + l15;
         if (n < N) {
           float v = acc[i][j][r];
-          if (a.bias) v += a.bias[n];
-          if (a.accumulate) v += yrow[n];
+          if constexpr (!SPLITK) {
+            if (a.bias) v += a.bias[n];
+            if (a.accumulate) v += yrow[n];
+          }
           yrow[n] = v;
         }
       }
@@ -237,10 +255,45 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_kernel(const ConvArgs a) 
   }
 }
 
-template <int BM, int BN, int WTM, int WTN, int BK, bool VEC, bool BVEC, int MINW = 1>
+template <int BM, int BN, int WTM, int WTN, int BK, bool VEC, bool BVEC>
 static void conv_launch(const ConvArgs& a, int maxM, hipStream_t s) {
+  if constexpr (VEC && BVEC) {
+    if (a.ksplit > 1) {
+      dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase * a.ksplit);
+      hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, BK, true, true, true>), grid, dim3(256), 0, s, a);
+      return;
+    }
+  }
   dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, BK, VEC, BVEC, MINW>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, BK, VEC, BVEC, false>), grid, dim3(256), 0, s, a);
+}
+
+// y (+)= bias + sum over the K-split slabs (fixed order)
+__global__ void conv_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ y, const float* __restrict__ bias,
+                                         size_t total, int y_ps, int N, int ksplit, int accumulate) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % y_ps);
+    if (n >= N) continue;
+    float v = bias ? bias[n] : 0.f;
+    for (int k = 0; k < ksplit; ++k) v += ws[(size_t)k * total + i];
+    y[i] = accumulate ? y[i] + v : v;
+  }
+}
+
+// K-split factor for launches that cannot fill the 256 CUs with output tiles (small M x N, long K)
+int conv_pick_ksplit(const ConvArgs& a) {
+  if (a.N <= 16 || a.C % 32 != 0 || a.N % 4 != 0) return 1;
+  int maxM = 0, minTiles = 1 << 30;
+  for (int p = 0; p < a.nphase; ++p) {
+    maxM = std::max(maxM, a.NB * a.ph[p].OHp * a.ph[p].OWp);
+    minTiles = std::min(minTiles, a.ph[p].Ty * a.ph[p].Tx * (a.C / 32));
+  }
+  const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase;
+  if (t64 >= 384) return 1;
+  int ks = (int)((512 + t64 - 1) / t64);
+  ks = std::min(ks, 8);
+  ks = std::min(ks, minTiles / 4);   // at least 4 K tiles (128 of K) per split
+  return ks < 2 ? 1 : ks;
 }
 
 // k32: C % 32 == 0 -> K step 32 (half the barriers / address arithmetic per MFMA)
@@ -262,7 +315,8 @@ static const char* conv_dispatch(const ConvArgs& a, int maxM, bool avec, bool bv
   return nf;
 }
 
-double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_name) {
+double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel_name) {
+  ConvArgs a = a_in;
   int maxM = 0;
   double flops = 0;
   for (int p = 0; p < a.nphase; ++p) {
@@ -272,6 +326,7 @@ double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_na
   }
   const bool avec = (a.C % 16 == 0) && (a.x_ps % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
   const bool bvec = (a.N % 4 == 0) && (a.ldw % 4 == 0) && (a.w_ts % 4 == 0) && (((uintptr_t)a.wgt & 15) == 0);
+  if (!(avec && bvec) || a.N <= 16 || !a.ws) a.ksplit = 1;   // only the fully vectorised kernels have a split-K form
   const long long blocks128 = (long long)((maxM + 127) / 128) * ((a.N + 127) / 128) * a.nphase;
   const char* nm;
   if (a.N <= 16) {
@@ -285,8 +340,9 @@ double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_na
     // pick the tile by CU load balance: the MFMA pipe is the bottleneck, so what matters is how evenly the
     // tiles divide over the 256 CUs (measured: 4 vs 3 resident blocks per CU changes nothing), times the
     // per-tile efficiency of each configuration (64x64 runs at ~0.8 of the 128x128 tile's rate)
-    const long long t128 = blocks128;
-    const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase;
+    const int ksp = a.ksplit > 1 ? a.ksplit : 1;
+    const long long t128 = blocks128 * ksp;
+    const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase * ksp;
     auto balance = [](long long tiles) {
       const long long per_cu = (tiles + 255) / 256;
       return (double)tiles / (double)(per_cu * 256);
@@ -299,6 +355,13 @@ double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_na
     else
       nm = conv_dispatch<64, 64, 32, 32>(a, maxM, avec, bvec, s, "conv_gemm<64,64,vec>", "conv_gemm<64,64,avec>",
                                          "conv_gemm<64,64,flat>");
+  }
+  if (a.ksplit > 1) {
+    const size_t total = a.y_total;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.ws, a.y, a.bias, total, a.y_ps,
+                       a.N, a.ksplit, a.accumulate);
   }
   if (kernel_name) *kernel_name = nm;
   return flops;

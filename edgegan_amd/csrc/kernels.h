@@ -31,12 +31,16 @@ struct ConvArgs {
   int ldw;
   int reflect;       // 1: out-of-range input index is mirrored (tf.pad REFLECT), 0: contributes zero
   int accumulate;    // 1: y += result
+  int ksplit;        // > 1: K is split over ksplit blocks writing partial slabs to ws, reduced afterwards
+  float* ws;         // ksplit * y_total floats
+  size_t y_total;    // NB*OHf*OWf*y_ps
   int nphase;
   ConvPhase ph[4];
 };
 
 // flops (2*M*N*K summed over phases) are returned for the profiler.
 double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_name);
+int conv_pick_ksplit(const ConvArgs& a);
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[wt(tap)][c][n] = sum_m X[pix_in(m,tap)][c] * dY[m][n], m over NB*OH*OW

@@ -148,6 +148,17 @@ const float* wref_transposed(Ctx& c, WRef* w) {
   return buf;
 }
 
+// launch one implicit-GEMM conv; layers too small to fill the chip with output tiles split K over blocks
+static void run_conv(Ctx& c, ConvArgs& a) {
+  a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
+  a.ksplit = conv_pick_ksplit(a);
+  a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
+  const char* nm;
+  ProfScope ps(c);
+  const double fl = launch_conv_gemm(a, c.stream, &nm);
+  ps.done(nm, fl);
+}
+
 static void same_pad(int n, int k, int s, int* out, int* before) {
   *out = (n + s - 1) / s;
   int total = (*out - 1) * s + k - n;
@@ -192,10 +203,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
       a.OWf = Wp;
       a.accumulate = 0;
       a.ph[0] = ConvPhase{Hp, Wp, 0, 0, k, k, 0, 0, 0, 0};
-      const char* nm;
-      ProfScope ps(c);
-      const double fl = launch_conv_gemm(a, c.stream, &nm);
-      ps.done(nm, fl);
+      run_conv(c, a);
       int acc;
       float* dx = grad_acc(c, x, &acc);
       launch_reflect_fold(dpad, dx, acc, x->n, x->h, x->w, Cin, pt, c.stream);
@@ -233,10 +241,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
         p.offx = (px + pl - kw0) / 2;
       }
   }
-  const char* nm;
-  ProfScope ps(c);
-  const double fl = launch_conv_gemm(a, c.stream, &nm);
-  ps.done(nm, fl);
+  run_conv(c, a);
 }
 
 static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, const float* dy, int OH, int OW,
@@ -318,12 +323,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   a.accumulate = accumulate_into ? 1 : 0;
   a.nphase = 1;
   a.ph[0] = ConvPhase{OH, OW, 0, 0, k, k, 0, 0, -pt, -pl};
-  {
-    const char* nm;
-    ProfScope ps(c);
-    const double fl = launch_conv_gemm(a, c.stream, &nm);
-    ps.done(nm, fl);
-  }
+  run_conv(c, a);
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
   if (need) {
     y->needs_grad = true;
@@ -381,12 +381,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
       a.ph[py * 2 + px] = ConvPhase{x->h, x->w, py, px, (k - kh0 + 1) / 2, (k - kw0 + 1) / 2, kh0, kw0,
                                     (py + pt - kh0) / 2, (px + pt - kw0) / 2};
     }
-  {
-    const char* nm;
-    ProfScope ps(c);
-    const double fl = launch_conv_gemm(a, c.stream, &nm);
-    ps.done(nm, fl);
-  }
+  run_conv(c, a);
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
   if (need) {
     y->needs_grad = true;
@@ -425,10 +420,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
         b.ldw = Cin;
         b.nphase = 1;
         b.ph[0] = ConvPhase{x->h, x->w, 0, 0, 5, 5, 0, 0, -1, -1};
-        const char* nm;
-        ProfScope ps(c);
-        const double fl = launch_conv_gemm(b, c.stream, &nm);
-        ps.done(nm, fl);
+        run_conv(c, b);
       }
     });
   }
