@@ -221,34 +221,50 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg --------------------------
+  // ---- epilogue: the MFMA operands are swapped (D^T = B^T A^T), so lane l holds, for pixel row lane&15, the 4
+  // consecutive output channels (lane>>4)*4 + reg: one 16-byte store per accumulator instead of four scalars
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + l15;
+    if (m >= M) continue;
+    const int ox = m % ph.OWp;
+    const int t2 = m / ph.OWp;
+    const int oy = t2 % ph.OHp;
+    const int nb = t2 / ph.OHp;
+    float* yrow = (SPLITK ? a.ws + (size_t)zsplit * a.y_total : a.y) +
+                  ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wm * WTM + i * 16 + lq * 4 + r;
-      if (m >= M) continue;
-      const int ox = m % ph.OWp;
-      const int t2 = m / ph.OWp;
-      const int oy = t2 % ph.OHp;
-      const int nb = t2 / ph.OHp;
-      float* yrow = (SPLITK ? a.ws + (size_t)zsplit * a.y_total : a.y) +
-                    ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wn * WTN + j * 16 + l15;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + lq * 4;
+      if constexpr (BVEC) {   // N % 4 == 0: whole float4 in range or not at all
         if (n < N) {
-          float v = acc[i][j][r];
+          float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
           if constexpr (!SPLITK) {
-            if (a.bias) v += a.bias[n];
-            if (a.accumulate) v += yrow[n];
+            if (a.bias) {
+              const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);
+              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            }
+            if (a.accumulate) {
+              const float4 o = *reinterpret_cast<const float4*>(yrow + n);
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
           }
-          yrow[n] = v;
+          *reinterpret_cast<float4*>(yrow + n) = v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < N) {
+            float v = acc[i][j][r];
+            if (a.bias) v += a.bias[n + r];
+            if (a.accumulate) v += yrow[n + r];
+            yrow[n + r] = v;
+          }
         }
       }
     }
