@@ -525,31 +525,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
     }
   }
 
   const int T = a.KH * a.KW;
+  // operands swapped (see conv_gemm_kernel): lane l owns filter row c = ..+(lane&15) and the 4 consecutive output
+  // channels (lane>>4)*4 + reg
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i) {
+    const int c = c0 + wm * WTM + i * 16 + l15;
+    if (c >= C) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = c0 + wm * WTM + i * 16 + lq * 4 + r;
-      if (c >= C) continue;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wn * WTN + j * 16 + l15;
-        if (n >= N) continue;
-        if (dense_out) {  // partial slab [split][T][C][N]
-          out[(((size_t)blockIdx.z * T + tap) * C + c) * N + n] = acc[i][j][r];
-        } else {
-          float* q = out + (size_t)tap * a.w_ts + (size_t)c * a.ldw + n;
-          *q = a.accumulate ? *q + acc[i][j][r] : acc[i][j][r];
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + lq * 4;
+      float* q = dense_out ? out + (((size_t)blockIdx.z * T + tap) * C + c) * N + n  // partial slab [split][T][C][N]
+                           : out + (size_t)tap * a.w_ts + (size_t)c * a.ldw + n;
+      if constexpr (VEC) {
+        if (n < N) {
+          float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          if (!dense_out && a.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(q);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          *reinterpret_cast<float4*>(q) = v;
         }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) q[r] = (!dense_out && a.accumulate) ? q[r] + acc[i][j][r] : acc[i][j][r];
       }
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -758,7 +767,8 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
   float* out = direct ? a.dw : a.ws;
   const int dense = direct ? 0 : 1;
   const bool vec = (a.C % 4 == 0) && (a.N % 4 == 0) && (a.x_ps % 4 == 0) && (a.dy_ps % 4 == 0) &&
-                   (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
+                   (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0) && (a.ldw % 4 == 0) &&
+                   (a.w_ts % 4 == 0) && (((uintptr_t)out & 15) == 0);
   const char* nm;
   if (wgrad_flatm(a)) {
     dim3 grid(((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64), a.nsplit);
