@@ -45,7 +45,7 @@ def pmc_traffic(kernel_label):
                 continue
             flags = re.findall(r'(true|false)', k)
             want = {'vec': ['true', 'true'], 'avec': ['true', 'false'], 'flat': ['false', 'false']}.get(mode)
-            if base == 'conv_gemm' and want and flags[-2:] != want:
+            if base == 'conv_gemm' and want and (flags[:2] != want or flags[2:3] == ['true']):
                 continue
             if base == 'wgrad' and mode and flags[-1:] != (['true'] if mode == 'vec' else ['false']):
                 continue

@@ -740,7 +740,7 @@ int wgrad_pick_splits(const WgradArgs& a) {
   const int bm = wgrad_big(a) ? 128 : 64;
   const long long tiles = (long long)((a.C + bm - 1) / bm) * ((a.N + bm - 1) / bm) * a.KH * a.KW;
   const long long M = (long long)a.NB * a.OH * a.OW;
-  long long s = (768 + tiles - 1) / tiles;
+  long long s = (1024 + tiles - 1) / tiles;
   const long long smax = (M + 255) / 256;
   if (s > smax) s = smax;
   if (s < 1) s = 1;
