@@ -143,3 +143,25 @@ def test_tensorboard_event_file_round_trip(tmp_path, built_lib):
     with pytest.raises(ValueError, match='checksum'):
         S.read_events(w.path)
     assert set(S.SCALAR_TAGS) >= {'joint_dis_dloss', 'image_dis_dloss', 'edge_dis_dloss', 'loss_d_ac', 'zl_loss'}
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_reference_example_images_through_the_pipeline():
+    """The reference's own example PNGs: training pairs span 0..255 (identity through imresize), test sketches
+    have min 126, so scipy<=1.2's float bytescale stretches them to the full [-1, 1] range."""
+    ds = D.Dataset(GOLDEN, 'dataset_example', np.inf, 1, CFG, None, 'test')
+    assert [os.path.basename(f) for f in ds.data] == ['14809.png', '14810.png', '14811.png', '14812.png']
+    img, files = ds[0]
+    raw = np.array(Image.open(files[0])).astype(np.float64)
+    assert raw.min() == 126 and raw.max() == 255
+    assert img.shape == (1, 64, 128, 3) and img.min() == -1.0 and img.max() == 1.0
+    want = np.floor((raw - 126.0) * (255.0 / 129.0) + 0.5).clip(0, 255) / 127.5 - 1.0
+    assert np.allclose(img[0], want, atol=1e-6)
+    tr = D.Dataset(GOLDEN, 'dataset_example', np.inf, 2, CFG, 14, 'train')
+    images, z, files = tr[0]
+    assert images.shape == (2, 64, 128, 3) and np.all(z[:, -1] == 3)
+    raw = np.array(Image.open(files[0])).astype(np.float64)
+    if raw.min() == 0 and raw.max() == 255:
+        assert np.allclose(images[0], raw / 127.5 - 1.0, atol=1e-6)

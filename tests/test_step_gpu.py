@@ -208,3 +208,24 @@ def test_full_size_classifier_step_equals_mean_of_small_shards():
     assert abs(loss - loss_big) / abs(loss_big) < 1e-5
     for n in names:
         assert parity.rel_l2(want[n], acc[n]) < 1e-3, (n, parity.rel_l2(want[n], acc[n]))
+
+
+def test_inference_on_reference_example_sketches():
+    """SURVEY 8c golden item (iv): E -> G1, G2 on the reference's 4 example test PNGs (loaded through the data
+    pipeline, class from the directory name, fixed eps), batch 1 like edgegan.test, against the oracle."""
+    from edgegan_amd import data as D
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    dcfg = {'input_height': 64, 'input_width': 128, 'output_height': 64, 'output_width': 128, 'crop': False}
+    ds = D.Dataset(golden, 'dataset_example', np.inf, 1, dcfg, None, 'test')
+    cfg = ea.Config(batch_size=1)
+    values = ea.init_variables(cfg, 7)
+    net = ea.EdgeGAN(cfg, values)
+    om = O.OracleModel(parity.oracle_config(cfg), values, dtype=torch.float64)
+    assert len(ds) == 4
+    for idx in range(len(ds)):
+        imgs, files = ds[idx]
+        cls = np.array([int(os.path.basename(os.path.dirname(files[0])))], dtype=np.int32)
+        e_ref, i_ref = om.infer(parity.t64(imgs), torch.tensor(cls), 0.3, -0.7)
+        e, i = net.infer(imgs, cls, eps2=[0.3, -0.7])
+        assert parity.relerr(e, e_ref.numpy()) < 1e-4 and parity.relerr(i, i_ref.numpy()) < 1e-4, files[0]
+    net.close()
