@@ -160,6 +160,7 @@ int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long 
   EG_HIP(hipMemcpyAsync(d, host, n * 4, hipMemcpyHostToDevice, ctx->c.stream));
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
   ctx->c.sn_valid = false;
+  ctx->c.gen_cache_valid[0] = ctx->c.gen_cache_valid[1] = false;
   EG_API_END(ctx)
 }
 
@@ -186,6 +187,7 @@ int eg_upload_batch(eg_ctx* ctx, const float* images, const float* z, const floa
   EG_HIP(hipMemcpyAsync(c.d_z, z, (size_t)cfg.B * zc * 4, hipMemcpyHostToDevice, c.stream));
   EG_HIP(hipMemcpyAsync(c.d_alpha, alpha, (size_t)3 * cfg.B * 4, hipMemcpyHostToDevice, c.stream));
   EG_HIP(hipMemcpyAsync(c.d_eps, eps, 4, hipMemcpyHostToDevice, c.stream));
+  c.gen_cache_valid[0] = c.gen_cache_valid[1] = false;
   EG_HIP(hipStreamSynchronize(c.stream));
   EG_API_END(ctx)
 }

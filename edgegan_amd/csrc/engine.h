@@ -96,6 +96,10 @@ struct Ctx {
   float* d_losses = nullptr;  // [64]
   int* d_classes = nullptr;
   long long step_count = 0;
+  // generator outputs of the D-phase (sub-steps 1-3 share G1(z), G2(z): G is frozen until sub-step 5)
+  float* d_gen_cache[2] = {nullptr, nullptr};
+  float* d_gen_bn[2] = {nullptr, nullptr};   // batch statistics of that forward, for the moving-average updates
+  bool gen_cache_valid[2] = {false, false};
 
   // profiling
   bool prof_on = false;
@@ -152,7 +156,7 @@ T in_act(Ctx& c, T x, int act, T* stats_out = nullptr);
 T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int act);
 T act(Ctx& c, T x, int a);
 T act_tangent(Ctx& c, T tx, T out_prim, int a);
-T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times);
+T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times, T* stats_out = nullptr);
 T add(Ctx& c, T a, T b, bool relu);
 T pool2(Ctx& c, T x);
 T gmean(Ctx& c, T x, bool pre_relu);
@@ -179,7 +183,7 @@ struct DiscSave {
   T out[4] = {nullptr, nullptr, nullptr, nullptr};
   T stats[4] = {nullptr, nullptr, nullptr, nullptr};
 };
-T generator_forward(Ctx& c, int group, T zin, int bn_times);
+T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out = nullptr);
 T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_of);
 T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out = nullptr, T* ls_out = nullptr);
 T classifier_forward(Ctx& c, T x);

@@ -231,6 +231,10 @@ void build_context(Ctx& c) {
   EG_HIP(hipMalloc(&c.d_eps, 16 * 4));
   EG_HIP(hipMalloc(&c.d_losses, 64 * 4));
   EG_HIP(hipMalloc(&c.d_classes, (size_t)cfg.B * 4));
+  for (int i = 0; i < 2; ++i) {
+    EG_HIP(hipMalloc(&c.d_gen_cache[i], img / 2 * 4));
+    EG_HIP(hipMalloc(&c.d_gen_bn[i], (size_t)2 * cfg.gf * 8 * 4));
+  }
   EG_HIP(hipMemsetAsync(c.d_losses, 0, 64 * 4, c.stream));
   EG_HIP(hipMemsetAsync(c.d_eps, 0, 16 * 4, c.stream));
   EG_HIP(hipStreamSynchronize(c.stream));
@@ -240,7 +244,7 @@ void build_context(Ctx& c) {
 // networks
 // ---------------------------------------------------------------------------------------------
 // generator.py:35-74 (_convnet): linear -> reshape -> BatchNorm(!) -> ReLU -> 3x[deconv,IN,ReLU] -> deconv -> tanh
-T generator_forward(Ctx& c, int group, T zin, int bn_times) {
+T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out) {
   const Config& cfg = c.cfg;
   const std::string p = kGroupPrefix[group];
   const int gf = cfg.gf, h16 = cfg.H / 16, w16 = cfg.W / 2 / 16;
@@ -249,7 +253,7 @@ T generator_forward(Ctx& c, int group, T zin, int bn_times) {
   T x = reshape(c, z_, zin->n, h16, w16, gf * 8);
   x = bn_relu(c, x, P(c, p + "/batch_norm/BatchNorm/gamma"), P(c, p + "/batch_norm/BatchNorm/beta"),
               P(c, p + "/batch_norm/BatchNorm/moving_mean"), P(c, p + "/batch_norm/BatchNorm/moving_variance"),
-              bn_times);
+              bn_times, bn_stats_out);
   const int ch[5] = {gf * 8, gf * 4, gf * 2, gf, cfg.c_dim};
   for (int i = 1; i <= 4; ++i) {
     const std::string b = p + "/g_dconv_" + std::to_string(i) + "/deconv2d/";
@@ -400,6 +404,8 @@ static T make_zin(Ctx& c) {
 // E's update overlaps sub-step 7) -- run_substep() waits for exactly the groups it reads.
 static void apply_group(Ctx& c, int group) {
   NetGroup& g = c.groups[group];
+  if (group == G_G1) c.gen_cache_valid[0] = false;
+  if (group == G_G2) c.gen_cache_valid[1] = false;
   for (Param* p : g.params)
     if (p->trainable && !p->dead) EG_CHECK(p->g_set, "variable %s received no gradient", p->name.c_str());
   if (c.nccl_comm) {
@@ -463,6 +469,29 @@ static void disc_substep(Ctx& c, int group, T real, T fake, const float* alpha_d
   set_want_grad(c, group, false);
 }
 
+// G1(z) / G2(z) for the discriminator sub-steps: evaluated once per iteration and shared by sub-steps 1-3 (the
+// reference re-evaluates them in each sess.run; the generators are frozen until sub-step 5, so the values are the
+// same -- SURVEY 7.2).  The BatchNorm moving statistics still advance once per reference evaluation.
+static T generator_output_nograd(Ctx& c, int group, T zin, int bn_t) {
+  const Config& cfg = c.cfg;
+  const int i = group == G_G1 ? 0 : 1;
+  const std::string p = kGroupPrefix[group];
+  const int C = cfg.gf * 8, R = cfg.B * (cfg.H / 16) * (cfg.W / 2 / 16);
+  if (c.gen_cache_valid[i]) {
+    if (bn_t > 0)
+      launch_bn_moving_update(P(c, p + "/batch_norm/BatchNorm/moving_mean")->w,
+                              P(c, p + "/batch_norm/BatchNorm/moving_variance")->w, c.d_gen_bn[i], C, R, 0.9f, bn_t,
+                              c.stream);
+    return wrap_tensor(c, c.d_gen_cache[i], cfg.B, cfg.H, cfg.W / 2, cfg.c_dim);
+  }
+  T st = nullptr;
+  T out = generator_forward(c, group, zin, bn_t, &st);
+  launch_copy(out->d, c.d_gen_cache[i], out->numel(), c.stream);
+  launch_copy(st->d, c.d_gen_bn[i], (size_t)2 * C, c.stream);
+  c.gen_cache_valid[i] = true;
+  return out;
+}
+
 static T right_half(Ctx& c, T images) { return slice_w(c, images, c.cfg.W / 2, c.cfg.W); }
 static T left_half(Ctx& c, T images) { return slice_w(c, images, 0, c.cfg.W / 2); }
 
@@ -491,21 +520,21 @@ void run_substep(Ctx& c, int k, bool apply) {
   switch (k) {
     case 1: {  // d_optim: joint discriminator
       T zin = make_zin(c);
-      T edge = generator_forward(c, G_G1, zin, bn_t);
-      T image = generator_forward(c, G_G2, zin, bn_t);
+      T edge = generator_output_nograd(c, G_G1, zin, bn_t);
+      T image = generator_output_nograd(c, G_G2, zin, bn_t);
       T joint = concat_w(c, edge, image);
       disc_substep(c, G_D, images, joint, c.d_alpha, L_JOINT_D, L_JOINT_GP, apply);
     } break;
     case 2: {  // d_optim_patch2: image discriminator on bicubic-resized right halves
       T zin = make_zin(c);
-      T image = generator_forward(c, G_G2, zin, bn_t);
+      T image = generator_output_nograd(c, G_G2, zin, bn_t);
       T r_real = resize(c, right_half(c, images), cfg.dis_size);
       T r_fake = resize(c, image, cfg.dis_size);
       disc_substep(c, G_DP2, r_real, r_fake, c.d_alpha + B, L_IMAGE_D, L_IMAGE_GP, apply);
     } break;
     case 3: {  // d_optim_patch3: edge discriminator
       T zin = make_zin(c);
-      T edge = generator_forward(c, G_G1, zin, bn_t);
+      T edge = generator_output_nograd(c, G_G1, zin, bn_t);
       T r_real = resize(c, left_half(c, images), cfg.dis_size);
       T r_fake = resize(c, edge, cfg.dis_size);
       disc_substep(c, G_DP3, r_real, r_fake, c.d_alpha + 2 * B, L_EDGE_D, L_EDGE_GP, apply);

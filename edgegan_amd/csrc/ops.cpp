@@ -548,11 +548,12 @@ T act_tangent(Ctx& c, T tx, T out_prim, int a) {
 }
 
 // generator.py:51-52 (quirk N1): contrib batch_norm, batch statistics, then ReLU
-T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times) {
+T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times, T* stats_out) {
   const int C = x->c, R = (int)x->pixels();
   T out = new_tensor(c, x->n, x->h, x->w, C, true);
   T st = new_tensor(c, 1, 1, 1, 2 * C, false);
   launch_bn_relu_fwd(x->d, gamma->w, beta->w, out->d, st->d, R, C, 1e-5f, c.stream);
+  if (stats_out) *stats_out = st;
   if (update_times > 0) launch_bn_moving_update(mm->w, mv->w, st->d, C, R, 0.9f, update_times, c.stream);
   const bool need = x->needs_grad || gamma->want_grad;
   out->needs_grad = need;
@@ -882,6 +883,10 @@ Ctx::~Ctx() {
   (void)hipFree(d_eps);
   (void)hipFree(d_losses);
   (void)hipFree(d_classes);
+  for (int i = 0; i < 2; ++i) {
+    (void)hipFree(d_gen_cache[i]);
+    (void)hipFree(d_gen_bn[i]);
+  }
   if (stream) (void)hipStreamDestroy(stream);
 }
 
