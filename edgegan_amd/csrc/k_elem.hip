@@ -168,11 +168,13 @@ __global__ __launch_bounds__(256) void col_sum_stage1_v(const float* __restrict_
   cq_reduce<1, 8>(s, red);
   if (pl == 0) st4(part + (size_t)blockIdx.y * C + c, s[0]);
 }
-size_t col_sum_scratch_floats(int C) { return (size_t)CS_RB * C; }
+static int col_sum_row_blocks(size_t R) {
+  size_t nrb = (R + 255) / 256;
+  return nrb > CS_RB ? CS_RB : (nrb < 1 ? 1 : (int)nrb);
+}
+size_t col_sum_scratch_floats(size_t R, int C) { return (size_t)col_sum_row_blocks(R) * C; }
 void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C, float* scratch, hipStream_t s) {
-  int nrb = (int)((R + 255) / 256);
-  if (nrb > CS_RB) nrb = CS_RB;
-  if (nrb < 1) nrb = 1;
+  const int nrb = col_sum_row_blocks(R);
   if (C % 32 == 0 && (((uintptr_t)dy & 15) == 0))
     hipLaunchKernelGGL(col_sum_stage1_v, dim3(C / 32, nrb), dim3(256), 0, s, dy, scratch, R, C);
   else

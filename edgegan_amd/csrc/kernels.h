@@ -122,7 +122,7 @@ void launch_blend(const float* real, const float* fake, const float* alpha, floa
 void launch_reflect_fold(const float* dpad, float* dx, int accumulate, int NB, int H, int W, int C, int p,
                          hipStream_t s);
 // bias gradient: db[c] (+)= sum_rows dy[r][c]
-size_t col_sum_scratch_floats(int C);
+size_t col_sum_scratch_floats(size_t R, int C);
 void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C, float* scratch, hipStream_t s);
 // 2x2 mean pool NHWC fwd / bwd
 void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hipStream_t s);

@@ -278,7 +278,7 @@ static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, c
 }
 
 static void bias_grad(Ctx& c, Param* b, const float* dy, size_t rows, int C) {
-  if (c.scratch_floats < col_sum_scratch_floats(C)) fail(1, "scratch too small for bias grad");
+  if (c.scratch_floats < col_sum_scratch_floats(rows, C)) fail(1, "scratch too small for bias grad");
   launch_col_sum(dy, b->g, b->g_set ? 1 : 0, rows, C, c.scratch, c.stream);
   b->g_set = true;
 }

@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import edgegan_amd as ea
-cfg = ea.Config(batch_size=int(os.environ.get('B', '16')))
+cfg = ea.Config(batch_size=int(os.environ.get('B', '16')), height=int(os.environ.get('H', '64')),
+                width=int(os.environ.get('W', '128')))
 net = ea.EdgeGAN(cfg, ea.init_variables(cfg, 0))
 rng = np.random.RandomState(0)
 base = ea.synthetic_batch(cfg)

@@ -176,6 +176,19 @@ def test_high_resolution_config_forwards():
     net.close()
 
 
+def test_substeps_high_resolution_config():
+    """configs[4] geometry as a TRAINING step: 14-class 256x512, batch 1 -- all 7 sub-steps (gradients incl. the
+    WGAN-GP double backward through the 2x-decimating legacy bicubic into the patch discriminators, the 5-block
+    encoder, the 131072-wide generator projection) against oracle autograd in fp64."""
+    cfg = ea.Config(batch_size=1, height=256, width=512)
+    values = ea.init_variables(cfg, 7)
+    net = ea.EdgeGAN(cfg, values)
+    rows = parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=5))
+    assert len(rows) > 400
+    _assert(rows)
+    net.close()
+
+
 def test_full_size_classifier_step_equals_mean_of_small_shards():
     """Size-independent property at BASELINE's full size (batch 64, 14 classes): sub-step 4's loss is a batch
     mean over per-sample-independent computations (no BatchNorm on this path), so its gradient at B=64 must equal
