@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 # 14-class), minus the 2 generator forwards the engine legally shares across sub-steps 1-3 (2 x 0.3263)
 GFLOP_PER_IMAGE = 93.551 - 2 * 0.3263
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (never the 2:1-sparse figure)
 
 
 def pmc_traffic(kernel_label):
@@ -89,6 +90,9 @@ def main():
     ap.add_argument('--classes', type=int, default=14)
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help="f32 = BASELINE configs[2] (the headline metric); bf16 = configs[3]'s arithmetic: bf16 MFMA "
+                         "operands with fp32 accumulation / storage")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -113,7 +117,7 @@ def main():
         dist_mod.init_process_group('gloo', rank=rank, world_size=world)   # host-side rendezvous only
         dist = dist_mod
 
-    cfg_kwargs = dict(batch_size=args.batch, num_classes=args.classes, device=local)
+    cfg_kwargs = dict(batch_size=args.batch, num_classes=args.classes, device=local, compute_dtype=args.dtype)
     cfg = ea.Config(**cfg_kwargs)
     values = ea.init_variables(cfg, 0)                 # same weights on every rank
     net = ea.EdgeGAN(cfg, values)
@@ -167,8 +171,9 @@ def main():
             tot_ms = sum(k['ms'] for k in ks)
             tot_fl = sum(k['flops'] for k in ks)
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(dom['name']),
+            peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in dom['name'] else PEAK_FP32_MFMA_TFLOPS
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dom['name']),
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.csv)',
                     'kernel': dom['name'],
                     'launches_per_step': dom['launches'] / args.profile_steps,
@@ -189,8 +194,10 @@ def main():
             'metric': 'training images/sec (G+D step) at 64x128, 14-class',
             'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs[2]: 14-class 64x128 fp32 full G+D+classifier+E training iteration '
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': ('configs[2]: 14-class 64x128 fp32' if args.dtype == 'f32' else
+                                    'configs[3] arithmetic (bf16 MFMA operands, fp32 accumulate/storage): 14-class 64x128') +
+                                   ' full G+D+classifier+E training iteration '
                                    '(7 RMSProp sub-steps), batch 64 per GPU', 'global_batch': args.batch * world,
                        'per_gpu_batch': args.batch, 'num_classes': args.classes, 'parallelism': f'dp{world}'},
             'algorithmic_tflops_per_gpu': round(GFLOP_PER_IMAGE * value / world / 1e3, 2),

@@ -21,7 +21,7 @@ class _CConfig(C.Structure):
                 ('z_dim', C.c_int), ('gf_dim', C.c_int), ('df_dim', C.c_int), ('c_dim', C.c_int),
                 ('dis_size', C.c_int), ('lambda_gp', C.c_float), ('zl_weight', C.c_float),
                 ('learning_rate', C.c_float), ('joint_dweight', C.c_float), ('image_dweight', C.c_float),
-                ('edge_dweight', C.c_float), ('device', C.c_int)]
+                ('edge_dweight', C.c_float), ('device', C.c_int), ('compute_dtype', C.c_int)]
 
 
 @dataclass
@@ -43,6 +43,7 @@ class Config:
     image_dweight: float = 1.0
     edge_dweight: float = 1.0
     device: int = 0
+    compute_dtype: str = 'f32'  # 'bf16': dense contractions on the bf16 MFMA (fp32 accumulate / storage)
 
     @property
     def multiclasses(self) -> bool:
@@ -55,7 +56,8 @@ class Config:
     def to_c(self) -> _CConfig:
         return _CConfig(self.batch_size, self.height, self.width, self.num_classes, self.z_dim, self.gf_dim,
                         self.df_dim, self.c_dim, self.dis_size, self.lambda_gp, self.zl_weight,
-                        self.learning_rate, self.joint_dweight, self.image_dweight, self.edge_dweight, self.device)
+                        self.learning_rate, self.joint_dweight, self.image_dweight, self.edge_dweight, self.device,
+                        {'f32': 0, 'bf16': 1}[self.compute_dtype])
 
 
 EXPORTS = ['eg_default_config', 'eg_variable_count', 'eg_variable_info', 'eg_create', 'eg_destroy',

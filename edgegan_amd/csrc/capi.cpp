@@ -32,6 +32,7 @@ static Config to_config(const eg_config* k) {
   c.image_dweight = k->image_dweight;
   c.edge_dweight = k->edge_dweight;
   c.device = k->device;
+  c.bf16 = k->compute_dtype == 1;
   return c;
 }
 
@@ -54,7 +55,7 @@ extern "C" {
 
 int eg_default_config(eg_config* k) {
   if (!k) return 1;
-  *k = eg_config{64, 64, 128, 14, 100, 64, 64, 3, 128, 10.f, 10.f, 2e-4f, 1.f, 1.f, 1.f, 0};
+  *k = eg_config{64, 64, 128, 14, 100, 64, 64, 3, 128, 10.f, 10.f, 2e-4f, 1.f, 1.f, 1.f, 0, 0};
   return 0;
 }
 

@@ -14,6 +14,7 @@ struct Config {
   float lambda_gp = 10.f, zl_weight = 10.f, lr = 2e-4f;
   float joint_dweight = 1.f, image_dweight = 1.f, edge_dweight = 1.f;
   int device = 0;
+  bool bf16 = false;  // dense contractions on the bf16 MFMA (operands rounded, fp32 accumulate / storage)
   bool multiclasses() const { return num_classes > 0; }
   int g_in() const { return z_dim + (multiclasses() ? num_classes : 0); }
 };
@@ -36,6 +37,8 @@ struct WRef {
   bool* g_set = nullptr;
   bool want_grad = false;
   const float* wT = nullptr; // per-tap transpose [T][Cc][R] (built lazily, cached per sub-step)
+  unsigned short* wb = nullptr;   // bf16 copy, same layout      (compute_dtype bf16; lazily, per sub-step)
+  unsigned short* wbT = nullptr;  // bf16 copy, per-tap transposed
   int T = 1, R = 0, Cc = 0;
 };
 

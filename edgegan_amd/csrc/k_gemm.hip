@@ -365,7 +365,9 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     };
     const double e128 = a.N >= 128 ? 0.95 * balance(t128) : 0.0;
     const double e64 = 0.80 * balance(t64);
-    if (e128 >= e64)
+    if (conv_bf16_eligible(a))
+      nm = launch_conv_gemm_bf16(a, maxM, e128 >= e64, s);
+    else if (e128 >= e64)
       nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s, "conv_gemm<128,128,vec>", "conv_gemm<128,128,avec>",
                                            "conv_gemm<128,128,flat>");
     else
@@ -770,7 +772,9 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
                    (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0) && (a.ldw % 4 == 0) &&
                    (a.w_ts % 4 == 0) && (((uintptr_t)out & 15) == 0);
   const char* nm;
-  if (wgrad_flatm(a)) {
+  if (a.bf16 && vec && !wgrad_flatm(a)) {
+    nm = launch_wgrad_bf16(a, out, dense, wgrad_big(a), s);
+  } else if (wgrad_flatm(a)) {
     dim3 grid(((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64), a.nsplit);
     hipLaunchKernelGGL(wgrad_flatm_kernel, grid, dim3(256), 0, s, a, out, dense);
     nm = "wgrad_flatm<64,64>";

@@ -1,0 +1,435 @@
+// bf16-operand variants of the tap-gather implicit GEMMs (eg_config.compute_dtype == 1; BASELINE configs[1],[3],[4]).
+//
+// Mixed precision in the usual sense: activations, gradients, weights and optimizer state stay fp32 in HBM; the two
+// operands of every dense contraction are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way
+// into LDS and multiplied on v_mfma_f32_16x16x32_bf16 (fp32 accumulate, 16x the fp32 MFMA rate).  Everything that
+// is not a dense contraction with K-extent % 32 == 0 (norms, activations, losses, RMSProp, the thin 3/8-channel
+// layers, the linears) runs the fp32 kernels unchanged.
+//
+//   conv_gemm_bf16_kernel : Y[pix_out(m)][n] (+)= b[n] + sum_taps sum_c bf16(X[pix_in(m,tap)][c]) * Wb[tap][n][c]
+//                           Wb = bf16 copy of the filter with the CONTRACTED index contiguous (made once per
+//                           sub-step by launch_cvt_bf16 / launch_tap_transpose_bf16)
+//   wgrad_bf16_kernel     : dW[tap][c][n] = sum_m bf16(X[pix_in(m,tap)][c]) * bf16(dY[m][n])   (split over m)
+//
+// MFMA operand layout (16x16x32): lane l supplies row/col (l & 15) and the 8 consecutive k = (l >> 4) * 8 .. + 7, so
+// both LDS images are [row][32 k] with k contiguous (64-byte rows, no padding) and every fragment is ONE 16-byte
+// ds_read.  The four 16-byte chunks of a row are XOR-swizzled (lds_swz): with the gfx950 ds_read_b128 lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... each group's 16 reads then tile all 64 banks.
+// The wgrad contracts over pixels, which are the SLOW index of both NHWC operands; the transpose happens in the
+// register -> LDS store: a thread owns 4 channels x 2 pixels and writes 4 dwords (2 pixels packed) to 4 rows.  A
+// half wave is 8 channel quads (one 128-byte line per pixel, so the global loads stay coalesced) x 4 pixel pairs;
+// the swizzle plus a per-lane order of the 4 row stores makes every ds_write_b32 hit 32 distinct banks.
+#include "kernels.h"
+
+namespace eg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ uint4 pack_bf16x8(const float4& a, const float4& b) {
+  return make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
+}
+__device__ __forceinline__ int reflect_idx_b(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+
+constexpr int BKB = 32;   // contraction elements per K step (one MFMA)
+constexpr int ROWB = BKB; // LDS row pitch in bf16 elements (64 bytes)
+
+// physical 16-byte chunk = logical chunk ^ lds_swz(row)
+__device__ __forceinline__ int lds_swz(int row) { return ((-((row >> 2) & 3)) & 3) ^ ((row >> 4) & 1); }
+
+// =============================================================================================
+// conv_gemm_bf16_kernel
+// =============================================================================================
+template <int BM, int BN, int WTM, int WTN, bool SPLITK>
+__global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvArgs a) {
+  constexpr int WGN = BN / WTN;
+  constexpr int MI = WTM / 16, NJ = WTN / 16;
+  static_assert((BM / WTM) * (BN / WTN) == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) unsigned short As[BM * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[BN * ROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int zphase = SPLITK ? (int)blockIdx.z / a.ksplit : (int)blockIdx.z;
+  const int zsplit = SPLITK ? (int)blockIdx.z - zphase * a.ksplit : 0;
+  const ConvPhase ph = a.ph[zphase];
+  const int M = a.NB * ph.OHp * ph.OWp;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= M) return;
+  const int IH = a.IH, IW = a.IW, C = a.C, N = a.N;
+
+  constexpr int A_V = BM / 64, B_V = BN / 64;  // 8-element chunks per thread: row = tid/4 + 64*i, chunk = tid%4
+  const int q8 = (tid & 3) * 8;
+  const int st8 = ((tid & 3) ^ lds_swz(tid >> 2)) * 8;   // rows tid/4 + 64*i all share this swizzle
+  int r_iy0[A_V], r_ix0[A_V], r_base[A_V];
+#pragma unroll
+  for (int i = 0; i < A_V; ++i) {
+    const int m = m0 + (tid >> 2) + 64 * i;
+    if (m < M) {
+      const int ox = m % ph.OWp;
+      const int t2 = m / ph.OWp;
+      const int oy = t2 % ph.OHp;
+      const int nb = t2 / ph.OHp;
+      r_iy0[i] = oy * a.S + ph.offy;
+      r_ix0[i] = ox * a.S + ph.offx;
+      r_base[i] = nb * IH * IW;
+    } else {
+      r_iy0[i] = 0;
+      r_ix0[i] = 0;
+      r_base[i] = -1;
+    }
+  }
+
+  const int ntaps = ph.Ty * ph.Tx;
+  const int cpt = C / BKB;
+  const int nk = ntaps * cpt;
+  int nx_ty = 0, nx_tx = 0, nx_c0 = 0;
+  int kt_lo = 0, kt_hi = nk;
+  if constexpr (SPLITK) {
+    const int per = (nk + a.ksplit - 1) / a.ksplit;
+    kt_lo = zsplit * per;
+    kt_hi = min(nk, kt_lo + per);
+    const int tap0 = kt_lo / cpt;
+    nx_c0 = (kt_lo - tap0 * cpt) * BKB;
+    nx_ty = tap0 / ph.Tx;
+    nx_tx = tap0 - nx_ty * ph.Tx;
+  }
+
+  float4 ra[A_V][2];
+  uint4 rb[B_V];
+  auto load_tile = [&]() {
+    const int ty = nx_ty, tx = nx_tx, c0 = nx_c0;
+    const long long wt = (long long)((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * a.wbf_ts;
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+      int iy = r_iy0[i] + ty * a.D, ix = r_ix0[i] + tx * a.D;
+      if (a.reflect) {
+        iy = reflect_idx_b(iy, IH);
+        ix = reflect_idx_b(ix, IW);
+      }
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (r_base[i] >= 0 && iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
+        const float* px = a.x + (size_t)(r_base[i] + iy * IW + ix) * a.x_ps + c0 + q8;
+        v0 = *reinterpret_cast<const float4*>(px);
+        v1 = *reinterpret_cast<const float4*>(px + 4);
+      }
+      ra[i][0] = v0;
+      ra[i][1] = v1;
+    }
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) {
+      const int n = n0 + (tid >> 2) + 64 * i;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (n < N) v = *reinterpret_cast<const uint4*>(a.wgt_bf + wt + (size_t)n * a.ldwbf + c0 + q8);
+      rb[i] = v;
+    }
+    nx_c0 += BKB;
+    if (nx_c0 >= C) {
+      nx_c0 = 0;
+      if (++nx_tx == ph.Tx) {
+        nx_tx = 0;
+        ++nx_ty;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_V; ++i)
+      *reinterpret_cast<uint4*>(&As[((tid >> 2) + 64 * i) * ROWB + st8]) = pack_bf16x8(ra[i][0], ra[i][1]);
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) *reinterpret_cast<uint4*>(&Bs[((tid >> 2) + 64 * i) * ROWB + st8]) = rb[i];
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int fsw = (-(l15 >> 2)) & 3;   // lds_swz of a fragment row, without the (row >> 4) & 1 bit (= i & 1 below)
+  static_assert((WTM / 16) % 2 == 0 && (WTN / 16) % 2 == 0, "wave sub-tiles start at even 16-row blocks");
+  if (kt_lo < kt_hi) load_tile();
+  for (int kt = kt_lo; kt < kt_hi; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < kt_hi) load_tile();
+    bf16x8 af[MI], bf[NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * WTM + i * 16 + l15) * ROWB + (lq ^ fsw ^ (i & 1)) * 8]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * WTN + j * 16 + l15) * ROWB + (lq ^ fsw ^ (j & 1)) * 8]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    __syncthreads();
+  }
+
+  // operands swapped as in the fp32 kernel: lane l holds pixel row (l & 15) and output channels (l >> 4) * 4 + reg
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + l15;
+    if (m >= M) continue;
+    const int ox = m % ph.OWp;
+    const int t2 = m / ph.OWp;
+    const int oy = t2 % ph.OHp;
+    const int nb = t2 / ph.OHp;
+    float* yrow = (SPLITK ? a.ws + (size_t)zsplit * a.y_total : a.y) +
+                  ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + lq * 4;
+      if (n < N) {
+        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if constexpr (!SPLITK) {
+          if (a.bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          }
+          if (a.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(yrow + n);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+        }
+        *reinterpret_cast<float4*>(yrow + n) = v;
+      }
+    }
+  }
+}
+
+bool conv_bf16_eligible(const ConvArgs& a) {
+  return a.wgt_bf && a.C % BKB == 0 && a.N > 16 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.y_ps % 4 == 0 &&
+         a.ldwbf % 8 == 0 && a.wbf_ts % 8 == 0 && (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.y & 15) == 0) &&
+         (((uintptr_t)a.wgt_bf & 15) == 0) && (!a.bias || (((uintptr_t)a.bias & 15) == 0));
+}
+
+template <int BM, int BN, int WTM, int WTN>
+static void conv_bf16_launch(const ConvArgs& a, int maxM, hipStream_t s) {
+  if (a.ksplit > 1) {
+    dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase * a.ksplit);
+    hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, WTM, WTN, true>), grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase);
+    hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, WTM, WTN, false>), grid, dim3(256), 0, s, a);
+  }
+}
+
+const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s) {
+  if (big_tile) {
+    conv_bf16_launch<128, 128, 64, 64>(a, maxM, s);
+    return "conv_gemm_bf16<128,128>";
+  }
+  conv_bf16_launch<64, 64, 32, 32>(a, maxM, s);
+  return "conv_gemm_bf16<64,64>";
+}
+
+// =============================================================================================
+// wgrad_bf16_kernel
+// =============================================================================================
+template <int BM, int BN, int WTM, int WTN>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
+  constexpr int WGN = BN / WTN;
+  constexpr int MI = WTM / 16, NJ = WTN / 16;
+  __shared__ __attribute__((aligned(16))) unsigned short At[BM * ROWB];  // [c][pixel]
+  __shared__ __attribute__((aligned(16))) unsigned short Bt[BN * ROWB];  // [n][pixel]
+  __shared__ long long poff[2][BKB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int C = a.C, N = a.N, IH = a.IH, IW = a.IW;
+  const int ntn = (N + BN - 1) / BN;
+  const int c0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+  const int tap = blockIdx.y;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int M = a.NB * a.OH * a.OW;
+  int chunk = (M + a.nsplit - 1) / a.nsplit;
+  chunk = (chunk + BKB - 1) / BKB * BKB;
+  const int p_lo = blockIdx.z * chunk;
+  const int p_hi = min(M, p_lo + chunk);
+
+  // unit = (pixel pair mp, channel quad cq).  A half wave is 8 consecutive quads (128 contiguous bytes of one
+  // pixel) x 4 pixel pairs of ONE 8-pixel chunk; unit i of a thread adds 16 quads.
+  constexpr int A_U = BM / 64, B_U = BN / 64;
+  float4 ra[A_U][2], rb[B_U][2];
+  const int cq8 = tid & 7, mpl = (tid >> 3) & 3, rest = tid >> 5;
+  const int kch = rest & 3;                        // 8-pixel chunk of the K step
+  const int mp = kch * 4 + mpl;                 // pixel pair 0..15 of the 32-pixel K step
+  const int cqb = (rest >> 2) * 8 + cq8;          // + 16 * i
+  const int ex = cq8 & 1;                          // odd quads store their 4 rows in the order 1,0,3,2
+  const int st_col = (kch ^ (((-(cq8 & 3)) & 3) ^ (cq8 >> 2))) * 4 + mpl;   // dword column, swizzled (lds_swz(4*cq))
+
+  auto decode = [&](int p, int buf) {
+    if (tid < BKB) {
+      const int m = p + tid;
+      long long off = -1;
+      if (m < p_hi) {
+        const int ox = m % a.OW;
+        const int t2 = m / a.OW;
+        const int oy = t2 % a.OH;
+        const int nb = t2 / a.OH;
+        int iy = oy * a.S + kh - a.pad, ix = ox * a.S + kw - a.pad;
+        if (a.reflect) {
+          iy = reflect_idx_b(iy, IH);
+          ix = reflect_idx_b(ix, IW);
+        }
+        if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) off = (long long)((nb * IH + iy) * IW + ix) * a.x_ps;
+      }
+      poff[buf][tid] = off;
+    }
+  };
+  auto load_tile = [&](int p, int buf) {
+    const long long o0 = poff[buf][2 * mp], o1 = poff[buf][2 * mp + 1];
+    const int m = p + 2 * mp;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < A_U; ++i) {
+      const int c = c0 + (cqb + 16 * i) * 4;
+      ra[i][0] = (o0 >= 0 && c < C) ? *reinterpret_cast<const float4*>(a.x + o0 + c) : z;
+      ra[i][1] = (o1 >= 0 && c < C) ? *reinterpret_cast<const float4*>(a.x + o1 + c) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < B_U; ++i) {
+      const int n = n0 + (cqb + 16 * i) * 4;
+      rb[i][0] = (m < p_hi && n < N) ? *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.dy_ps + n) : z;
+      rb[i][1] = (m + 1 < p_hi && n < N) ? *reinterpret_cast<const float4*>(a.dy + (size_t)(m + 1) * a.dy_ps + n) : z;
+    }
+  };
+  // 4 channels x 2 pixels -> 4 packed dwords into rows 4*cq + (j ^ ex), j = 0..3
+  auto store_unit = [&](unsigned short* base, int cq, float4 lo, float4 hi) {
+    if (ex) {
+      float t;
+      t = lo.x; lo.x = lo.y; lo.y = t;
+      t = lo.z; lo.z = lo.w; lo.w = t;
+      t = hi.x; hi.x = hi.y; hi.y = t;
+      t = hi.z; hi.z = hi.w; hi.w = t;
+    }
+    unsigned* q = reinterpret_cast<unsigned*>(base) + (size_t)(4 * cq) * (ROWB / 2) + st_col;
+    q[(0 ^ ex) * (ROWB / 2)] = pack_bf16(lo.x, hi.x);
+    q[(1 ^ ex) * (ROWB / 2)] = pack_bf16(lo.y, hi.y);
+    q[(2 ^ ex) * (ROWB / 2)] = pack_bf16(lo.z, hi.z);
+    q[(3 ^ ex) * (ROWB / 2)] = pack_bf16(lo.w, hi.w);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_U; ++i) store_unit(At, cqb + 16 * i, ra[i][0], ra[i][1]);
+#pragma unroll
+    for (int i = 0; i < B_U; ++i) store_unit(Bt, cqb + 16 * i, rb[i][0], rb[i][1]);
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int fsw = (-(l15 >> 2)) & 3;
+  static_assert((WTM / 16) % 2 == 0 && (WTN / 16) % 2 == 0, "wave sub-tiles start at even 16-row blocks");
+  if (p_lo < p_hi) {
+    decode(p_lo, 0);
+    __syncthreads();
+    load_tile(p_lo, 0);
+    int it = 0;
+    for (int p = p_lo; p < p_hi; p += BKB, ++it) {
+      store_tile();
+      const bool more = p + BKB < p_hi;
+      if (more) decode(p + BKB, (it + 1) & 1);
+      __syncthreads();
+      if (more) load_tile(p + BKB, (it + 1) & 1);
+      bf16x8 af[MI], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(&At[(wm * WTM + i * 16 + l15) * ROWB + (lq ^ fsw ^ (i & 1)) * 8]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        bf[j] = *reinterpret_cast<const bf16x8*>(&Bt[(wn * WTN + j * 16 + l15) * ROWB + (lq ^ fsw ^ (j & 1)) * 8]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      __syncthreads();
+    }
+  }
+
+  const int T = a.KH * a.KW;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int c = c0 + wm * WTM + i * 16 + l15;
+    if (c >= C) continue;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + lq * 4;
+      if (n >= N) continue;
+      float* q = dense_out ? out + (((size_t)blockIdx.z * T + tap) * C + c) * N + n
+                           : out + (size_t)tap * a.w_ts + (size_t)c * a.ldw + n;
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (!dense_out && a.accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(q);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      *reinterpret_cast<float4*>(q) = v;
+    }
+  }
+}
+
+const char* launch_wgrad_bf16(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s) {
+  if (big_tile) {
+    dim3 grid(((a.C + 127) / 128) * ((a.N + 127) / 128), a.KH * a.KW, a.nsplit);
+    hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 64, 64>), grid, dim3(256), 0, s, a, out, dense);
+    return "wgrad_bf16<128,128>";
+  }
+  dim3 grid(((a.C + 63) / 64) * ((a.N + 63) / 64), a.KH * a.KW, a.nsplit);
+  hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64, 32, 32>), grid, dim3(256), 0, s, a, out, dense);
+  return "wgrad_bf16<64,64>";
+}
+
+// =============================================================================================
+// bf16 filter copies: [T][R][Cc] fp32 -> same layout bf16, or per-tap transposed [T][Cc][R] bf16
+// =============================================================================================
+__global__ void cvt_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    reinterpret_cast<uint2*>(out)[i] = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+  }
+}
+__global__ void tap_transpose_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const float* src = in + (size_t)t * R * Cc;
+  unsigned short* dst = out + (size_t)t * R * Cc;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < Cc) ? src[(size_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < Cc) dst[(size_t)c * R + r] = (unsigned short)(pack_bf16(tile[threadIdx.x][i], 0.f) & 0xffffu);
+  }
+}
+void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s) {
+  const size_t n4 = n / 4;  // callers guarantee n % 4 == 0 (K extent % 32 == 0)
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n4);
+}
+void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int R, int Cc, hipStream_t s) {
+  dim3 grid((Cc + 31) / 32, (R + 31) / 32, T);
+  hipLaunchKernelGGL(tap_transpose_bf16_kernel, grid, dim3(32, 8), 0, s, in, out, R, Cc);
+}
+
+}  // namespace eg

@@ -23,6 +23,9 @@ struct ConvArgs {
   const float* x;    // [NB][IH][IW] pixels, x_ps floats per pixel, C channels used
   const float* wgt;  // element (tap wt, c, n) at wgt[wt*w_ts + c*ldw + n]
   const float* bias; // [N] or null
+  const unsigned short* wgt_bf;  // optional bf16 filter, element (tap wt, n, c) at wgt_bf[wt*wbf_ts + n*ldwbf + c]:
+  long long wbf_ts;              // when set and the shape qualifies the contraction runs on the bf16 MFMA
+  int ldwbf;
   float* y;          // [NB][OHf][OWf] pixels, y_ps floats per pixel
   int NB, IH, IW, C, x_ps;
   int OHf, OWf, N, y_ps;
@@ -60,10 +63,18 @@ struct WgradArgs {
   int reflect;
   int accumulate;    // 1: dw += result
   int nsplit;
+  int bf16;          // 1: round both operands to bf16 and use the bf16 MFMA (fp32 accumulate)
 };
 int wgrad_pick_splits(const WgradArgs& a);
 size_t wgrad_workspace_floats(const WgradArgs& a);
 double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name);
+
+// bf16-operand kernels (k_gemm_bf16.hip); the tile choice is made by launch_conv_gemm / launch_wgrad
+bool conv_bf16_eligible(const ConvArgs& a);
+const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s);
+const char* launch_wgrad_bf16(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s);
+void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);
+void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int R, int Cc, hipStream_t s);
 
 // [T][R][Cc] -> [T][Cc][R] (per-tap transpose), optional scale by 1/(*inv_of) when inv_of != null.
 void launch_tap_transpose(const float* in, float* out, int T, int R, int Cc, const float* inv_of,

@@ -148,6 +148,22 @@ const float* wref_transposed(Ctx& c, WRef* w) {
   return buf;
 }
 
+// compute_dtype bf16: hand the conv a bf16 copy of the filter with the contracted index contiguous.  `transposed`
+// selects the per-tap transpose [T][Cc][R] (contracted index = R) or the stored layout [T][R][Cc] (contracted = Cc).
+static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
+  if (!c.cfg.bf16 || a.C % 32 != 0 || a.N <= 16 || a.N % 4 != 0) return;
+  unsigned short*& slot = transposed ? w->wbT : w->wb;
+  if (!slot) {
+    const size_t n = (size_t)w->T * w->R * w->Cc;
+    slot = reinterpret_cast<unsigned short*>(c.arena.allocf((n + 1) / 2));
+    if (transposed) launch_tap_transpose_bf16(w->w, slot, w->T, w->R, w->Cc, c.stream);
+    else launch_cvt_bf16(w->w, slot, n, c.stream);
+  }
+  a.wgt_bf = slot;
+  a.wbf_ts = (long long)a.C * a.N;
+  a.ldwbf = a.C;
+}
+
 // launch one implicit-GEMM conv; layers too small to fill the chip with output tiles split K over blocks
 static void run_conv(Ctx& c, ConvArgs& a) {
   a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
@@ -190,6 +206,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
   a.reflect = 0;
   a.S = 1;
   a.D = -1;
+  attach_bf16(c, a, w, false);   // rows = Cin, contracted = Cout: the filter as stored
   if (stride == 1) {
     a.kst = 1;
     a.os = 1;
@@ -267,6 +284,7 @@ static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, c
   g.ldw = N;
   g.reflect = reflect;
   g.accumulate = *w->g_set ? 1 : 0;
+  g.bf16 = c.cfg.bf16 ? 1 : 0;
   g.nsplit = wgrad_pick_splits(g);
   const size_t wsf = wgrad_workspace_floats(g);
   g.ws = wsf ? c.arena.allocf(wsf) : nullptr;
@@ -323,6 +341,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   a.accumulate = accumulate_into ? 1 : 0;
   a.nphase = 1;
   a.ph[0] = ConvPhase{OH, OW, 0, 0, k, k, 0, 0, -pt, -pl};
+  attach_bf16(c, a, w, true);    // rows = Cout, contracted = Cin
   run_conv(c, a);
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
   if (need) {
@@ -381,6 +400,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
       a.ph[py * 2 + px] = ConvPhase{x->h, x->w, py, px, (k - kh0 + 1) / 2, (k - kw0 + 1) / 2, kh0, kw0,
                                     (py + pt - kh0) / 2, (px + pt - kw0) / 2};
     }
+  attach_bf16(c, a, w, false);   // filter [25][Cout][Cin]: rows = Cout, contracted = Cin as stored
   run_conv(c, a);
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
   if (need) {
@@ -420,6 +440,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
         b.ldw = Cin;
         b.nphase = 1;
         b.ph[0] = ConvPhase{x->h, x->w, 0, 0, 5, 5, 0, 0, -1, -1};
+        attach_bf16(c, b, w, true);    // rows = Cin, contracted = Cout
         run_conv(c, b);
       }
     });

@@ -42,6 +42,9 @@ typedef struct eg_config {
   float learning_rate; /* train.py:18                                   */
   float joint_dweight, image_dweight, edge_dweight; /* train.py:68-73   */
   int device;          /* train.py:14 --gpu                             */
+  int compute_dtype;   /* no reference flag: 0 = fp32 everywhere (the reference's arithmetic), 1 = the dense
+                          conv/deconv contractions take bf16-rounded operands on the bf16 MFMA with fp32
+                          accumulation; storage, norms, losses and RMSProp stay fp32 (BASELINE configs 2,4,5) */
 } eg_config;
 
 int eg_default_config(eg_config* cfg);

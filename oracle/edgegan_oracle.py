@@ -29,6 +29,86 @@ import torch.nn.functional as F
 
 Tensor = torch.Tensor
 
+# --------------------------------------------------------------------------------------
+# bf16-operand emulation (for the engine's compute_dtype='bf16' mode; the reference itself is fp32)
+# --------------------------------------------------------------------------------------
+# Inside `with bf16_operands():` every dense contraction y = f(x, w) (conv, transposed conv, linear) is evaluated
+# the way the engine's bf16 mode evaluates it: each of its three bilinear maps -- forward,
+# input gradient, filter gradient -- rounds BOTH of its operands to bf16 (round-to-nearest-even) when that map
+# qualifies for the bf16 MFMA, and multiplies / accumulates exactly (in the oracle's own precision):
+#     y  = f(r(x), r(w))                      if conv rule(K = contracted channels, n_out)
+#     dx = f'_x(r(dy), r(w))                  if conv rule with the roles of the channel counts swapped
+#     dw = f'_w(r(x), r(dy))                  if wgrad rule
+# The backward maps are themselves differentiable (round() is a straight-through estimator there), so the
+# WGAN-GP double backward still works; the engine orders that computation differently (reverse-over-forward), so
+# for the gradient-penalty sub-steps the emulation is only accurate to bf16 rounding noise, not to fp32 noise.
+_BF16_OPERANDS = False
+
+
+class bf16_operands:
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _BF16_OPERANDS
+        self.prev = _BF16_OPERANDS
+        _BF16_OPERANDS = bool(self.enabled)
+
+    def __exit__(self, *exc):
+        global _BF16_OPERANDS
+        _BF16_OPERANDS = self.prev
+
+
+def bf16_conv_rule(k_channels: int, n_out: int) -> bool:
+    return k_channels % 32 == 0 and n_out > 16 and n_out % 4 == 0
+
+
+def bf16_wgrad_rule(c_gathered: int, n_dense: int) -> bool:
+    return c_gathered % 4 == 0 and n_dense % 4 == 0 and c_gathered > 16
+
+
+def _r16(t: Tensor) -> Tensor:
+    d = t.detach()
+    return t + (d.to(torch.float32).to(torch.bfloat16).to(t.dtype) - d)
+
+
+class _RoundedBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, f, rf, rdx, rdw):
+        ctx.f, ctx.flags = f, (rdx, rdw)
+        ctx.save_for_backward(x, w)
+        return f(_r16(x), _r16(w)) if rf else f(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        rdx, rdw = ctx.flags
+        f = ctx.f
+        dx = dw = None
+        with torch.enable_grad():
+            if ctx.needs_input_grad[0]:
+                xv = x.detach().requires_grad_()
+                dx = torch.autograd.grad(f(xv, _r16(w) if rdx else w), xv, _r16(dy) if rdx else dy, create_graph=True)[0]
+            if ctx.needs_input_grad[1]:
+                wv = w.detach().requires_grad_()
+                dw = torch.autograd.grad(f(_r16(x) if rdw else x, wv), wv, _r16(dy) if rdw else dy, create_graph=True)[0]
+        return dx, dw, None, None, None, None
+
+
+def _bilinear(f, x: Tensor, w: Tensor, c_in: int, n_out: int, c_wgrad: Optional[int] = None,
+              n_wgrad: Optional[int] = None) -> Tensor:
+    """f(x, w), with the engine's bf16 operand rounding when emulation is on.  c_in / n_out: contracted and produced
+    channel counts of the forward map; (c_wgrad, n_wgrad): gathered / dense operand channels of the engine's wgrad
+    launch (default: the forward's)."""
+    if not _BF16_OPERANDS:
+        return f(x, w)
+    rf = bf16_conv_rule(c_in, n_out)
+    rdx = bf16_conv_rule(n_out, c_in)
+    rdw = bf16_wgrad_rule(c_in if c_wgrad is None else c_wgrad, n_out if n_wgrad is None else n_wgrad)
+    if not (rf or rdx or rdw):
+        return f(x, w)
+    return _RoundedBilinear.apply(x, w, f, rf, rdx, rdw)
+
 
 # --------------------------------------------------------------------------------------
 # configuration (defaults = edgegan/train.py:14-74, edgegan/models/edgegan.py:46-48)
@@ -95,7 +175,7 @@ def conv2d(x: Tensor, w: Tensor, stride: int, pad: str, b: Optional[Tensor] = No
         xc = F.pad(xc, (pl, pr, pt, pb))
     else:
         assert pad == 'VALID'
-    y = F.conv2d(xc, w.permute(3, 2, 0, 1), stride=stride)
+    y = _bilinear(lambda xx, ww: F.conv2d(xx, ww.permute(3, 2, 0, 1), stride=stride), xc, w, w.shape[2], w.shape[3])
     if b is not None:
         y = y + b.view(1, -1, 1, 1)
     return _nhwc(y)
@@ -106,8 +186,9 @@ def deconv2d(x: Tensor, w: Tensor, b: Tensor, out_hw: Tuple[int, int]) -> Tensor
     filter [kh,kw,Cout,Cin], + bias.  TF defines it as the input-gradient of the k5-s2-SAME
     conv: y[o] += x[i] w[k], o = 2i + k - 1, cropped to out_hw."""
     assert w.shape[0] == 5 and w.shape[1] == 5
-    y = F.conv_transpose2d(_nchw(x), w.permute(3, 2, 0, 1), stride=2, padding=1)
-    y = y[:, :, :out_hw[0], :out_hw[1]]
+    # engine wgrad launch for a transposed conv: gathered operand = dy (Cout channels), dense operand = x (Cin)
+    y = _bilinear(lambda xx, ww: F.conv_transpose2d(xx, ww.permute(3, 2, 0, 1), stride=2, padding=1)[:, :, :out_hw[0], :out_hw[1]],
+                  _nchw(x), w, w.shape[3], w.shape[2], c_wgrad=w.shape[2], n_wgrad=w.shape[3])
     assert y.shape[2] == out_hw[0] and y.shape[3] == out_hw[1]
     y = y + b.view(1, -1, 1, 1)
     return _nhwc(y)
@@ -255,7 +336,7 @@ def spectral_normed_weight(W: Tensor, u: Tensor) -> Tensor:
 
 def linear(x: Tensor, W: Tensor, b: Tensor) -> Tensor:
     """edgegan/nn/modules/linear.py:10-31 / mlp :79-92."""
-    return x @ W + b
+    return _bilinear(lambda xx, ww: xx @ ww, x, W, W.shape[0], W.shape[1]) + b
 
 
 # --------------------------------------------------------------------------------------
@@ -457,11 +538,18 @@ def encoder(p: P, x: Tensor, eps, cfg: Config) -> Tuple[Tensor, Tensor, Tensor]:
     return z, mu, log_sigma
 
 
-def _sn_conv(p: P, scope: str, x: Tensor, k: int, act=None) -> Tensor:
-    """conv2d2 (conv.py:246-295): NCHW, SAME stride 1, SN weights, + biases (1,C,1,1), optional act."""
+def _sn_conv(p: P, scope: str, x: Tensor, k: int, act=None, split: int = 0) -> Tensor:
+    """conv2d2 (conv.py:246-295): NCHW, SAME stride 1, SN weights, + biases (1,C,1,1), optional act.
+    `split` only matters under bf16_operands(): the engine evaluates the gate conv over concat([h, x]) as
+    conv(h, W[:, :, :split]) + conv(x, W[:, :, split:]), and the bf16 rule applies to each part separately."""
     W = spectral_normed_weight(p[f'{scope}/weights'], p[_sn_u_name(scope)])
     pd = (k - 1) // 2
-    y = F.conv2d(x, W.permute(3, 2, 0, 1), padding=pd)
+    conv = lambda xx, ww: F.conv2d(xx, ww.permute(3, 2, 0, 1), padding=pd)
+    if _BF16_OPERANDS and split:
+        y = _bilinear(conv, x[:, :split], W[:, :, :split], split, W.shape[3]) + \
+            _bilinear(conv, x[:, split:], W[:, :, split:], W.shape[2] - split, W.shape[3])
+    else:
+        y = _bilinear(conv, x, W, W.shape[2], W.shape[3])
     y = y + p[f'{scope}/biases']
     if act is not None:
         y = act(y)
@@ -474,7 +562,7 @@ def mru_block(p: P, base: str, inp: Tensor, ht: Tensor, depth: int) -> Tensor:
     hidden = ht.shape[1]
     ht_orig = ht
     full = torch.cat([prelu(ht, p[f'{base}/norm_activation_in/prelu/param']), inp], dim=1)
-    rg = _sn_conv(p, f'{base}/update_gate', full, 3, act=lrelu_leak)
+    rg = _sn_conv(p, f'{base}/update_gate', full, 3, act=lrelu_leak, split=hidden)
     mn = rg.amin(dim=(2, 3), keepdim=True)
     mx = rg.amax(dim=(2, 3), keepdim=True)
     rg = (rg - mn) / (mx - mn)

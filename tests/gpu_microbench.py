@@ -23,7 +23,7 @@ SHAPES = [  # name, NB,H,W,C,N,k,stride,pad
 
 
 def main():
-    net = ea.EdgeGAN(ea.Config(batch_size=2))
+    net = ea.EdgeGAN(ea.Config(batch_size=2, compute_dtype=os.environ.get('DTYPE', 'f32')))
     rng = np.random.RandomState(0)
     print(f'{"shape":44s} {"kernel":26s} {"ms":>8s} {"TF/s":>8s}')
     for name, NB, H, W, C, N, k, s, pad in SHAPES:
