@@ -50,12 +50,12 @@ __device__ __forceinline__ int lds_swz(int row) { return ((-((row >> 2) & 3)) & 
 // conv_gemm_bf16_kernel
 // =============================================================================================
 template <int BM, int BN, int WTM, int WTN, bool SPLITK>
-__global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const ConvArgs a) {
   constexpr int WGN = BN / WTN;
   constexpr int MI = WTM / 16, NJ = WTN / 16;
   static_assert((BM / WTM) * (BN / WTN) == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) unsigned short As[BM * ROWB];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[BN * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * ROWB];   // double-buffered: one barrier per K step
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * ROWB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -104,9 +104,11 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvArgs a) {
     nx_tx = tap0 - nx_ty * ph.Tx;
   }
 
-  float4 ra[A_V][2];
-  uint4 rb[B_V];
-  auto load_tile = [&]() {
+  // two register staging sets: the global loads of K tiles t+1 and t+2 are in flight while tile t is multiplied
+  // (the kernel is bound by bytes in flight per CU, not by the MFMA pipe)
+  float4 ra0[A_V][2], ra1[A_V][2];
+  uint4 rb0[B_V], rb1[B_V];
+  auto load_tile = [&](float4 (&ra)[A_V][2], uint4 (&rb)[B_V]) {
     const int ty = nx_ty, tx = nx_tx, c0 = nx_c0;
     const long long wt = (long long)((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * a.wbf_ts;
 #pragma unroll
@@ -141,12 +143,12 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvArgs a) {
       }
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](const float4 (&ra)[A_V][2], const uint4 (&rb)[B_V], int buf) {
 #pragma unroll
     for (int i = 0; i < A_V; ++i)
-      *reinterpret_cast<uint4*>(&As[((tid >> 2) + 64 * i) * ROWB + st8]) = pack_bf16x8(ra[i][0], ra[i][1]);
+      *reinterpret_cast<uint4*>(&As[buf][((tid >> 2) + 64 * i) * ROWB + st8]) = pack_bf16x8(ra[i][0], ra[i][1]);
 #pragma unroll
-    for (int i = 0; i < B_V; ++i) *reinterpret_cast<uint4*>(&Bs[((tid >> 2) + 64 * i) * ROWB + st8]) = rb[i];
+    for (int i = 0; i < B_V; ++i) *reinterpret_cast<uint4*>(&Bs[buf][((tid >> 2) + 64 * i) * ROWB + st8]) = rb[i];
   };
 
   f32x4 acc[MI][NJ];
@@ -158,22 +160,43 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvArgs a) {
   const int l15 = lane & 15, lq = lane >> 4;
   const int fsw = (-(l15 >> 2)) & 3;   // lds_swz of a fragment row, without the (row >> 4) & 1 bit (= i & 1 below)
   static_assert((WTM / 16) % 2 == 0 && (WTN / 16) % 2 == 0, "wave sub-tiles start at even 16-row blocks");
-  if (kt_lo < kt_hi) load_tile();
-  for (int kt = kt_lo; kt < kt_hi; ++kt) {
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < kt_hi) load_tile();
+  auto compute = [&](int buf) {
     bf16x8 af[MI], bf[NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
-      af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * WTM + i * 16 + l15) * ROWB + (lq ^ fsw ^ (i & 1)) * 8]);
+      af[i] = *reinterpret_cast<const bf16x8*>(&As[buf][(wm * WTM + i * 16 + l15) * ROWB + (lq ^ fsw ^ (i & 1)) * 8]);
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * WTN + j * 16 + l15) * ROWB + (lq ^ fsw ^ (j & 1)) * 8]);
+      bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][(wn * WTN + j * 16 + l15) * ROWB + (lq ^ fsw ^ (j & 1)) * 8]);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+  };
+
+  // step t: LDS buffer t&1 holds tile t; tile t+1 goes from its staging set into the other buffer (whose readers
+  // passed the previous barrier), that set is refilled with tile t+3
+  const int nt = kt_hi - kt_lo;
+  if (nt > 0) load_tile(ra0, rb0);
+  if (nt > 1) load_tile(ra1, rb1);
+  if (nt > 0) {
+    store_tile(ra0, rb0, 0);
+    if (nt > 2) load_tile(ra0, rb0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; t += 2) {
+    if (t + 1 < nt) {
+      store_tile(ra1, rb1, 1);
+      if (t + 3 < nt) load_tile(ra1, rb1);
+    }
+    compute(0);
+    __syncthreads();
+    if (t + 1 >= nt) break;
+    if (t + 2 < nt) {
+      store_tile(ra0, rb0, 0);
+      if (t + 4 < nt) load_tile(ra0, rb0);
+    }
+    compute(1);
     __syncthreads();
   }
 
@@ -239,12 +262,12 @@ const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hi
 // wgrad_bf16_kernel
 // =============================================================================================
 template <int BM, int BN, int WTM, int WTN>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
   constexpr int WGN = BN / WTN;
   constexpr int MI = WTM / 16, NJ = WTN / 16;
-  __shared__ __attribute__((aligned(16))) unsigned short At[BM * ROWB];  // [c][pixel]
-  __shared__ __attribute__((aligned(16))) unsigned short Bt[BN * ROWB];  // [n][pixel]
-  __shared__ long long poff[2][BKB];
+  __shared__ __attribute__((aligned(16))) unsigned short At[2][BM * ROWB];  // [c][pixel], double-buffered
+  __shared__ __attribute__((aligned(16))) unsigned short Bt[2][BN * ROWB];  // [n][pixel]
+  __shared__ long long poff[2][256];   // gathered-pixel offsets, decoded 256 pixels (8 K steps) at a time
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -262,70 +285,80 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a, floa
   // unit = (pixel pair mp, channel quad cq).  A half wave is 8 consecutive quads (128 contiguous bytes of one
   // pixel) x 4 pixel pairs of ONE 8-pixel chunk; unit i of a thread adds 16 quads.
   constexpr int A_U = BM / 64, B_U = BN / 64;
-  float4 ra[A_U][2], rb[B_U][2];
+  float4 ra0[A_U][2], rb0[B_U][2], ra1[A_U][2], rb1[B_U][2];   // two staging sets (tiles t+1, t+2 in flight)
   const int cq8 = tid & 7, mpl = (tid >> 3) & 3, rest = tid >> 5;
   const int kch = rest & 3;                        // 8-pixel chunk of the K step
-  const int mp = kch * 4 + mpl;                 // pixel pair 0..15 of the 32-pixel K step
+  const int mp = kch * 4 + mpl;                    // pixel pair 0..15 of the 32-pixel K step
   const int cqb = (rest >> 2) * 8 + cq8;          // + 16 * i
   const int ex = cq8 & 1;                          // odd quads store their 4 rows in the order 1,0,3,2
+  const unsigned exmask = 0u - (unsigned)ex;
   const int st_col = (kch ^ (((-(cq8 & 3)) & 3) ^ (cq8 >> 2))) * 4 + mpl;   // dword column, swizzled (lds_swz(4*cq))
 
-  auto decode = [&](int p, int buf) {
-    if (tid < BKB) {
-      const int m = p + tid;
-      long long off = -1;
-      if (m < p_hi) {
-        const int ox = m % a.OW;
-        const int t2 = m / a.OW;
-        const int oy = t2 % a.OH;
-        const int nb = t2 / a.OH;
-        int iy = oy * a.S + kh - a.pad, ix = ox * a.S + kw - a.pad;
-        if (a.reflect) {
-          iy = reflect_idx_b(iy, IH);
-          ix = reflect_idx_b(ix, IW);
-        }
-        if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) off = (long long)((nb * IH + iy) * IW + ix) * a.x_ps;
+  // every thread decodes one pixel of a 256-pixel block (8 K steps): the integer divisions leave the per-step path
+  auto decode_block = [&](int blk) {
+    const int m = p_lo + blk * 256 + tid;
+    long long off = -1;
+    if (m < p_hi) {
+      const int ox = m % a.OW;
+      const int t2 = m / a.OW;
+      const int oy = t2 % a.OH;
+      const int nb = t2 / a.OH;
+      int iy = oy * a.S + kh - a.pad, ix = ox * a.S + kw - a.pad;
+      if (a.reflect) {
+        iy = reflect_idx_b(iy, IH);
+        ix = reflect_idx_b(ix, IW);
       }
-      poff[buf][tid] = off;
+      if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) off = (long long)((nb * IH + iy) * IW + ix) * a.x_ps;
     }
+    poff[blk & 1][tid] = off;
   };
-  auto load_tile = [&](int p, int buf) {
-    const long long o0 = poff[buf][2 * mp], o1 = poff[buf][2 * mp + 1];
-    const int m = p + 2 * mp;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_tile = [&](int t, float4 (&ra)[A_U][2], float4 (&rb)[B_U][2]) {
+    const long long* po = &poff[(t >> 3) & 1][(t & 7) * 32 + 2 * mp];
+    const long long o0 = po[0], o1 = po[1];
+    const int m = p_lo + t * BKB + 2 * mp;
+    // (no `cond ? *ptr : zero`: that selects between a global and a stack ADDRESS and loads through a flat pointer)
 #pragma unroll
     for (int i = 0; i < A_U; ++i) {
       const int c = c0 + (cqb + 16 * i) * 4;
-      ra[i][0] = (o0 >= 0 && c < C) ? *reinterpret_cast<const float4*>(a.x + o0 + c) : z;
-      ra[i][1] = (o1 >= 0 && c < C) ? *reinterpret_cast<const float4*>(a.x + o1 + c) : z;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (c < C) {
+        if (o0 >= 0) v0 = *reinterpret_cast<const float4*>(a.x + o0 + c);
+        if (o1 >= 0) v1 = *reinterpret_cast<const float4*>(a.x + o1 + c);
+      }
+      ra[i][0] = v0;
+      ra[i][1] = v1;
     }
 #pragma unroll
     for (int i = 0; i < B_U; ++i) {
       const int n = n0 + (cqb + 16 * i) * 4;
-      rb[i][0] = (m < p_hi && n < N) ? *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.dy_ps + n) : z;
-      rb[i][1] = (m + 1 < p_hi && n < N) ? *reinterpret_cast<const float4*>(a.dy + (size_t)(m + 1) * a.dy_ps + n) : z;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (n < N) {
+        if (m < p_hi) v0 = *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.dy_ps + n);
+        if (m + 1 < p_hi) v1 = *reinterpret_cast<const float4*>(a.dy + (size_t)(m + 1) * a.dy_ps + n);
+      }
+      rb[i][0] = v0;
+      rb[i][1] = v1;
     }
   };
   // 4 channels x 2 pixels -> 4 packed dwords into rows 4*cq + (j ^ ex), j = 0..3
-  auto store_unit = [&](unsigned short* base, int cq, float4 lo, float4 hi) {
-    if (ex) {
-      float t;
-      t = lo.x; lo.x = lo.y; lo.y = t;
-      t = lo.z; lo.z = lo.w; lo.w = t;
-      t = hi.x; hi.x = hi.y; hi.y = t;
-      t = hi.z; hi.z = hi.w; hi.w = t;
-    }
+  auto store_unit = [&](unsigned short* base, int cq, const float4& lo, const float4& hi) {
+    // instruction j writes channel j ^ ex to row 4*cq + (j ^ ex); branch-free swap of the packed pairs (a select
+    // on the float4 components makes the compiler index the staging registers through scratch memory)
+    const unsigned p0 = pack_bf16(lo.x, hi.x), p1 = pack_bf16(lo.y, hi.y);
+    const unsigned p2 = pack_bf16(lo.z, hi.z), p3 = pack_bf16(lo.w, hi.w);
+    const unsigned s01 = (p0 ^ p1) & exmask, s23 = (p2 ^ p3) & exmask;
+    const unsigned d0 = p0 ^ s01, d1 = p1 ^ s01, d2 = p2 ^ s23, d3 = p3 ^ s23;
     unsigned* q = reinterpret_cast<unsigned*>(base) + (size_t)(4 * cq) * (ROWB / 2) + st_col;
-    q[(0 ^ ex) * (ROWB / 2)] = pack_bf16(lo.x, hi.x);
-    q[(1 ^ ex) * (ROWB / 2)] = pack_bf16(lo.y, hi.y);
-    q[(2 ^ ex) * (ROWB / 2)] = pack_bf16(lo.z, hi.z);
-    q[(3 ^ ex) * (ROWB / 2)] = pack_bf16(lo.w, hi.w);
+    q[(0 ^ ex) * (ROWB / 2)] = d0;
+    q[(1 ^ ex) * (ROWB / 2)] = d1;
+    q[(2 ^ ex) * (ROWB / 2)] = d2;
+    q[(3 ^ ex) * (ROWB / 2)] = d3;
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](const float4 (&ra)[A_U][2], const float4 (&rb)[B_U][2], int buf) {
 #pragma unroll
-    for (int i = 0; i < A_U; ++i) store_unit(At, cqb + 16 * i, ra[i][0], ra[i][1]);
+    for (int i = 0; i < A_U; ++i) store_unit(At[buf], cqb + 16 * i, ra[i][0], ra[i][1]);
 #pragma unroll
-    for (int i = 0; i < B_U; ++i) store_unit(Bt, cqb + 16 * i, rb[i][0], rb[i][1]);
+    for (int i = 0; i < B_U; ++i) store_unit(Bt[buf], cqb + 16 * i, rb[i][0], rb[i][1]);
   };
 
   f32x4 acc[MI][NJ];
@@ -337,28 +370,47 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a, floa
   const int l15 = lane & 15, lq = lane >> 4;
   const int fsw = (-(l15 >> 2)) & 3;
   static_assert((WTM / 16) % 2 == 0 && (WTN / 16) % 2 == 0, "wave sub-tiles start at even 16-row blocks");
-  if (p_lo < p_hi) {
-    decode(p_lo, 0);
+  auto compute = [&](int buf) {
+    bf16x8 af[MI], bf[NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      af[i] = *reinterpret_cast<const bf16x8*>(&At[buf][(wm * WTM + i * 16 + l15) * ROWB + (lq ^ fsw ^ (i & 1)) * 8]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      bf[j] = *reinterpret_cast<const bf16x8*>(&Bt[buf][(wn * WTN + j * 16 + l15) * ROWB + (lq ^ fsw ^ (j & 1)) * 8]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+  };
+
+  // step t: multiply tile t (LDS buffer t&1), move tile t+1 from its staging set to the other buffer, refill that
+  // set with tile t+3.  Offset block b (tiles 8b..8b+7) is decoded at step 8b-6, two barriers before its first use
+  // by the loads of step 8b-3, into the half last read at step 8b-12.
+  const int nt = (p_hi - p_lo + BKB - 1) / BKB;
+  if (nt > 0) {
+    decode_block(0);
+    if (nt > 8) decode_block(1);
     __syncthreads();
-    load_tile(p_lo, 0);
-    int it = 0;
-    for (int p = p_lo; p < p_hi; p += BKB, ++it) {
-      store_tile();
-      const bool more = p + BKB < p_hi;
-      if (more) decode(p + BKB, (it + 1) & 1);
+    load_tile(0, ra0, rb0);
+    if (nt > 1) load_tile(1, ra1, rb1);
+    store_tile(ra0, rb0, 0);
+    if (nt > 2) load_tile(2, ra0, rb0);
+    __syncthreads();
+    for (int t = 0; t < nt; t += 2) {
+      if (t + 1 < nt) {
+        store_tile(ra1, rb1, 1);
+        if (t + 3 < nt) load_tile(t + 3, ra1, rb1);
+      }
+      if ((t & 7) == 2 && (t >> 3) + 2 < (nt + 7) / 8) decode_block((t >> 3) + 2);
+      compute(0);
       __syncthreads();
-      if (more) load_tile(p + BKB, (it + 1) & 1);
-      bf16x8 af[MI], bf[NJ];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(&At[(wm * WTM + i * 16 + l15) * ROWB + (lq ^ fsw ^ (i & 1)) * 8]);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        bf[j] = *reinterpret_cast<const bf16x8*>(&Bt[(wn * WTN + j * 16 + l15) * ROWB + (lq ^ fsw ^ (j & 1)) * 8]);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      if (t + 1 >= nt) break;
+      if (t + 2 < nt) {
+        store_tile(ra0, rb0, 0);
+        if (t + 4 < nt) load_tile(t + 4, ra0, rb0);
+      }
+      compute(1);
       __syncthreads();
     }
   }
