@@ -14,6 +14,8 @@
 // (WTM/16)x(WTN/16) 16x16 accumulators.  Global->register prefetch of the next K tile overlaps the
 // MFMA work on the current one (register-staged, write-after-barrier).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -381,6 +383,10 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.ws, a.y, a.bias, total, a.y_ps,
                        a.N, a.ksplit, a.accumulate);
   }
+  static const bool trace = getenv("EG_TRACE_GEMM") != nullptr;   // shape log for offline tile/split tuning
+  if (trace)
+    fprintf(stderr, "EG_GEMM conv maxM=%d N=%d C=%d nphase=%d taps0=%d ksplit=%d kernel=%s gflop=%.3f\n", maxM, a.N, a.C,
+            a.nphase, a.ph[0].Ty * a.ph[0].Tx, a.ksplit, nm, flops * 1e-9);
   if (kernel_name) *kernel_name = nm;
   return flops;
 }
@@ -728,26 +734,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 static bool wgrad_big(const WgradArgs& a) { return a.C >= 128 && a.N >= 128; }
 static bool wgrad_flatm(const WgradArgs& a) { return a.C <= 16; }
 
+// Split count over the pixel dimension.  The kernels are MFMA-bound, so a CU retires blocks at a fixed rate however
+// many are resident; what costs time is the TAIL: with tiles*s = 1026 blocks two CUs get a 5th block and the launch
+// takes 5 block-times instead of 4.008 (measured: 88 vs 106 TFLOP/s on the 3x3 128->128 layer).  Pick the smallest
+// s near the occupancy target whose block count divides evenly over the 256 CUs; fewer splits also mean fewer
+// partial slabs for the second-stage reduction.
+static int pick_balanced_splits(long long tiles, long long target_blocks, long long smax) {
+  if (smax < 1) smax = 1;
+  long long s0 = (target_blocks + tiles - 1) / tiles;
+  if (s0 > smax) s0 = smax;
+  if (s0 <= 1) return 1;
+  auto eff = [&](long long s) {
+    const long long blocks = tiles * s;
+    return (double)blocks / (double)(((blocks + 255) / 256) * 256);
+  };
+  const long long lo = std::max(1LL, (s0 * 5) / 8), hi = std::min(smax, s0 + s0 / 8);
+  double best = 0.0;
+  for (long long s = lo; s <= hi; ++s) best = std::max(best, eff(s));
+  for (long long s = lo; s <= hi; ++s)
+    if (eff(s) >= best - 0.015) return (int)s;
+  return (int)s0;
+}
+
 int wgrad_pick_splits(const WgradArgs& a) {
+  const long long M = (long long)a.NB * a.OH * a.OW;
   if (wgrad_flatm(a)) {
     const long long tiles = (long long)((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64);
-    const long long M = (long long)a.NB * a.OH * a.OW;
-    long long s = (2048 + tiles - 1) / tiles;
-    const long long smax = (M + 511) / 512;
-    if (s > smax) s = smax;
-    if (s < 1) s = 1;
-    if (s > 1024) s = 1024;
-    return (int)s;
+    return pick_balanced_splits(tiles, 2048, std::min(1024LL, (M + 511) / 512));
   }
   const int bm = wgrad_big(a) ? 128 : 64;
   const long long tiles = (long long)((a.C + bm - 1) / bm) * ((a.N + bm - 1) / bm) * a.KH * a.KW;
-  const long long M = (long long)a.NB * a.OH * a.OW;
-  long long s = (1024 + tiles - 1) / tiles;
-  const long long smax = (M + 255) / 256;
-  if (s > smax) s = smax;
-  if (s < 1) s = 1;
-  if (s > 256) s = 256;
-  return (int)s;
+  return pick_balanced_splits(tiles, 1024, std::min(256LL, (M + 255) / 256));
 }
 
 size_t wgrad_workspace_floats(const WgradArgs& a) {
@@ -790,6 +807,10 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, a.ws, a.dw,
                        a.KH * a.KW, a.C, a.N, a.w_ts, a.ldw, a.nsplit, a.accumulate);
   }
+  static const bool trace = getenv("EG_TRACE_GEMM") != nullptr;
+  if (trace)
+    fprintf(stderr, "EG_GEMM wgrad M=%d N=%d C=%d taps=%d nsplit=%d kernel=%s gflop=%.3f\n", a.NB * a.OH * a.OW, a.N, a.C,
+            a.KH * a.KW, a.nsplit, nm, 2e-9 * a.NB * a.OH * a.OW * (double)a.N * a.C * a.KH * a.KW);
   if (kernel_name) *kernel_name = nm;
   return 2.0 * a.NB * a.OH * a.OW * (double)a.N * a.C * a.KH * a.KW;
 }
