@@ -168,6 +168,32 @@ __global__ __launch_bounds__(256) void col_sum_stage1_v(const float* __restrict_
   cq_reduce<1, 8>(s, red);
   if (pl == 0) st4(part + (size_t)blockIdx.y * C + c, s[0]);
 }
+// narrow form (C <= 128, not a multiple of 32: the 3 / 8 / 14 / 100-channel biases): the block walks its rows as one
+// flat stream with a stride that is a multiple of C, so every thread stays on one channel and all lanes load
+__global__ __launch_bounds__(256) void col_sum_stage1_narrow(const float* __restrict__ dy, float* __restrict__ part,
+                                                             size_t R, int C) {
+  __shared__ float red[256];
+  const int S = (256 / C) * C;
+  const size_t rows_per = (R + gridDim.x - 1) / gridDim.x;
+  const size_t r0 = blockIdx.x * rows_per, r1 = (r0 + rows_per < R) ? r0 + rows_per : R;
+  float s0 = 0.f, s1 = 0.f;
+  if ((int)threadIdx.x < S && r0 < r1) {
+    const size_t e1 = r1 * C;
+    size_t e = r0 * C + threadIdx.x;
+    for (; e + S < e1; e += 2 * (size_t)S) {
+      s0 += dy[e];
+      s1 += dy[e + S];
+    }
+    if (e < e1) s0 += dy[e];
+  }
+  red[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    float t = 0.f;
+    for (int i = threadIdx.x; i < S; i += C) t += red[i];
+    part[(size_t)blockIdx.x * C + threadIdx.x] = t;
+  }
+}
 static int col_sum_row_blocks(size_t R) {
   size_t nrb = (R + 255) / 256;
   return nrb > CS_RB ? CS_RB : (nrb < 1 ? 1 : (int)nrb);
@@ -177,6 +203,8 @@ void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C,
   const int nrb = col_sum_row_blocks(R);
   if (C % 32 == 0 && (((uintptr_t)dy & 15) == 0))
     hipLaunchKernelGGL(col_sum_stage1_v, dim3(C / 32, nrb), dim3(256), 0, s, dy, scratch, R, C);
+  else if (C <= 128)
+    hipLaunchKernelGGL(col_sum_stage1_narrow, dim3(nrb), dim3(256), 0, s, dy, scratch, R, C);
   else
     hipLaunchKernelGGL(col_sum_stage1, dim3((C + 63) / 64, nrb), dim3(256), 0, s, dy, scratch, R, C);
   hipLaunchKernelGGL(col_sum_stage2, dim3((C + 63) / 64), dim3(256), 0, s, scratch, db, accumulate, C, nrb);
@@ -328,6 +356,41 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
   }
 }
+// float4 form (n % 4 == 0, 16-byte aligned buffers)
+__global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ leak_p, float leak_c,
+                                                          float* __restrict__ dx, int acc_dx, float* __restrict__ part,
+                                                          size_t n4) {
+  __shared__ float sm[4];
+  const float lk = leak_p ? *leak_p : leak_c;
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i], g = reinterpret_cast<const float4*>(dy)[i];
+    const bool f0 = lk * v.x >= v.x, f1 = lk * v.y >= v.y, f2 = lk * v.z >= v.z, f3 = lk * v.w >= v.w;
+    if (dx) {
+      float4 o = make_float4(f0 ? lk * g.x : g.x, f1 ? lk * g.y : g.y, f2 ? lk * g.z : g.z, f3 ? lk * g.w : g.w);
+      if (acc_dx) {
+        const float4 d = reinterpret_cast<const float4*>(dx)[i];
+        o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+      }
+      reinterpret_cast<float4*>(dx)[i] = o;
+    }
+    s += (f0 ? g.x * v.x : 0.f) + (f1 ? g.y * v.y : 0.f) + (f2 ? g.z * v.z : 0.f) + (f3 ? g.w * v.w : 0.f);
+  }
+  if (part) {
+    const float tot = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  }
+}
+__global__ void prelu_fwd_v_kernel(const float* __restrict__ x, const float* __restrict__ leak_p, float leak_c,
+                                   float* __restrict__ y, size_t n4) {
+  const float lk = leak_p ? *leak_p : leak_c;
+  GRID_STRIDE(i, n4) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<float4*>(y)[i] = make_float4(fmaxf(lk * v.x, v.x), fmaxf(lk * v.y, v.y), fmaxf(lk * v.z, v.z),
+                                                  fmaxf(lk * v.w, v.w));
+  }
+}
 __global__ void sum_partials_kernel(const float* __restrict__ part, int np, float* __restrict__ out, int acc,
                                     float scale) {
   __shared__ float sm[4];
@@ -336,15 +399,29 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, int np, floa
   const float tot = block_sum(s, sm);
   if (threadIdx.x == 0) *out = acc ? *out + tot * scale : tot * scale;
 }
+static bool ew_vec_ok(size_t n, const void* a, const void* b, const void* c = nullptr) {
+  return (n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
 void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s) {
+  if (ew_vec_ok(n, x, y)) {
+    hipLaunchKernelGGL(prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, leak_p, leak_c, y, n / 4);
+    return;
+  }
   hipLaunchKernelGGL(prelu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, leak_p, leak_c, y, n);
 }
-size_t prelu_scratch_floats() { return 1024; }
+size_t prelu_scratch_floats() { return 2048; }
 void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, float leak_c, float* dx, int acc_dx,
                       float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s) {
-  const int nb = ew_blocks(n, 1024);
-  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, s, x, dy, leak_p, leak_c, dx, acc_dx,
-                     dleak ? scratch : nullptr, n);
+  int nb;
+  if (ew_vec_ok(n, x, dy, dx)) {
+    nb = ew_blocks(n / 4, 2048);
+    hipLaunchKernelGGL(prelu_bwd_v_kernel, dim3(nb), dim3(256), 0, s, x, dy, leak_p, leak_c, dx, acc_dx,
+                       dleak ? scratch : nullptr, n / 4);
+  } else {
+    nb = ew_blocks(n, 1024);
+    hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, s, x, dy, leak_p, leak_c, dx, acc_dx,
+                       dleak ? scratch : nullptr, n);
+  }
   if (dleak) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, nb, dleak, acc_dleak, 1.0f);
 }
 
@@ -540,14 +617,34 @@ void launch_gate_bwd(const float* rg, const float* img, const float* dout, float
 }
 
 // ---- N == 1 linear head (d_linear_5, discriminator.py:74) --------------------------------------
-__global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ b, float* __restrict__ y, int K) {
-  __shared__ float sm[4];
+// one 1024-thread block per row: with only B (64..128) rows there are fewer blocks than CUs, so each block must
+// keep many loads in flight itself (8 independent 16-byte loads per thread at K = 32768)
+__global__ __launch_bounds__(1024) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y, int K) {
+  __shared__ float sm[16];
   const float* xr = x + (size_t)blockIdx.x * K;
   float s = 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) s += xr[k] * w[k];
-  const float tot = block_sum(s, sm);
-  if (threadIdx.x == 0) y[blockIdx.x] = tot + (b ? b[0] : 0.f);
+  if ((K & 3) == 0 && (((uintptr_t)xr | (uintptr_t)w) & 15) == 0) {
+    const float4* x4 = reinterpret_cast<const float4*>(xr);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int k = threadIdx.x; k < K / 4; k += 1024) {
+      const float4 a = x4[k], c = w4[k];
+      s0 += a.x * c.x; s1 += a.y * c.y; s2 += a.z * c.z; s3 += a.w * c.w;
+    }
+    s = (s0 + s1) + (s2 + s3);
+  } else {
+    for (int k = threadIdx.x; k < K; k += 1024) s += xr[k] * w[k];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += sm[i];
+    y[blockIdx.x] = tot + (b ? b[0] : 0.f);
+  }
 }
 __global__ void gemv_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
                                   int acc, int K, size_t n) {
@@ -556,8 +653,46 @@ __global__ void gemv_bwd_x_kernel(const float* __restrict__ dy, const float* __r
     dx[i] = acc ? dx[i] + g : g;
   }
 }
-__global__ void gemv_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                  int acc_w, float* __restrict__ db, int acc_b, int R, int K) {
+// dw[k] (+)= sum_r x[r][k] dy[r]: block = 16 column quads x 16 row lanes (64 columns), lane l sums rows l, l+16, ...;
+// the 16 lane totals are added in lane order (deterministic).  db (+)= sum_r dy[r] by block 0.
+__global__ __launch_bounds__(256) void gemv_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ dw, int acc_w, float* __restrict__ db,
+                                                         int acc_b, int R, int K) {
+  __shared__ float4 red[16][17];
+  const int q = threadIdx.x & 15, l = threadIdx.x >> 4;
+  const int k = (blockIdx.x * 16 + q) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < K)
+    for (int r = l; r < R; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * K + k);
+      const float g = dy[r];
+      s.x += v.x * g; s.y += v.y * g; s.z += v.z * g; s.w += v.w * g;
+    }
+  red[l][q] = s;
+  __syncthreads();
+  if (l == 0 && k < K) {
+    float4 t = red[0][q];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+      const float4 v = red[i][q];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    float4* o = reinterpret_cast<float4*>(dw + k);
+    if (acc_w) {
+      const float4 v = *o;
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *o = t;
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+    float sb = 0.f;
+    for (int r = 0; r < R; ++r) sb += dy[r];
+    db[0] = acc_b ? db[0] + sb : sb;
+  }
+}
+// scalar form for K % 4 != 0 or unaligned buffers
+__global__ void gemv_bwd_w_scalar_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                         int acc_w, float* __restrict__ db, int acc_b, int R, int K) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < K) {
     float s = 0.f;
@@ -571,7 +706,7 @@ __global__ void gemv_bwd_w_kernel(const float* __restrict__ x, const float* __re
   }
 }
 void launch_gemv_fwd(const float* x, const float* w, const float* b, float* y, int R, int K, hipStream_t s) {
-  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(R), dim3(256), 0, s, x, w, b, y, K);
+  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(R), dim3(1024), 0, s, x, w, b, y, K);
 }
 void launch_gemv_bwd_x(const float* dy, const float* w, float* dx, int accumulate, int R, int K, hipStream_t s) {
   const size_t n = (size_t)R * K;
@@ -579,7 +714,10 @@ void launch_gemv_bwd_x(const float* dy, const float* w, float* dx, int accumulat
 }
 void launch_gemv_bwd_w(const float* x, const float* dy, float* dw, int acc_w, float* db, int acc_b, int R, int K,
                        hipStream_t s) {
-  hipLaunchKernelGGL(gemv_bwd_w_kernel, dim3((K + 255) / 256), dim3(256), 0, s, x, dy, dw, acc_w, db, acc_b, R, K);
+  if ((K & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)dw)) & 15) == 0)
+    hipLaunchKernelGGL(gemv_bwd_w_kernel, dim3((K / 4 + 15) / 16), dim3(256), 0, s, x, dy, dw, acc_w, db, acc_b, R, K);
+  else
+    hipLaunchKernelGGL(gemv_bwd_w_scalar_kernel, dim3((K + 255) / 256), dim3(256), 0, s, x, dy, dw, acc_w, db, acc_b, R, K);
 }
 
 // ---- spectral norm, batched over a device table of weights (normalization.py:38-76) -----------
@@ -608,26 +746,36 @@ __global__ __launch_bounds__(256) void sn_normalize_t_kernel(const SNDesc* __res
   for (int k = threadIdx.x; k < d.K; k += 256) d.t[k] *= inv;
   if (threadIdx.x == 0) d.scal[0] = nt;
 }
-// sv[c] = sum_k v[k]*W[k][c]
+// sv[c] = sum_k v[k]*W[k][c]: the K rows are split over SN_KS blocks (the 23 weights x 12 column blocks alone
+// leave the chip idle on a 6912-row serial loop); partials go to sv[(1+z)*Co + c], summed in fixed order by sn_sigma
+#define SN_KS 16
 __global__ __launch_bounds__(256) void sn_coldot_kernel(const SNDesc* __restrict__ tab) {
   __shared__ float red[4 * 64];
   const SNDesc d = tab[blockIdx.y];
   const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   if (blockIdx.x * 64 >= d.Co) return;
+  const int per = (d.K + SN_KS - 1) / SN_KS;
+  const int k0 = blockIdx.z * per, k1 = min(d.K, k0 + per);
   float s = 0.f;
   if (c < d.Co)
-    for (int k = py; k < d.K; k += 4) s += d.t[k] * d.W[(size_t)k * d.Co + c];
+    for (int k = k0 + py; k < k1; k += 4) s += d.t[k] * d.W[(size_t)k * d.Co + c];
   red[py * 64 + cx] = s;
   __syncthreads();
-  if (py == 0 && c < d.Co) d.sv[c] = red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx];
+  if (py == 0 && c < d.Co) d.sv[(size_t)(1 + blockIdx.z) * d.Co + c] = red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx];
 }
-// ns = |sv| ; sigma = ns^2/(ns+eps)  (= v W u'^T with u' = sv/(ns+eps))
+// sv = sum of the K-split partials; ns = |sv| ; sigma = ns^2/(ns+eps)  (= v W u'^T with u' = sv/(ns+eps))
 __global__ __launch_bounds__(256) void sn_sigma_kernel(const SNDesc* __restrict__ tab) {
   __shared__ float sm[4];
   const SNDesc d = tab[blockIdx.x];
   float s = 0.f;
-  for (int c = threadIdx.x; c < d.Co; c += 256) s += d.sv[c] * d.sv[c];
+  for (int c = threadIdx.x; c < d.Co; c += 256) {
+    float v = 0.f;
+#pragma unroll
+    for (int z = 0; z < SN_KS; ++z) v += d.sv[(size_t)(1 + z) * d.Co + c];
+    d.sv[c] = v;
+    s += v * v;
+  }
   const float ns = sqrtf(block_sum(s, sm));
   if (threadIdx.x == 0) {
     d.scal[1] = ns;
@@ -640,10 +788,11 @@ __global__ void sn_scale_kernel(const SNDesc* __restrict__ tab) {
   const size_t n = (size_t)d.K * d.Co;
   GRID_STRIDE(i, n) d.Wbar[i] = d.W[i] * inv;
 }
+int sn_sv_floats(int Co) { return (1 + SN_KS) * Co; }
 void launch_sn_fwd(const SNDesc* tab, int count, int maxK, int maxCo, hipStream_t s) {
   hipLaunchKernelGGL(sn_rowdot_kernel, dim3((maxK + 3) / 4, count), dim3(256), 0, s, tab, 0);
   hipLaunchKernelGGL(sn_normalize_t_kernel, dim3(count), dim3(256), 0, s, tab);
-  hipLaunchKernelGGL(sn_coldot_kernel, dim3((maxCo + 63) / 64, count), dim3(256), 0, s, tab);
+  hipLaunchKernelGGL(sn_coldot_kernel, dim3((maxCo + 63) / 64, count, SN_KS), dim3(256), 0, s, tab);
   hipLaunchKernelGGL(sn_sigma_kernel, dim3(count), dim3(256), 0, s, tab);
   hipLaunchKernelGGL(sn_scale_kernel, dim3(256, count), dim3(256), 0, s, tab);
 }

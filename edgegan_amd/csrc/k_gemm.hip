@@ -731,6 +731,53 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// float4 form (N % 4 == 0): 64 element quads x 4 split lanes per block; lane l sums splits l, l+4, ... with 4
+// independent loads in flight, the 4 lane totals are added in lane order -> deterministic, 16-byte coalesced.
+__global__ __launch_bounds__(256) void wgrad_reduce_v_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                             int T, int C, int N, long long w_ts, int ldw, int nsplit,
+                                                             int accumulate) {
+  __shared__ float4 red[4][64];
+  const size_t total4 = (size_t)T * C * N / 4;
+  const int e = threadIdx.x & 63, l = threadIdx.x >> 6;
+  const size_t i4 = (size_t)blockIdx.x * 64 + e;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (i4 < total4) {
+    const float4* p = reinterpret_cast<const float4*>(ws) + i4;
+    int z = l;
+    for (; z + 12 < nsplit; z += 16) {
+      const float4 a0 = p[(size_t)z * total4], a1 = p[(size_t)(z + 4) * total4], a2 = p[(size_t)(z + 8) * total4],
+                   a3 = p[(size_t)(z + 12) * total4];
+      s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+      s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+      s2.x += a2.x; s2.y += a2.y; s2.z += a2.z; s2.w += a2.w;
+      s3.x += a3.x; s3.y += a3.y; s3.z += a3.z; s3.w += a3.w;
+    }
+    for (; z < nsplit; z += 4) {
+      const float4 a0 = p[(size_t)z * total4];
+      s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+    }
+  }
+  red[l][e] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                          (s0.w + s1.w) + (s2.w + s3.w));
+  __syncthreads();
+  if (l == 0 && i4 < total4) {
+    const float4 r0 = red[0][e], r1 = red[1][e], r2 = red[2][e], r3 = red[3][e];
+    float4 t = make_float4((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (r0.z + r1.z) + (r2.z + r3.z),
+                           (r0.w + r1.w) + (r2.w + r3.w));
+    const size_t i = i4 * 4;
+    const int n = (int)(i % N);
+    const size_t t2 = i / N;
+    const int c = (int)(t2 % C);
+    const int tp = (int)(t2 / C);
+    float4* q = reinterpret_cast<float4*>(dw + (size_t)tp * w_ts + (size_t)c * ldw + n);
+    if (accumulate) {
+      const float4 o = *q;
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    *q = t;
+  }
+}
+
 static bool wgrad_big(const WgradArgs& a) { return a.C >= 128 && a.N >= 128; }
 static bool wgrad_flatm(const WgradArgs& a) { return a.C <= 16; }
 
@@ -804,8 +851,14 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
   }
   if (!direct) {
     const size_t total = (size_t)a.KH * a.KW * a.C * a.N;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, a.ws, a.dw,
-                       a.KH * a.KW, a.C, a.N, a.w_ts, a.ldw, a.nsplit, a.accumulate);
+    const bool rv = (a.N % 4 == 0) && (a.ldw % 4 == 0) && (a.w_ts % 4 == 0) && (((uintptr_t)a.dw & 15) == 0) &&
+                    (((uintptr_t)a.ws & 15) == 0);
+    if (rv)
+      hipLaunchKernelGGL(wgrad_reduce_v_kernel, dim3((unsigned)((total / 4 + 63) / 64)), dim3(256), 0, s, a.ws, a.dw,
+                         a.KH * a.KW, a.C, a.N, a.w_ts, a.ldw, a.nsplit, a.accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, a.ws, a.dw,
+                         a.KH * a.KW, a.C, a.N, a.w_ts, a.ldw, a.nsplit, a.accumulate);
   }
   static const bool trace = getenv("EG_TRACE_GEMM") != nullptr;
   if (trace)

@@ -176,7 +176,7 @@ struct SNDesc {
   const float* u;   // [Co]
   float* Wbar;      // [K][Co] = W/sigma
   float* t;         // [K]  scratch: W u^T  (then v)
-  float* sv;        // [Co] scratch: v W
+  float* sv;        // [sn_sv_floats(Co)]: v W in the first Co floats, then the K-split partials
   float* scal;      // [80]: 0 nt, 1 ns, 2 sigma, 3 dot(dWbar,W), 4 P=dot(dv,v), 5 ds coefficient, 8.. partials
   const float* dWbar;  // backward input
   float* dW;        // backward output
@@ -184,6 +184,7 @@ struct SNDesc {
   int K, Co;
   int acc_dW;
 };
+int sn_sv_floats(int Co);
 void launch_sn_fwd(const SNDesc* d_table, int count, int maxK, int maxCo, hipStream_t s);
 void launch_sn_bwd(const SNDesc* d_table, int count, int maxK, int maxCo, hipStream_t s);
 

@@ -207,7 +207,7 @@ void build_context(Ctx& c) {
       EG_HIP(hipMalloc(&s.dWbar, p->numel * 4));
       EG_HIP(hipMalloc(&s.t, (size_t)s.K * 4));
       EG_HIP(hipMalloc(&s.dv, (size_t)s.K * 4));
-      EG_HIP(hipMalloc(&s.sv, (size_t)s.Co * 4));
+      EG_HIP(hipMalloc(&s.sv, (size_t)sn_sv_floats(s.Co) * 4));
       EG_HIP(hipMalloc(&s.scal, 80 * 4));
       c.sn_index[p] = (int)c.sn.size();
       c.sn.push_back(s);
