@@ -318,9 +318,55 @@ __global__ void resize_kernel(const float* __restrict__ x, float* __restrict__ y
     y[i] = acc ? y[i] + s : s;
   }
 }
+// 3-channel images (every call of the reference): one thread per output PIXEL, so the tap tables and the index
+// arithmetic are read once for the three channels
+__global__ void resize3_kernel(const float* __restrict__ x, float* __restrict__ y, int acc, int IH, int IW, int OH,
+                               int OW, const int* __restrict__ ty_i, const float* __restrict__ ty_w, int tyn,
+                               const int* __restrict__ tx_i, const float* __restrict__ tx_w, int txn, size_t npix) {
+  GRID_STRIDE(i, npix) {
+    const int ox = (int)(i % OW);
+    size_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const size_t nb = t / OH;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int a = 0; a < tyn; ++a) {
+      const float wy = ty_w[oy * tyn + a];
+      if (wy == 0.f) continue;
+      const float* row = x + ((nb * IH + ty_i[oy * tyn + a]) * IW) * 3;
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+      for (int b = 0; b < txn; ++b) {
+        const float wx = tx_w[ox * txn + b];
+        if (wx != 0.f) {
+          const float* px = row + (size_t)tx_i[ox * txn + b] * 3;
+          r0 += wx * px[0];
+          r1 += wx * px[1];
+          r2 += wx * px[2];
+        }
+      }
+      s0 += wy * r0;
+      s1 += wy * r1;
+      s2 += wy * r2;
+    }
+    float* o = y + i * 3;
+    if (acc) {
+      s0 += o[0];
+      s1 += o[1];
+      s2 += o[2];
+    }
+    o[0] = s0;
+    o[1] = s1;
+    o[2] = s2;
+  }
+}
 void launch_resize(const float* x, float* y, int accumulate, int NB, int IH, int IW, int OH, int OW, int C,
                    const int* ty_i, const float* ty_w, int tyn, const int* tx_i, const float* tx_w, int txn,
                    hipStream_t s) {
+  if (C == 3) {
+    const size_t npix = (size_t)NB * OH * OW;
+    hipLaunchKernelGGL(resize3_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, y, accumulate, IH, IW, OH, OW, ty_i,
+                       ty_w, tyn, tx_i, tx_w, txn, npix);
+    return;
+  }
   const size_t n = (size_t)NB * OH * OW * C;
   hipLaunchKernelGGL(resize_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, accumulate, IH, IW, OH, OW, C, ty_i,
                      ty_w, tyn, tx_i, tx_w, txn, n);
