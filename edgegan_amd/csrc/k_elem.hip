@@ -247,12 +247,61 @@ __global__ void pool2_bwd_kernel(const float* __restrict__ dy, float* __restrict
     dx[i] = acc ? dx[i] + g : g;
   }
 }
+// float4 forms (C % 4 == 0, < 2^31 elements): one thread per OUTPUT quad, 32-bit index arithmetic
+__global__ void pool2_fwd_v_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C4, unsigned n4) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+    const unsigned c = i % C4;
+    unsigned t = i / C4;
+    const unsigned ox = t % Wo;
+    t /= Wo;
+    const unsigned oy = t % Ho, nb = t / Ho;
+    const float4* p = reinterpret_cast<const float4*>(x) + ((size_t)(nb * H + 2 * oy) * W + 2 * ox) * C4 + c;
+    const float4 a = p[0], b = p[(size_t)W * C4], d = p[C4], e = p[(size_t)W * C4 + C4];
+    reinterpret_cast<float4*>(y)[i] = make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f,
+                                                  (a.z + b.z + d.z + e.z) * 0.25f, (a.w + b.w + d.w + e.w) * 0.25f);
+  }
+}
+__global__ void pool2_bwd_v_kernel(const float* __restrict__ dy, float* __restrict__ dx, int acc, int H, int W, int C4,
+                                   unsigned n4) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+    const unsigned c = i % C4;
+    unsigned t = i / C4;
+    const unsigned ox = t % Wo;
+    t /= Wo;
+    const unsigned oy = t % Ho, nb = t / Ho;
+    const float4 g0 = reinterpret_cast<const float4*>(dy)[i];
+    const float4 g = make_float4(0.25f * g0.x, 0.25f * g0.y, 0.25f * g0.z, 0.25f * g0.w);
+    float4* p = reinterpret_cast<float4*>(dx) + ((size_t)(nb * H + 2 * oy) * W + 2 * ox) * C4 + c;
+    const size_t offs[4] = {0, (size_t)C4, (size_t)W * C4, (size_t)W * C4 + C4};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 v = g;
+      if (acc) {
+        const float4 o = p[offs[k]];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      p[offs[k]] = v;
+    }
+  }
+}
 void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hipStream_t s) {
   const size_t n = (size_t)NB * (H / 2) * (W / 2) * C;
+  if (C % 4 == 0 && (size_t)NB * H * W * C < (1ull << 31) && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+    hipLaunchKernelGGL(pool2_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, y, H, W, C / 4, (unsigned)(n / 4));
+    return;
+  }
   hipLaunchKernelGGL(pool2_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, H, W, C, n);
 }
 void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s) {
   const size_t n = (size_t)NB * H * W * C;
+  if (C % 4 == 0 && n < (1ull << 31) && H % 2 == 0 && W % 2 == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0) {
+    const size_t no4 = n / 16;   // output quads
+    hipLaunchKernelGGL(pool2_bwd_v_kernel, dim3(ew_blocks(no4)), dim3(256), 0, s, dy, dx, accumulate, H, W, C / 4,
+                       (unsigned)no4);
+    return;
+  }
   hipLaunchKernelGGL(pool2_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, dx, accumulate, H, W, C, n);
 }
 
@@ -323,11 +372,11 @@ __global__ void resize_kernel(const float* __restrict__ x, float* __restrict__ y
 __global__ void resize3_kernel(const float* __restrict__ x, float* __restrict__ y, int acc, int IH, int IW, int OH,
                                int OW, const int* __restrict__ ty_i, const float* __restrict__ ty_w, int tyn,
                                const int* __restrict__ tx_i, const float* __restrict__ tx_w, int txn, size_t npix) {
-  GRID_STRIDE(i, npix) {
-    const int ox = (int)(i % OW);
-    size_t t = i / OW;
-    const int oy = (int)(t % OH);
-    const size_t nb = t / OH;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < npix; i += gridDim.x * 256u) {   // 32-bit index arithmetic
+    const int ox = (int)(i % (unsigned)OW);
+    unsigned t = i / (unsigned)OW;
+    const int oy = (int)(t % (unsigned)OH);
+    const size_t nb = t / (unsigned)OH;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int a = 0; a < tyn; ++a) {
       const float wy = ty_w[oy * tyn + a];
@@ -347,7 +396,7 @@ __global__ void resize3_kernel(const float* __restrict__ x, float* __restrict__ 
       s1 += wy * r1;
       s2 += wy * r2;
     }
-    float* o = y + i * 3;
+    float* o = y + (size_t)i * 3;
     if (acc) {
       s0 += o[0];
       s1 += o[1];
@@ -361,7 +410,7 @@ __global__ void resize3_kernel(const float* __restrict__ x, float* __restrict__ 
 void launch_resize(const float* x, float* y, int accumulate, int NB, int IH, int IW, int OH, int OW, int C,
                    const int* ty_i, const float* ty_w, int tyn, const int* tx_i, const float* tx_w, int txn,
                    hipStream_t s) {
-  if (C == 3) {
+  if (C == 3 && (size_t)NB * OH * OW < (1ull << 31)) {
     const size_t npix = (size_t)NB * OH * OW;
     hipLaunchKernelGGL(resize3_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, y, accumulate, IH, IW, OH, OW, ty_i,
                        ty_w, tyn, tx_i, tx_w, txn, npix);

@@ -229,6 +229,54 @@ __global__ __launch_bounds__(256) void in_fwd_v(const float* __restrict__ x, flo
   }
 }
 
+// register-cached form for HW <= 32 * NP: x is read from memory ONCE (the generic kernel re-reads it for the centred
+// variance and for the apply pass; at 128 KB per block those re-reads miss L2)
+template <int NP>
+__global__ __launch_bounds__(256) void in_fwd_vr(const float* __restrict__ x, float* __restrict__ out,
+                                                 float* __restrict__ stats, int HW, int C, int act) {
+  constexpr int CQ = 8, PL = 32;
+  __shared__ float4 red[4 * CQ];
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+  const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
+  const float* xp = x + (size_t)n * HW * C + c;
+  float4 xv[NP];
+  float4 s[1] = {f4_zero()};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = pl + i * PL;
+    xv[i] = p < HW ? ld4(xp + (size_t)p * C) : f4_zero();
+    s[0].x += xv[i].x; s[0].y += xv[i].y; s[0].z += xv[i].z; s[0].w += xv[i].w;
+  }
+  cq_reduce<1, CQ>(s, red);
+  const float inv = 1.f / HW;
+  const float4 mean = make_float4(s[0].x * inv, s[0].y * inv, s[0].z * inv, s[0].w * inv);
+  float4 q[1] = {f4_zero()};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (pl + i * PL < HW) {
+      const float dx = xv[i].x - mean.x, dy = xv[i].y - mean.y, dz = xv[i].z - mean.z, dw = xv[i].w - mean.w;
+      q[0].x += dx * dx; q[0].y += dy * dy; q[0].z += dz * dz; q[0].w += dw * dw;
+    }
+  }
+  cq_reduce<1, CQ>(q, red);
+  const float4 sigma = make_float4(sqrtf(q[0].x * inv), sqrtf(q[0].y * inv), sqrtf(q[0].z * inv), sqrtf(q[0].w * inv));
+  const float4 r = make_float4(1.f / (sigma.x + IN_EPS), 1.f / (sigma.y + IN_EPS), 1.f / (sigma.z + IN_EPS),
+                               1.f / (sigma.w + IN_EPS));
+  float* op = out + (size_t)n * HW * C + c;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = pl + i * PL;
+    if (p < HW)
+      st4(op + (size_t)p * C, act4(make_float4((xv[i].x - mean.x) * r.x, (xv[i].y - mean.y) * r.y,
+                                               (xv[i].z - mean.z) * r.z, (xv[i].w - mean.w) * r.w), act));
+  }
+  if (pl == 0) {
+    float* sp = stats + ((size_t)n * C + c) * 2;
+    sp[0] = mean.x; sp[1] = sigma.x; sp[2] = mean.y; sp[3] = sigma.y;
+    sp[4] = mean.z; sp[5] = sigma.z; sp[6] = mean.w; sp[7] = sigma.w;
+  }
+}
+
 struct Stat4 { float4 mean, sigma, r; };
 __device__ __forceinline__ Stat4 load_stats4(const float* stats, size_t nc) {
   const float4 a = ld4(stats + nc * 2), b = ld4(stats + nc * 2 + 4);
@@ -286,9 +334,67 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
   }
 }
 
+// IN+act backward with e = dout * act'(out) and (x - mean) held in registers between the reduction and the apply
+// pass (HW <= 32 * NP): out / dout / x are read from memory once
+template <int NP>
+__global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, const float* __restrict__ out,
+                                                 const float* __restrict__ v, const float* __restrict__ stats,
+                                                 float* __restrict__ dst, int accumulate, int HW, int C, int act) {
+  constexpr int CQ = 8, PL = 32;
+  __shared__ float4 red[2 * 4 * CQ];
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+  const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
+  const size_t base = (size_t)n * HW * C + c;
+  const Stat4 st = load_stats4(stats, (size_t)n * C + c);
+  float4 ev[NP], xc[NP];
+  float4 s[2] = {f4_zero(), f4_zero()};
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = pl + k * PL;
+    ev[k] = f4_zero();
+    xc[k] = f4_zero();
+    if (p < HW) {
+      const size_t i = base + (size_t)p * C;
+      float4 e = ld4(v + i);
+      const float4 g = actg4(ld4(out + i), act);
+      e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w;
+      const float4 xv = ld4(x + i);
+      ev[k] = e;
+      xc[k] = make_float4(xv.x - st.mean.x, xv.y - st.mean.y, xv.z - st.mean.z, xv.w - st.mean.w);
+      s[0].x += e.x; s[0].y += e.y; s[0].z += e.z; s[0].w += e.w;
+      s[1].x += e.x * xc[k].x; s[1].y += e.y * xc[k].y; s[1].z += e.z * xc[k].z; s[1].w += e.w * xc[k].w;
+    }
+  }
+  cq_reduce<2, CQ>(s, red);
+  const float hw = (float)HW;
+  const float4 eb = make_float4(s[0].x / hw, s[0].y / hw, s[0].z / hw, s[0].w / hw);
+  const float4 k2 = make_float4(st.r.x * st.r.x * s[1].x / (hw * st.sigma.x), st.r.y * st.r.y * s[1].y / (hw * st.sigma.y),
+                                st.r.z * st.r.z * s[1].z / (hw * st.sigma.z), st.r.w * st.r.w * s[1].w / (hw * st.sigma.w));
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = pl + k * PL;
+    if (p < HW) {
+      const size_t i = base + (size_t)p * C;
+      float4 res = make_float4(st.r.x * (ev[k].x - eb.x) - k2.x * xc[k].x, st.r.y * (ev[k].y - eb.y) - k2.y * xc[k].y,
+                               st.r.z * (ev[k].z - eb.z) - k2.z * xc[k].z, st.r.w * (ev[k].w - eb.w) - k2.w * xc[k].w);
+      if (accumulate) {
+        const float4 d = ld4(dst + i);
+        res.x += d.x; res.y += d.y; res.z += d.z; res.w += d.w;
+      }
+      st4(dst + i, res);
+    }
+  }
+}
+
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s) {
   if (C % 32 == 0) {
-    hipLaunchKernelGGL(in_fwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, out, stats, HW, C, act);
+    const dim3 grid(NB, C / 32);
+    if (HW <= 64) hipLaunchKernelGGL(in_fwd_vr<2>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    else if (HW <= 128) hipLaunchKernelGGL(in_fwd_vr<4>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    else if (HW <= 256) hipLaunchKernelGGL(in_fwd_vr<8>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    else if (HW <= 512) hipLaunchKernelGGL(in_fwd_vr<16>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    else if (HW <= 1024) hipLaunchKernelGGL(in_fwd_vr<32>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    else hipLaunchKernelGGL(in_fwd_v<8>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
     return;
   }
 
@@ -297,8 +403,15 @@ void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
                    int accumulate, int NB, int HW, int C, int act, hipStream_t s) {
   if (C % 32 == 0) {
-    hipLaunchKernelGGL((in_japply_v<0, 8>), dim3(NB, C / 32), dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW,
-                       C, act);
+    const dim3 grid(NB, C / 32);
+#define EG_IN_BWD(NP) hipLaunchKernelGGL(in_bwd_vr<NP>, grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act)
+    if (HW <= 64) EG_IN_BWD(2);
+    else if (HW <= 128) EG_IN_BWD(4);
+    else if (HW <= 256) EG_IN_BWD(8);
+    else if (HW <= 512) EG_IN_BWD(16);
+    else
+      hipLaunchKernelGGL((in_japply_v<0, 8>), grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act);
+#undef EG_IN_BWD
     return;
   }
   hipLaunchKernelGGL(in_japply_kernel<0>, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, dout, stats, dx,
