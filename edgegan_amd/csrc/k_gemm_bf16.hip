@@ -385,8 +385,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, f
   };
 
   // step t: multiply tile t (LDS buffer t&1), move tile t+1 from its staging set to the other buffer, refill that
-  // set with tile t+3.  Offset block b (tiles 8b..8b+7) is decoded at step 8b-6, two barriers before its first use
-  // by the loads of step 8b-3, into the half last read at step 8b-12.
+  // set with tile t+3 (even part) / t+4 (odd part).  Offset block b (tiles 8b..8b+7) lives in half b&1, whose previous
+  // tenant b-2 is last read by the load of tile 8b-9 in the even part of step 8b-12; block b is decoded at step 8b-10
+  // (after that step's barriers) and first read by the load of tile 8b in the odd part of step 8b-4.
   const int nt = (p_hi - p_lo + BKB - 1) / BKB;
   if (nt > 0) {
     decode_block(0);
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, f
         store_tile(ra1, rb1, 1);
         if (t + 3 < nt) load_tile(t + 3, ra1, rb1);
       }
-      if ((t & 7) == 2 && (t >> 3) + 2 < (nt + 7) / 8) decode_block((t >> 3) + 2);
+      if ((t & 7) == 6 && (t >> 3) + 2 < (nt + 7) / 8) decode_block((t >> 3) + 2);
       compute(0);
       __syncthreads();
       if (t + 1 >= nt) break;

@@ -539,6 +539,22 @@ def real_shape_checks(net, nbs=(4, 8), bf16=False):
     return rows
 
 
+LONG_M_CASES = [
+    # many pixels per wgrad block: exercises the multi-block pixel-offset ring of the bf16 wgrad (> 16 K steps per
+    # block) and the deep split reductions, at shapes the batch-2 network tests never reach
+    ('long-M 3x3 C64->64', 16, 64, 64, 64, 64, 3, 1, 0, True),
+    ('long-M 4x4s2 C32->128', 8, 128, 128, 32, 128, 4, 2, 0, False),
+    ('long-M REFLECT 3x3 C32->32', 4, 96, 96, 32, 32, 3, 1, 1, True),
+]
+
+
+def long_m_checks(net, bf16=False):
+    rows = []
+    for case in LONG_M_CASES:
+        rows += check_conv(net, case, seed=31, bf16=bf16)
+    return rows
+
+
 def bf16_op_checks(net):
     """Every conv / deconv case of the fp32 op tests, on an engine created with compute_dtype='bf16'."""
     rows = []
@@ -546,4 +562,4 @@ def bf16_op_checks(net):
         rows += check_conv(net, case, bf16=True)
     for case in DECONV_CASES:
         rows += check_deconv(net, case, bf16=True)
-    return rows + real_shape_checks(net, bf16=True)
+    return rows + real_shape_checks(net, bf16=True) + long_m_checks(net, bf16=True)

@@ -30,6 +30,12 @@ def test_deconv2d(net, case):
     _assert(parity.check_deconv(net, case))
 
 
+@pytest.mark.parametrize('case', parity.LONG_M_CASES, ids=[c[0] for c in parity.LONG_M_CASES])
+def test_conv2d_many_pixels_per_wgrad_block(net, case):
+    """Long pixel runs per weight-gradient block (deep split reductions, > 16 K steps per block)."""
+    _assert(parity.check_conv(net, case, seed=31))
+
+
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_instance_norm_act(net, act):
     _assert(parity.check_in_act(net, act))
