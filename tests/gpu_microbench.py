@@ -26,7 +26,10 @@ def main():
     net = ea.EdgeGAN(ea.Config(batch_size=2, compute_dtype=os.environ.get('DTYPE', 'f32')))
     rng = np.random.RandomState(0)
     print(f'{"shape":44s} {"kernel":26s} {"ms":>8s} {"TF/s":>8s}')
+    only = os.environ.get('SHAPES')
     for name, NB, H, W, C, N, k, s, pad in SHAPES:
+        if only and not any(t in name for t in only.split(',')):
+            continue
         x = rng.normal(size=(NB, H, W, C)).astype(np.float32)
         w = (rng.normal(size=(k, k, C, N)) * 0.05).astype(np.float32)
         OH, OW = (H + s - 1) // s, (W + s - 1) // s
