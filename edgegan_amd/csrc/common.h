@@ -135,6 +135,11 @@ struct Param {
   float* mom = nullptr;
   bool want_grad = false;    // set per sub-step for the networks being optimised
   bool g_set = false;
+  // per-tap transposed copy of a conv filter, kept across sub-steps until the variable changes (the discriminators'
+  // filters are transposed for the input gradient in sub-steps 1-3, 5 and 7 but only change in their own sub-step)
+  float* wT = nullptr;
+  bool wT_valid = false;
+  bool cache_T = false;      // network variables only (per-op test scaffolding re-uses Param slots)
 };
 
 struct Ctx;

@@ -37,6 +37,7 @@ struct WRef {
   bool* g_set = nullptr;
   bool want_grad = false;
   const float* wT = nullptr; // per-tap transpose [T][Cc][R] (built lazily, cached per sub-step)
+  Param* param = nullptr;    // set when the weights ARE a variable (enables the persistent transpose cache)
   unsigned short* wb = nullptr;   // bf16 copy, same layout      (compute_dtype bf16; lazily, per sub-step)
   unsigned short* wbT = nullptr;  // bf16 copy, per-tap transposed
   int T = 1, R = 0, Cc = 0;

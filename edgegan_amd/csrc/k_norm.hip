@@ -231,10 +231,10 @@ __global__ __launch_bounds__(256) void in_fwd_v(const float* __restrict__ x, flo
 
 // register-cached form for HW <= 32 * NP: x is read from memory ONCE (the generic kernel re-reads it for the centred
 // variance and for the apply pass; at 128 KB per block those re-reads miss L2)
-template <int NP>
+template <int NP, int CQ>
 __global__ __launch_bounds__(256) void in_fwd_vr(const float* __restrict__ x, float* __restrict__ out,
                                                  float* __restrict__ stats, int HW, int C, int act) {
-  constexpr int CQ = 8, PL = 32;
+  constexpr int PL = 256 / CQ;   // CQ = 4 for the 32x32 layers: 16 channels per block -> twice the blocks, half the registers
   __shared__ float4 red[4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
   const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
@@ -336,11 +336,11 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
 
 // IN+act backward with e = dout * act'(out) and (x - mean) held in registers between the reduction and the apply
 // pass (HW <= 32 * NP): out / dout / x are read from memory once
-template <int NP>
+template <int NP, int CQ>
 __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, const float* __restrict__ out,
                                                  const float* __restrict__ v, const float* __restrict__ stats,
                                                  float* __restrict__ dst, int accumulate, int HW, int C, int act) {
-  constexpr int CQ = 8, PL = 32;
+  constexpr int PL = 256 / CQ;
   __shared__ float4 red[2 * 4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
   const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
@@ -389,11 +389,12 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s) {
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
-    if (HW <= 64) hipLaunchKernelGGL(in_fwd_vr<2>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
-    else if (HW <= 128) hipLaunchKernelGGL(in_fwd_vr<4>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
-    else if (HW <= 256) hipLaunchKernelGGL(in_fwd_vr<8>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
-    else if (HW <= 512) hipLaunchKernelGGL(in_fwd_vr<16>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
-    else if (HW <= 1024) hipLaunchKernelGGL(in_fwd_vr<32>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    if (HW <= 64) hipLaunchKernelGGL((in_fwd_vr<2, 8>), grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    else if (HW <= 128) hipLaunchKernelGGL((in_fwd_vr<4, 8>), grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    else if (HW <= 256) hipLaunchKernelGGL((in_fwd_vr<8, 8>), grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    else if (HW <= 512) hipLaunchKernelGGL((in_fwd_vr<16, 8>), grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    else if (HW <= 1024)
+      hipLaunchKernelGGL((in_fwd_vr<16, 4>), dim3(NB, C / 16), dim3(256), 0, s, x, out, stats, HW, C, act);
     else hipLaunchKernelGGL(in_fwd_v<8>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
     return;
   }
@@ -404,11 +405,14 @@ void launch_in_bwd(const float* x, const float* out, const float* dout, const fl
                    int accumulate, int NB, int HW, int C, int act, hipStream_t s) {
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
-#define EG_IN_BWD(NP) hipLaunchKernelGGL(in_bwd_vr<NP>, grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act)
+#define EG_IN_BWD(NP) hipLaunchKernelGGL((in_bwd_vr<NP, 8>), grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act)
     if (HW <= 64) EG_IN_BWD(2);
     else if (HW <= 128) EG_IN_BWD(4);
     else if (HW <= 256) EG_IN_BWD(8);
     else if (HW <= 512) EG_IN_BWD(16);
+    else if (HW <= 1024)
+      hipLaunchKernelGGL((in_bwd_vr<16, 4>), dim3(NB, C / 16), dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW,
+                         C, act);
     else
       hipLaunchKernelGGL((in_japply_v<0, 8>), grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act);
 #undef EG_IN_BWD

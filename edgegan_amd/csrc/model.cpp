@@ -147,6 +147,7 @@ void build_context(Ctx& c) {
     p->init_param = vi.init_param;
     p->numel = 1;
     for (int d : vi.shape) p->numel *= (size_t)d;
+    p->cache_T = true;
     c.by_name[p->name] = p.get();
     c.groups[vi.group].params.push_back(p.get());
     c.params.push_back(std::move(p));
@@ -406,6 +407,7 @@ static void apply_group(Ctx& c, int group) {
   NetGroup& g = c.groups[group];
   if (group == G_G1) c.gen_cache_valid[0] = false;
   if (group == G_G2) c.gen_cache_valid[1] = false;
+  for (Param* p : g.params) p->wT_valid = false;
   for (Param* p : g.params)
     if (p->trainable && !p->dead) EG_CHECK(p->g_set, "variable %s received no gradient", p->name.c_str());
   if (c.nccl_comm) {

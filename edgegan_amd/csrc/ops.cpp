@@ -99,6 +99,7 @@ WRef* wref_param(Ctx& c, Param* p, int T_, int R, int Cc) {
   w->T = T_;
   w->R = R;
   w->Cc = Cc;
+  w->param = p;
   c.wref_cache[p] = w;
   return w;
 }
@@ -134,6 +135,16 @@ WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_
 }
 const float* wref_transposed(Ctx& c, WRef* w) {
   if (w->wT) return w->wT;
+  if (w->param && w->param->cache_T) {
+    Param* p = w->param;
+    if (!p->wT) EG_HIP(hipMalloc(&p->wT, p->numel * sizeof(float)));
+    if (!p->wT_valid) {
+      launch_tap_transpose(w->w, p->wT, w->T, w->R, w->Cc, nullptr, c.stream);
+      p->wT_valid = true;
+    }
+    w->wT = p->wT;
+    return w->wT;
+  }
   float* buf = nullptr;
   // SN weights keep their transpose in a persistent buffer
   for (auto& s : c.sn)
@@ -881,6 +892,8 @@ Ctx::~Ctx() {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
+  for (auto& p : params)
+    if (p->wT) (void)hipFree(p->wT);
   for (auto& g : groups) {
     (void)hipFree(g.w);
     (void)hipFree(g.g);
