@@ -93,12 +93,16 @@ def test_bf16_train_step_is_deterministic_and_finite():
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
 
 
-def test_bf16_full_size_gradients_track_fp32():
-    """BASELINE's full size (batch 64, 14 classes): every sub-step's gradients from the bf16 engine against the fp32
-    engine on the same weights and batch.  The batch-2 tests above never reach the production shapes (128x128 tiles,
-    tens of K steps per weight-gradient block, 84-way split reductions); a kernel bug there shows up as O(1) error,
-    bf16 rounding as a few percent (the encoder sub-step ~0.3, see the module docstring)."""
-    cfg32, cfg16 = ea.Config(batch_size=64), ea.Config(batch_size=64, compute_dtype='bf16')
+@pytest.mark.parametrize('shape', [(64, 64, 128), (4, 256, 512)], ids=['configs3_b64_64x128', 'configs4_b4_256x512'])
+def test_bf16_full_size_gradients_track_fp32(shape):
+    """BASELINE's full sizes (configs[3]: batch 64 at 64x128; configs[4]'s 256x512 geometry at batch 4), 14 classes:
+    every sub-step's gradients from the bf16 engine against the fp32 engine on the same weights and batch.  The
+    batch-2 tests above never reach the production shapes (128x128 tiles, tens of K steps per weight-gradient block,
+    84-way split reductions); a kernel bug there shows up as O(1) error, bf16 rounding as a few percent (the encoder
+    sub-step ~0.3, see the module docstring)."""
+    B, H, W = shape
+    cfg32 = ea.Config(batch_size=B, height=H, width=W)
+    cfg16 = ea.Config(batch_size=B, height=H, width=W, compute_dtype='bf16')
     values = ea.init_variables(cfg32, 0)
     batch = ea.synthetic_batch(cfg32)
     n32, n16 = ea.EdgeGAN(cfg32, values), ea.EdgeGAN(cfg16, values)
