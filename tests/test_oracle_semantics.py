@@ -151,3 +151,42 @@ def test_lazy_graph_matches_full_graph_and_substep_dependencies():
     part = O.forward_graph(m.p, inp, cfg, 0.3, want=['zl_loss'])
     assert set(part) == {'zl_loss', 'z_recon'} and torch.allclose(part['zl_loss'], full['zl_loss'])
     assert m.substep_names() == [n for n in O.SUBSTEPS if n != 'd_optim2']      # edgegan.py:115-116
+
+
+def test_bf16_operand_emulation_rounds_each_bilinear_map():
+    """oracle.bf16_operands(): forward, input gradient and filter gradient of a qualifying contraction each use
+    bf16-rounded operands (round-to-nearest-even) with exact products and sums; non-qualifying shapes are untouched;
+    the backward maps stay differentiable (needed for the gradient-penalty double backward)."""
+    import torch
+    torch.manual_seed(0)
+    r = lambda t: t.detach().float().bfloat16().double()
+    x = torch.randn(2, 6, 6, 64, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(3, 3, 64, 32, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(2, 6, 6, 32, dtype=torch.float64)
+    with O.bf16_operands():
+        y = O.conv2d(x, w, 1, 'SAME')
+        gx, gw = torch.autograd.grad((y * dy).sum(), [x, w])
+    assert torch.equal(y, O.conv2d(r(x), r(w), 1, 'SAME'))
+    assert torch.equal(gx, torch.autograd.grad((O.conv2d(x, r(w), 1, 'SAME') * r(dy)).sum(), x)[0])
+    assert torch.equal(gw, torch.autograd.grad((O.conv2d(r(x), w, 1, 'SAME') * r(dy)).sum(), w)[0])
+    # 0.1 is not a bf16 number: round-to-nearest-even gives 0.10009765625
+    assert float(r(torch.tensor([0.1], dtype=torch.float64))[0]) == 0.10009765625
+    # a 3-channel input does not qualify (contracted channels % 32 != 0): bit-identical to the exact path
+    x3 = torch.randn(1, 5, 5, 3, dtype=torch.float64)
+    w3 = torch.randn(4, 4, 3, 64, dtype=torch.float64)
+    with O.bf16_operands():
+        y3 = O.conv2d(x3, w3, 2, 'SAME')
+    assert torch.equal(y3, O.conv2d(x3, w3, 2, 'SAME'))
+    # transposed conv: forward qualifies on (Cin, Cout), its filter gradient on (Cout, Cin) as the engine launches it
+    xd = torch.randn(1, 4, 4, 64, dtype=torch.float64, requires_grad=True)
+    wd = torch.randn(5, 5, 32, 64, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(32, dtype=torch.float64)
+    with O.bf16_operands():
+        yd = O.deconv2d(xd, wd, b, (8, 8))
+    assert torch.equal(yd, O.deconv2d(r(xd), r(wd), b, (8, 8)))
+    # double backward through the emulated maps
+    with O.bf16_operands():
+        g1 = torch.autograd.grad(O.conv2d(x, w, 1, 'SAME').tanh().sum(), x, create_graph=True)[0]
+        g2 = torch.autograd.grad((g1 ** 2).sum(), w)[0]
+    assert torch.isfinite(g2).all() and float(g2.abs().max()) > 0
+    assert not O._BF16_OPERANDS
