@@ -37,6 +37,9 @@ static Config to_config(const eg_config* k) {
 }
 
 #define EG_API_BEGIN try {
+// entry points that enqueue work: always start on lane 0 (the context's own stream; train_step ends there too, and
+// an error in the middle of a concurrent iteration may have left another lane active)
+#define EG_API_BEGIN_CTX(ctxp) try { use_lane((ctxp)->c, 0);
 #define EG_API_END(ctxp)                                  \
   }                                                       \
   catch (const eg::Error& e) {                            \
@@ -153,7 +156,7 @@ static float* resolve_var(Ctx& c, const std::string& name, size_t* numel, bool f
 }
 
 int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long numel) {
-  EG_API_BEGIN
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   size_t n;
   float* d = resolve_var(ctx->c, name, &n, true);
@@ -167,7 +170,7 @@ int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long 
 }
 
 int eg_get_variable(eg_ctx* ctx, const char* name, float* host, long long numel) {
-  EG_API_BEGIN
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   size_t n;
   float* d = resolve_var(ctx->c, name, &n, false);
@@ -178,7 +181,7 @@ int eg_get_variable(eg_ctx* ctx, const char* name, float* host, long long numel)
 }
 
 int eg_upload_batch(eg_ctx* ctx, const float* images, const float* z, const float* alpha, const float* eps) {
-  EG_API_BEGIN
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   Ctx& c = ctx->c;
   const Config& cfg = c.cfg;
@@ -195,19 +198,19 @@ int eg_upload_batch(eg_ctx* ctx, const float* images, const float* z, const floa
 }
 
 int eg_substep(eg_ctx* ctx, int k, int apply) {
-  EG_API_BEGIN
+  EG_API_BEGIN_CTX(ctx)
   run_substep(ctx->c, k, apply != 0);
   EG_API_END(ctx)
 }
 
 int eg_train_step(eg_ctx* ctx) {
-  EG_API_BEGIN
+  EG_API_BEGIN_CTX(ctx)
   train_step(ctx->c);
   EG_API_END(ctx)
 }
 
 int eg_read_losses(eg_ctx* ctx, float* out12) {
-  EG_API_BEGIN
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   EG_HIP(hipMemcpyAsync(out12, ctx->c.d_losses, L_COUNT * 4, hipMemcpyDeviceToHost, ctx->c.stream));
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
@@ -216,7 +219,7 @@ int eg_read_losses(eg_ctx* ctx, float* out12) {
 
 int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const float* eps2, float* edge_out,
              float* image_out) {
-  EG_API_BEGIN
+  EG_API_BEGIN_CTX(ctx)
   Ctx& c = ctx->c;
   const Config& cfg = c.cfg;
   EG_CHECK(nb >= 1 && nb <= 4096, "nb out of range");
@@ -245,7 +248,7 @@ int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const
 }
 
 int eg_sync(eg_ctx* ctx) {
-  EG_API_BEGIN
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
   EG_API_END(ctx)
@@ -311,8 +314,13 @@ int eg_profile_end(eg_ctx* ctx, char* buf, int cap) {
 
 int eg_memory_stats(eg_ctx* ctx, long long* peak, long long* reserved) {
   EG_API_BEGIN
-  *peak = (long long)ctx->c.arena.peak();
-  *reserved = (long long)ctx->c.arena.reserved();
+  size_t pk = ctx->c.arena.peak(), rs = ctx->c.arena.reserved();   // active lane + the parked ones
+  for (int i = 0; i < Ctx::kLanes; ++i) {
+    pk += ctx->c.lanes[i].arena.peak();
+    rs += ctx->c.lanes[i].arena.reserved();
+  }
+  *peak = (long long)pk;
+  *reserved = (long long)rs;
   EG_API_END(ctx)
 }
 
@@ -378,7 +386,7 @@ struct OpIO {
 
 int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* inputs, const long long* in_numel,
                int n_ip, const int* ip, int n_out, float* const* outputs, const long long* out_numel) {
-  EG_API_BEGIN
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   Ctx& c = ctx->c;
   reset_step(c);
@@ -571,7 +579,7 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
 
 int eg_net_forward(eg_ctx* ctx, const char* net_, const float* input, int nb, int h, int w, int ch, float eps,
                    float* out, long long out_numel) {
-  EG_API_BEGIN
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   Ctx& c = ctx->c;
   reset_step(c);

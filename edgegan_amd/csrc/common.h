@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -93,6 +94,15 @@ class Arena {
   }
   size_t peak() const { return peak_; }
   size_t reserved() const { return total_; }
+  void swap(Arena& o) {
+    chunks_.swap(o.chunks_);
+    std::swap(chunk_bytes_, o.chunk_bytes_);
+    std::swap(cur_, o.cur_);
+    std::swap(off_, o.off_);
+    std::swap(used_, o.used_);
+    std::swap(peak_, o.peak_);
+    std::swap(total_, o.total_);
+  }
 
  private:
   struct Chunk {

@@ -105,6 +105,21 @@ struct Ctx {
   float* d_gen_bn[2] = {nullptr, nullptr};   // batch statistics of that forward, for the moving-average updates
   bool gen_cache_valid[2] = {false, false};
 
+  // Lanes: sub-steps without data dependencies run on separate streams (own arena and reduction scratch each) so
+  // that the HBM-bound kernels of one overlap the MFMA-bound kernels of another; `stream` / `arena` / `scratch`
+  // above always belong to the ACTIVE lane (use_lane swaps them), lanes[i].arena parks lane i's arena meanwhile.
+  struct Lane {
+    Arena arena;
+    hipStream_t stream = nullptr;
+    float* scratch = nullptr;
+    hipEvent_t done = nullptr;
+  };
+  static constexpr int kLanes = 4;
+  Lane lanes[kLanes];
+  int cur_lane = 0;
+  bool lanes_on = true;
+  hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr;
+
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -197,7 +212,15 @@ enum LossSlot {
   L_CLS_G, L_ZL, L_COUNT
 };
 // k in 1..7 (edgegan.py:109-124 order); apply=false computes gradients only (parity tests)
-void run_substep(Ctx& c, int k, bool apply);
+// Adjustments train_step makes when it runs independent sub-steps concurrently (all null / -1 = the plain
+// sequential meaning of the sub-step).
+struct SubOpts {
+  int bn_times_g1 = -1, bn_times_g2 = -1;   // BatchNorm moving-statistics updates to apply for G1 / G2 in this sub-step
+  hipEvent_t record_after_gen = nullptr;      // recorded once the shared G1(z), G2(z) are available (sub-step 1)
+  hipEvent_t record_after_g1_fwd = nullptr;   // recorded after G1's forward has been enqueued (sub-step 6)
+  hipEvent_t wait_before_apply = nullptr;     // the optimizer of this sub-step may not start before this event
+};
+void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts = nullptr);
 void train_step(Ctx& c);
 void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const float* d_eps2, float* d_edge,
            float* d_image);
@@ -206,6 +229,7 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
 void comm_unique_id(Ctx& c, char* out128);
 void comm_init(Ctx& c, const char* id128, int rank, int nranks);
 void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream);
+void use_lane(Ctx& c, int lane);                // model.cpp
 void comm_wait_groups(Ctx& c, unsigned mask);   // main stream waits for the pending updates of these groups
 void comm_wait_all(Ctx& c);
 void comm_destroy(Ctx& c);

@@ -1,6 +1,7 @@
 // Variable registry, the seven networks' forward graphs and the seven optimizer sub-steps of
 // EdgeGAN.update_model (edgegan/models/edgegan.py:87-130, 202-342), on the tape ops of ops.cpp.
 #include <cmath>
+#include <cstdlib>
 
 #include "engine.h"
 
@@ -239,6 +240,29 @@ void build_context(Ctx& c) {
   EG_HIP(hipMemsetAsync(c.d_losses, 0, 64 * 4, c.stream));
   EG_HIP(hipMemsetAsync(c.d_eps, 0, 16 * 4, c.stream));
   EG_HIP(hipStreamSynchronize(c.stream));
+  // lane 0 is the context's own stream / scratch; lanes 1.. get their own
+  c.lanes[0].stream = c.stream;
+  c.lanes[0].scratch = c.scratch;
+  for (int i = 0; i < Ctx::kLanes; ++i) {
+    if (i > 0) {
+      EG_HIP(hipStreamCreateWithFlags(&c.lanes[i].stream, hipStreamNonBlocking));
+      EG_HIP(hipMalloc(&c.lanes[i].scratch, c.scratch_floats * 4));
+    }
+    EG_HIP(hipEventCreateWithFlags(&c.lanes[i].done, hipEventDisableTiming));
+  }
+  EG_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+  EG_HIP(hipEventCreateWithFlags(&c.ev_gen, hipEventDisableTiming));
+  EG_HIP(hipEventCreateWithFlags(&c.ev_g1fwd, hipEventDisableTiming));
+  if (const char* e = getenv("EG_LANES")) c.lanes_on = atoi(e) != 0;
+}
+
+void use_lane(Ctx& c, int lane) {
+  if (lane == c.cur_lane) return;
+  c.arena.swap(c.lanes[c.cur_lane].arena);   // park the active arena in its slot
+  c.arena.swap(c.lanes[lane].arena);         // bring lane's arena in (its slot keeps the empty placeholder)
+  c.stream = c.lanes[lane].stream;
+  c.scratch = c.lanes[lane].scratch;
+  c.cur_lane = lane;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -497,7 +521,7 @@ static T generator_output_nograd(Ctx& c, int group, T zin, int bn_t) {
 static T right_half(Ctx& c, T images) { return slice_w(c, images, c.cfg.W / 2, c.cfg.W); }
 static T left_half(Ctx& c, T images) { return slice_w(c, images, 0, c.cfg.W / 2); }
 
-void run_substep(Ctx& c, int k, bool apply) {
+void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
   const Config& cfg = c.cfg;
   const int B = cfg.B;
   EG_CHECK(k >= 1 && k <= 7, "sub-step index 1..7");
@@ -519,24 +543,30 @@ void run_substep(Ctx& c, int k, bool apply) {
   // contrib batch_norm updates its moving statistics whenever a generator forward is evaluated in a
   // training run (updates_collections=None); gradient-only probes (apply=false) leave them alone.
   const int bn_t = apply ? 1 : 0;
+  const int bn1 = (opts && opts->bn_times_g1 >= 0) ? opts->bn_times_g1 : bn_t;   // G1 / G2 moving-statistics updates
+  const int bn2 = (opts && opts->bn_times_g2 >= 0) ? opts->bn_times_g2 : bn_t;
+  auto before_apply = [&]() {
+    if (opts && opts->wait_before_apply) EG_HIP(hipStreamWaitEvent(c.stream, opts->wait_before_apply, 0));
+  };
   switch (k) {
     case 1: {  // d_optim: joint discriminator
       T zin = make_zin(c);
-      T edge = generator_output_nograd(c, G_G1, zin, bn_t);
-      T image = generator_output_nograd(c, G_G2, zin, bn_t);
+      T edge = generator_output_nograd(c, G_G1, zin, bn1);
+      T image = generator_output_nograd(c, G_G2, zin, bn2);
+      if (opts && opts->record_after_gen) EG_HIP(hipEventRecord(opts->record_after_gen, c.stream));
       T joint = concat_w(c, edge, image);
       disc_substep(c, G_D, images, joint, c.d_alpha, L_JOINT_D, L_JOINT_GP, apply);
     } break;
     case 2: {  // d_optim_patch2: image discriminator on bicubic-resized right halves
       T zin = make_zin(c);
-      T image = generator_output_nograd(c, G_G2, zin, bn_t);
+      T image = generator_output_nograd(c, G_G2, zin, bn2);
       T r_real = resize(c, right_half(c, images), cfg.dis_size);
       T r_fake = resize(c, image, cfg.dis_size);
       disc_substep(c, G_DP2, r_real, r_fake, c.d_alpha + B, L_IMAGE_D, L_IMAGE_GP, apply);
     } break;
     case 3: {  // d_optim_patch3: edge discriminator
       T zin = make_zin(c);
-      T edge = generator_output_nograd(c, G_G1, zin, bn_t);
+      T edge = generator_output_nograd(c, G_G1, zin, bn1);
       T r_real = resize(c, left_half(c, images), cfg.dis_size);
       T r_fake = resize(c, edge, cfg.dis_size);
       disc_substep(c, G_DP3, r_real, r_fake, c.d_alpha + 2 * B, L_EDGE_D, L_EDGE_GP, apply);
@@ -555,8 +585,8 @@ void run_substep(Ctx& c, int k, bool apply) {
       set_want_grad(c, G_G1, true);
       set_want_grad(c, G_G2, true);
       T zin = make_zin(c);
-      T edge = generator_forward(c, G_G1, zin, bn_t);
-      T image = generator_forward(c, G_G2, zin, bn_t);
+      T edge = generator_forward(c, G_G1, zin, bn1);
+      T image = generator_forward(c, G_G2, zin, bn2);
       T joint = concat_w(c, edge, image);
       T dj = disc_forward(c, G_D, joint, nullptr, nullptr);
       T de = disc_forward(c, G_DP3, resize(c, edge, cfg.dis_size), nullptr, nullptr);
@@ -578,6 +608,7 @@ void run_substep(Ctx& c, int k, bool apply) {
       }
       c.tape.backward();
       if (apply) {
+        before_apply();
         apply_group(c, G_G1);
         apply_group(c, G_G2);
       }
@@ -585,7 +616,8 @@ void run_substep(Ctx& c, int k, bool apply) {
     case 6: {  // e_optim: L1 latent reconstruction through G1 (edgegan.py:275,337-342)
       set_want_grad(c, G_E, true);
       T zin = make_zin(c);
-      T edge = generator_forward(c, G_G1, zin, bn_t);
+      T edge = generator_forward(c, G_G1, zin, bn1);
+      if (opts && opts->record_after_g1_fwd) EG_HIP(hipEventRecord(opts->record_after_g1_fwd, c.stream));
       T zr = encoder_forward(c, edge, c.d_eps);
       seed_grad(c, zr);
       launch_l1(c.d_z, cfg.multiclasses() ? cfg.z_dim + 1 : cfg.z_dim, zr->d, c.d_losses + L_ZL, zr->g, B, cfg.z_dim,
@@ -597,8 +629,88 @@ void run_substep(Ctx& c, int k, bool apply) {
   if (apply && (k == 4)) c.sn_valid = false;
 }
 
+// Transposed copies of a group's conv filters, made on the CURRENT stream (used before two lanes read the same
+// generator: the lazily built cache would otherwise be filled on one lane's stream and read on the other's).
+static void warm_transposes(Ctx& c, int group) {
+  for (Param* p : c.groups[group].params) {
+    if (!p->cache_T || p->shape.size() != 4 || p->wT_valid) continue;
+    if (!p->wT) EG_HIP(hipMalloc(&p->wT, p->numel * sizeof(float)));
+    launch_tap_transpose(p->w, p->wT, p->shape[0] * p->shape[1], p->shape[2], p->shape[3], nullptr, c.stream);
+    p->wT_valid = true;
+  }
+}
+
+// One iteration = the 7 sub-steps of update_model in the reference's order.  Their data dependencies are sparser
+// than that order: 1-4 train four networks with disjoint variables on inputs that nothing in 1-4 changes (the
+// generators are frozen until 5), 5 needs all of them, 6 (encoder, reads G1) and 7 (generators) are independent
+// except that 7's update of G1 must come after 6's G1 forward.  train_step enqueues {1,2,3,4} on four lanes, 5 on
+// lane 0, {6,7} on two lanes; every kernel still sees exactly the inputs of the sequential schedule, so the results
+// are bitwise those of run_substep(1..7) (tests/test_step_gpu.py).  Measured gain: see DESIGN.md section 6.
 void train_step(Ctx& c) {
-  for (int k = 1; k <= 7; ++k) run_substep(c, k, true);
+  const bool conc = c.lanes_on && !c.prof_on;
+  if (!conc) {
+    for (int k = 1; k <= 7; ++k) run_substep(c, k, true);
+    ++c.step_count;
+    return;
+  }
+  const bool cls = c.cfg.multiclasses();
+  auto fork = [&](int nl) {   // lanes 1..nl-1 start after everything already enqueued on lane 0
+    EG_HIP(hipEventRecord(c.ev_fork, c.lanes[0].stream));
+    for (int i = 1; i < nl; ++i) EG_HIP(hipStreamWaitEvent(c.lanes[i].stream, c.ev_fork, 0));
+  };
+  auto join = [&](int nl) {   // lane 0 continues after lanes 1..nl-1
+    use_lane(c, 0);
+    for (int i = 1; i < nl; ++i) {
+      EG_HIP(hipEventRecord(c.lanes[i].done, c.lanes[i].stream));
+      EG_HIP(hipStreamWaitEvent(c.lanes[0].stream, c.lanes[i].done, 0));
+    }
+  };
+  use_lane(c, 0);
+  // ---- phase A: the four discriminator-side sub-steps ------------------------------------------------------
+  fork(4);
+  {
+    // sub-steps 1, 2, 3 share one evaluation of G1(z), G2(z); each reference evaluation advances the BatchNorm
+    // moving statistics once (G1: sub-steps 1 and 3, G2: 1 and 2) -- applied here as two updates by sub-step 1
+    SubOpts o1;
+    o1.bn_times_g1 = 2;
+    o1.bn_times_g2 = 2;
+    o1.record_after_gen = c.ev_gen;
+    run_substep(c, 1, true, &o1);
+    SubOpts o23;
+    o23.bn_times_g1 = 0;
+    o23.bn_times_g2 = 0;
+    use_lane(c, 1);
+    EG_HIP(hipStreamWaitEvent(c.stream, c.ev_gen, 0));
+    run_substep(c, 2, true, &o23);
+    use_lane(c, 2);
+    EG_HIP(hipStreamWaitEvent(c.stream, c.ev_gen, 0));
+    run_substep(c, 3, true, &o23);
+    if (cls) {
+      use_lane(c, 3);
+      run_substep(c, 4, true);
+    }
+  }
+  join(4);
+  // ---- phase B: generators against all four ----------------------------------------------------------------
+  run_substep(c, 5, true);
+  // ---- phase C: encoder (reads G1) next to the second generator step (updates G1 at its end) -----------------
+  comm_wait_groups(c, 1u << G_G1);   // G1's pending update (data parallel) must be in before its filters are read
+  warm_transposes(c, G_G1);
+  fork(2);
+  {
+    SubOpts o6;
+    o6.bn_times_g1 = 0;              // sub-step 7 evaluates the same G1 forward: it applies both updates
+    o6.record_after_g1_fwd = c.ev_g1fwd;
+    use_lane(c, 1);
+    run_substep(c, 6, true, &o6);
+    SubOpts o7;
+    o7.bn_times_g1 = 2;
+    o7.bn_times_g2 = 1;
+    o7.wait_before_apply = c.ev_g1fwd;
+    use_lane(c, 0);
+    run_substep(c, 7, true, &o7);
+  }
+  join(2);
   ++c.step_count;
 }
 

@@ -910,7 +910,7 @@ Ctx::~Ctx() {
     (void)hipFree(s.scal);
   }
   (void)hipFree(sn_table);
-  (void)hipFree(scratch);
+  (void)hipFree(lanes[0].scratch ? lanes[0].scratch : scratch);
   (void)hipFree(d_images);
   (void)hipFree(d_z);
   (void)hipFree(d_alpha);
@@ -921,6 +921,18 @@ Ctx::~Ctx() {
     (void)hipFree(d_gen_cache[i]);
     (void)hipFree(d_gen_bn[i]);
   }
+  // the context's own stream / scratch are lane 0's; make them the active ones again before freeing
+  if (lanes[0].stream) stream = lanes[0].stream;
+  for (int i = 0; i < kLanes; ++i) {
+    if (i > 0) {
+      if (lanes[i].stream) (void)hipStreamDestroy(lanes[i].stream);
+      if (lanes[i].scratch) (void)hipFree(lanes[i].scratch);
+    }
+    if (lanes[i].done) (void)hipEventDestroy(lanes[i].done);
+  }
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (ev_gen) (void)hipEventDestroy(ev_gen);
+  if (ev_g1fwd) (void)hipEventDestroy(ev_g1fwd);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
