@@ -158,7 +158,9 @@ def main():
     losses = net.losses()
     finite = all(np.isfinite(v) for v in losses.values())
 
-    # roofline of the dominant kernel: HIP events around every GEMM-shaped launch on the engine's stream
+    # roofline of the dominant kernel: HIP events around every GEMM-shaped launch on the engine's stream.  While the
+    # profiler is on, train_step runs its sub-steps one after another on one stream (a kernel is measured in isolation;
+    # the timed region above overlaps independent sub-steps on several streams, which stretches individual kernels)
     roof = None
     if rank == 0 and args.profile_steps > 0:
         net.profile_begin()
@@ -176,6 +178,7 @@ def main():
                     'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dom['name']),
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.csv)',
                     'kernel': dom['name'],
+                    'measured': 'HIP events, sub-steps serialised (EG_LANES=0 semantics) so that kernels do not overlap',
                     'launches_per_step': dom['launches'] / args.profile_steps,
                     'avg_launch_ms': round(dom['ms'] / dom['launches'], 4),
                     'flops_per_launch': dom['flops'] / dom['launches'],
