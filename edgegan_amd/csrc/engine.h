@@ -118,6 +118,7 @@ struct Ctx {
   Lane lanes[kLanes];
   int cur_lane = 0;
   bool lanes_on = true;
+  int lanes_mask = 3;
   hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr;
 
   // profiling

@@ -253,7 +253,10 @@ void build_context(Ctx& c) {
   EG_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_gen, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_g1fwd, hipEventDisableTiming));
-  if (const char* e = getenv("EG_LANES")) c.lanes_on = atoi(e) != 0;
+  if (const char* e = getenv("EG_LANES")) {   // 0 = one stream; bit 0 = sub-steps 1-4 concurrent, bit 1 = 6/7 concurrent
+    c.lanes_mask = atoi(e);
+    c.lanes_on = c.lanes_mask != 0;
+  }
 }
 
 void use_lane(Ctx& c, int lane) {
@@ -666,7 +669,11 @@ void train_step(Ctx& c) {
     }
   };
   use_lane(c, 0);
+  const bool conc_a = c.lanes_mask & 1, conc_c = c.lanes_mask & 2;
   // ---- phase A: the four discriminator-side sub-steps ------------------------------------------------------
+  if (!conc_a) {
+    for (int k = 1; k <= 4; ++k) run_substep(c, k, true);
+  } else {
   fork(4);
   {
     // sub-steps 1, 2, 3 share one evaluation of G1(z), G2(z); each reference evaluation advances the BatchNorm
@@ -691,9 +698,16 @@ void train_step(Ctx& c) {
     }
   }
   join(4);
+  }
   // ---- phase B: generators against all four ----------------------------------------------------------------
   run_substep(c, 5, true);
   // ---- phase C: encoder (reads G1) next to the second generator step (updates G1 at its end) -----------------
+  if (!conc_c) {
+    run_substep(c, 6, true);
+    run_substep(c, 7, true);
+    ++c.step_count;
+    return;
+  }
   comm_wait_groups(c, 1u << G_G1);   // G1's pending update (data parallel) must be in before its filters are read
   warm_transposes(c, G_G1);
   fork(2);
