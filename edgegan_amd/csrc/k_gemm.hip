@@ -307,8 +307,15 @@ int conv_pick_ksplit(const ConvArgs& a) {
     minTiles = std::min(minTiles, a.ph[p].Ty * a.ph[p].Tx * (a.C / 32));
   }
   const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase;
-  if (t64 >= 384) return 1;
-  int ks = (int)((512 + t64 - 1) / t64);
+  // Split K whenever the output tiles alone would leave CUs short of resident blocks: the target, 3072 64x64-tile
+  // equivalents = 768 128x128 blocks, is 3 resident blocks on each of the 256 CUs -- what the register budget of the
+  // 128x128 kernel allows -- so a wave waiting on its loads always has MFMA work from another block next to it.
+  // (Measured: threshold/target 384/512 -> 2048/3072 = +2.5 % on the iteration; the 4096-pixel layers of the
+  // classifier's last unit and the discriminators' conv4 move from 64x64 tiles to 128x128 tiles x 3-4 K slabs.)
+  // The bf16 kernels multiply 16x faster, the slab reduction does not: they keep the conservative rule (measured).
+  const int thr = a.wgt_bf ? 384 : 2048, tgt = a.wgt_bf ? 512 : 3072;
+  if (t64 >= thr) return 1;
+  int ks = (int)((tgt + t64 - 1) / t64);
   ks = std::min(ks, 8);
   ks = std::min(ks, minTiles / 4);   // at least 4 K tiles (128 of K) per split
   return ks < 2 ? 1 : ks;
