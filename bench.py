@@ -28,27 +28,25 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (never the 2:1-spa
 
 
 def pmc_traffic(kernel_label):
-    """HBM bytes per launch of `kernel_label` (e.g. 'conv_gemm<128,128,vec>') from the committed rocprofv3 PMC
-    summary (profiles/pmc_hbm_traffic_latest.csv: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read
-    correction -- tools/pmc_summary.py).  None if there is no matching row."""
+    """HBM bytes per launch of `kernel_label` (e.g. 'conv_gemm<128,128,vec>', 'conv_gemm<128,128,vec,splitk>') from
+    the committed rocprofv3 PMC summary (profiles/pmc_hbm_traffic_latest.csv: separate FETCH_SIZE / WRITE_SIZE
+    passes, gfx950 x2 read correction -- tools/pmc_summary.py).  None if there is no matching row."""
     import csv
     import re
     path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic_latest.csv')
-    m = re.match(r'(\w+)<(\d+),(\d+)(?:,(\w+))?>', kernel_label)
+    m = re.match(r'(\w+)<(\d+),(\d+)(?:,(\w+))?(?:,(splitk))?>', kernel_label)
     if not m or not os.path.exists(path):
         return None
-    base, bm, bn, mode = m.group(1), m.group(2), m.group(3), m.group(4)
+    base, bm, bn, mode, splitk = m.groups()
     best = None
     with open(path) as f:
         for r in csv.DictReader(f):
             k = r['Kernel']
-            if f'{base}_kernel<{bm}, {bn},' not in k and f'{base}_kernel<' not in k:
-                continue
-            if f'<{bm}, {bn},' not in k:
+            if f'{base}_kernel<{bm}, {bn},' not in k:
                 continue
             flags = re.findall(r'(true|false)', k)
             want = {'vec': ['true', 'true'], 'avec': ['true', 'false'], 'flat': ['false', 'false']}.get(mode)
-            if base == 'conv_gemm' and want and (flags[:2] != want or flags[2:3] == ['true']):
+            if base == 'conv_gemm' and want and (flags[:2] != want or (flags[2:3] == ['true']) != bool(splitk)):
                 continue
             if base == 'wgrad' and mode and flags[-1:] != (['true'] if mode == 'vec' else ['false']):
                 continue

@@ -377,11 +377,13 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     if (conv_bf16_eligible(a))
       nm = launch_conv_gemm_bf16(a, maxM, e128 >= e64, s);
     else if (e128 >= e64)
-      nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s, "conv_gemm<128,128,vec>", "conv_gemm<128,128,avec>",
-                                           "conv_gemm<128,128,flat>");
+      nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s,
+                                           a.ksplit > 1 ? "conv_gemm<128,128,vec,splitk>" : "conv_gemm<128,128,vec>",
+                                           "conv_gemm<128,128,avec>", "conv_gemm<128,128,flat>");
     else
-      nm = conv_dispatch<64, 64, 32, 32>(a, maxM, avec, bvec, s, "conv_gemm<64,64,vec>", "conv_gemm<64,64,avec>",
-                                         "conv_gemm<64,64,flat>");
+      nm = conv_dispatch<64, 64, 32, 32>(a, maxM, avec, bvec, s,
+                                         a.ksplit > 1 ? "conv_gemm<64,64,vec,splitk>" : "conv_gemm<64,64,vec>",
+                                         "conv_gemm<64,64,avec>", "conv_gemm<64,64,flat>");
   }
   if (a.ksplit > 1) {
     const size_t total = a.y_total;
