@@ -583,8 +583,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, float* __
 // MRU unit, the generator's 3-channel output): the GEMM M dimension is the FLATTENED (tap, c) index,
 // so dY is streamed once instead of once per tap.
 // ---------------------------------------------------------------------------------------------
+template <int BK>
 __global__ __launch_bounds__(256) void wgrad_flatm_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
-  constexpr int BM = 64, BN = 64, BK = 16, LD = 64 + 16;
+  constexpr int BM = 64, BN = 64, LD = 64 + 16;
+  constexpr int AR = BK / 4, BR = BK / 16;   // A rows / B row groups per thread
   __shared__ __attribute__((aligned(16))) float At[BK * LD];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
   __shared__ int pinfo[2][BK][3];
@@ -624,11 +626,11 @@ __global__ __launch_bounds__(256) void wgrad_flatm_kernel(const WgradArgs a, flo
       pinfo[buf][tid][2] = ix0;
     }
   };
-  float ra[4];
-  float4 rb;
+  float ra[AR];
+  float4 rb[BR];
   auto load_tile = [&](int p, int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AR; ++i) {
       const int k = (tid >> 6) + 4 * i;
       const int b = pinfo[buf][k][0];
       int iy = pinfo[buf][k][1] + kh, ix = pinfo[buf][k][2] + kw;
@@ -640,24 +642,29 @@ __global__ __launch_bounds__(256) void wgrad_flatm_kernel(const WgradArgs a, flo
       if (mv && b >= 0 && iy >= 0 && iy < IH && ix >= 0 && ix < IW) v = a.x[(size_t)(b + iy * IW + ix) * a.x_ps + cch];
       ra[i] = v;
     }
-    const int k = tid >> 4, n = n0 + (tid & 15) * 4, m = p + k;
-    rb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m < p_hi) {
-      const float* row = a.dy + (size_t)m * a.dy_ps;
-      if (nvec && n + 3 < N) {
-        rb = *reinterpret_cast<const float4*>(row + n);
-      } else {
-        if (n < N) rb.x = row[n];
-        if (n + 1 < N) rb.y = row[n + 1];
-        if (n + 2 < N) rb.z = row[n + 2];
-        if (n + 3 < N) rb.w = row[n + 3];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const int k = (tid >> 4) + 16 * j, n = n0 + (tid & 15) * 4, m = p + k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < p_hi) {
+        const float* row = a.dy + (size_t)m * a.dy_ps;
+        if (nvec && n + 3 < N) {
+          v = *reinterpret_cast<const float4*>(row + n);
+        } else {
+          if (n < N) v.x = row[n];
+          if (n + 1 < N) v.y = row[n + 1];
+          if (n + 2 < N) v.z = row[n + 2];
+          if (n + 3 < N) v.w = row[n + 3];
+        }
       }
+      rb[j] = v;
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) At[((tid >> 6) + 4 * i) * LD + (tid & 63)] = ra[i];
-    *reinterpret_cast<float4*>(&Bs[(tid >> 4) * LD + (tid & 15) * 4]) = rb;
+    for (int i = 0; i < AR; ++i) At[((tid >> 6) + 4 * i) * LD + (tid & 63)] = ra[i];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(&Bs[((tid >> 4) + 16 * j) * LD + (tid & 15) * 4]) = rb[j];
   };
 
   f32x4 acc[2][2];
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(256) void wgrad_flatm_kernel(const WgradArgs a, flo
       __syncthreads();
       if (more) load_tile(p + BK, (it + 1) & 1);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < BK / 4; ++kk) {
         float af[2], bf[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[i] = At[(kk * 4 + lq) * LD + wm * 32 + i * 16 + l15];
@@ -849,7 +856,7 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
     nm = launch_wgrad_bf16(a, out, dense, wgrad_big(a), s);
   } else if (wgrad_flatm(a)) {
     dim3 grid(((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64), a.nsplit);
-    hipLaunchKernelGGL(wgrad_flatm_kernel, grid, dim3(256), 0, s, a, out, dense);
+    hipLaunchKernelGGL(wgrad_flatm_kernel<32>, grid, dim3(256), 0, s, a, out, dense);
     nm = "wgrad_flatm<64,64>";
   } else if (wgrad_big(a)) {
     if (vec) { wgrad_launch<128, 128, 64, 64, true>(a, out, dense, s); nm = "wgrad<128,128,vec>"; }
