@@ -38,6 +38,16 @@ def test_substeps_14_classes():
     net.close()
 
 
+def test_substeps_odd_batch():
+    """Batch 3: pixel counts that are not multiples of the 64 / 128-row tiles in every layer (ragged last tiles,
+    partial split-K slabs, odd BatchNorm row counts)."""
+    cfg = ea.Config(batch_size=3)
+    values = ea.init_variables(cfg, 11)
+    net = ea.EdgeGAN(cfg, values)
+    _assert(parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=3)))
+    net.close()
+
+
 def test_substeps_single_class_batch4():
     """config[0]: single-class 64x128, batch 4 (edgegan.train --nomulticlasses)."""
     cfg = ea.Config(batch_size=4, num_classes=0)
