@@ -286,15 +286,25 @@ static void conv_launch(const ConvArgs& a, int maxM, hipStream_t s) {
   hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WTM, WTN, BK, VEC, BVEC, false>), grid, dim3(256), 0, s, a);
 }
 
-// y (+)= bias + sum over the K-split slabs (fixed order)
+// y (+)= bias + sum over the K-split slabs (fixed order).  float4 form: the split-K kernels only exist for N % 4 == 0,
+// so a quad never straddles a pixel row; y_ps4 / N4 in float4 units, 32-bit index arithmetic.
 __global__ void conv_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ y, const float* __restrict__ bias,
-                                         size_t total, int y_ps, int N, int ksplit, int accumulate) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int n = (int)(i % y_ps);
-    if (n >= N) continue;
-    float v = bias ? bias[n] : 0.f;
-    for (int k = 0; k < ksplit; ++k) v += ws[(size_t)k * total + i];
-    y[i] = accumulate ? y[i] + v : v;
+                                         unsigned total4, int y_ps4, int N4, int ksplit, int accumulate) {
+  const float4* w4 = reinterpret_cast<const float4*>(ws);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+    const int n4 = y_ps4 == N4 ? (int)(i % (unsigned)N4) : (int)(i % (unsigned)y_ps4);
+    if (n4 >= N4) continue;
+    float4 v = bias ? reinterpret_cast<const float4*>(bias)[n4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < ksplit; ++k) {
+      const float4 p = w4[(size_t)k * total4 + i];
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    float4* o = reinterpret_cast<float4*>(y) + i;
+    if (accumulate) {
+      const float4 q = *o;
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    *o = v;
   }
 }
 
@@ -351,7 +361,9 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
   }
   const bool avec = (a.C % 16 == 0) && (a.x_ps % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
   const bool bvec = (a.N % 4 == 0) && (a.ldw % 4 == 0) && (a.w_ts % 4 == 0) && (((uintptr_t)a.wgt & 15) == 0);
-  if (!(avec && bvec) || a.N <= 16 || !a.ws) a.ksplit = 1;   // only the fully vectorised kernels have a split-K form
+  if (!(avec && bvec) || a.N <= 16 || !a.ws || a.y_ps % 4 != 0 || (((uintptr_t)a.y | (uintptr_t)a.bias) & 15) != 0 ||
+      a.y_total / 4 >= (1ull << 32))
+    a.ksplit = 1;   // only the fully vectorised kernels have a split-K form
   const long long blocks128 = (long long)((maxM + 127) / 128) * ((a.N + 127) / 128) * a.nphase;
   const char* nm;
   if (a.N <= 16) {
@@ -386,11 +398,11 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
                                          "conv_gemm<64,64,avec>", "conv_gemm<64,64,flat>");
   }
   if (a.ksplit > 1) {
-    const size_t total = a.y_total;
-    size_t blocks = (total + 255) / 256;
+    const size_t total4 = a.y_total / 4;   // split-K requires N % 4 == 0 and a 16-byte aligned, y_ps % 4 == 0 output
+    size_t blocks = (total4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.ws, a.y, a.bias, total, a.y_ps,
-                       a.N, a.ksplit, a.accumulate);
+    hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.ws, a.y, a.bias,
+                       (unsigned)total4, a.y_ps / 4, a.N / 4, a.ksplit, a.accumulate);
   }
   static const bool trace = getenv("EG_TRACE_GEMM") != nullptr;   // shape log for offline tile/split tuning
   if (trace)
