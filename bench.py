@@ -86,6 +86,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
     ap.add_argument('--classes', type=int, default=14)
+    ap.add_argument('--height', type=int, default=64, help='64 (configs[2], the metric) or 256 (configs[4] geometry)')
+    ap.add_argument('--width', type=int, default=128)
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
@@ -115,7 +117,10 @@ def main():
         dist_mod.init_process_group('gloo', rank=rank, world_size=world)   # host-side rendezvous only
         dist = dist_mod
 
-    cfg_kwargs = dict(batch_size=args.batch, num_classes=args.classes, device=local, compute_dtype=args.dtype)
+    cfg_kwargs = dict(batch_size=args.batch, num_classes=args.classes, device=local, compute_dtype=args.dtype,
+                      height=args.height, width=args.width)
+    # algorithmic GFLOP per image and iteration; both minus the two shared generator forwards
+    gflop_per_image = {(64, 128): GFLOP_PER_IMAGE, (256, 512): 1102.3 - 2 * 5.22}.get((args.height, args.width))
     cfg = ea.Config(**cfg_kwargs)
     values = ea.init_variables(cfg, 0)                 # same weights on every rank
     net = ea.EdgeGAN(cfg, values)
@@ -173,7 +178,8 @@ def main():
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in dom['name'] else PEAK_FP32_MFMA_TFLOPS
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dom['name']),
+                    'frac': round(ach / peak, 4),
+                    'traffic': pmc_traffic(dom['name']) if (args.height, args.width, args.batch) == (64, 128, 64) else None,
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.csv)',
                     'kernel': dom['name'],
                     'measured': 'HIP events, sub-steps serialised (EG_LANES=0 semantics) so that kernels do not overlap',
@@ -192,23 +198,26 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
         out = {
-            'metric': 'training images/sec (G+D step) at 64x128, 14-class',
+            'metric': f'training images/sec (G+D step) at {args.height}x{args.width}, 14-class',
             'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': ('configs[2]: 14-class 64x128 fp32' if args.dtype == 'f32' else
-                                    'configs[3] arithmetic (bf16 MFMA operands, fp32 accumulate/storage): 14-class 64x128') +
+            'config': {'workload': ((('configs[2]: 14-class 64x128 fp32' if args.dtype == 'f32' else
+                                      'configs[3] arithmetic (bf16 MFMA operands, fp32 accumulate/storage): 14-class 64x128')
+                                     if (args.height, args.width) == (64, 128) else
+                                     f'configs[4] geometry: 14-class {args.height}x{args.width} {args.dtype}')) +
                                    ' full G+D+classifier+E training iteration '
-                                   '(7 RMSProp sub-steps), batch 64 per GPU', 'global_batch': args.batch * world,
+                                   f'(7 RMSProp sub-steps), batch {args.batch} per GPU', 'global_batch': args.batch * world,
                        'per_gpu_batch': args.batch, 'num_classes': args.classes, 'parallelism': f'dp{world}'},
-            'algorithmic_tflops_per_gpu': round(GFLOP_PER_IMAGE * value / world / 1e3, 2),
-            'frac_of_fp32_mfma_peak': round(GFLOP_PER_IMAGE * value / world / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+            'algorithmic_tflops_per_gpu': round(gflop_per_image * value / world / 1e3, 2) if gflop_per_image else None,
+            'frac_of_fp32_mfma_peak': round(gflop_per_image * value / world / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)
+            if gflop_per_image else None,
             'losses_finite': bool(finite), 'memory': net.memory_stats(),
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out['cpu_baseline'] = cpu_baseline(dict(num_classes=args.classes))
+                out['cpu_baseline'] = cpu_baseline(dict(num_classes=args.classes, height=args.height, width=args.width))
             except Exception as e:  # the baseline must never hide the GPU number
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
         print(json.dumps(out))
