@@ -225,13 +225,23 @@ int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const
   EG_CHECK(nb >= 1 && nb <= 4096, "nb out of range");
   EG_CHECK(!cfg.multiclasses() || classes, "classes required");
   const size_t in_n = (size_t)nb * cfg.H * cfg.W * cfg.c_dim, out_n = in_n / 2;
-  float *d_in, *d_e, *d_i, *d_eps;
-  int* d_cls;
-  EG_HIP(hipMalloc(&d_in, in_n * 4));
-  EG_HIP(hipMalloc(&d_e, out_n * 4));
-  EG_HIP(hipMalloc(&d_i, out_n * 4));
-  EG_HIP(hipMalloc(&d_eps, 8));
-  EG_HIP(hipMalloc(&d_cls, (size_t)nb * 4));
+  if ((size_t)nb > c.inf_cap) {   // staging buffers are kept between calls (no allocation on the steady-state path)
+    (void)hipFree(c.inf_in);
+    (void)hipFree(c.inf_edge);
+    (void)hipFree(c.inf_image);
+    (void)hipFree(c.inf_cls);
+    c.inf_in = c.inf_edge = c.inf_image = nullptr;
+    c.inf_cls = nullptr;
+    c.inf_cap = 0;
+    EG_HIP(hipMalloc(&c.inf_in, in_n * 4));
+    EG_HIP(hipMalloc(&c.inf_edge, out_n * 4));
+    EG_HIP(hipMalloc(&c.inf_image, out_n * 4));
+    EG_HIP(hipMalloc(&c.inf_cls, (size_t)nb * 4));
+    if (!c.inf_eps) EG_HIP(hipMalloc(&c.inf_eps, 8));
+    c.inf_cap = nb;
+  }
+  float *d_in = c.inf_in, *d_e = c.inf_edge, *d_i = c.inf_image, *d_eps = c.inf_eps;
+  int* d_cls = c.inf_cls;
   EG_HIP(hipMemcpyAsync(d_in, images, in_n * 4, hipMemcpyHostToDevice, c.stream));
   EG_HIP(hipMemcpyAsync(d_eps, eps2, 8, hipMemcpyHostToDevice, c.stream));
   if (classes) EG_HIP(hipMemcpyAsync(d_cls, classes, (size_t)nb * 4, hipMemcpyHostToDevice, c.stream));
@@ -239,11 +249,6 @@ int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const
   EG_HIP(hipMemcpyAsync(edge_out, d_e, out_n * 4, hipMemcpyDeviceToHost, c.stream));
   EG_HIP(hipMemcpyAsync(image_out, d_i, out_n * 4, hipMemcpyDeviceToHost, c.stream));
   EG_HIP(hipStreamSynchronize(c.stream));
-  (void)hipFree(d_in);
-  (void)hipFree(d_e);
-  (void)hipFree(d_i);
-  (void)hipFree(d_eps);
-  (void)hipFree(d_cls);
   EG_API_END(ctx)
 }
 

@@ -121,6 +121,11 @@ struct Ctx {
   int lanes_mask = 3;
   hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr;
 
+  // inference staging buffers (host <-> device hand-over of eg_infer), grown on demand and kept
+  float *inf_in = nullptr, *inf_edge = nullptr, *inf_image = nullptr, *inf_eps = nullptr;
+  int* inf_cls = nullptr;
+  size_t inf_cap = 0;   // images the buffers hold
+
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;

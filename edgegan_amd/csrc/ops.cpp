@@ -894,6 +894,11 @@ Ctx::~Ctx() {
   }
   for (auto& p : params)
     if (p->wT) (void)hipFree(p->wT);
+  (void)hipFree(inf_in);
+  (void)hipFree(inf_edge);
+  (void)hipFree(inf_image);
+  (void)hipFree(inf_eps);
+  (void)hipFree(inf_cls);
   for (auto& g : groups) {
     (void)hipFree(g.w);
     (void)hipFree(g.g);
