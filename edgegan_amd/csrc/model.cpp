@@ -676,6 +676,13 @@ void train_step(Ctx& c) {
   } else {
   fork(4);
   {
+    // the classifier sub-step is the longest of the four and the one whose gradient exchange (69 MB under data
+    // parallelism) sub-step 5 waits for: enqueue it first so its all-reduce runs under the discriminator sub-steps
+    if (cls) {
+      use_lane(c, 3);
+      run_substep(c, 4, true);
+      use_lane(c, 0);
+    }
     // sub-steps 1, 2, 3 share one evaluation of G1(z), G2(z); each reference evaluation advances the BatchNorm
     // moving statistics once (G1: sub-steps 1 and 3, G2: 1 and 2) -- applied here as two updates by sub-step 1
     SubOpts o1;
@@ -692,10 +699,6 @@ void train_step(Ctx& c) {
     use_lane(c, 2);
     EG_HIP(hipStreamWaitEvent(c.stream, c.ev_gen, 0));
     run_substep(c, 3, true, &o23);
-    if (cls) {
-      use_lane(c, 3);
-      run_substep(c, 4, true);
-    }
   }
   join(4);
   }
