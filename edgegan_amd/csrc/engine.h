@@ -225,6 +225,9 @@ struct SubOpts {
   hipEvent_t record_after_gen = nullptr;      // recorded once the shared G1(z), G2(z) are available (sub-step 1)
   hipEvent_t record_after_g1_fwd = nullptr;   // recorded after G1's forward has been enqueued (sub-step 6)
   hipEvent_t wait_before_apply = nullptr;     // the optimizer of this sub-step may not start before this event
+  // sub-step 5 right behind the concurrent sub-steps 1-4: instead of waiting for all of them up front, wait for a
+  // network's update (event of the lane that trained it) only where that network is first used
+  const hipEvent_t* wait_for_group = nullptr;  // [G_COUNT], null entries = no wait
 };
 void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts = nullptr);
 void train_step(Ctx& c);

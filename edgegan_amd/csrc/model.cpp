@@ -538,7 +538,10 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
                                       1u << G_G1 | 1u << G_G2 | 1u << G_D | 1u << G_DP2 | 1u << G_DP3 | 1u << G_D2,
                                       1u << G_G1 | 1u << G_E,
                                       1u << G_G1 | 1u << G_G2 | 1u << G_D | 1u << G_DP2 | 1u << G_DP3 | 1u << G_D2};
-    comm_wait_groups(c, reads[k]);
+    unsigned mask = reads[k];
+    if (opts && opts->wait_for_group)   // the discriminators' / classifier's pending updates are awaited at first use
+      mask &= ~(1u << G_D | 1u << G_DP2 | 1u << G_DP3 | 1u << G_D2);
+    comm_wait_groups(c, mask);
   }
   reset_step(c);
   for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);
@@ -548,6 +551,11 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
   const int bn_t = apply ? 1 : 0;
   const int bn1 = (opts && opts->bn_times_g1 >= 0) ? opts->bn_times_g1 : bn_t;   // G1 / G2 moving-statistics updates
   const int bn2 = (opts && opts->bn_times_g2 >= 0) ? opts->bn_times_g2 : bn_t;
+  auto await_group = [&](int g) {   // see SubOpts::wait_for_group
+    if (!(opts && opts->wait_for_group)) return;
+    if (opts->wait_for_group[g]) EG_HIP(hipStreamWaitEvent(c.stream, opts->wait_for_group[g], 0));
+    comm_wait_groups(c, 1u << g);
+  };
   auto before_apply = [&]() {
     if (opts && opts->wait_before_apply) EG_HIP(hipStreamWaitEvent(c.stream, opts->wait_before_apply, 0));
   };
@@ -591,9 +599,13 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       T edge = generator_forward(c, G_G1, zin, bn1);
       T image = generator_forward(c, G_G2, zin, bn2);
       T joint = concat_w(c, edge, image);
+      await_group(G_D);
       T dj = disc_forward(c, G_D, joint, nullptr, nullptr);
-      T de = disc_forward(c, G_DP3, resize(c, edge, cfg.dis_size), nullptr, nullptr);
-      T di = disc_forward(c, G_DP2, resize(c, image, cfg.dis_size), nullptr, nullptr);
+      T r_edge = resize(c, edge, cfg.dis_size), r_image = resize(c, image, cfg.dis_size);
+      await_group(G_DP3);
+      T de = disc_forward(c, G_DP3, r_edge, nullptr, nullptr);
+      await_group(G_DP2);
+      T di = disc_forward(c, G_DP2, r_image, nullptr, nullptr);
       launch_mean_neg(dj->d, c.d_losses + L_JOINT_G, B, c.stream);
       launch_mean_neg(de->d, c.d_losses + L_EDGE_G, B, c.stream);
       launch_mean_neg(di->d, c.d_losses + L_IMAGE_G, B, c.stream);
@@ -604,6 +616,7 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       launch_fill(de->g, -cfg.edge_dweight / B, B, c.stream);
       launch_fill(di->g, -cfg.image_dweight / B, B, c.stream);
       if (cfg.multiclasses()) {
+        await_group(G_D2);
         T lf = classifier_forward(c, image);
         seed_grad(c, lf);
         launch_acgan_loss(lf->d, c.d_z + cfg.z_dim, cfg.z_dim + 1, c.d_losses + L_CLS_G, lf->g, B, cfg.num_classes,
@@ -700,10 +713,23 @@ void train_step(Ctx& c) {
     EG_HIP(hipStreamWaitEvent(c.stream, c.ev_gen, 0));
     run_substep(c, 3, true, &o23);
   }
-  join(4);
+  // no join: sub-step 5 follows sub-step 1 on lane 0 and waits for lanes 1-3 only where it first uses the network
+  // each of them trained, so its generator forwards and the joint-discriminator pass overlap the tail of phase A
+  use_lane(c, 0);
+  for (int i = 1; i < 4; ++i) EG_HIP(hipEventRecord(c.lanes[i].done, c.lanes[i].stream));
   }
   // ---- phase B: generators against all four ----------------------------------------------------------------
-  run_substep(c, 5, true);
+  if (conc_a) {
+    hipEvent_t ev[G_COUNT] = {};
+    ev[G_DP2] = c.lanes[1].done;
+    ev[G_DP3] = c.lanes[2].done;
+    ev[G_D2] = c.lanes[3].done;
+    SubOpts o5;
+    o5.wait_for_group = ev;
+    run_substep(c, 5, true, &o5);
+  } else {
+    run_substep(c, 5, true);
+  }
   // ---- phase C: encoder (reads G1) next to the second generator step (updates G1 at its end) -----------------
   if (!conc_c) {
     run_substep(c, 6, true);
