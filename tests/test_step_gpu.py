@@ -109,6 +109,29 @@ def test_train_step_equals_sequential_substeps_and_is_deterministic():
     assert np.all(outs[0]['D2/Conv_1/weights/RMSProp'] == 1)
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_concurrent_lanes_equal_one_stream_over_many_iterations(dtype, monkeypatch):
+    """The concurrent sub-step schedule against the one-stream schedule: 25 iterations with a fresh
+    batch each must leave every variable and optimizer slot bitwise identical (a race between lanes would not)."""
+    import hashlib
+    cfg = ea.Config(batch_size=8, compute_dtype=dtype)
+    values = ea.init_variables(cfg, 3)
+    digests = []
+    for lanes in ('3', '0', '3'):
+        monkeypatch.setenv('EG_LANES', lanes)       # read when the context is created
+        net = ea.EdgeGAN(cfg, values)
+        for it in range(25):
+            b = ea.synthetic_batch(cfg, seed=100 + it)
+            net.update_model(b['images'], b['z'], alpha=b['alpha'], eps=b['eps'])
+        h = hashlib.sha256()
+        for name, v in sorted(net.get_variables(slots=True).items()):
+            h.update(name.encode())
+            h.update(np.ascontiguousarray(v).tobytes())
+        digests.append(h.hexdigest())
+        net.close()
+    assert digests[0] == digests[1] == digests[2], digests
+
+
 def test_rccl_single_rank_allreduce_and_overlap_path():
     """nranks=1 communicator: exercises the RCCL binding, the all-reduce on the real library and the side-stream
     overlap of (all-reduce + RMSProp) with the next sub-step's compute.  With one rank the exchange is the
