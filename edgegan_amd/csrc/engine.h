@@ -184,6 +184,9 @@ T act_tangent(Ctx& c, T tx, T out_prim, int a);
 T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times, T* stats_out = nullptr);
 T add(Ctx& c, T a, T b, bool relu);
 T pool2(Ctx& c, T x);
+// pool2(a + b) in one pass (the MRU unit's `mean_pool(proj + h_new)`, conv.py:239-243); a and b must have no other
+// consumer: their gradients are then ONE shared buffer (both equal the up-sampled output gradient / 4)
+T add_pool2(Ctx& c, T a, T b);
 T gmean(Ctx& c, T x, bool pre_relu);
 T resize(Ctx& c, T x, int size);
 T concat_w(Ctx& c, T a, T b);

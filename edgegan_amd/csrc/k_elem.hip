@@ -286,6 +286,39 @@ __global__ void pool2_bwd_v_kernel(const float* __restrict__ dy, float* __restri
     }
   }
 }
+// y = pool2(a + b): the element-wise sum first (as the reference does), then pooling.py's add_n order
+__global__ void add_pool2_fwd_v_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                       int H, int W, int C4, unsigned n4) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+    const unsigned c = i % C4;
+    unsigned t = i / C4;
+    const unsigned ox = t % Wo;
+    t /= Wo;
+    const unsigned oy = t % Ho, nb = t / Ho;
+    const size_t base = ((size_t)(nb * H + 2 * oy) * W + 2 * ox) * C4 + c;
+    const float4* pa = reinterpret_cast<const float4*>(a) + base;
+    const float4* pb = reinterpret_cast<const float4*>(b) + base;
+    const size_t o1 = (size_t)W * C4, o2 = C4, o3 = (size_t)W * C4 + C4;
+    const float4 a0 = pa[0], a1 = pa[o1], a2 = pa[o2], a3 = pa[o3];
+    const float4 b0 = pb[0], b1 = pb[o1], b2 = pb[o2], b3 = pb[o3];
+    float4 r;
+    r.x = ((a0.x + b0.x) + (a1.x + b1.x) + (a2.x + b2.x) + (a3.x + b3.x)) * 0.25f;
+    r.y = ((a0.y + b0.y) + (a1.y + b1.y) + (a2.y + b2.y) + (a3.y + b3.y)) * 0.25f;
+    r.z = ((a0.z + b0.z) + (a1.z + b1.z) + (a2.z + b2.z) + (a3.z + b3.z)) * 0.25f;
+    r.w = ((a0.w + b0.w) + (a1.w + b1.w) + (a2.w + b2.w) + (a3.w + b3.w)) * 0.25f;
+    reinterpret_cast<float4*>(y)[i] = r;
+  }
+}
+bool launch_add_pool2_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s) {
+  const size_t n = (size_t)NB * (H / 2) * (W / 2) * C;
+  if (!(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (size_t)NB * H * W * C < (1ull << 31) &&
+        ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0))
+    return false;
+  hipLaunchKernelGGL(add_pool2_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, a, b, y, H, W, C / 4,
+                     (unsigned)(n / 4));
+  return true;
+}
 void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hipStream_t s) {
   const size_t n = (size_t)NB * (H / 2) * (W / 2) * C;
   if (C % 4 == 0 && (size_t)NB * H * W * C < (1ull << 31) && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {

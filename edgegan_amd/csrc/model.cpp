@@ -407,7 +407,7 @@ T classifier_forward(Ctx& c, T x) {
     c1 = prelu(c, c1, P(c, b + "/Conv_1/prelu/param"), 0.f);
     T c2 = conv2d(c, c1, wref_sn(c, P(c, b + "/Conv_2/weights")), P(c, b + "/Conv_2/biases"), 3, 1, PAD_SAME);
     T proj = conv2d(c, h, wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
-    h = pool2(c, add(c, proj, c2, false));
+    h = add_pool2(c, proj, c2);   // proj and c2 are conv outputs with no other consumer
     hidden = depth;
   }
   h = prelu(c, h, P(c, "D2/mru_conv_unit_last_norm/prelu/param"), 0.f);  // conv.py:353-355

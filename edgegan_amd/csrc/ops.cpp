@@ -646,6 +646,42 @@ T pool2(Ctx& c, T x) {
   return out;
 }
 
+T add_pool2(Ctx& c, T a, T b) {
+  EG_CHECK(a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c, "add_pool2 shapes");
+  EG_CHECK(a->h % 2 == 0 && a->w % 2 == 0, "add_pool2 needs even extents");
+  T out = new_tensor(c, a->n, a->h / 2, a->w / 2, a->c, a->needs_grad || b->needs_grad);
+  if (!launch_add_pool2_fwd(a->d, b->d, out->d, a->n, a->h, a->w, a->c, c.stream)) {
+    float* sum = c.arena.allocf(a->numel());
+    launch_add(a->d, b->d, sum, 0, a->numel(), c.stream);
+    launch_pool2_fwd(sum, out->d, a->n, a->h, a->w, a->c, c.stream);
+  }
+  if (out->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      // d(a) = d(b) = up-sampled d(out) / 4: computed once; inputs whose gradient is still unset share the buffer
+      float* shared = nullptr;
+      for (T in : {a, b}) {
+        if (!in->needs_grad) continue;
+        if (!in->g_set && !in->g) {
+          if (!shared) {
+            shared = c.arena.allocf(in->numel());
+            launch_pool2_bwd(out->g, shared, 0, in->n, in->h, in->w, in->c, c.stream);
+          }
+          in->g = shared;
+          in->g_set = true;
+        } else {
+          int acc;
+          float* d = grad_acc(c, in, &acc);
+          launch_pool2_bwd(out->g, d, acc, in->n, in->h, in->w, in->c, c.stream);
+        }
+      }
+    });
+  }
+  return out;
+}
+
 T gmean(Ctx& c, T x, bool pre_relu) {
   T out = new_tensor(c, x->n, 1, 1, x->c, x->needs_grad);
   const int HW = x->h * x->w;
