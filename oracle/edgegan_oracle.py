@@ -110,6 +110,57 @@ def _bilinear(f, x: Tensor, w: Tensor, c_in: int, n_out: int, c_wgrad: Optional[
     return _RoundedBilinear.apply(x, w, f, rf, rdx, rdw)
 
 
+
+# --------------------------------------------------------------------------------------
+# kink recorder (fixture conditioning; tests/golden/select_fixtures.py, tests/test_margin_gpu.py)
+# --------------------------------------------------------------------------------------
+# ReLU / LeakyReLU / PReLU / |.| have discontinuous derivatives at 0.  An fp32 implementation whose
+# pre-activation differs from the fp64 value by rounding noise takes the OTHER slope when the fp64 value lies
+# within that noise of 0; in a layer with a small normalisation extent (InstanceNorm over 4x4 .. 16x16) one
+# such flip moves that channel's gradient by ~1/(B*H*W).  Inside `with kink_recorder() as rec:` every
+# piecewise-linear activation records, per call, how close its argument comes to the kink relative to the
+# argument's RMS -- fixtures whose small-extent layers keep a margin can then be compared at tight tolerance.
+_KINK_REC = None
+
+
+class kink_recorder:
+    """rec.rows: list of (tag, elements per (n, c) slice, numel, min|x|/rms(x))."""
+
+    def __enter__(self):
+        global _KINK_REC
+        self.prev, self.rows = _KINK_REC, []
+        _KINK_REC = self
+        return self
+
+    def __exit__(self, *exc):
+        global _KINK_REC
+        _KINK_REC = self.prev
+
+    def margin(self, max_extent: int = 1 << 30) -> float:
+        """Smallest recorded margin over the calls whose per-(n,c) extent is <= max_extent."""
+        m = [r[3] for r in self.rows if r[1] <= max_extent]
+        return min(m) if m else float('inf')
+
+
+def _kink(tag: str, x: Tensor) -> None:
+    if _KINK_REC is None or x.numel() == 0:
+        return
+    d = x.detach()
+    if d.dim() == 4:            # NHWC or NCHW: either way numel / (n * channels) elements per slice
+        ch = d.shape[3] if tag.endswith('nhwc') else d.shape[1]
+        extent = d.numel() // (d.shape[0] * ch)
+    else:
+        extent = 1
+    rms = float(d.pow(2).mean().sqrt())
+    _KINK_REC.rows.append((tag, extent, d.numel(), float(d.abs().min()) / max(rms, 1e-300)))
+
+
+def relu(x: Tensor) -> Tensor:
+    """tf.nn.relu (slope 0 at 0)."""
+    _kink('relu/nhwc', x)
+    return torch.relu(x)
+
+
 # --------------------------------------------------------------------------------------
 # configuration (defaults = edgegan/train.py:14-74, edgegan/models/edgegan.py:46-48)
 # --------------------------------------------------------------------------------------
@@ -215,8 +266,9 @@ def batch_norm_train(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5):
 def activation(x: Tensor, name: Optional[str]) -> Tensor:
     """edgegan/nn/modules/activation.py:4-15."""
     if name == 'relu':
-        return torch.relu(x)
+        return relu(x)
     if name == 'lrelu':
+        _kink('lrelu/nhwc', x)
         return torch.maximum(x, 0.2 * x)
     if name == 'tanh':
         return torch.tanh(x)
@@ -235,11 +287,13 @@ def norm(x: Tensor, kind: Optional[str]) -> Tensor:
 
 def prelu(x: Tensor, leak: Tensor) -> Tensor:
     """activation.py:23-27: tf.maximum(leak*x, x), scalar learnable `param` (init 0.2)."""
+    _kink('prelu/nchw', x)
     return torch.maximum(leak * x, x)
 
 
 def lrelu_leak(x: Tensor, leak: float = 0.2) -> Tensor:
     """activation.py:30-32."""
+    _kink('lrelu_leak/nchw', x)
     return torch.maximum(leak * x, x)
 
 
@@ -489,12 +543,12 @@ def generator(p: P, prefix: str, z: Tensor, cfg: Config, bn_stats: Optional[list
                                   p[f'{prefix}/batch_norm/BatchNorm/beta'])
     if bn_stats is not None:
         bn_stats.append((bm.detach(), bv.detach(), h0.shape[0] * h0.shape[1] * h0.shape[2]))
-    x = torch.relu(h0)
+    x = relu(h0)
     for i in range(1, 5):
         x = deconv2d(x, p[f'{prefix}/g_dconv_{i}/deconv2d/w'], p[f'{prefix}/g_dconv_{i}/deconv2d/b'],
                      sizes[4 - i])
         if i < 4:
-            x = torch.relu(instance_norm(x))
+            x = relu(instance_norm(x))
     return torch.tanh(x)
 
 
@@ -514,22 +568,22 @@ def discriminator(p: P, prefix: str, x: Tensor) -> Tuple[Tensor, Tensor]:
 def residual(p: P, base: str, x: Tensor) -> Tensor:
     """edgegan/nn/modules/conv.py:70-85 with norm='instance', pad='REFLECT', bias=True."""
     out = conv2d(x, p[f'{base}/res1/conv2d/w'], 1, 'REFLECT', p[f'{base}/res1/conv2d/b'])
-    out = torch.relu(instance_norm(out))
+    out = relu(instance_norm(out))
     out = conv2d(out, p[f'{base}/res2/conv2d/w'], 1, 'REFLECT', p[f'{base}/res2/conv2d/b'])
     out = instance_norm(out)
     sc = conv2d(x, p[f'{base}/shortcut/conv2d/w'], 1, 'REFLECT', p[f'{base}/shortcut/conv2d/b'])
-    return torch.relu(sc + out)
+    return relu(sc + out)
 
 
 def encoder(p: P, x: Tensor, eps, cfg: Config) -> Tuple[Tensor, Tensor, Tensor]:
     """edgegan/models/encoder.py:54-84.  eps is ONE scalar N(0,1) draw per run (quirk N3,
     encoder.py:78-79), supplied explicitly."""
     E = conv2d(x, p['E/e_resnet_64_0/conv2d/w'], 2, 'SAME', p['E/e_resnet_64_0/conv2d/b'])
-    E = torch.relu(E)
+    E = relu(E)
     for i, n in enumerate(encoder_filters(cfg)):
         E = residual(p, f'E/e_resnet_{n}_{i + 1}', E)
         E = avg_pool2(E)
-    E = torch.relu(E)
+    E = relu(E)
     E = avg_pool_same(E, 8)
     E = E.reshape(E.shape[0], -1)
     mu = linear(E, p['E/FC8_mu/w'], p['E/FC8_mu/b'])
@@ -606,6 +660,7 @@ def generator_ganloss(output: Tensor) -> Tensor:
 
 
 def l1loss(output: Tensor, target: Tensor, weight: float) -> Tensor:
+    _kink('abs', output - target)
     return weight * torch.mean(torch.abs(output - target))         # functional.py:40-41
 
 
