@@ -152,7 +152,8 @@ def _kink(tag: str, x: Tensor) -> None:
     else:
         extent = 1
     rms = float(d.pow(2).mean().sqrt())
-    _KINK_REC.rows.append((tag, extent, d.numel(), float(d.abs().min()) / max(rms, 1e-300)))
+    nz = d[d != 0]      # exact zeros are structural (relu of an already rectified, pooled tensor), the same in fp32
+    _KINK_REC.rows.append((tag, extent, d.numel(), (float(nz.abs().min()) if nz.numel() else float('inf')) / max(rms, 1e-300)))
 
 
 def relu(x: Tensor) -> Tensor:
