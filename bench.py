@@ -110,13 +110,6 @@ def main():
     import numpy as np
     import edgegan_amd as ea
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist_mod.init_process_group('gloo', rank=rank, world_size=world)   # host-side rendezvous only
-        dist = dist_mod
-
     cfg_kwargs = dict(batch_size=args.batch, num_classes=args.classes, device=local, compute_dtype=args.dtype,
                       height=args.height, width=args.width)
     # algorithmic GFLOP per image and iteration; both minus the two shared generator forwards
@@ -125,17 +118,14 @@ def main():
     values = ea.init_variables(cfg, 0)                 # same weights on every rank
     net = ea.EdgeGAN(cfg, values)
     batch = ea.synthetic_batch(cfg, seed=1234, rank=rank)   # each rank its own shard of the global batch
-    if world > 1:
-        import torch
-        uid = [net.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        net.comm_init(uid[0], rank, world)
+    if world > 1:       # the 128-byte RCCL id travels through a file; every later exchange runs over RCCL itself
+        from edgegan_amd import rendezvous
+        rendezvous.init_data_parallel(net, rank, world)
     net.upload_batch(batch['images'], batch['z'], batch['alpha'], batch['eps'])
 
     def barrier_sync():
         net.sync()
-        if dist is not None:
-            dist.barrier()
+        net.comm_barrier()          # RCCL all-reduce of one scalar + stream sync: returns when every rank has arrived
         try:
             import torch
             if torch.cuda.is_available():
@@ -153,11 +143,8 @@ def main():
         net.train_step()
     barrier_sync()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+    if world > 1:
+        dt = float(net.comm_reduce_scalars([dt], 'max')[0])       # MAX over ranks
     losses = net.losses()
     finite = all(np.isfinite(v) for v in losses.values())
 
@@ -191,8 +178,7 @@ def main():
                                          'executed_gflop_per_image': round(tot_fl / args.profile_steps / args.batch / 1e9, 2)},
                     'per_kernel': {k['name']: {'ms_per_step': round(k['ms'] / args.profile_steps, 3),
                                                'tflops': round(k['flops'] / (k['ms'] * 1e-3) / 1e12, 2)} for k in ks}}
-    if dist is not None:
-        dist.barrier()
+    net.comm_barrier()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -222,8 +208,6 @@ def main():
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
         print(json.dumps(out))
     net.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

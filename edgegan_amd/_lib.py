@@ -63,6 +63,7 @@ class Config:
 EXPORTS = ['eg_default_config', 'eg_variable_count', 'eg_variable_info', 'eg_create', 'eg_destroy',
            'eg_last_error', 'eg_set_variable', 'eg_get_variable', 'eg_upload_batch', 'eg_substep',
            'eg_train_step', 'eg_read_losses', 'eg_infer', 'eg_sync', 'eg_comm_unique_id', 'eg_comm_init',
+           'eg_comm_reduce_scalars',
            'eg_profile_begin', 'eg_profile_end', 'eg_memory_stats', 'eg_test_op', 'eg_net_forward', 'eg_crc32c']
 
 _lib = None
@@ -94,6 +95,7 @@ def load_library() -> C.CDLL:
     lib.eg_sync.argtypes = [C.c_void_p]
     lib.eg_comm_unique_id.argtypes = [C.c_void_p, C.c_char_p]
     lib.eg_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    lib.eg_comm_reduce_scalars.argtypes = [C.c_void_p, fp, C.c_int, C.c_int]
     lib.eg_profile_begin.argtypes = [C.c_void_p]
     lib.eg_profile_end.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.eg_memory_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]

@@ -61,7 +61,7 @@ def _match_name(want: str, have: Dict[str, np.ndarray]) -> Optional[str]:
     return None
 
 
-def load(net, checkpoint_dir: str, strict: bool = False) -> Tuple[bool, int]:
+def load(net, checkpoint_dir: str, strict: bool = True) -> Tuple[bool, int]:
     print(' [*] Reading checkpoints {}...'.format(checkpoint_dir))
     latest, _ = tf_bundle.read_checkpoint_state(checkpoint_dir)
     if not latest:
@@ -72,15 +72,18 @@ def load(net, checkpoint_dir: str, strict: bool = False) -> Tuple[bool, int]:
     missing = []
     for s in net.specs:
         k = _match_name(s.name, have)
-        if k is None or have[k].size != int(np.prod(s.shape, dtype=np.int64)):
-            missing.append(s.name)
+        if k is None or tuple(have[k].shape) != tuple(s.shape):
+            missing.append(s.name if k is None else f'{s.name} (shape {tuple(have[k].shape)} != {tuple(s.shape)})')
             continue
         net.set_variable(s.name, have[k].astype(np.float32))
         for slot in ('/RMSProp', '/RMSProp_1'):
             if s.trainable and s.name + slot in have:
+                if tuple(have[s.name + slot].shape) != tuple(s.shape):
+                    missing.append(f'{s.name + slot} (shape {tuple(have[s.name + slot].shape)} != {tuple(s.shape)})')
+                    continue
                 net.set_variable(s.name + slot, have[s.name + slot].astype(np.float32))
     if missing and strict:
-        raise KeyError(f'checkpoint lacks {len(missing)} variables, e.g. {missing[:5]}')
+        raise KeyError(f'checkpoint {ckpt_name} lacks or mis-shapes {len(missing)} variables, e.g. {missing[:5]}')
     if missing:
         print(f' [!] {len(missing)} variables not found in the checkpoint (kept at their current values), '
               f'e.g. {missing[:3]}')

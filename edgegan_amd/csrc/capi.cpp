@@ -270,6 +270,13 @@ int eg_comm_init(eg_ctx* ctx, const char* id128, int rank, int nranks) {
   EG_API_END(ctx)
 }
 
+int eg_comm_reduce_scalars(eg_ctx* ctx, float* inout, int n, int op) {
+  EG_API_BEGIN
+  EG_CHECK(inout, "null argument");
+  comm_reduce_scalars(ctx->c, inout, n, op);
+  EG_API_END(ctx)
+}
+
 int eg_profile_begin(eg_ctx* ctx) {
   EG_API_BEGIN
   Ctx& c = ctx->c;

@@ -71,12 +71,28 @@ void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream) {
   check(c, sym<fn_allreduce>(c, "ncclAllReduce")(buf, buf, n, 7, 0, c.nccl_comm, stream), "ncclAllReduce");
 }
 
+// Every lane's stream waits (not only the active one): pending[g] is cleared for the whole context, so a lane that
+// did not fork from the active lane after this point must not be able to read the group's weights early.
 void comm_wait_groups(Ctx& c, unsigned mask) {
   for (int g = 0; g < G_COUNT; ++g)
     if ((mask >> g & 1u) && c.pending[g]) {
-      EG_HIP(hipStreamWaitEvent(c.stream, c.ev_applied[g], 0));
+      for (int i = 0; i < Ctx::kLanes; ++i)
+        if (c.lanes[i].stream) EG_HIP(hipStreamWaitEvent(c.lanes[i].stream, c.ev_applied[g], 0));
       c.pending[g] = false;
     }
+}
+
+// Host scalars reduced over the ranks on the communication stream (also the host barrier of the data-parallel
+// loop: returns when every rank has arrived).  op: 0 sum, 2 max, 3 min (ncclRedOp_t)
+void comm_reduce_scalars(Ctx& c, float* inout, int n, int op) {
+  EG_CHECK(c.nccl_comm, "comm_reduce_scalars without comm_init");
+  EG_CHECK(n >= 1 && n <= 64 && (op == 0 || op == 2 || op == 3), "comm_reduce_scalars: n in 1..64, op in {0,2,3}");
+  if (!c.comm_scal) EG_HIP(hipMalloc(&c.comm_scal, 64 * sizeof(float)));
+  EG_HIP(hipMemcpyAsync(c.comm_scal, inout, n * sizeof(float), hipMemcpyHostToDevice, c.comm_stream));
+  check(c, sym<fn_allreduce>(c, "ncclAllReduce")(c.comm_scal, c.comm_scal, (size_t)n, 7, op, c.nccl_comm, c.comm_stream),
+        "ncclAllReduce(scalars)");
+  EG_HIP(hipMemcpyAsync(inout, c.comm_scal, n * sizeof(float), hipMemcpyDeviceToHost, c.comm_stream));
+  EG_HIP(hipStreamSynchronize(c.comm_stream));
 }
 
 void comm_wait_all(Ctx& c) { comm_wait_groups(c, ~0u); }
@@ -91,6 +107,8 @@ void comm_destroy(Ctx& c) {
     }
     (void)hipStreamDestroy(c.comm_stream);
     c.comm_stream = nullptr;
+    (void)hipFree(c.comm_scal);
+    c.comm_scal = nullptr;
   }
   if (c.nccl_comm) {
     (void)sym<fn_destroy>(c, "ncclCommDestroy")(c.nccl_comm);

@@ -140,6 +140,7 @@ struct Ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_ready[G_COUNT] = {}, ev_applied[G_COUNT] = {};
   bool pending[G_COUNT] = {};
+  float* comm_scal = nullptr;   // device staging of comm_reduce_scalars
 
   ~Ctx();
 };
@@ -241,6 +242,7 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
 void comm_unique_id(Ctx& c, char* out128);
 void comm_init(Ctx& c, const char* id128, int rank, int nranks);
 void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream);
+void comm_reduce_scalars(Ctx& c, float* inout, int n, int op);
 void use_lane(Ctx& c, int lane);                // model.cpp
 void comm_wait_groups(Ctx& c, unsigned mask);   // main stream waits for the pending updates of these groups
 void comm_wait_all(Ctx& c);

@@ -1067,9 +1067,10 @@ __global__ void acgan_kernel(const float* __restrict__ logits, const float* __re
   float coef_pj, coef_y;  // dl_j = coef_pj * p_j + (j==y) * coef_y
   if (mode == 0) {
     per_loss[b] = (1.f - py) * (1.f - py) * ce;
-    // f = (1-py)^2 * (-log py) ; df/dpy = 2(1-py) log py - (1-py)^2/py ; dpy/dl_j = py (delta - p_j)
-    const float dfdpy = 2.f * (1.f - py) * (-ce) - (1.f - py) * (1.f - py) / py;
-    const float k = dfdpy * py / B;
+    // f = (1-py)^2 * (-log py) ; df/dpy = 2(1-py) log py - (1-py)^2/py ; dpy/dl_j = py (delta - p_j).
+    // k = df/dpy * py / B with py cancelled algebraically: py = exp(l_y - lse) underflows to 0 for a logit gap > ~88
+    // and (1-py)^2/py * py would be inf * 0 = NaN
+    const float k = (2.f * (1.f - py) * (-ce) * py - (1.f - py) * (1.f - py)) / B;
     coef_pj = -k;
     coef_y = k;
   } else {

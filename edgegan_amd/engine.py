@@ -29,7 +29,11 @@ class EdgeGAN:
         if rc != 0:
             raise EdgeGANLibError(f'eg_create failed ({rc}): {self._lib.eg_last_error(None).decode()}')
         self.specs = variable_specs(config)
-        self._rng = np.random.RandomState(6666)
+        # alpha (random_blend, edgegan.py:33-34) is drawn per sample: under data parallelism every rank draws ITS OWN
+        # rows (comm_init re-seeds by rank); eps (encoder.py:78) is ONE scalar per run: the same on every rank
+        self._rng_alpha = np.random.RandomState(6666)
+        self._rng_eps = np.random.RandomState(6667)
+        self.rank, self.nranks = 0, 1
         if variables is not None:
             self.set_variables(variables)
 
@@ -89,9 +93,9 @@ class EdgeGAN:
         if z.shape != (cfg.batch_size, cfg.z_cols):
             raise ValueError(f'z must be {(cfg.batch_size, cfg.z_cols)}, got {z.shape}')
         if alpha is None:   # the reference draws these inside the graph (edgegan.py:33-34)
-            alpha = self._rng.uniform(0, 1, size=(3, cfg.batch_size))
+            alpha = self._rng_alpha.uniform(0, 1, size=(3, cfg.batch_size))
         if eps is None:     # encoder.py:78
-            eps = self._rng.normal(0, 1, size=(4,))
+            eps = self._rng_eps.normal(0, 1, size=(4,))
         alpha = np.ascontiguousarray(alpha, dtype=np.float32)
         eps = np.ascontiguousarray(np.asarray(eps, dtype=np.float32).reshape(-1))
         assert alpha.shape == (3, cfg.batch_size) and eps.size >= 1
@@ -134,7 +138,7 @@ class EdgeGAN:
         nb = images.shape[0]
         assert images.shape[1:] == (cfg.height, cfg.width, cfg.c_dim)
         if eps2 is None:
-            eps2 = self._rng.normal(0, 1, size=(2,))
+            eps2 = self._rng_eps.normal(0, 1, size=(2,))
         eps2 = np.ascontiguousarray(np.asarray(eps2, dtype=np.float32).reshape(2))
         cls = None
         if cfg.multiclasses:
@@ -156,6 +160,18 @@ class EdgeGAN:
     def comm_init(self, unique_id: bytes, rank: int, nranks: int):
         assert len(unique_id) == 128
         self._check(self._lib.eg_comm_init(self._ctx, unique_id, rank, nranks))
+        self.rank, self.nranks = rank, nranks
+        self._rng_alpha = np.random.RandomState(6666 + 7919 * rank)
+
+    def comm_reduce_scalars(self, values, op: str = 'sum') -> np.ndarray:
+        """All-reduce of up to 64 host floats over the ranks (RCCL); returns when every rank has arrived."""
+        a = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
+        self._check(self._lib.eg_comm_reduce_scalars(self._ctx, fptr(a), a.size, {'sum': 0, 'max': 2, 'min': 3}[op]))
+        return a
+
+    def comm_barrier(self):
+        if self.nranks > 1:
+            self.comm_reduce_scalars([0.0])
 
     # -- measurement ------------------------------------------------------------------------------
     def profile_begin(self):

@@ -62,7 +62,9 @@ def main(argv=None):
     fl.z_dim = 100                                                                   # EdgeGAN default, edgegan.py:47
     cfg = engine_config(fl, int(fl.gpu))
     net = EdgeGAN(cfg)
-    loaded, _ = checkpoint.load(net, fl.checkpoint_dir)
+    # strict: the engine starts from zero / constant weights, a checkpoint that lacks or mis-shapes a variable must fail
+    # like Saver.restore (NotFoundError), not run inference on partly uninitialised networks
+    loaded, _ = checkpoint.load(net, fl.checkpoint_dir, strict=True)
     if not loaded:
         print(' [!] Load failed...')                                                # edgegan.py:587-589
         return

@@ -1,8 +1,12 @@
 """``python -m edgegan_amd.train`` -- flag-compatible stand-in for ``python -m edgegan.train``
 (edgegan/train.py:109-138 + the loop of edgegan/models/edgegan.py:425-489) on the HIP engine.
 
-Under a multi-process launcher (RANK / WORLD_SIZE / LOCAL_RANK) the batches are sharded data-parallel: rank r
-trains on batch idx*world+r of every epoch, gradients are all-reduced inside the engine, rank 0 prints and saves."""
+Under a multi-process launcher (RANK / WORLD_SIZE / LOCAL_RANK) the batches are sharded data-parallel: every rank
+holds the SAME per-epoch permutation (one seed drawn by rank 0 and shared at start-up, then RandomState(seed + epoch)),
+rank r trains on batch idx*world+r of it -- a partition of the epoch -- while the z draws and the gradient-penalty
+alpha rows stay rank-specific; gradients are all-reduced inside the engine, rank 0 prints and saves.  The host needs
+no collective library of its own: the communicator id and the seed travel through edgegan_amd.rendezvous, everything
+else over RCCL."""
 from __future__ import annotations
 
 import json
@@ -44,6 +48,16 @@ def engine_config(fl, device: int) -> Config:
                   device=device)
 
 
+def epoch_permutation(n: int, seed: int, epoch: int) -> np.ndarray:
+    """The data order of one epoch under data parallelism: identical on every rank."""
+    return np.random.RandomState((seed + epoch) % (2 ** 32)).permutation(n)
+
+
+def rank_batches(n_batches: int, world: int, rank: int):
+    """Batch indices rank `rank` trains on: with every rank on the same permutation, a partition (drop-last)."""
+    return [i * world + rank for i in range(n_batches // world)]
+
+
 def main(argv=None):
     fl = update_flags(F.parse(sys.argv[1:] if argv is None else argv, F.TRAIN_FLAGS))
     F.check_supported(fl)
@@ -62,26 +76,33 @@ def main(argv=None):
     from .variables import init_variables
     cfg = engine_config(fl, local)
     net = EdgeGAN(cfg, init_variables(cfg, seed=0))        # tf.global_variables_initializer (edgegan.py:437-440)
+    shuffle_seed = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-        uid = [net.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        net.comm_init(uid[0], rank, world)
+        from . import rendezvous
+        seed_bytes = rendezvous.broadcast_bytes('seed', str(np.random.randint(2 ** 31)).encode() if rank == 0 else None, rank)
+        shuffle_seed = int(seed_bytes)
+        rendezvous.init_data_parallel(net, rank, world)
+        rendezvous.cleanup(['seed'], rank)
     writer = SummaryWriter(fl.logdir) if rank == 0 else None                      # edgegan.py:443
     counter = 1
     start_time = time.time()
-    loaded, ckpt_counter = checkpoint.load(net, fl.checkpoint_dir)               # edgegan.py:447-453
+    # Saver.restore raises on a missing / mis-shaped variable: so does strict=True (a silent partial restore would
+    # resume on partly re-initialised weights)
+    loaded, ckpt_counter = checkpoint.load(net, fl.checkpoint_dir, strict=True)   # edgegan.py:447-453
     if loaded:
         counter = ckpt_counter
         print(' [*] Load SUCCESS')
     else:
         print(' [!] Load failed...')
     for epoch in range(fl.epoch):
-        dataset.shuffle()
+        if world == 1:
+            dataset.shuffle()                                                        # edgegan.py:457
+        else:
+            if epoch == 0:
+                base_order = list(dataset.data)
+            dataset.data = [base_order[i] for i in epoch_permutation(len(base_order), shuffle_seed, epoch)]
         steps = len(dataset) // world
-        for it, (idx, images, z, _) in enumerate(Prefetcher(dataset, [i * world + rank for i in range(steps)])):
+        for it, (idx, images, z, _) in enumerate(Prefetcher(dataset, rank_batches(len(dataset), world, rank))):
             net.update_model(images, z)                                              # edgegan.py:461
             l = net.losses()                                                         # edgegan.py:464-481
             discriminator_err = l['joint_dis_dloss'] + l['image_dis_dloss'] + l['edge_dis_dloss']

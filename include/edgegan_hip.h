@@ -99,6 +99,9 @@ int eg_sync(eg_ctx* ctx);
  * group's flat gradient buffer and averages before RMSProp. */
 int eg_comm_unique_id(eg_ctx* ctx, char* out128);
 int eg_comm_init(eg_ctx* ctx, const char* id128, int rank, int nranks);
+/* all-reduce of n <= 64 host floats over the ranks (op: 0 sum, 2 max, 3 min); returns when every rank has arrived,
+ * i.e. it is also the host barrier of the data-parallel loop -- the host needs no other collective library */
+int eg_comm_reduce_scalars(eg_ctx* ctx, float* inout, int n, int op);
 
 /* ---- measurement -------------------------------------------------------------------------------
  * Between begin/end every GEMM-shaped launch is bracketed by HIP events on the engine's stream;

@@ -103,3 +103,52 @@ def test_bench_refuses_multi_gpu_without_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True,
                        env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
     assert r.returncode == 2 and 'torch.distributed.run' in r.stderr
+
+
+def _shard_worker(rank, world, key, root, out):
+    """What edgegan_amd/train.py does per rank before and inside an epoch, minus the GPU: rendezvous of the shuffle
+    seed (file-based, no torch), the shared permutation, this rank's batches."""
+    os.environ['EG_RDZV_KEY'] = key
+    os.environ['EG_RDZV_DIR'] = out
+    sys.path.insert(0, ROOT)
+    from edgegan_amd import rendezvous
+    from edgegan_amd.data import Dataset
+    from edgegan_amd.train import epoch_permutation, rank_batches
+    np.random.seed(1000 + rank)          # the ranks' global np.random streams differ (they are unseeded in production)
+    seed = int(rendezvous.broadcast_bytes('seed', str(np.random.randint(2 ** 31)).encode() if rank == 0 else None, rank))
+    dcfg = {'input_height': 64, 'input_width': 128, 'output_height': 64, 'output_width': 128, 'crop': False, 'z_dim': 100}
+    ds = Dataset(root, 'toy', np.inf, 2, dcfg, 2, 'train')
+    base = list(ds.data)
+    seen = []
+    for epoch in range(2):
+        ds.data = [base[i] for i in epoch_permutation(len(base), seed, epoch)]
+        files = [f for b in rank_batches(len(ds), world, rank) for f in ds.filenames(b)]
+        z = ds.draw_z(ds.filenames(0))
+        seen.append({'files': files, 'z0': z[:, :3].tolist(), 'order': list(ds.data)})
+    import json
+    with open(os.path.join(out, f'shard{rank}.json'), 'w') as f:
+        json.dump({'seed': seed, 'epochs': seen}, f)
+
+
+def test_data_parallel_shards_are_a_partition_of_every_epoch(tmp_path):
+    """with an unseeded per-rank shuffle the shards overlapped.  Now: one seed from rank 0, identical
+    per-epoch permutation on every rank, rank r takes batches i*world + r => disjoint, jointly covering the epoch
+    (drop-last), different order per epoch; the z draws stay rank-specific."""
+    import json
+    root = tmp_path / 'data'
+    for c in (0, 1):
+        os.makedirs(root / 'toy' / 'train' / str(c))
+        for i in range(9):
+            (root / 'toy' / 'train' / str(c) / f'{i}.png').write_bytes(b'')     # names only: nothing is decoded here
+    out = str(tmp_path)
+    mp.spawn(_shard_worker, args=(2, f'test{os.getpid()}', str(root), out), nprocs=2, join=True)
+    r = [json.load(open(os.path.join(out, f'shard{k}.json'))) for k in (0, 1)]
+    assert r[0]['seed'] == r[1]['seed']
+    for e in (0, 1):
+        a, b = r[0]['epochs'][e], r[1]['epochs'][e]
+        assert a['order'] == b['order']                               # same permutation on both ranks
+        assert not set(a['files']) & set(b['files'])                  # disjoint shards
+        assert len(a['files']) == len(b['files']) == 8                # 18 files -> 9 batches of 2 -> 4 per rank
+        assert set(a['files']) | set(b['files']) <= set(a['order']) and len(set(a['files']) | set(b['files'])) == 16
+        assert a['z0'] != b['z0']                                     # z stays rank-specific
+    assert r[0]['epochs'][0]['order'] != r[0]['epochs'][1]['order']   # reshuffled per epoch
