@@ -165,7 +165,7 @@ int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long 
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
   ctx->c.sn_valid = false;
   ctx->c.gen_cache_valid[0] = ctx->c.gen_cache_valid[1] = false;
-  for (auto& p : ctx->c.params) p->wT_valid = false;
+  for (auto& p : ctx->c.params) p->wT_valid = p->wM_valid = false;
   EG_API_END(ctx)
 }
 
@@ -321,6 +321,26 @@ int eg_profile_end(eg_ctx* ctx, char* buf, int cap) {
   const std::string s = os.str();
   EG_CHECK((int)s.size() + 1 <= cap, "profile buffer too small");
   strcpy(buf, s.c_str());
+  EG_API_END(ctx)
+}
+
+// one CSV line per GEMM-shaped launch recorded since eg_profile_begin (call BEFORE eg_profile_end, which also works
+// afterwards: the records are kept until the next eg_profile_begin)
+int eg_profile_layers(eg_ctx* ctx, char* buf, long long cap) {
+  EG_API_BEGIN
+  Ctx& c = ctx->c;
+  EG_HIP(hipStreamSynchronize(c.stream));
+  std::ostringstream os;
+  os << "label,kernel,M,N,C,taps,nphase,split,us,gflop\n";
+  for (auto& r : c.prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    os << r.label << "," << '"' << r.name << '"' << "," << (r.shape.empty() ? ",,,,," : r.shape) << "," << ms * 1e3 << ","
+       << r.flops * 1e-9 << "\n";
+  }
+  const std::string s = os.str();
+  EG_CHECK((long long)s.size() + 1 <= cap, "profile buffer too small: need %zu bytes", s.size() + 1);
+  memcpy(buf, s.c_str(), s.size() + 1);
   EG_API_END(ctx)
 }
 

@@ -150,6 +150,9 @@ struct Param {
   float* wT = nullptr;
   bool wT_valid = false;
   bool cache_T = false;      // network variables only (per-op test scaffolding re-uses Param slots)
+  // phase-merged 3x3 form of a stride-2 filter with 3 image channels (ops.cpp: merged_filter), same life cycle as wT
+  float* wM = nullptr;
+  bool wM_valid = false;
 };
 
 struct Ctx;

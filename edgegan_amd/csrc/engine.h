@@ -41,6 +41,7 @@ struct WRef {
   unsigned short* wb = nullptr;   // bf16 copy, same layout      (compute_dtype bf16; lazily, per sub-step)
   unsigned short* wbT = nullptr;  // bf16 copy, per-tap transposed
   int T = 1, R = 0, Cc = 0;
+  std::string name;          // variable name (profiler labels)
 };
 
 // persistent per-weight spectral-norm buffers (classifier)
@@ -64,6 +65,8 @@ struct ProfRec {
   const char* name;
   double flops;
   hipEvent_t a, b;
+  std::string label;   // "<variable> <fwd|dgrad|wgrad>" of the launching op
+  std::string shape;   // "M,N,C,taps,nphase,split"
 };
 
 struct Ctx {
@@ -131,6 +134,7 @@ struct Ctx {
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   std::string prof_report;
+  std::string cur_label;   // set by the op that launches next (profiling only)
 
   // data parallel (RCCL, loaded lazily)
   void* nccl_lib = nullptr;
@@ -177,7 +181,8 @@ T deconv2d(Ctx& c, T x, WRef* w /*[25][Cout][Cin]*/, Param* bias, int cout);
 T linear(Ctx& c, T x, WRef* w /*[1][in][out]*/, Param* bias);
 T linear1(Ctx& c, T x, Param* w /*[K][1]*/, Param* bias /*nullable*/);
 T reshape(Ctx& c, T src, int n, int h, int w, int ch);
-WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_, int R, int Cc);
+WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_, int R, int Cc,
+               const std::string& name = std::string());
 T in_act(Ctx& c, T x, int act, T* stats_out = nullptr);
 T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int act);
 T act(Ctx& c, T x, int a);
@@ -203,7 +208,7 @@ struct ProfScope {
   Ctx& c;
   int idx = -1;
   explicit ProfScope(Ctx& c_);
-  void done(const char* name, double flops);
+  void done(const char* name, double flops, const std::string& shape = std::string());
 };
 
 // ---- networks and sub-steps (model.cpp) --------------------------------------------------------

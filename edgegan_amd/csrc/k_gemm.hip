@@ -238,6 +238,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     const int t2 = m / ph.OWp;
     const int oy = t2 % ph.OHp;
     const int nb = t2 / ph.OHp;
+    if constexpr (BN == 16) {
+      if (a.shuf) {   // phase-merged stride-2 layer: 12 channels -> a 2x2 block of 3-channel output pixels
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = lq * 4 + r;
+          if (n < 12) {
+            const int p = n / 3, ch = n - 3 * p;
+            float* q = a.y + ((size_t)(nb * a.OHf + 2 * oy + (p >> 1)) * a.OWf + 2 * ox + (p & 1)) * a.y_ps + ch;
+            float v = acc[i][0][r];
+            if (a.bias) v += a.bias[ch];
+            if (a.accumulate) v += *q;
+            *q = v;
+          }
+        }
+        continue;
+      }
+    }
     float* yrow = (SPLITK ? a.ws + (size_t)zsplit * a.y_total : a.y) +
                   ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
 #pragma unroll
@@ -916,6 +933,22 @@ __global__ void tap_transpose_kernel(const float* __restrict__ in, float* __rest
     const int c = c0 + i, r = r0 + threadIdx.x;
     if (r < R && c < Cc) dst[(size_t)c * R + r] = tile[threadIdx.x][i] * sc;
   }
+}
+
+__global__ void merge_phase_filter_kernel(const float* __restrict__ w, float* __restrict__ wm, int k, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 9 * C * 12
+  if (i >= 9 * C * 12) return;
+  const int n = i % 12, c = (i / 12) % C, tap = i / (12 * C);
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int p = n / 3, ch = n - 3 * p;
+  const int kh = (p >> 1) + 1 - 2 * dy, kw = (p & 1) + 1 - 2 * dx;
+  float v = 0.f;
+  if (kh >= 0 && kh < k && kw >= 0 && kw < k) v = w[((size_t)(kh * k + kw) * 3 + ch) * C + c];
+  wm[i] = v;
+}
+void launch_merge_phase_filter(const float* w, float* wm, int k, int C, hipStream_t s) {
+  const int n = 9 * C * 12;
+  hipLaunchKernelGGL(merge_phase_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wm, k, C);
 }
 
 void launch_tap_transpose(const float* in, float* out, int T, int R, int Cc, const float* inv_of, hipStream_t s) {

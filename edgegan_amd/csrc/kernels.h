@@ -34,6 +34,8 @@ struct ConvArgs {
   int ldw;
   int reflect;       // 1: out-of-range input index is mirrored (tf.pad REFLECT), 0: contributes zero
   int accumulate;    // 1: y += result
+  int shuf;          // 1 (N == 12, tiles <*,16> only): channel n = (py*2+px)*3 + ch is stored to output pixel
+                     //    (2*oy+py, 2*ox+px), channel ch of a [NB][OHf][OWf][y_ps] image; bias is indexed by ch
   int ksplit;        // > 1: K is split over ksplit blocks writing partial slabs to ws, reduced afterwards
   float* ws;         // ksplit * y_total floats
   size_t y_total;    // NB*OHf*OWf*y_ps
@@ -75,6 +77,13 @@ const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hi
 const char* launch_wgrad_bf16(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s);
 void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);
 void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int R, int Cc, hipStream_t s);
+
+// Phase-merged filter of a stride-2 layer with 3 image channels: the 4 sub-pixel phases of a transposed convolution
+// (or of a stride-2 convolution's input gradient) become 12 output channels n = (py*2+px)*3 + ch of ONE 3x3 stride-1
+// convolution over the coarse grid, wm[(dy+1)*3 + (dx+1)][c][n] = w[kh][kw] with kh = py + 1 - 2*dy (0 where kh, kw fall
+// outside the k x k filter).  mode 0: w is a deconv filter [k*k][3][C]; mode 1: w is a conv filter HWIO [k*k][3][C]
+// (both: image channel before the contracted channel).
+void launch_merge_phase_filter(const float* w, float* wm, int k, int C, hipStream_t s);
 
 // [T][R][Cc] -> [T][Cc][R] (per-tap transpose), optional scale by 1/(*inv_of) when inv_of != null.
 void launch_tap_transpose(const float* in, float* out, int T, int R, int Cc, const float* inv_of,

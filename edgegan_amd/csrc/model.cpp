@@ -394,8 +394,8 @@ T classifier_forward(Ctx& c, T x) {
         *full->g_set = true;
       });
     }
-    WRef* wr_h = wref_raw(c, w_h, g_h, f_h, full->want_grad, 9, hidden, hidden);
-    WRef* wr_x = wref_raw(c, w_x, g_x, f_x, full->want_grad, 9, 3, hidden);
+    WRef* wr_h = wref_raw(c, w_h, g_h, f_h, full->want_grad, 9, hidden, hidden, wg->name + "[hidden rows]");
+    WRef* wr_x = wref_raw(c, w_x, g_x, f_x, full->want_grad, 9, 3, hidden, wg->name + "[image rows]");
     T rg = conv2d(c, hp, wr_h, P(c, b + "/update_gate/biases"), 3, 1, PAD_SAME);
     conv2d(c, xin, wr_x, nullptr, 3, 1, PAD_SAME, rg);
     rg = prelu(c, rg, nullptr, 0.2f);  // lrelu (activation.py:30-32)
@@ -434,7 +434,7 @@ static void apply_group(Ctx& c, int group) {
   NetGroup& g = c.groups[group];
   if (group == G_G1) c.gen_cache_valid[0] = false;
   if (group == G_G2) c.gen_cache_valid[1] = false;
-  for (Param* p : g.params) p->wT_valid = false;
+  for (Param* p : g.params) p->wT_valid = p->wM_valid = false;
   for (Param* p : g.params)
     if (p->trainable && !p->dead) EG_CHECK(p->g_set, "variable %s received no gradient", p->name.c_str());
   if (c.nccl_comm) {
@@ -653,6 +653,13 @@ static void warm_transposes(Ctx& c, int group) {
     if (!p->wT) EG_HIP(hipMalloc(&p->wT, p->numel * sizeof(float)));
     launch_tap_transpose(p->w, p->wT, p->shape[0] * p->shape[1], p->shape[2], p->shape[3], nullptr, c.stream);
     p->wT_valid = true;
+  }
+  for (Param* p : c.groups[group].params) {   // the generator's last deconv runs phase-merged (ops.cpp: merged_filter)
+    if (!p->cache_T || p->shape.size() != 4 || p->shape[2] != 3 || p->shape[3] % 16 != 0 || p->wM_valid) continue;
+    const size_t n = (size_t)9 * p->shape[3] * 12;
+    if (!p->wM) EG_HIP(hipMalloc(&p->wM, n * sizeof(float)));
+    launch_merge_phase_filter(p->w, p->wM, p->shape[0], p->shape[3], c.stream);
+    p->wM_valid = true;
   }
 }
 

@@ -22,16 +22,18 @@ static hipEvent_t get_event(Ctx& c) {
 }
 ProfScope::ProfScope(Ctx& c_) : c(c_) {
   if (c.prof_on) {
-    ProfRec r{"", 0.0, get_event(c), get_event(c)};
+    ProfRec r{"", 0.0, get_event(c), get_event(c), std::string(), std::string()};
     EG_HIP(hipEventRecord(r.a, c.stream));
     c.prof.push_back(r);
     idx = (int)c.prof.size() - 1;
   }
 }
-void ProfScope::done(const char* name, double flops) {
+void ProfScope::done(const char* name, double flops, const std::string& shape) {
   if (idx >= 0) {
     c.prof[idx].name = name;
     c.prof[idx].flops = flops;
+    c.prof[idx].label = c.cur_label;
+    c.prof[idx].shape = shape;
     EG_HIP(hipEventRecord(c.prof[idx].b, c.stream));
   }
 }
@@ -100,6 +102,7 @@ WRef* wref_param(Ctx& c, Param* p, int T_, int R, int Cc) {
   w->R = R;
   w->Cc = Cc;
   w->param = p;
+  w->name = p->name;
   c.wref_cache[p] = w;
   return w;
 }
@@ -117,11 +120,13 @@ WRef* wref_sn(Ctx& c, Param* p) {
   w->R = s.K / s.T;
   w->Cc = s.Co;
   if (s.wT_valid) w->wT = s.WbarT;
+  w->name = p->name;
   c.wref_cache[p] = w;
   return w;
 }
 // an ad-hoc dense weight (e.g. a channel slice of an SN filter) living in the arena
-WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_, int R, int Cc) {
+WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_, int R, int Cc,
+               const std::string& name) {
   c.wrefs.emplace_back();
   WRef* w = &c.wrefs.back();
   w->w = w_;
@@ -131,6 +136,7 @@ WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_
   w->T = T_;
   w->R = R;
   w->Cc = Cc;
+  w->name = name;
   return w;
 }
 const float* wref_transposed(Ctx& c, WRef* w) {
@@ -159,6 +165,60 @@ const float* wref_transposed(Ctx& c, WRef* w) {
   return buf;
 }
 
+static void run_conv(Ctx& c, ConvArgs& a);
+
+// Phase-merged 3x3 filter [9][C][12] of a stride-2 filter [k*k][3][C] with 3 image channels (kernels.h:
+// launch_merge_phase_filter); kept per variable until the variable changes, like the per-tap transposes.
+static const float* merged_filter(Ctx& c, WRef* w, int k, int C) {
+  const size_t n = (size_t)9 * C * 12;
+  if (w->param && w->param->cache_T) {
+    Param* p = w->param;
+    if (!p->wM) EG_HIP(hipMalloc(&p->wM, n * sizeof(float)));
+    if (!p->wM_valid) {
+      launch_merge_phase_filter(w->w, p->wM, k, C, c.stream);
+      p->wM_valid = true;
+    }
+    return p->wM;
+  }
+  float* buf = c.arena.allocf(n);
+  launch_merge_phase_filter(w->w, buf, k, C, c.stream);
+  return buf;
+}
+
+// One launch for all 4 sub-pixel phases of a 3-image-channel stride-2 layer: a 3x3 stride-1 conv over the coarse grid
+// [NB][IH][IW][C] producing 12 channels that the epilogue scatters to the 2x2 output pixels ([NB][2IH][2IW][3]).
+// Against 4 phase launches with a 3 -> 16 padded tile this reads the coarse operand 9 instead of 16 times and issues
+// 9 x 16 instead of 16 x 16 padded MACs per coarse pixel and channel.
+static void run_merged_phases(Ctx& c, const float* x, int NB, int IH, int IW, int C, const float* wm, const float* bias,
+                              float* y, int accumulate) {
+  ConvArgs a{};
+  a.x = x;
+  a.wgt = wm;
+  a.bias = bias;
+  a.y = y;
+  a.NB = NB;
+  a.IH = IH;
+  a.IW = IW;
+  a.C = C;
+  a.x_ps = C;
+  a.OHf = 2 * IH;
+  a.OWf = 2 * IW;
+  a.N = 12;
+  a.y_ps = 3;
+  a.KW = 3;
+  a.kst = 1;
+  a.S = 1;
+  a.D = 1;
+  a.os = 1;
+  a.w_ts = (long long)C * 12;
+  a.ldw = 12;
+  a.accumulate = accumulate;
+  a.shuf = 1;
+  a.nphase = 1;
+  a.ph[0] = ConvPhase{IH, IW, 0, 0, 3, 3, 0, 0, -1, -1};
+  run_conv(c, a);
+}
+
 // compute_dtype bf16: hand the conv a bf16 copy of the filter with the contracted index contiguous.  `transposed`
 // selects the per-tap transpose [T][Cc][R] (contracted index = R) or the stored layout [T][R][Cc] (contracted = Cc).
 static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
@@ -183,7 +243,16 @@ static void run_conv(Ctx& c, ConvArgs& a) {
   const char* nm;
   ProfScope ps(c);
   const double fl = launch_conv_gemm(a, c.stream, &nm);
-  ps.done(nm, fl);
+  if (c.prof_on) {
+    int maxM = 0, taps = 0;
+    for (int p = 0; p < a.nphase; ++p) {
+      maxM = std::max(maxM, a.NB * a.ph[p].OHp * a.ph[p].OWp);
+      taps += a.ph[p].Ty * a.ph[p].Tx;
+    }
+    char buf[96];
+    snprintf(buf, sizeof buf, "%d,%d,%d,%d,%d,%d", maxM, a.N, a.C, taps, a.nphase, a.ksplit);
+    ps.done(nm, fl, buf);
+  }
 }
 
 static void same_pad(int n, int k, int s, int* out, int* before) {
@@ -200,6 +269,7 @@ static void same_pad(int n, int k, int s, int* out, int* before) {
 static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, int pt, int pl) {
   const int Cin = x->c, N = y->c;
   const float* wT = wref_transposed(c, w);  // [T][N][Cin]
+  if (c.prof_on) c.cur_label = w->name + " dgrad";
   ConvArgs a{};
   a.x = y->g;
   a.wgt = wT;
@@ -245,6 +315,12 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
     a.ph[0] = ConvPhase{x->h, x->w, 0, 0, k, k, 0, 0, pt, pl};
   } else {
     EG_CHECK(stride == 2 && x->h % 2 == 0 && x->w % 2 == 0, "stride-2 dgrad needs even extents");
+    if (Cin == 3 && k == 4 && pt == 1 && pl == 1 && N % 16 == 0) {   // d_conv_0 / encoder stem: phase-merged form
+      int acc;
+      float* dx = grad_acc(c, x, &acc);
+      run_merged_phases(c, y->g, x->n, y->h, y->w, N, merged_filter(c, w, 4, N), nullptr, dx, acc);
+      return;
+    }
     int acc;
     a.y = grad_acc(c, x, &acc);
     a.accumulate = acc;
@@ -300,9 +376,14 @@ static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, c
   const size_t wsf = wgrad_workspace_floats(g);
   g.ws = wsf ? c.arena.allocf(wsf) : nullptr;
   const char* nm;
+  if (c.prof_on) c.cur_label = w->name + " wgrad";
   ProfScope ps(c);
   const double fl = launch_wgrad(g, c.stream, &nm);
-  ps.done(nm, fl);
+  if (c.prof_on) {
+    char buf[96];
+    snprintf(buf, sizeof buf, "%d,%d,%d,%d,1,%d", NB * OH * OW, N, C, k * k, g.nsplit);
+    ps.done(nm, fl, buf);
+  }
   *w->g_set = true;
 }
 
@@ -353,6 +434,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   a.nphase = 1;
   a.ph[0] = ConvPhase{OH, OW, 0, 0, k, k, 0, 0, -pt, -pl};
   attach_bf16(c, a, w, true);    // rows = Cout, contracted = Cin
+  if (c.prof_on) c.cur_label = w->name + " fwd";
   run_conv(c, a);
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
   if (need) {
@@ -382,7 +464,12 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
   EG_CHECK(w->T == 25 && w->R == cout && w->Cc == Cin, "deconv2d weight shape");
   const int OH = x->h * 2, OW = x->w * 2;
   T y = new_tensor(c, x->n, OH, OW, cout, false);
-  const float* wT = wref_transposed(c, w);  // [25][Cin][Cout]
+  const bool merged = cout == 3 && Cin % 16 == 0;   // g_dconv_4: all 4 phases in one 3x3 launch over the coarse grid
+  if (merged) {
+    if (c.prof_on) c.cur_label = w->name + " fwd";
+    run_merged_phases(c, x->d, x->n, x->h, x->w, Cin, merged_filter(c, w, 5, Cin), bias ? bias->w : nullptr, y->d, 0);
+  }
+  const float* wT = merged ? nullptr : wref_transposed(c, w);  // [25][Cin][Cout]
   ConvArgs a{};
   a.x = x->d;
   a.wgt = wT;
@@ -412,7 +499,8 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
                                     (py + pt - kh0) / 2, (px + pt - kw0) / 2};
     }
   attach_bf16(c, a, w, false);   // filter [25][Cout][Cin]: rows = Cout, contracted = Cin as stored
-  run_conv(c, a);
+  if (c.prof_on) c.cur_label = w->name + " fwd";
+  if (!merged) run_conv(c, a);
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
   if (need) {
     y->needs_grad = true;
@@ -452,6 +540,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
         b.nphase = 1;
         b.ph[0] = ConvPhase{x->h, x->w, 0, 0, 5, 5, 0, 0, -1, -1};
         attach_bf16(c, b, w, true);    // rows = Cin, contracted = Cout
+        if (c.prof_on) c.cur_label = w->name + " dgrad";
         run_conv(c, b);
       }
     });
@@ -929,7 +1018,10 @@ Ctx::~Ctx() {
     (void)hipEventDestroy(r.b);
   }
   for (auto& p : params)
-    if (p->wT) (void)hipFree(p->wT);
+    {
+      if (p->wT) (void)hipFree(p->wT);
+      if (p->wM) (void)hipFree(p->wM);
+    }
   (void)hipFree(inf_in);
   (void)hipFree(inf_edge);
   (void)hipFree(inf_image);

@@ -182,6 +182,12 @@ class EdgeGAN:
         self._check(self._lib.eg_profile_end(self._ctx, buf, len(buf)))
         return json.loads(buf.value.decode())
 
+    def profile_layers(self) -> str:
+        """CSV, one line per GEMM-shaped launch since profile_begin (label, kernel, shape, us, gflop)."""
+        buf = C.create_string_buffer(8 << 20)
+        self._check(self._lib.eg_profile_layers(self._ctx, buf, len(buf)))
+        return buf.value.decode()
+
     def memory_stats(self):
         a, b = C.c_longlong(), C.c_longlong()
         self._check(self._lib.eg_memory_stats(self._ctx, C.byref(a), C.byref(b)))

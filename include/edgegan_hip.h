@@ -108,6 +108,9 @@ int eg_comm_reduce_scalars(eg_ctx* ctx, float* inout, int n, int op);
  * end writes a JSON object {"kernels":[{"name","launches","ms","flops"}...]} into buf. */
 int eg_profile_begin(eg_ctx* ctx);
 int eg_profile_end(eg_ctx* ctx, char* buf, int cap);
+/* one CSV line per recorded launch: "<variable> <fwd|dgrad|wgrad>", kernel, GEMM shape, microseconds, GFLOP --
+ * the per-layer roofline table of profiles/ (tools/layer_table.py) */
+int eg_profile_layers(eg_ctx* ctx, char* buf, long long cap);
 int eg_memory_stats(eg_ctx* ctx, long long* arena_peak_bytes, long long* arena_reserved_bytes);
 
 /* ---- per-op / per-network test entry points (parity tests against oracle/) ----------------------
