@@ -62,7 +62,7 @@ class Config:
 
 EXPORTS = ['eg_default_config', 'eg_variable_count', 'eg_variable_info', 'eg_create', 'eg_destroy',
            'eg_last_error', 'eg_set_variable', 'eg_get_variable', 'eg_upload_batch', 'eg_substep',
-           'eg_train_step', 'eg_read_losses', 'eg_infer', 'eg_sync', 'eg_comm_unique_id', 'eg_comm_init',
+           'eg_train_step', 'eg_read_losses', 'eg_infer', 'eg_infer_upload', 'eg_infer_run', 'eg_infer_download', 'eg_sync', 'eg_comm_unique_id', 'eg_comm_init',
            'eg_comm_reduce_scalars',
            'eg_profile_begin', 'eg_profile_end', 'eg_profile_layers', 'eg_memory_stats', 'eg_test_op', 'eg_net_forward', 'eg_crc32c']
 
@@ -92,6 +92,9 @@ def load_library() -> C.CDLL:
     lib.eg_train_step.argtypes = [C.c_void_p]
     lib.eg_read_losses.argtypes = [C.c_void_p, fp]
     lib.eg_infer.argtypes = [C.c_void_p, fp, ip, C.c_int, fp, fp, fp]
+    lib.eg_infer_upload.argtypes = [C.c_void_p, fp, ip, C.c_int, fp]
+    lib.eg_infer_run.argtypes = [C.c_void_p]
+    lib.eg_infer_download.argtypes = [C.c_void_p, fp, fp]
     lib.eg_sync.argtypes = [C.c_void_p]
     lib.eg_comm_unique_id.argtypes = [C.c_void_p, C.c_char_p]
     lib.eg_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]

@@ -217,39 +217,69 @@ int eg_read_losses(eg_ctx* ctx, float* out12) {
   EG_API_END(ctx)
 }
 
-int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const float* eps2, float* edge_out,
-             float* image_out) {
+// staging buffers of the inference entry points: grown on demand and kept (no allocation on the steady-state path)
+static void infer_reserve(Ctx& c, int nb) {
+  const Config& cfg = c.cfg;
+  EG_CHECK(nb >= 1 && nb <= 4096, "nb out of range");
+  const size_t in_n = (size_t)nb * cfg.H * cfg.W * cfg.c_dim, out_n = in_n / 2;
+  if ((size_t)nb <= c.inf_cap) return;
+  (void)hipFree(c.inf_in);
+  (void)hipFree(c.inf_edge);
+  (void)hipFree(c.inf_image);
+  (void)hipFree(c.inf_cls);
+  c.inf_in = c.inf_edge = c.inf_image = nullptr;
+  c.inf_cls = nullptr;
+  c.inf_cap = 0;
+  EG_HIP(hipMalloc(&c.inf_in, in_n * 4));
+  EG_HIP(hipMalloc(&c.inf_edge, out_n * 4));
+  EG_HIP(hipMalloc(&c.inf_image, out_n * 4));
+  EG_HIP(hipMalloc(&c.inf_cls, (size_t)nb * 4));
+  if (!c.inf_eps) EG_HIP(hipMalloc(&c.inf_eps, 8));
+  c.inf_cap = nb;
+}
+
+int eg_infer_upload(eg_ctx* ctx, const float* images, const int* classes, int nb, const float* eps2) {
   EG_API_BEGIN_CTX(ctx)
   Ctx& c = ctx->c;
   const Config& cfg = c.cfg;
-  EG_CHECK(nb >= 1 && nb <= 4096, "nb out of range");
+  EG_CHECK(images && eps2, "null argument");
   EG_CHECK(!cfg.multiclasses() || classes, "classes required");
-  const size_t in_n = (size_t)nb * cfg.H * cfg.W * cfg.c_dim, out_n = in_n / 2;
-  if ((size_t)nb > c.inf_cap) {   // staging buffers are kept between calls (no allocation on the steady-state path)
-    (void)hipFree(c.inf_in);
-    (void)hipFree(c.inf_edge);
-    (void)hipFree(c.inf_image);
-    (void)hipFree(c.inf_cls);
-    c.inf_in = c.inf_edge = c.inf_image = nullptr;
-    c.inf_cls = nullptr;
-    c.inf_cap = 0;
-    EG_HIP(hipMalloc(&c.inf_in, in_n * 4));
-    EG_HIP(hipMalloc(&c.inf_edge, out_n * 4));
-    EG_HIP(hipMalloc(&c.inf_image, out_n * 4));
-    EG_HIP(hipMalloc(&c.inf_cls, (size_t)nb * 4));
-    if (!c.inf_eps) EG_HIP(hipMalloc(&c.inf_eps, 8));
-    c.inf_cap = nb;
-  }
-  float *d_in = c.inf_in, *d_e = c.inf_edge, *d_i = c.inf_image, *d_eps = c.inf_eps;
-  int* d_cls = c.inf_cls;
-  EG_HIP(hipMemcpyAsync(d_in, images, in_n * 4, hipMemcpyHostToDevice, c.stream));
-  EG_HIP(hipMemcpyAsync(d_eps, eps2, 8, hipMemcpyHostToDevice, c.stream));
-  if (classes) EG_HIP(hipMemcpyAsync(d_cls, classes, (size_t)nb * 4, hipMemcpyHostToDevice, c.stream));
-  infer(c, d_in, d_cls, nb, d_eps, d_e, d_i);
-  EG_HIP(hipMemcpyAsync(edge_out, d_e, out_n * 4, hipMemcpyDeviceToHost, c.stream));
-  EG_HIP(hipMemcpyAsync(image_out, d_i, out_n * 4, hipMemcpyDeviceToHost, c.stream));
+  infer_reserve(c, nb);
+  const size_t in_n = (size_t)nb * cfg.H * cfg.W * cfg.c_dim;
+  EG_HIP(hipMemcpyAsync(c.inf_in, images, in_n * 4, hipMemcpyHostToDevice, c.stream));
+  EG_HIP(hipMemcpyAsync(c.inf_eps, eps2, 8, hipMemcpyHostToDevice, c.stream));
+  if (classes) EG_HIP(hipMemcpyAsync(c.inf_cls, classes, (size_t)nb * 4, hipMemcpyHostToDevice, c.stream));
+  c.inf_nb = nb;
   EG_HIP(hipStreamSynchronize(c.stream));
   EG_API_END(ctx)
+}
+
+int eg_infer_run(eg_ctx* ctx) {
+  EG_API_BEGIN_CTX(ctx)
+  Ctx& c = ctx->c;
+  EG_CHECK(c.inf_nb > 0, "eg_infer_run without eg_infer_upload");
+  infer(c, c.inf_in, c.inf_cls, c.inf_nb, c.inf_eps, c.inf_edge, c.inf_image);
+  EG_API_END(ctx)
+}
+
+int eg_infer_download(eg_ctx* ctx, float* edge_out, float* image_out) {
+  EG_API_BEGIN_CTX(ctx)
+  Ctx& c = ctx->c;
+  const Config& cfg = c.cfg;
+  EG_CHECK(c.inf_nb > 0 && edge_out && image_out, "eg_infer_download: nothing resident / null argument");
+  const size_t out_n = (size_t)c.inf_nb * cfg.H * (cfg.W / 2) * cfg.c_dim;
+  EG_HIP(hipMemcpyAsync(edge_out, c.inf_edge, out_n * 4, hipMemcpyDeviceToHost, c.stream));
+  EG_HIP(hipMemcpyAsync(image_out, c.inf_image, out_n * 4, hipMemcpyDeviceToHost, c.stream));
+  EG_HIP(hipStreamSynchronize(c.stream));
+  EG_API_END(ctx)
+}
+
+int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const float* eps2, float* edge_out,
+             float* image_out) {
+  int rc = eg_infer_upload(ctx, images, classes, nb, eps2);
+  if (rc == 0) rc = eg_infer_run(ctx);
+  if (rc == 0) rc = eg_infer_download(ctx, edge_out, image_out);
+  return rc;
 }
 
 int eg_sync(eg_ctx* ctx) {

@@ -128,6 +128,7 @@ struct Ctx {
   float *inf_in = nullptr, *inf_edge = nullptr, *inf_image = nullptr, *inf_eps = nullptr;
   int* inf_cls = nullptr;
   size_t inf_cap = 0;   // images the buffers hold
+  int inf_nb = 0;       // images currently resident (eg_infer_upload)
 
   // profiling
   bool prof_on = false;

@@ -151,6 +151,28 @@ class EdgeGAN:
                                        fptr(eps2), fptr(edge), fptr(image)))
         return edge, image
 
+    def infer_upload(self, images: np.ndarray, classes: Optional[np.ndarray] = None, eps2=(0.0, 0.0)):
+        """Makes an inference batch resident in HBM (the feed_dict copy of edgegan.py:606-609)."""
+        cfg = self.config
+        images = np.ascontiguousarray(images, dtype=np.float32)
+        assert images.shape[1:] == (cfg.height, cfg.width, cfg.c_dim)
+        cls = np.ascontiguousarray(classes, dtype=np.int32) if cfg.multiclasses else None
+        eps2 = np.ascontiguousarray(np.asarray(eps2, dtype=np.float32).reshape(2))
+        self._infer_nb = images.shape[0]
+        self._check(self._lib.eg_infer_upload(self._ctx, fptr(images), iptr(cls) if cls is not None else None,
+                                              images.shape[0], fptr(eps2)))
+
+    def infer_run(self):
+        """E -> G1, E -> G2 on the resident batch (enqueue only)."""
+        self._check(self._lib.eg_infer_run(self._ctx))
+
+    def infer_download(self):
+        cfg = self.config
+        edge = np.empty((self._infer_nb, cfg.height, cfg.width // 2, cfg.c_dim), dtype=np.float32)
+        image = np.empty_like(edge)
+        self._check(self._lib.eg_infer_download(self._ctx, fptr(edge), fptr(image)))
+        return edge, image
+
     # -- data parallel ----------------------------------------------------------------------------
     def comm_unique_id(self) -> bytes:
         buf = C.create_string_buffer(128)

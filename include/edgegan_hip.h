@@ -90,6 +90,12 @@ int eg_read_losses(eg_ctx* ctx, float* out12);
  *      (ignored without classes), eps2 = the two scalar encoder draws; outputs [nb,H,W/2,3]. ---- */
 int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const float* eps2, float* edge_out,
              float* image_out);
+/* the same in three steps, for callers that keep a batch resident in HBM (serving loops, bench.py --mode infer):
+ * upload = the feed_dict copy, run = the two sess.run calls (enqueue only), download = the fetch + sync.
+ * eg_infer is exactly upload + run + download. */
+int eg_infer_upload(eg_ctx* ctx, const float* images, const int* classes, int nb, const float* eps2);
+int eg_infer_run(eg_ctx* ctx);
+int eg_infer_download(eg_ctx* ctx, float* edge_out, float* image_out);
 
 int eg_sync(eg_ctx* ctx);
 
