@@ -217,6 +217,37 @@ int eg_read_losses(eg_ctx* ctx, float* out12) {
   EG_API_END(ctx)
 }
 
+int eg_eval_losses(eg_ctx* ctx, const float* alpha, float eps, int bn_updates, const eg_eval_outputs* out) {
+  EG_API_BEGIN_CTX(ctx)
+  Ctx& c = ctx->c;
+  const Config& cfg = c.cfg;
+  const int B = cfg.B;
+  EG_CHECK(alpha && out && out->losses12, "null argument");
+  EG_CHECK(bn_updates >= 0 && bn_updates <= 64, "bn_updates out of range");
+  float* d_alpha = c.d_eval + 16 + (size_t)6 * B;
+  float* d_eps = d_alpha + (size_t)3 * B;
+  EG_HIP(hipMemcpyAsync(d_alpha, alpha, (size_t)3 * B * 4, hipMemcpyHostToDevice, c.stream));
+  EG_HIP(hipMemcpyAsync(d_eps, &eps, 4, hipMemcpyHostToDevice, c.stream));
+  EG_HIP(hipStreamSynchronize(c.stream));   // `eps` lives on this frame
+  EvalResult r;
+  eval_losses(c, d_alpha, d_eps, bn_updates, &r);
+  auto down = [&](float* host, const float* dev, size_t n) {
+    if (host) EG_HIP(hipMemcpyAsync(host, dev, n * 4, hipMemcpyDeviceToHost, c.stream));
+  };
+  down(out->losses12, c.d_eval, L_COUNT);
+  down(out->d_logits, c.d_eval + 16, (size_t)6 * B);
+  const size_t half = (size_t)B * cfg.H * (cfg.W / 2) * cfg.c_dim, rs = (size_t)B * cfg.dis_size * cfg.dis_size * cfg.c_dim;
+  down(out->edge_output, r.edge, half);
+  down(out->image_output, r.image, half);
+  const bool same = cfg.H == cfg.dis_size && cfg.W / 2 == cfg.dis_size;   // resize is the identity then
+  down(out->resized_inputs, r.resized[0], same ? half : rs);
+  down(out->resized_image_output, r.resized[1], same ? half : rs);
+  down(out->resized_edges, r.resized[2], same ? half : rs);
+  down(out->resized_edge_output, r.resized[3], same ? half : rs);
+  EG_HIP(hipStreamSynchronize(c.stream));
+  EG_API_END(ctx)
+}
+
 // staging buffers of the inference entry points: grown on demand and kept (no allocation on the steady-state path)
 static void infer_reserve(Ctx& c, int nb) {
   const Config& cfg = c.cfg;

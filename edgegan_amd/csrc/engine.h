@@ -101,6 +101,7 @@ struct Ctx {
   // resident batch (device)
   float *d_images = nullptr, *d_z = nullptr, *d_alpha = nullptr, *d_eps = nullptr;
   float* d_losses = nullptr;  // [64]
+  float* d_eval = nullptr;    // eval_losses: [16 losses | 6 x B discriminator logits | 3 x B alpha | 4 eps]
   int* d_classes = nullptr;
   long long step_count = 0;
   // generator outputs of the D-phase (sub-steps 1-3 share G1(z), G2(z): G is frozen until sub-step 5)
@@ -241,6 +242,10 @@ struct SubOpts {
 };
 void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts = nullptr);
 void train_step(Ctx& c);
+struct EvalResult {   // device pointers valid until the next enqueueing call
+  const float *edge = nullptr, *image = nullptr, *resized[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+void eval_losses(Ctx& c, const float* alpha_dev, const float* eps_dev, int bn_updates, EvalResult* r);
 void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const float* d_eps2, float* d_edge,
            float* d_image);
 

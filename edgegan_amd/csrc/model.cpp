@@ -233,6 +233,8 @@ void build_context(Ctx& c) {
   EG_HIP(hipMalloc(&c.d_eps, 16 * 4));
   EG_HIP(hipMalloc(&c.d_losses, 64 * 4));
   EG_HIP(hipMalloc(&c.d_classes, (size_t)cfg.B * 4));
+  EG_HIP(hipMalloc(&c.d_eval, ((size_t)16 + 6 * cfg.B + 3 * cfg.B + 4) * 4));   // [16 losses | 6 x B logits | alpha | eps]
+  EG_HIP(hipMemsetAsync(c.d_eval, 0, ((size_t)16 + 9 * cfg.B + 4) * 4, c.stream));
   for (int i = 0; i < 2; ++i) {
     EG_HIP(hipMalloc(&c.d_gen_cache[i], img / 2 * 4));
     EG_HIP(hipMalloc(&c.d_gen_bn[i], (size_t)2 * cfg.gf * 8 * 4));
@@ -762,6 +764,76 @@ void train_step(Ctx& c) {
   }
   join(2);
   ++c.step_count;
+}
+
+// Forward-only evaluation of every loss with the CURRENT weights -- what the reference's observe-only runs compute
+// after update_model (sess.run(d_sum), sess.run(g_sum) and the five evaluate() calls of edgegan.py:427-433,464-480):
+// fresh random_blend draws (alpha), a fresh encoder noise scalar, and the generators' BatchNorm moving statistics
+// advanced once per run that evaluates them (bn_updates; 6 mirrors the reference loop: d_sum, g_sum, joint_dis_dloss,
+// one patch loss, edge_gloss, image_gloss).  The gradient penalty still needs the input gradient of each
+// discriminator (one first-order reverse sweep, no parameter gradients).
+void eval_losses(Ctx& c, const float* alpha_dev, const float* eps_dev, int bn_updates, EvalResult* r) {
+  const Config& cfg = c.cfg;
+  const int B = cfg.B;
+  comm_wait_all(c);
+  reset_step(c);
+  for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);
+  T images = wrap_tensor(c, c.d_images, B, cfg.H, cfg.W, cfg.c_dim);
+  T zin = make_zin(c);
+  T edge = generator_forward(c, G_G1, zin, bn_updates);
+  T image = generator_forward(c, G_G2, zin, bn_updates);
+  T joint = concat_w(c, edge, image);
+  T r_pic = resize(c, right_half(c, images), cfg.dis_size), r_img = resize(c, image, cfg.dis_size);
+  T r_edges = resize(c, left_half(c, images), cfg.dis_size), r_edge_out = resize(c, edge, cfg.dis_size);
+  float* L = c.d_eval;
+  struct Branch {
+    int group;
+    T real, fake;
+    int slot_d, slot_gp, slot_g;
+  } br[3] = {{G_D, images, joint, L_JOINT_D, L_JOINT_GP, L_JOINT_G},
+             {G_DP2, r_pic, r_img, L_IMAGE_D, L_IMAGE_GP, L_IMAGE_G},
+             {G_DP3, r_edges, r_edge_out, L_EDGE_D, L_EDGE_GP, L_EDGE_G}};
+  for (int i = 0; i < 3; ++i) {
+    const Branch& b = br[i];
+    T xhat = new_tensor(c, b.real->n, b.real->h, b.real->w, b.real->c, true);
+    const size_t per = xhat->numel() / B;
+    launch_blend(b.real->d, b.fake->d, alpha_dev + (size_t)i * B, xhat->d, B, per, c.stream);
+    const size_t mark = c.tape.ops.size();
+    T d_hat = disc_forward(c, b.group, xhat, nullptr, nullptr);
+    seed_grad(c, d_hat);
+    launch_gp_head(d_hat->d, nullptr, d_hat->g, nullptr, B, 0, c.stream);
+    c.param_grad_enabled = false;
+    c.tape.backward_range(mark, c.tape.ops.size());
+    c.param_grad_enabled = true;
+    float* v = c.arena.allocf(xhat->numel());
+    float* norms = c.arena.allocf(B);
+    launch_gp_v(xhat->g, v, norms, L + b.slot_gp, B, per, cfg.lambda_gp, c.stream);
+    c.tape.ops.resize(mark);
+    reset_grads(c);
+    T rf = new_tensor(c, 2 * B, b.real->h, b.real->w, b.real->c, false);
+    launch_copy(b.real->d, rf->d, b.real->numel(), c.stream);
+    launch_copy(b.fake->d, rf->d + b.real->numel(), b.fake->numel(), c.stream);
+    T d_rf = disc_forward(c, b.group, rf, nullptr, nullptr);
+    launch_mean_diff(d_rf->d + B, d_rf->d, L + b.slot_d, B, c.stream);
+    launch_mean_neg(d_rf->d + B, L + b.slot_g, B, c.stream);
+    launch_copy(d_rf->d, c.d_eval + 16 + (size_t)i * 2 * B, (size_t)2 * B, c.stream);   // logits: real [B] | fake [B]
+  }
+  if (cfg.multiclasses()) {
+    T lr = classifier_forward(c, right_half(c, images));
+    launch_acgan_loss(lr->d, c.d_z + cfg.z_dim, cfg.z_dim + 1, L + L_CLS_D, nullptr, B, cfg.num_classes, 0, c.scratch, c.stream);
+    T lf = classifier_forward(c, image);
+    launch_acgan_loss(lf->d, c.d_z + cfg.z_dim, cfg.z_dim + 1, L + L_CLS_G, nullptr, B, cfg.num_classes, 1, c.scratch, c.stream);
+  }
+  T zr = encoder_forward(c, edge, eps_dev);
+  launch_l1(c.d_z, cfg.multiclasses() ? cfg.z_dim + 1 : cfg.z_dim, zr->d, L + L_ZL, nullptr, B, cfg.z_dim, cfg.zl_weight,
+            c.stream);
+  c.tape.clear();
+  r->edge = edge->d;
+  r->image = image->d;
+  r->resized[0] = r_pic->d;
+  r->resized[1] = r_img->d;
+  r->resized[2] = r_edges->d;
+  r->resized[3] = r_edge_out->d;
 }
 
 // edgegan.py:492-517,606-609: E(left half) -> z (+ one-hot) -> G1 ; second run -> G2 (own eps draw)

@@ -1049,6 +1049,7 @@ Ctx::~Ctx() {
   (void)hipFree(d_alpha);
   (void)hipFree(d_eps);
   (void)hipFree(d_losses);
+  (void)hipFree(d_eval);
   (void)hipFree(d_classes);
   for (int i = 0; i < 2; ++i) {
     (void)hipFree(d_gen_cache[i]);

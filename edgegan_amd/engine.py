@@ -12,7 +12,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from ._lib import Config, EdgeGANLibError, fptr, iptr, load_library, variable_specs
+from ._lib import Config, EdgeGANLibError, _CEvalOutputs, fptr, iptr, load_library, variable_specs
 
 SUBSTEPS = ['d_optim', 'd_optim_patch2', 'd_optim_patch3', 'd_optim2', 'g_optim_u', 'e_optim', 'g_optim_b']
 LOSS_NAMES = ['joint_wgan', 'joint_gp', 'image_wgan', 'image_gp', 'edge_wgan', 'edge_gp', 'loss_d_ac',
@@ -113,9 +113,40 @@ class EdgeGAN:
         self.upload_batch(images, z, alpha, eps)
         self.train_step()
 
+    def evaluate(self, alpha=None, eps=None, bn_updates: int = 0, tensors: bool = False) -> Dict[str, object]:
+        """Post-update evaluation with the reference's semantics (edgegan.py:427-433,464-480): forward-only on the
+        resident batch with the CURRENT weights and fresh alpha / eps draws.  Returns the losses (same keys as
+        losses()); with tensors=True also 'd_logits' [6,B] and the generator outputs / resized tensors the reference's
+        histogram and image summaries show.  bn_updates: BatchNorm moving-average updates applied per generator
+        (6 mirrors the reference's seven observe-only runs per iteration; 0 = none)."""
+        cfg = self.config
+        B = cfg.batch_size
+        alpha = self._rng_alpha.uniform(0, 1, size=(3, B)) if alpha is None else alpha
+        eps = float(self._rng_eps.normal()) if eps is None else float(np.asarray(eps).reshape(-1)[0])
+        alpha = np.ascontiguousarray(alpha, dtype=np.float32)
+        assert alpha.shape == (3, B)
+        out = {'losses12': np.zeros(12, dtype=np.float32)}
+        if tensors:
+            half = (B, cfg.height, cfg.width // 2, cfg.c_dim)
+            rs = half if (cfg.height, cfg.width // 2) == (cfg.dis_size, cfg.dis_size) else (B, cfg.dis_size, cfg.dis_size, cfg.c_dim)
+            out.update(d_logits=np.zeros((6, B), np.float32), edge_output=np.zeros(half, np.float32),
+                       image_output=np.zeros(half, np.float32), resized_inputs=np.zeros(rs, np.float32),
+                       resized_image_output=np.zeros(rs, np.float32), resized_edges=np.zeros(rs, np.float32),
+                       resized_edge_output=np.zeros(rs, np.float32))
+        co = _CEvalOutputs(**{k: fptr(v.reshape(-1)) for k, v in out.items()})
+        self._check(self._lib.eg_eval_losses(self._ctx, fptr(alpha), eps, int(bn_updates), C.byref(co)))
+        d = self._compose_losses(out.pop('losses12'))
+        d.update(out)
+        return d
+
     def losses(self) -> Dict[str, float]:
+        """Losses captured INSIDE the sub-steps of the last iteration (pre-update / mixed-stage weights; free).  The
+        reference prints post-update re-evaluations instead: evaluate()."""
         out = np.zeros(12, dtype=np.float32)
         self._check(self._lib.eg_read_losses(self._ctx, fptr(out)))
+        return self._compose_losses(out)
+
+    def _compose_losses(self, out) -> Dict[str, float]:
         d = dict(zip(LOSS_NAMES, out.tolist()))
         # composites the reference evaluates / prints (edgegan.py:278-321,468-486)
         d['joint_dis_dloss'] = d['joint_wgan'] + d['joint_gp']

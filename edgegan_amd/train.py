@@ -21,7 +21,7 @@ from . import checkpoint, flags as F
 from ._lib import Config
 from .data import Dataset, Prefetcher
 from .engine import EdgeGAN
-from .summary import SCALAR_TAGS, SummaryWriter
+from .summary import HISTOGRAM_TAGS, IMAGE_TAGS, SCALAR_TAGS, SummaryWriter
 
 
 def update_flags(fl):
@@ -104,7 +104,17 @@ def main(argv=None):
         steps = len(dataset) // world
         for it, (idx, images, z, _) in enumerate(Prefetcher(dataset, rank_batches(len(dataset), world, rank))):
             net.update_model(images, z)                                              # edgegan.py:461
-            l = net.losses()                                                         # edgegan.py:464-481
+            if fl.reference_evaluation:      # the reference's observe-only runs: post-update weights, fresh draws, BN x6
+                l = net.evaluate(bn_updates=6, tensors=writer is not None)           # edgegan.py:427-433,464-481
+                if writer is not None:
+                    hist = {t: (1.0 / (1.0 + np.exp(-l[k][i]))) for t, (k, i) in HISTOGRAM_TAGS.items()}   # D = sigmoid(logits)
+                    hist['z'] = z
+                    writer.add_histograms(hist, counter)
+                    imgs = {t: l[k] for t, k in IMAGE_TAGS.items()}
+                    imgs['inputs'] = images
+                    writer.add_images(imgs, counter)
+            else:                            # default: the values the sub-steps computed on their way (no extra passes)
+                l = net.losses()
             discriminator_err = l['joint_dis_dloss'] + l['image_dis_dloss'] + l['edge_dis_dloss']
             generator_err = l['edge_gloss'] + l['image_gloss']
             if writer is not None:                                                   # edgegan.py:427-433,462

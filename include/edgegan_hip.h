@@ -85,6 +85,28 @@ int eg_train_step(eg_ctx* ctx);
  *              joint_dis_gloss, edge_dis_gloss, image_dis_gloss, loss_g_ac, zl_loss */
 int eg_read_losses(eg_ctx* ctx, float* out12);
 
+/* Post-update evaluation with the reference's semantics -- replaces the observe-only runs the reference issues AFTER
+ * update_model: sess.run(d_sum), sess.run(g_sum) (models/edgegan.py:427-433) and the five evaluate() calls
+ * (models/edgegan.py:464-480).  Forward-only on the resident batch with the CURRENT weights; alpha [3][B] and eps are
+ * the fresh random_blend / encoder-noise draws those runs make (caller-supplied); bn_updates = how many times the
+ * generators' BatchNorm moving statistics are advanced (contrib batch_norm updates them in every run that evaluates
+ * a generator: 6 mirrors one iteration of the reference loop, 0 leaves them alone).  losses12 as eg_read_losses;
+ * every other pointer is optional (NULL = not wanted) and feeds the histogram / image summaries of
+ * models/edgegan.py:344-411: d_logits [6][B] = joint real, joint fake, image real, image fake, edge real, edge fake
+ * (D_logits; "d" / "d_" are their sigmoids); edge_output / image_output [B,H,W/2,3] ("G1", "G2"); the four resized
+ * tensors [B,dis,dis,3] ("resized_inputs_image", "resized_G_image", "resized_inputs_p3_image", "resized_G_p3_image"). */
+typedef struct eg_eval_outputs {
+  float* losses12;
+  float* d_logits;
+  float* edge_output;
+  float* image_output;
+  float* resized_inputs;
+  float* resized_image_output;
+  float* resized_edges;
+  float* resized_edge_output;
+} eg_eval_outputs;
+int eg_eval_losses(eg_ctx* ctx, const float* alpha, float eps, int bn_updates, const eg_eval_outputs* out);
+
 /* ---- inference: replaces the two sess.run calls of EdgeGAN.test (models/edgegan.py:606-609) on
  *      the graph of define_test_input (models/edgegan.py:492-517).  images [nb,H,W,3], classes [nb]
  *      (ignored without classes), eps2 = the two scalar encoder draws; outputs [nb,H,W/2,3]. ---- */

@@ -165,3 +165,36 @@ def test_reference_example_images_through_the_pipeline():
     raw = np.array(Image.open(files[0])).astype(np.float64)
     if raw.min() == 0 and raw.max() == 255:
         assert np.allclose(images[0], raw / 127.5 - 1.0, atol=1e-6)
+
+
+def test_histogram_and_image_summaries(tmp_path):
+    """f4: tf.summary.histogram / tf.summary.image members of d_sum / g_sum (edgegan.py:344-411) without TF."""
+    import struct
+    from edgegan_amd import summary as S
+    lim = S.default_bucket_limits()
+    assert lim[len(lim) // 2] == 0.0 and lim[-1] == np.finfo(np.float64).max and np.all(np.diff(lim) > 0)
+    assert abs(lim[len(lim) // 2 + 1] - 1e-12) < 1e-24 and abs(lim[len(lim) // 2 + 2] / lim[len(lim) // 2 + 1] - 1.1) < 1e-12
+    v = np.array([-1.5, 0.0, 0.25, 0.25, 3.0])
+    pb = S.histogram_proto(v)
+    from edgegan_amd.tf_bundle import _pb_fields
+    f = {k: x for k, _, x in _pb_fields(pb)}
+    dbl = lambda x: struct.unpack('<d', struct.pack('<Q', x))[0]
+    assert dbl(f[1]) == -1.5 and dbl(f[2]) == 3.0 and dbl(f[3]) == 5 and dbl(f[4]) == 2.0 and dbl(f[5]) == 11.375
+    limits = np.frombuffer(f[6], dtype='<f8')
+    counts = np.frombuffer(f[7], dtype='<f8')
+    assert len(limits) == len(counts) and counts.sum() == 5 and np.all(np.diff(limits) > 0)
+    for x in v:                                   # every value sits in the first bucket whose limit exceeds it
+        i = np.searchsorted(limits, x, side='right')
+        assert counts[i] >= 1
+    # float image normalisation: negatives -> 128-centred, non-negative -> max to 255
+    a = np.array([[[-1.0], [0.0]], [[0.5], [1.0]]], dtype=np.float32)
+    assert S.normalize_float_image(a).reshape(-1).tolist() == [1, 128, 191, 255]
+    assert S.normalize_float_image(np.abs(a)).reshape(-1).tolist() == [255, 0, 127, 255]
+    w = S.SummaryWriter(str(tmp_path))
+    w.add_histograms({'d': v, 'z': np.random.RandomState(0).normal(size=(4, 100))}, 3)
+    w.add_images({'G1': np.random.RandomState(1).uniform(-1, 1, size=(5, 8, 8, 3)).astype(np.float32)}, 3)
+    w.close()
+    ev = S.read_event_tags(w.path)
+    assert ev[1] == (3, {'d': 'histo', 'z': 'histo'})
+    assert ev[2] == (3, {'G1/image/0': 'image', 'G1/image/1': 'image', 'G1/image/2': 'image'})
+    S.read_events(w.path)                         # both CRCs of every record verify

@@ -202,6 +202,14 @@ def test_train_and_test_command_lines_end_to_end(tmp_path, monkeypatch):
     from edgegan_amd import summary
     ev = summary.read_events(str(next((out / 'logs').glob('events.out.tfevents.*'))))
     assert len(ev) == 1 + 2 and set(ev[1][1]) == set(summary.SCALAR_TAGS) and ev[1][0] == 1 and ev[2][0] == 2
+    # the reference's own read-back semantics: post-update evaluation + histogram / image summaries (edgegan.py:344-411)
+    TR.main(['--name=t2', f'--dataroot={root}', '--batch_size=2', '--epoch=1', '--reference_evaluation'])
+    tags = summary.read_event_tags(str(next((tmp_path / 'outputs' / 't2' / 'logs').glob('events.out.tfevents.*'))))
+    kinds = {}
+    for _, t in tags:
+        kinds.update(t)
+    assert kinds['d'] == kinds['edgeDfake'] == kinds['z'] == 'histo' and kinds['G1/image/0'] == kinds['inputs/image/1'] == 'image'
+    assert kinds['resized_G_p3_image/image/0'] == 'image' and kinds['joint_dis_dloss'] == 'scalar'
     TE.main(['--name=t1', f'--dataroot={root}'])
     pngs = sorted((out / 'test_output' / 'class14').rglob('*.png'))
     assert len(pngs) == 4
@@ -289,4 +297,51 @@ def test_inference_on_reference_example_sketches():
         e_ref, i_ref = om.infer(parity.t64(imgs), torch.tensor(cls), 0.3, -0.7)
         e, i = net.infer(imgs, cls, eps2=[0.3, -0.7])
         assert parity.relerr(e, e_ref.numpy()) < 1e-4 and parity.relerr(i, i_ref.numpy()) < 1e-4, files[0]
+    net.close()
+
+
+def test_post_update_evaluation_matches_oracle_forward_graph():
+    """eg_eval_losses = the reference's observe-only runs after update_model (edgegan.py:427-433,464-480): forward-only
+    with the current weights, caller-supplied alpha / eps, BatchNorm moving statistics advanced bn_updates times."""
+    cfg = ea.Config(batch_size=3)
+    values = ea.init_variables(cfg, 4)
+    b = ea.synthetic_batch(cfg, seed=21)
+    net = ea.EdgeGAN(cfg, values)
+    net.upload_batch(**b)
+    net.train_step()                      # evaluate with POST-update weights
+    cur = net.get_variables()
+    rng = np.random.RandomState(1)
+    alpha, eps = rng.uniform(size=(3, 3)).astype(np.float32), 0.7
+    ev = net.evaluate(alpha=alpha, eps=eps, bn_updates=6, tensors=True)
+    om = O.OracleModel(parity.oracle_config(cfg), cur, dtype=torch.float64)
+    inp = O.StepInputs(parity.t64(b['images']), parity.t64(b['z']), parity.t64(alpha), parity.t64([eps]))
+    bn = {}
+    ref = O.forward_graph(om.p, inp, om.cfg, eps, bn_stats=bn)
+    for k in ('joint_dis_dloss', 'image_dis_dloss', 'edge_dis_dloss', 'loss_d_ac', 'edge_gloss', 'image_gloss', 'zl_loss',
+              'joint_dis_gloss', 'edge_dis_gloss', 'image_dis_gloss', 'loss_g_ac'):
+        assert abs(ev[k] - float(ref[k])) <= 2e-4 * abs(float(ref[k])) + 1e-6, (k, ev[k], float(ref[k]))
+    # discriminator logits behind the "d" / "d_" / "imageD" ... histograms
+    W2 = cfg.width // 2
+    edge, image = O.generator(om.p, 'G1', O.z_onehot(inp.z, om.cfg)[0], om.cfg), O.generator(om.p, 'G2', O.z_onehot(inp.z, om.cfg)[0], om.cfg)
+    assert parity.relerr(ev['edge_output'], edge.detach().numpy()) < 1e-4
+    assert parity.relerr(ev['image_output'], image.detach().numpy()) < 1e-4
+    d_real = O.discriminator(om.p, 'D', inp.images)[1].detach().numpy().reshape(-1)
+    d_fake = O.discriminator(om.p, 'D', torch.cat([edge, image], dim=2))[1].detach().numpy().reshape(-1)
+    assert parity.relerr(ev['d_logits'][0], d_real) < 1e-3 and parity.relerr(ev['d_logits'][1], d_fake) < 1e-3
+    r_edges = O.resize_bicubic(inp.images[:, :, :W2, :], cfg.dis_size).numpy()
+    assert parity.relerr(ev['resized_edges'], r_edges) < 1e-5
+    # BatchNorm moving statistics advanced 6 times with the (identical) batch statistics of this forward
+    for g in ('G1', 'G2'):
+        bm, bv, n = bn[g]
+        for name, stat in (('moving_mean', bm), ('moving_variance', bv * (n / (n - 1)))):
+            vn = f'{g}/batch_norm/BatchNorm/{name}'
+            want = torch.tensor(cur[vn], dtype=torch.float64)
+            for _ in range(6):
+                want = 0.9 * want + 0.1 * stat
+            assert parity.relerr(net.get_variable(vn), want.numpy()) < 1e-4, vn
+    # the weights themselves are untouched by an evaluation
+    after = net.get_variables()
+    for k, v in cur.items():
+        if 'moving_' not in k:
+            assert np.array_equal(v, after[k]), k
     net.close()
