@@ -14,8 +14,10 @@ the published pretrained model (README.md:69):
   tensorflow/core/util/tensor_bundle/tensor_bundle.cc).
 * ``.data-XXXXX-of-YYYYY`` holds the raw little-endian tensor bytes at the recorded offsets.
 
-Verified here by round trips and the format's own invariants (magic, per-block and per-tensor CRCs); it could
-not be cross-checked against TensorFlow itself in this environment (no TF available) -- see DESIGN.md.
+Verified here by round trips, the format's own invariants (magic, per-block and per-tensor CRCs) and, byte for byte,
+against a bundle laid out BY HAND from the format specification by an independent script
+(tests/golden/make_bundle_golden.py -> tests/golden/bundle_golden.*).  It could not be cross-checked against
+TensorFlow itself in this environment (no TF available) -- see DESIGN.md.
 """
 from __future__ import annotations
 
@@ -237,22 +239,49 @@ def _write_block(f, contents: bytes) -> Tuple[int, int]:
     return off, len(contents)
 
 
+def _shortest_separator(start: bytes, limit: bytes) -> bytes:
+    """table_builder.cc FindShortestSeparator: a short key k with start <= k < limit (index key between two blocks)."""
+    n = min(len(start), len(limit))
+    i = 0
+    while i < n and start[i] == limit[i]:
+        i += 1
+    if i < n and start[i] < 0xff and start[i] + 1 < limit[i]:
+        return start[:i] + bytes([start[i] + 1])
+    return start
+
+
+def _short_successor(key: bytes) -> bytes:
+    """table_builder.cc FindShortSuccessor: a short key >= key (index key of the last block)."""
+    for i, b in enumerate(key):
+        if b != 0xff:
+            return key[:i] + bytes([b + 1])
+    return key
+
+
 def write_table(path: str, items: List[Tuple[bytes, bytes]]):
+    """TableBuilder::Add / Flush / Finish: the index entry of a flushed block is added when the NEXT key arrives (a
+    shortest separator between the two) or at Finish (a short successor of the last key)."""
     items = sorted(items, key=lambda kv: kv[0])
     with open(path, 'wb') as f:
         index = _BlockBuilder(1)
         blk = _BlockBuilder(RESTART_INTERVAL)
         last_key = b''
+        pending = None                                   # handle of a flushed block whose index entry is still due
         for k, v in items:
+            if pending is not None:
+                index.add(_shortest_separator(last_key, k), pending)
+                pending = None
             blk.add(k, v)
             last_key = k
             if blk.size_estimate() >= BLOCK_SIZE:
                 off, size = _write_block(f, blk.finish())
-                index.add(last_key, _varint(off) + _varint(size))
+                pending = _varint(off) + _varint(size)
                 blk = _BlockBuilder(RESTART_INTERVAL)
-        if not blk.empty() or not items:
+        if not blk.empty():
             off, size = _write_block(f, blk.finish())
-            index.add(last_key, _varint(off) + _varint(size))
+            pending = _varint(off) + _varint(size)
+        if pending is not None:
+            index.add(_short_successor(last_key), pending)
         meta_off, meta_size = _write_block(f, _BlockBuilder(RESTART_INTERVAL).finish())
         idx_off, idx_size = _write_block(f, index.finish())
         footer = _varint(meta_off) + _varint(meta_size) + _varint(idx_off) + _varint(idx_size)

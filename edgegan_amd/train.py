@@ -107,7 +107,7 @@ def main(argv=None):
             if fl.reference_evaluation:      # the reference's observe-only runs: post-update weights, fresh draws, BN x6
                 l = net.evaluate(bn_updates=6, tensors=writer is not None)           # edgegan.py:427-433,464-481
                 if writer is not None:
-                    hist = {t: (1.0 / (1.0 + np.exp(-l[k][i]))) for t, (k, i) in HISTOGRAM_TAGS.items()}   # D = sigmoid(logits)
+                    hist = {t: 0.5 * (1.0 + np.tanh(0.5 * l[k][i].astype(np.float64))) for t, (k, i) in HISTOGRAM_TAGS.items()}   # D = sigmoid(logits)
                     hist['z'] = z
                     writer.add_histograms(hist, counter)
                     imgs = {t: l[k] for t, k in IMAGE_TAGS.items()}
