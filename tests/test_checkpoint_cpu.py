@@ -149,7 +149,7 @@ def test_bundle_matches_hand_derived_golden_bytes(tmp_path):
     # known bytes: BundleHeaderProto{num_shards=1, version{producer=1}} and the table magic
     assert want_index[:9] == bytes.fromhex('00000608011a020801') and want_index[-8:] == bytes.fromhex('57fb808b247547db')
     # index-key helpers (table_builder.cc FindShortestSeparator / FindShortSuccessor)
-    assert B._short_successor(b'b/c') == b'c' and B._short_successor(b'\\xff\\xffa') == b'\\xff\\xffb'
+    assert B._short_successor(b'b/c') == b'c' and B._short_successor(b'\xff\xffa') == b'\xff\xffb'
     assert B._shortest_separator(b'abcd', b'abzz') == b'abd' and B._shortest_separator(b'ab', b'abc') == b'ab'
     assert B._shortest_separator(b'abc', b'abd') == b'abc'
 
