@@ -49,7 +49,9 @@ __device__ __forceinline__ int lds_swz(int row) { return ((-((row >> 2) & 3)) & 
 // =============================================================================================
 // conv_gemm_bf16_kernel
 // =============================================================================================
-template <int BM, int BN, int WTM, int WTN, bool SPLITK>
+// ABF: the gathered operand is read from a bf16 copy of the activation (a.x_bf, same [pixel][x_ps] layout): half the
+// bytes per K step through L2 (the kernel's limiter) and no conversion on the way into LDS.
+template <int BM, int BN, int WTM, int WTN, bool SPLITK, bool ABF>
 __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const ConvArgs a) {
   constexpr int WGN = BN / WTN;
   constexpr int MI = WTM / 16, NJ = WTN / 16;
@@ -106,9 +108,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const ConvArgs a
 
   // two register staging sets: the global loads of K tiles t+1 and t+2 are in flight while tile t is multiplied
   // (the kernel is bound by bytes in flight per CU, not by the MFMA pipe)
-  float4 ra0[A_V][2], ra1[A_V][2];
+  constexpr int AW = ABF ? 1 : 2;   // 16-byte registers per gathered 8-element chunk
+  float4 ra0[A_V][AW], ra1[A_V][AW];
   uint4 rb0[B_V], rb1[B_V];
-  auto load_tile = [&](float4 (&ra)[A_V][2], uint4 (&rb)[B_V]) {
+  auto load_tile = [&](float4 (&ra)[A_V][AW], uint4 (&rb)[B_V]) {
     const int ty = nx_ty, tx = nx_tx, c0 = nx_c0;
     const long long wt = (long long)((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * a.wbf_ts;
 #pragma unroll
@@ -120,12 +123,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const ConvArgs a
       }
       float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
       if (r_base[i] >= 0 && iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
-        const float* px = a.x + (size_t)(r_base[i] + iy * IW + ix) * a.x_ps + c0 + q8;
-        v0 = *reinterpret_cast<const float4*>(px);
-        v1 = *reinterpret_cast<const float4*>(px + 4);
+        if constexpr (ABF) {
+          v0 = *reinterpret_cast<const float4*>(a.x_bf + (size_t)(r_base[i] + iy * IW + ix) * a.x_ps + c0 + q8);
+        } else {
+          const float* px = a.x + (size_t)(r_base[i] + iy * IW + ix) * a.x_ps + c0 + q8;
+          v0 = *reinterpret_cast<const float4*>(px);
+          v1 = *reinterpret_cast<const float4*>(px + 4);
+        }
       }
       ra[i][0] = v0;
-      ra[i][1] = v1;
+      if constexpr (!ABF) ra[i][1] = v1;
     }
 #pragma unroll
     for (int i = 0; i < B_V; ++i) {
@@ -143,10 +150,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const ConvArgs a
       }
     }
   };
-  auto store_tile = [&](const float4 (&ra)[A_V][2], const uint4 (&rb)[B_V], int buf) {
+  auto store_tile = [&](const float4 (&ra)[A_V][AW], const uint4 (&rb)[B_V], int buf) {
 #pragma unroll
-    for (int i = 0; i < A_V; ++i)
-      *reinterpret_cast<uint4*>(&As[buf][((tid >> 2) + 64 * i) * ROWB + st8]) = pack_bf16x8(ra[i][0], ra[i][1]);
+    for (int i = 0; i < A_V; ++i) {
+      if constexpr (ABF)
+        *reinterpret_cast<float4*>(&As[buf][((tid >> 2) + 64 * i) * ROWB + st8]) = ra[i][0];
+      else
+        *reinterpret_cast<uint4*>(&As[buf][((tid >> 2) + 64 * i) * ROWB + st8]) = pack_bf16x8(ra[i][0], ra[i][AW - 1]);
+    }
 #pragma unroll
     for (int i = 0; i < B_V; ++i) *reinterpret_cast<uint4*>(&Bs[buf][((tid >> 2) + 64 * i) * ROWB + st8]) = rb[i];
   };
@@ -240,12 +251,15 @@ bool conv_bf16_eligible(const ConvArgs& a) {
 
 template <int BM, int BN, int WTM, int WTN>
 static void conv_bf16_launch(const ConvArgs& a, int maxM, hipStream_t s) {
+  const bool abf = a.x_bf != nullptr && (((uintptr_t)a.x_bf & 15) == 0) && a.x_ps % 8 == 0;
   if (a.ksplit > 1) {
     dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase * a.ksplit);
-    hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, WTM, WTN, true>), grid, dim3(256), 0, s, a);
+    if (abf) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, WTM, WTN, true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, WTM, WTN, true, false>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase);
-    hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, WTM, WTN, false>), grid, dim3(256), 0, s, a);
+    if (abf) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, WTM, WTN, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, WTM, WTN, false, false>), grid, dim3(256), 0, s, a);
   }
 }
 

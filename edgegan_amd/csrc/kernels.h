@@ -21,6 +21,7 @@ struct ConvPhase {
 
 struct ConvArgs {
   const float* x;    // [NB][IH][IW] pixels, x_ps floats per pixel, C channels used
+  const unsigned short* x_bf;   // optional bf16 copy of x (same pixel pitch, in elements): read by the bf16 kernels
   const float* wgt;  // element (tap wt, c, n) at wgt[wt*w_ts + c*ldw + n]
   const float* bias; // [N] or null
   const unsigned short* wgt_bf;  // optional bf16 filter, element (tap wt, n, c) at wgt_bf[wt*wbf_ts + n*ldwbf + c]:

@@ -240,6 +240,13 @@ static void run_conv(Ctx& c, ConvArgs& a) {
   a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
   a.ksplit = conv_pick_ksplit(a);
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
+  static const bool shadow_exp = getenv("EG_BF16_SHADOW_EXPERIMENT") != nullptr;
+  if (shadow_exp && a.wgt_bf && !a.x_bf && a.x_ps == a.C && a.C % 32 == 0 && a.N > 16) {
+    const size_t n = (size_t)a.NB * a.IH * a.IW * a.x_ps;
+    unsigned short* xb = reinterpret_cast<unsigned short*>(c.arena.allocf((n + 1) / 2));
+    launch_cvt_bf16(a.x, xb, n, c.stream);
+    a.x_bf = xb;
+  }
   const char* nm;
   ProfScope ps(c);
   const double fl = launch_conv_gemm(a, c.stream, &nm);
