@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = 93.551 - 2 * 0.3263
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (never the 2:1-sparse figure)
+X3_LIMB_PRODUCTS = 6            # limb products issued per fp32 product in f32x3 mode (edgegan_amd/csrc/k_gemm_x3.hip)
 
 
 def pmc_traffic(kernel_label):
@@ -112,6 +113,26 @@ def cpu_baseline(cfg_kwargs, batch_all=64, batch_one=2):
                             'sample': f'1 full iteration at batch {batch_one}, 1 thread, {dt_one:.1f} s'}}
 
 
+def alt_mode(ea, cfg_kwargs, values, batch, args):
+    """The same iteration with the dense contractions on the exact-fp32 MFMA instruction (compute_dtype 'f32'), timed in
+    the same process right after the main measurement: the two fp32 implementations side by side."""
+    cfg = ea.Config(**cfg_kwargs)
+    n2 = ea.EdgeGAN(cfg, values)
+    n2.upload_batch(batch['images'], batch['z'], batch['alpha'], batch['eps'])
+    steps = max(5, args.steps // 2)
+    for _ in range(2):
+        n2.train_step()
+    n2.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        n2.train_step()
+    n2.sync()
+    dt = time.perf_counter() - t0
+    n2.close()
+    return {'value': round(args.batch * steps / dt, 2), 'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+            'steps': steps, 'note': 'dense contractions on v_mfma_f32_16x16x4_f32 (python bench.py --dtype f32)'}
+
+
 INFER_GFLOP_PER_IMAGE = 2.228     # SURVEY Appendix D: E (1.575) + G1 + G2 (2 x 0.326), 64x128
 
 
@@ -119,7 +140,7 @@ def infer_bench(args, ea, np, rank, world, local):
     """BASELINE configs[1]: single-class 64x128, batch 64, generator-only inference (edgegan.test: E -> G1, E -> G2 = the
     two sess.run calls of edgegan/models/edgegan.py:606-609), bf16 contractions, inputs resident in HBM.  A step = one
     batch through both runs.  N > 1: independent replicas (inference has no exchange step)."""
-    dtype = 'bf16' if args.dtype == 'f32' and '--dtype' not in sys.argv else args.dtype
+    dtype = 'bf16' if '--dtype' not in sys.argv else args.dtype
     cfg = ea.Config(batch_size=args.batch, num_classes=0 if '--classes' not in sys.argv else args.classes, device=local,
                     compute_dtype=dtype, height=args.height, width=args.width)
     net = ea.EdgeGAN(cfg, ea.init_variables(cfg, 0))
@@ -190,12 +211,15 @@ def main():
     ap.add_argument('--width', type=int, default=128)
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt', action='store_true', help='skip the side measurement of the exact-fp32-MFMA mode')
     ap.add_argument('--cpu-baseline-batch', type=int, default=64)
     ap.add_argument('--mode', choices=['train', 'infer'], default='train',
                     help='train = BASELINE configs[2] (the headline metric); infer = configs[1]: single-class 64x128 bf16 '
                          'generator-only inference (edgegan.test path E -> G1, E -> G2), batch 64, inputs resident in HBM')
-    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
-                    help="f32 = BASELINE configs[2] (the headline metric); bf16 = configs[3]'s arithmetic: bf16 MFMA "
+    ap.add_argument('--dtype', choices=['f32x3', 'f32', 'bf16'], default='f32x3',
+                    help="f32x3 (default) and f32 = BASELINE configs[2] (the headline metric) in fp32: f32x3 forms every fp32 "
+                         "product of the dense contractions from exact bf16-limb products on the bf16 MFMA (fp32 accumulate), "
+                         "f32 uses the exact-fp32 MFMA instruction; bf16 = configs[3]'s arithmetic: bf16 MFMA "
                          "operands with fp32 accumulation / storage")
     args = ap.parse_args()
 
@@ -270,10 +294,16 @@ def main():
             dom = max(ks, key=lambda k: k['ms'])
             tot_ms = sum(k['ms'] for k in ks)
             tot_fl = sum(k['flops'] for k in ks)
-            ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in dom['name'] else PEAK_FP32_MFMA_TFLOPS
+            alg = dom['flops'] / (dom['ms'] * 1e-3) / 1e12       # algorithmic fp32 (or bf16) TFLOP/s of the kernel
+            limb = 'x3' in dom['name']         # limb kernels execute 6 bf16 MFMA flops per algorithmic fp32 flop
+            ach = alg * (X3_LIMB_PRODUCTS if limb else 1)
+            peak = PEAK_BF16_MFMA_TFLOPS if ('bf16' in dom['name'] or limb) else PEAK_FP32_MFMA_TFLOPS
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4),
+                    'achieved_is': ('executed bf16-limb MFMA flops = 6 x the algorithmic fp32 flops of the launch, against the '
+                                    'dense bf16 MFMA peak' if limb else 'algorithmic flops of the launch'),
+                    'algorithmic_tflops': round(alg, 2),
+                    'algorithmic_frac_of_fp32_mfma_peak': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                     'traffic': pmc_traffic(dom['name']) if (args.height, args.width, args.batch) == (64, 128, 64) else None,
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.csv)',
                     'kernel': dom['name'],
@@ -295,8 +325,14 @@ def main():
             'metric': f'training images/sec (G+D step) at {args.height}x{args.width}, 14-class',
             'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': ((('configs[2]: 14-class 64x128 fp32' if args.dtype == 'f32' else
+            'dtype': 'f32' if args.dtype == 'f32x3' else args.dtype, 'data': 'synthetic',
+            'arithmetic': {'f32x3': 'fp32 storage / accumulation / optimizer; each fp32 operand of a dense contraction is split '
+                                    'EXACTLY into three bf16 limbs and the product is formed from 6 exact limb products on '
+                                    'v_mfma_f32_32x32x16_bf16 (dropped terms < 2^-23 of the product); thin layers, filter '
+                                    'gradients, norms, losses: fp32 instructions',
+                           'f32': 'fp32 everywhere; dense contractions on v_mfma_f32_16x16x4_f32 (exact fp32 products)',
+                           'bf16': 'operands of dense contractions ROUNDED to bf16, fp32 accumulation / storage'}[args.dtype],
+            'config': {'workload': ((('configs[2]: 14-class 64x128 fp32' if args.dtype in ('f32', 'f32x3') else
                                       'configs[3] arithmetic (bf16 MFMA operands, fp32 accumulate/storage): 14-class 64x128')
                                      if (args.height, args.width) == (64, 128) else
                                      f'configs[4] geometry: 14-class {args.height}x{args.width} {args.dtype}')) +
@@ -310,6 +346,8 @@ def main():
             'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
             'roofline': roof,
         }
+        if world == 1 and args.dtype == 'f32x3' and not args.no_alt:
+            out['exact_fp32_mfma_mode'] = alt_mode(ea, dict(cfg_kwargs, compute_dtype='f32'), values, batch, args)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(dict(num_classes=args.classes, height=args.height, width=args.width),

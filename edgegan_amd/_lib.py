@@ -57,7 +57,16 @@ class Config:
         return _CConfig(self.batch_size, self.height, self.width, self.num_classes, self.z_dim, self.gf_dim,
                         self.df_dim, self.c_dim, self.dis_size, self.lambda_gp, self.zl_weight,
                         self.learning_rate, self.joint_dweight, self.image_dweight, self.edge_dweight, self.device,
-                        {'f32': 0, 'bf16': 1}[self.compute_dtype])
+                        {'f32': 0, 'bf16': 1, 'f32x3': 2}[_dtype_override(self.compute_dtype)])
+
+
+def _dtype_override(dtype: str) -> str:
+    """EG_F32_MODE=f32x3 | f32 re-maps the 'f32' compute type (test / A-B switch: the whole fp32 test-suite can be run on
+    either fp32 implementation); explicit 'bf16' / 'f32x3' requests are never re-mapped."""
+    import os
+    if dtype == 'f32':
+        return os.environ.get('EG_F32_MODE', 'f32')
+    return dtype
 
 
 class _CEvalOutputs(C.Structure):

@@ -33,6 +33,7 @@ static Config to_config(const eg_config* k) {
   c.edge_dweight = k->edge_dweight;
   c.device = k->device;
   c.bf16 = k->compute_dtype == 1;
+  c.x3 = k->compute_dtype == 2;
   return c;
 }
 

@@ -15,6 +15,7 @@ struct Config {
   float joint_dweight = 1.f, image_dweight = 1.f, edge_dweight = 1.f;
   int device = 0;
   bool bf16 = false;  // dense contractions on the bf16 MFMA (operands rounded, fp32 accumulate / storage)
+  bool x3 = false;    // fp32 contractions as three-limb bf16 splits on the bf16 MFMA (exact limb products, fp32 accumulate)
   bool multiclasses() const { return num_classes > 0; }
   int g_in() const { return z_dim + (multiclasses() ? num_classes : 0); }
 };
@@ -40,6 +41,8 @@ struct WRef {
   Param* param = nullptr;    // set when the weights ARE a variable (enables the persistent transpose cache)
   unsigned short* wb = nullptr;   // bf16 copy, same layout      (compute_dtype bf16; lazily, per sub-step)
   unsigned short* wbT = nullptr;  // bf16 copy, per-tap transposed
+  unsigned short* wl = nullptr;   // three bf16 limb planes, same layout   (compute_dtype f32x3; lazily, per sub-step)
+  unsigned short* wlT = nullptr;  // three bf16 limb planes, per-tap transposed
   int T = 1, R = 0, Cc = 0;
   std::string name;          // variable name (profiler labels)
 };

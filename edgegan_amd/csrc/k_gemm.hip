@@ -326,8 +326,43 @@ __global__ void conv_split_reduce_kernel(const float* __restrict__ ws, float* __
 }
 
 // K-split factor for launches that cannot fill the 256 CUs with output tiles (small M x N, long K)
-int conv_pick_ksplit(const ConvArgs& a) {
+// Limb-mode (k_gemm_x3.hip) launches: tile family and K split from a small cost model.  Unit of time = one K step
+// (32 channels of one tap) of a 128x128 tile at the ping-pong kernel's rate (~1.3 us per CU).  The ping-pong block
+// (two 128x128 tiles, one block per CU) advances 2 tiles per 2 units; two 64x64 blocks share a CU at ~0.66 of that
+// kernel's per-flop rate; a K split adds the slab reduction (HBM-bound) and needs >= 4 K steps per slab.
+static int pick_x3(ConvArgs& a) {
+  int maxM = 0, nk = 1 << 30;
+  for (int p = 0; p < a.nphase; ++p) {
+    maxM = std::max(maxM, a.NB * a.ph[p].OHp * a.ph[p].OWp);
+    nk = std::min(nk, a.ph[p].Ty * a.ph[p].Tx * (a.C / 32));
+  }
+  const long long tpp = (long long)((maxM + 255) / 256) * ((a.N + 127) / 128) * a.nphase;
+  const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase;
+  const bool pp_ok = a.N >= 128 && a.x_bytes != 0 && a.wbf_bytes != 0;
+  const double out_bytes = 4.0 * (double)maxM * a.nphase * a.N;
+  double best = 1e300;
+  int best_ks = 1, best_tile = 2;
+  for (int tile = pp_ok ? 1 : 2; tile <= 2; ++tile)
+    for (int ks = 1; ks <= 8; ++ks) {
+      if (ks > 1 && nk / ks < 4) break;
+      const long long blocks = (tile == 1 ? tpp : t64) * ks;
+      const long long slots = tile == 1 ? 256 : 512;
+      const double steps = (double)((nk + ks - 1) / ks);
+      double t = (double)((blocks + slots - 1) / slots) * steps * (tile == 1 ? 2.0 : 0.76) + (tile == 1 ? 3.0 : 1.0);
+      if (ks > 1) t += (ks + 1) * out_bytes / 3.0e12 / 1.3e-6 + 4.0;   // slab reduction + its launch
+      if (t < best) {
+        best = t;
+        best_ks = ks;
+        best_tile = tile;
+      }
+    }
+  a.x3_tile = best_tile;
+  return best_ks;
+}
+
+int conv_pick_ksplit(ConvArgs& a) {
   if (a.N <= 16 || a.C % 32 != 0 || a.N % 4 != 0) return 1;
+  if (a.limbs == 3 && a.wgt_bf) return pick_x3(a);
   int maxM = 0, minTiles = 1 << 30;
   for (int p = 0; p < a.nphase; ++p) {
     maxM = std::max(maxM, a.NB * a.ph[p].OHp * a.ph[p].OWp);
@@ -403,7 +438,9 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     };
     const double e128 = a.N >= 128 ? 0.95 * balance(t128) : 0.0;
     const double e64 = 0.80 * balance(t64);
-    if (conv_bf16_eligible(a))
+    if (conv_x3_eligible(a))
+      nm = launch_conv_gemm_x3(a, maxM, a.x3_tile ? a.x3_tile == 1 : e128 >= e64, s);
+    else if (conv_bf16_eligible(a))
       nm = launch_conv_gemm_bf16(a, maxM, e128 >= e64, s);
     else if (e128 >= e64)
       nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s,

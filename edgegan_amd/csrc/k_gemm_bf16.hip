@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16_kernel(const ConvArgs a
 }
 
 bool conv_bf16_eligible(const ConvArgs& a) {
-  return a.wgt_bf && a.C % BKB == 0 && a.N > 16 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.y_ps % 4 == 0 &&
+  return a.wgt_bf && a.limbs == 0 && a.C % BKB == 0 && a.N > 16 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.y_ps % 4 == 0 &&
          a.ldwbf % 8 == 0 && a.wbf_ts % 8 == 0 && (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.y & 15) == 0) &&
          (((uintptr_t)a.wgt_bf & 15) == 0) && (!a.bias || (((uintptr_t)a.bias & 15) == 0));
 }

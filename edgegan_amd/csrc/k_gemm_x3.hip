@@ -1,0 +1,744 @@
+// fp32 contractions on the bf16 matrix pipe: three-limb operand split (eg_config.compute_dtype == 2).
+//
+// An fp32 number a is EXACTLY the sum of three bf16 numbers: a0 = rne_bf16(a), a1 = rne_bf16(a - a0),
+// a2 = a - a0 - a1 (each residual is exactly representable in fp32 and the last one fits bf16's 8 significant bits),
+// with |a1| <= 2^-8 |a| and |a2| <= 2^-16 |a|.  A product of two fp32 numbers is therefore the exact sum of the nine
+// limb products a_i * b_j, every one of which the bf16 MFMA forms exactly (8 x 8 significant bits) and accumulates in
+// fp32.  The kernels issue the limb products down to relative magnitude 2^-16 -- (0,0) (0,1) (1,0) (1,1) (0,2) (2,0),
+// "NPROD = 6" -- or all nine (NPROD = 9); the three terms NPROD = 6 drops are bounded by 2^-23 |a b| together, i.e.
+// below one fp32 unit in the last place of the product they belong to, and enter a sum whose own fp32 accumulation
+// rounds at 2^-24 of the running total per step.  Measured against the fp64 oracle the results are as close as the
+// exact-fp32 MFMA's (tests/test_x3_gpu.py); v_mfma_f32_16x16x32_bf16 runs 16x the rate of v_mfma_f32_16x16x4_f32,
+// so six limb products cost 6/16 of the fp32 instruction's time.
+//
+//   conv_gemm_x3_kernel : Y[pix_out(m)][n] (+)= b[n] + sum_taps sum_c X[pix_in(m,tap)][c] * W[tap][c][n]
+//                         X is gathered as fp32 and split on its way into LDS; W comes as three bf16 planes with the
+//                         contracted index contiguous (launch_split_bf16x3 / launch_tap_transpose_bf16x3)
+//   wgrad_x3_kernel     : dW[tap][c][n] = sum_m X[pix_in(m,tap)][c] * dY[m][n]      (both operands split in the kernel)
+//
+// LDS images are the bf16 kernels' ([row][32 k], 64-byte rows, XOR chunk swizzle: every fragment is one conflict-free
+// ds_read_b128), three planes per operand.  One LDS stage (48 KB for the 128x128 tile) + register-staged prefetch of
+// the next K tile: two blocks per CU, so one block's split / LDS traffic runs under the other block's MFMAs.
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace eg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BKX = 32;    // contraction elements per K step (one MFMA)
+constexpr int ROWX = BKX;  // LDS row pitch in bf16 elements (64 bytes)
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_f(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// (x, y) -> packed limb pairs p0, p1, p2 with x = lo(p0) + lo(p1) + lo(p2) exactly (same for y in the high halves)
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = pack2(x, y);
+  const float rx = x - lo_f(p0), ry = y - hi_f(p0);
+  p1 = pack2(rx, ry);
+  p2 = pack2(rx - lo_f(p1), ry - hi_f(p1));
+}
+__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& l0, uint4& l1, uint4& l2) {
+  split_pair(a.x, a.y, l0.x, l1.x, l2.x);
+  split_pair(a.z, a.w, l0.y, l1.y, l2.y);
+  split_pair(b.x, b.y, l0.z, l1.z, l2.z);
+  split_pair(b.z, b.w, l0.w, l1.w, l2.w);
+}
+__device__ __forceinline__ void split8v(const f32x4& a, const f32x4& b, u32x4& l0, u32x4& l1, u32x4& l2) {
+  unsigned p[4][3];
+  split_pair(a[0], a[1], p[0][0], p[0][1], p[0][2]);
+  split_pair(a[2], a[3], p[1][0], p[1][1], p[1][2]);
+  split_pair(b[0], b[1], p[2][0], p[2][1], p[2][2]);
+  split_pair(b[2], b[3], p[3][0], p[3][1], p[3][2]);
+  l0 = (u32x4){p[0][0], p[1][0], p[2][0], p[3][0]};
+  l1 = (u32x4){p[0][1], p[1][1], p[2][1], p[3][1]};
+  l2 = (u32x4){p[0][2], p[1][2], p[2][2], p[3][2]};
+}
+__device__ __forceinline__ int reflect_x(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+// physical 16-byte chunk = logical chunk ^ swz(row)   (k_gemm_bf16.hip: lds_swz)
+__device__ __forceinline__ int swz(int row) { return ((-((row >> 2) & 3)) & 3) ^ ((row >> 4) & 1); }
+
+// the limb products of one K step for a wave's MI x NJ accumulators; the fragment loads are ordered so that at most
+// four limb fragment sets are live at a time
+template <int MI, int NJ, int NPROD, typename LA, typename LB>
+__device__ __forceinline__ void limb_products(f32x4 (&acc)[MI][NJ], LA load_a, LB load_b) {
+  auto mm = [&](const bf16x8 (&af)[MI], const bf16x8 (&bf)[NJ]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+  };
+  bf16x8 b0[NJ], b1[NJ];
+  {
+    bf16x8 a0[MI];
+    load_a(0, a0);
+    load_b(0, b0);
+    mm(a0, b0);
+    load_b(1, b1);
+    mm(a0, b1);
+    bf16x8 b2[NJ];
+    load_b(2, b2);
+    mm(a0, b2);
+    if constexpr (NPROD >= 8) {
+      bf16x8 a1[MI];
+      load_a(1, a1);
+      mm(a1, b0);
+      mm(a1, b1);
+      mm(a1, b2);
+      bf16x8 a2[MI];
+      load_a(2, a2);
+      mm(a2, b0);
+      mm(a2, b1);
+      if constexpr (NPROD >= 9) mm(a2, b2);
+      return;
+    }
+  }
+  {
+    bf16x8 a1[MI];
+    load_a(1, a1);
+    mm(a1, b0);
+    mm(a1, b1);
+  }
+  bf16x8 a2[MI];
+  load_a(2, a2);
+  mm(a2, b0);
+}
+
+// The same with v_mfma_f32_32x32x16_bf16 (wave tile 64 x 64 = 2 x 2 accumulators of 32 x 32, two K halves of 16 per K
+// step): half as many, twice as long matrix instructions -- a 32-cycle MFMA leaves room for ~5 other instructions of the
+// SIMD's second wave per MFMA, a 16-cycle one for ~1, and the limb split needs ~2.6 per 32-cycle MFMA.
+// A fragment set is [block 0..1][K half 0..1]; lane l supplies row l & 31 and the 8 k of K-half chunk l >> 5.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NPROD, typename LA, typename LB>
+__device__ __forceinline__ void limb_products32(f32x16 (&acc)[2][2], LA load_a, LB load_b) {
+  auto mm = [&](const bf16x8 (&af)[2][2], const bf16x8 (&bf)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+  };
+  bf16x8 b0[2][2], b1[2][2];
+  {
+    bf16x8 a0[2][2];
+    load_a(0, a0);
+    load_b(0, b0);
+    mm(a0, b0);
+    load_b(1, b1);
+    mm(a0, b1);
+    bf16x8 b2[2][2];
+    load_b(2, b2);
+    mm(a0, b2);
+    if constexpr (NPROD >= 8) {
+      bf16x8 a1[2][2];
+      load_a(1, a1);
+      mm(a1, b0);
+      mm(a1, b1);
+      mm(a1, b2);
+      bf16x8 a2[2][2];
+      load_a(2, a2);
+      mm(a2, b0);
+      mm(a2, b1);
+      if constexpr (NPROD >= 9) mm(a2, b2);
+      return;
+    }
+  }
+  {
+    bf16x8 a1[2][2];
+    load_a(1, a1);
+    mm(a1, b0);
+    mm(a1, b1);
+  }
+  bf16x8 a2[2][2];
+  load_a(2, a2);
+  mm(a2, b0);
+}
+
+}  // namespace
+
+// =============================================================================================
+// conv_gemm_x3_kernel
+// =============================================================================================
+template <int BM, int BN, int WTM, int WTN, bool SPLITK, int NPROD>
+__global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const ConvArgs a) {
+  constexpr int WGN = BN / WTN;
+  constexpr int MI = WTM / 16, NJ = WTN / 16;
+  static_assert((BM / WTM) * (BN / WTN) == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) unsigned short As[3][BM * ROWX];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN * ROWX];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int zphase = SPLITK ? (int)blockIdx.z / a.ksplit : (int)blockIdx.z;
+  const int zsplit = SPLITK ? (int)blockIdx.z - zphase * a.ksplit : 0;
+  const ConvPhase ph = a.ph[zphase];
+  const int M = a.NB * ph.OHp * ph.OWp;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= M) return;
+  const int IH = a.IH, IW = a.IW, C = a.C, N = a.N;
+
+  constexpr int A_V = BM / 64, B_V = BN / 64;  // 8-element chunks per thread: row = tid/4 + 64*i, chunk = tid%4
+  const int q8 = (tid & 3) * 8;
+  const int st8 = ((tid & 3) ^ swz(tid >> 2)) * 8;   // rows tid/4 + 64*i all share this swizzle
+  int r_iy0[A_V], r_ix0[A_V], r_base[A_V];
+#pragma unroll
+  for (int i = 0; i < A_V; ++i) {
+    const int m = m0 + (tid >> 2) + 64 * i;
+    if (m < M) {
+      const int ox = m % ph.OWp;
+      const int t2 = m / ph.OWp;
+      const int oy = t2 % ph.OHp;
+      const int nb = t2 / ph.OHp;
+      r_iy0[i] = oy * a.S + ph.offy;
+      r_ix0[i] = ox * a.S + ph.offx;
+      r_base[i] = nb * IH * IW;
+    } else {
+      r_iy0[i] = 0;
+      r_ix0[i] = 0;
+      r_base[i] = -1;
+    }
+  }
+
+  const int ntaps = ph.Ty * ph.Tx;
+  const int cpt = C / BKX;
+  const int nk = ntaps * cpt;
+  int nx_ty = 0, nx_tx = 0, nx_c0 = 0;
+  int kt_lo = 0, kt_hi = nk;
+  if constexpr (SPLITK) {
+    const int per = (nk + a.ksplit - 1) / a.ksplit;
+    kt_lo = zsplit * per;
+    kt_hi = min(nk, kt_lo + per);
+    const int tap0 = kt_lo / cpt;
+    nx_c0 = (kt_lo - tap0 * cpt) * BKX;
+    nx_ty = tap0 / ph.Tx;
+    nx_tx = tap0 - nx_ty * ph.Tx;
+  }
+
+  float4 ra[A_V][2];
+  uint4 rb[B_V][3];
+  auto load_tile = [&]() {
+    const int ty = nx_ty, tx = nx_tx, c0 = nx_c0;
+    const long long wt = ((long long)((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * cpt + c0 / BKX) * N * BKX;
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+      int iy = r_iy0[i] + ty * a.D, ix = r_ix0[i] + tx * a.D;
+      if (a.reflect) {
+        iy = reflect_x(iy, IH);
+        ix = reflect_x(ix, IW);
+      }
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (r_base[i] >= 0 && iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
+        const float* px = a.x + (size_t)(r_base[i] + iy * IW + ix) * a.x_ps + c0 + q8;
+        v0 = *reinterpret_cast<const float4*>(px);
+        v1 = *reinterpret_cast<const float4*>(px + 4);
+      }
+      ra[i][0] = v0;
+      ra[i][1] = v1;
+    }
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) {
+      const int n = n0 + (tid >> 2) + 64 * i;
+      const unsigned short* pw = a.wgt_bf + wt + (size_t)n * BKX + q8;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (n < N) v = *reinterpret_cast<const uint4*>(pw + (size_t)p * a.wbf_plane);
+        rb[i][p] = v;
+      }
+    }
+    nx_c0 += BKX;
+    if (nx_c0 >= C) {
+      nx_c0 = 0;
+      if (++nx_tx == ph.Tx) {
+        nx_tx = 0;
+        ++nx_ty;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+      uint4 l0, l1, l2;
+      split8(ra[i][0], ra[i][1], l0, l1, l2);
+      const int o = ((tid >> 2) + 64 * i) * ROWX + st8;
+      *reinterpret_cast<uint4*>(&As[0][o]) = l0;
+      *reinterpret_cast<uint4*>(&As[1][o]) = l1;
+      *reinterpret_cast<uint4*>(&As[2][o]) = l2;
+    }
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) {
+      const int o = ((tid >> 2) + 64 * i) * ROWX + st8;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(&Bs[p][o]) = rb[i][p];
+    }
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int fsw = (-(l15 >> 2)) & 3;   // swz of a fragment row, without the (row >> 4) & 1 bit (= i & 1 below)
+  static_assert((WTM / 16) % 2 == 0 && (WTN / 16) % 2 == 0, "wave sub-tiles start at even 16-row blocks");
+  auto load_a = [&](int p, bf16x8 (&f)[MI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      f[i] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * WTM + i * 16 + l15) * ROWX + (lq ^ fsw ^ (i & 1)) * 8]);
+  };
+  auto load_b = [&](int p, bf16x8 (&f)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      f[j] = *reinterpret_cast<const bf16x8*>(&Bs[p][(wn * WTN + j * 16 + l15) * ROWX + (lq ^ fsw ^ (j & 1)) * 8]);
+  };
+
+  if (kt_lo < kt_hi) load_tile();
+  for (int kt = kt_lo; kt < kt_hi; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < kt_hi) load_tile();
+    limb_products<MI, NJ, NPROD>(acc, load_a, load_b);
+    __syncthreads();
+  }
+
+  // operands swapped as in the fp32 kernel: lane l holds pixel row (l & 15) and output channels (l >> 4) * 4 + reg
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + l15;
+    if (m >= M) continue;
+    const int ox = m % ph.OWp;
+    const int t2 = m / ph.OWp;
+    const int oy = t2 % ph.OHp;
+    const int nb = t2 / ph.OHp;
+    float* yrow = (SPLITK ? a.ws + (size_t)zsplit * a.y_total : a.y) +
+                  ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + lq * 4;
+      if (n < N) {
+        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if constexpr (!SPLITK) {
+          if (a.bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          }
+          if (a.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(yrow + n);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+        }
+        *reinterpret_cast<float4*>(yrow + n) = v;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// conv_gemm_x3pp_kernel: two 128x128 tiles per 512-thread block in explicit anti-phase ("ping-pong").  Waves 0-3 (group
+// X) and 4-7 (group Y) own the tiles of rows m0 and m0 + 128 of the SAME 128 output channels; a SIMD hosts one wave of
+// each group.  A K step of a group is a VALU / LDS-store phase (limb split of the tile fetched during its previous
+// MFMA phase, LDS stores, buffer loads of the next tile) followed by an MFMA phase (24 fragment reads + 96 MFMAs); the
+// block-wide barrier between phases keeps the groups exactly half a step apart, so the MFMA pipe of a SIMD always has
+// one wave feeding it while the other wave's VALU / DS / VMEM instructions issue in the gaps.  The filter tile is shared:
+// group X stages it (double-buffered, no arithmetic), both groups multiply with it.
+//   * both operands come through buffer loads: the per-thread byte offset sits in a VGPR (an out-of-range offset returns
+//     zeros -- that is how padding taps and rows beyond M are read: no branches, no selects on the data), the K-step
+//     position in the uniform soffset;
+//   * every wave-level load covers whole 128-byte lines: 8 lanes x 16 bytes = the 32 fp32 channels of one gathered pixel,
+//     and the limb planes are stored K-step-major ([plane][tap][C/32][N][32]) so a filter tile is one contiguous 8 KB run;
+//   * zero padding: a row's offset is linear in the tap (off0 + a uniform per-tap delta) and "tap inside the image" is
+//     one bit of a per-row mask -- a handful of VALU instructions per K step; REFLECT keeps the index arithmetic.
+// =============================================================================================
+template <bool SPLITK, int NPROD, bool REFLECT, bool TIMING = false>
+__global__ __launch_bounds__(512, 1) void conv_gemm_x3pp_kernel(const ConvArgs a) {
+  constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64;
+  constexpr int MI = WTM / 16, NJ = WTN / 16;
+  __shared__ __attribute__((aligned(16))) unsigned short AsG[2][3][BM * ROWX];   // per group
+  __shared__ __attribute__((aligned(16))) unsigned short BsG[3][3][BN * ROWX];   // per K step mod 3
+
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);   // uniform
+  const int wm = wave >> 1, wn = wave & 1;
+  unsigned short (&As)[3][BM * ROWX] = AsG[grp];
+  const int zphase = SPLITK ? (int)blockIdx.z / a.ksplit : (int)blockIdx.z;
+  const int zsplit = SPLITK ? (int)blockIdx.z - zphase * a.ksplit : 0;
+  const ConvPhase ph = a.ph[zphase];
+  const int M = a.NB * ph.OHp * ph.OWp;
+  const int m0 = (blockIdx.x * 2 + grp) * BM, n0 = blockIdx.y * BN;   // m0 >= M: the group only keeps the barriers
+  const int IH = a.IH, IW = a.IW, C = a.C, N = a.N;
+
+  // A: row j*32 + tid/8, floats 4*(tid%8) .. +3 of the K step
+  constexpr int A_R = BM / 32;
+  const int c4 = tid & 7, ar = tid >> 3;
+  const int ast = ((c4 >> 1) ^ swz(ar)) * 8 + (c4 & 1) * 4;   // swz(j*32 + ar) == swz(ar)
+  int r_iy0[REFLECT ? A_R : 1], r_ix0[REFLECT ? A_R : 1], r_base[REFLECT ? A_R : 1];
+  unsigned r_off0[A_R], r_mask[A_R];
+#pragma unroll
+  for (int j = 0; j < A_R; ++j) {
+    const int m = m0 + j * 32 + ar;
+    int iy0 = 0, ix0 = 0, base = -1;
+    r_mask[j] = 0u;
+    if (m < M) {
+      const int ox = m % ph.OWp;
+      const int t2 = m / ph.OWp;
+      const int oy = t2 % ph.OHp;
+      const int nb = t2 / ph.OHp;
+      iy0 = oy * a.S + ph.offy;
+      ix0 = ox * a.S + ph.offx;
+      base = nb * IH * IW;
+      if constexpr (!REFLECT) {
+        for (int ty = 0; ty < ph.Ty; ++ty)
+          for (int tx = 0; tx < ph.Tx; ++tx) {
+            const int iy = iy0 + ty * a.D, ix = ix0 + tx * a.D;
+            if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) r_mask[j] |= 1u << (ty * ph.Tx + tx);
+          }
+      }
+    }
+    r_off0[j] = (unsigned)(((base + iy0 * IW + ix0) * a.x_ps + c4 * 4) * 4);
+    if constexpr (REFLECT) {
+      r_iy0[j] = iy0;
+      r_ix0[j] = ix0;
+      r_base[j] = base;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wgt_bf), 0, a.wbf_bytes, 0x00020000);
+  // B (group X) goes global -> LDS directly (buffer_load ... lds, no registers, no LDS store instructions): one wave
+  // instruction fills 16 consecutive 64-byte rows of a plane (lane l -> LDS bytes 16*l .. +15 behind M0), so the XOR
+  // chunk swizzle is applied on the GLOBAL side: lane l fetches logical chunk (l & 3) ^ swz(row) of row l / 4.
+  constexpr int B_V = BN / 64;
+  unsigned woff[B_V];
+  {
+    const int lsw = (((-((lane >> 4) & 3)) & 3) ^ (wave & 1));   // swz(i*64 + wave*16 + lane/4)
+#pragma unroll
+    for (int i = 0; i < B_V; ++i)
+      woff[i] = (unsigned)(((size_t)min(n0 + i * 64 + wave * 16 + (lane >> 2), N - 1) * BKX + ((lane & 3) ^ lsw) * 8) * 2);
+  }
+  const int plane_bytes = (int)(a.wbf_plane * 2);
+
+  const int ntaps = ph.Ty * ph.Tx;
+  const int cpt = C / BKX;
+  const int nk = ntaps * cpt;
+  int nx_ty = 0, nx_tx = 0, nx_cc = 0;
+  int kt_lo = 0, kt_hi = nk;
+  if constexpr (SPLITK) {
+    const int per = (nk + a.ksplit - 1) / a.ksplit;
+    kt_lo = zsplit * per;
+    kt_hi = min(nk, kt_lo + per);
+    const int tap0 = kt_lo / cpt;
+    nx_cc = kt_lo - tap0 * cpt;
+    nx_ty = tap0 / ph.Tx;
+    nx_tx = tap0 - nx_ty * ph.Tx;
+  }
+  const int wtile = N * BKX * 2;   // bytes of one (tap, channel chunk) filter tile of a plane
+
+  // The gathered operand has two register staging sets: tile k+1 is requested BEFORE tile k is split, so every load has a
+  // whole VALU + MFMA phase to land and its address processing overlaps the split arithmetic.
+  f32x4 ra0[A_R], ra1[A_R];
+  int kx_ty = nx_ty, kx_tx = nx_tx, kx_cc = nx_cc;   // position of the next FILTER tile (steps separately from A's)
+  auto step = [&](int& ty, int& tx, int& cc) __attribute__((always_inline)) {
+    cc += 1;
+    const bool wc = cc == cpt;
+    cc = wc ? 0 : cc;
+    tx += wc ? 1 : 0;
+    const bool wx = tx == ph.Tx;
+    tx = wx ? 0 : tx;
+    ty += wx ? 1 : 0;
+  };
+  auto load_a_tile = [&](f32x4 (&ra)[A_R]) __attribute__((always_inline)) {
+    const int ty = nx_ty, tx = nx_tx, cc = nx_cc;
+    const int tapbit = ty * ph.Tx + tx;
+    const unsigned delta = (unsigned)(((ty * IW + tx) * a.D * a.x_ps) * 4);
+#pragma unroll
+    for (int j = 0; j < A_R; ++j) {
+      unsigned off;
+      if constexpr (REFLECT) {
+        const int iy = reflect_x(r_iy0[j] + ty * a.D, IH), ix = reflect_x(r_ix0[j] + tx * a.D, IW);
+        const bool ok = r_base[j] >= 0 && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+        off = ok ? (unsigned)(((r_base[j] + iy * IW + ix) * a.x_ps + c4 * 4) * 4) : 0x80000000u;
+      } else {
+        off = ((r_mask[j] >> tapbit) & 1u) ? r_off0[j] + delta : 0x80000000u;
+      }
+      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, cc * (BKX * 4), 0));
+    }
+    step(nx_ty, nx_tx, nx_cc);
+  };
+  auto dma_b_tile = [&](int par) __attribute__((always_inline)) {   // filter tile -> BsG[par], 6 x 1 KB per wave
+    const int wsoff = (((ph.kh0 + kx_ty * a.kst) * a.KW + (ph.kw0 + kx_tx * a.kst)) * cpt + kx_cc) * wtile;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < B_V; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (__attribute__((address_space(3))) void*)&BsG[par][p][(i * 64 + wave * 16) * ROWX],
+                                                 16, woff[i], wsoff + p * plane_bytes, 0, 0);
+    step(kx_ty, kx_tx, kx_cc);
+  };
+  auto store_a_tile = [&](const f32x4 (&ra)[A_R]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < A_R; ++j) {
+      unsigned p0a, p1a, p2a, p0b, p1b, p2b;
+      split_pair(ra[j][0], ra[j][1], p0a, p1a, p2a);
+      split_pair(ra[j][2], ra[j][3], p0b, p1b, p2b);
+      const int o = (j * 32 + ar) * ROWX + ast;
+      *reinterpret_cast<u32x2*>(&As[0][o]) = (u32x2){p0a, p0b};
+      *reinterpret_cast<u32x2*>(&As[1][o]) = (u32x2){p1a, p1b};
+      *reinterpret_cast<u32x2*>(&As[2][o]) = (u32x2){p2a, p2b};
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int fsw = swz(l31);   // == swz(row) for every fragment row: the block offsets are multiples of 32
+  const unsigned short* Bcur = &BsG[0][0][0];
+  auto load_a = [&](int p, bf16x8 (&f)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        f[i][kk] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * WTM + i * 32 + l31) * ROWX + ((kk * 2 + lh) ^ fsw) * 8]);
+  };
+  auto load_b = [&](int p, bf16x8 (&f)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        f[j][kk] = *reinterpret_cast<const bf16x8*>(Bcur + p * (BN * ROWX) + (wn * WTN + j * 32 + l31) * ROWX + ((kk * 2 + lh) ^ fsw) * 8);
+  };
+
+  // barrier slots: X stores in even slots and multiplies in odd ones, Y the other way round (one idle slot each);
+  // filter tile k lives in BsG[k & 1]: written by X in slot 2k, read by X in slot 2k+1 and by Y in slot 2k+2
+  const int nt = kt_hi - kt_lo;
+  const bool tim = TIMING && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && wave == 0;
+  long long* tbuf = reinterpret_cast<long long*>(a.ws) + grp * 64;
+  // Filter tile k lives in BsG[k % 3].  X requests tile k+2 at the END of its MFMA phase k (slot 2k+1: the buffer's
+  // previous tenant, tile k-1, was last read by Y in slot 2k; no LDS read of this phase follows the request, so the
+  // compiler's "DMA in flight may alias this LDS read" wait only appears in MFMA phase k+1, ~2 phases later), and it is
+  // read by X in slot 2k+5 and by Y in slot 2k+6.  X's VMEM stream completes in order: ... A(k+1) x4, DMA B(k+2) x6,
+  // A(k+2) x4 ...  The two groups run separate instantiations of the loop and its steady state has no run-time
+  // conditions (the compiler's outstanding-load bookkeeping merges control-flow paths pessimistically).
+  // Raw barrier, no fences: a fence would drain the DMA in flight before every barrier; what the barrier orders here is
+  // LDS traffic only.
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto run = [&](auto GRP) __attribute__((always_inline)) {
+    constexpr bool X = decltype(GRP)::value == 0;
+    auto valu_phase = [&](auto HASNEXT, int k, const f32x4 (&ra)[A_R], f32x4 (&ran)[A_R]) __attribute__((always_inline)) {
+      if (tim && k >= 8 && k < 12) tbuf[(k - 8) * 8 + 0] = __builtin_amdgcn_s_memtime();
+      if constexpr (decltype(HASNEXT)::value) {   // (a run-time test here would make the compiler wait for the NEW loads)
+        load_a_tile(ran);
+        __builtin_amdgcn_sched_barrier(0);   // the requests go out BEFORE the split, not wherever the scheduler likes
+      }
+      store_a_tile(ra);
+      if (tim && k >= 8 && k < 12) tbuf[(k - 8) * 8 + 1] = __builtin_amdgcn_s_memtime();
+    };
+    auto mfma_phase = [&](auto DMA, int k, int bpar, int bpar_dma) __attribute__((always_inline)) {
+      lds_barrier();
+      if (tim && k >= 8 && k < 12) tbuf[(k - 8) * 8 + 2] = __builtin_amdgcn_s_memtime();
+      Bcur = &BsG[bpar][0][0];
+      limb_products32<NPROD>(acc, load_a, load_b);
+      if constexpr (X && decltype(DMA)::value) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_b_tile(bpar_dma);
+      }
+      if (tim && k >= 8 && k < 12) tbuf[(k - 8) * 8 + 3] = __builtin_amdgcn_s_memtime();
+      lds_barrier();
+      if (tim && k >= 8 && k < 12) tbuf[(k - 8) * 8 + 4] = __builtin_amdgcn_s_memtime();
+    };
+    constexpr std::true_type yes{};
+    constexpr std::false_type no{};
+    if (nt > 0) {
+      if constexpr (X) {
+        dma_b_tile(0);
+        if (nt > 1) dma_b_tile(1);
+      }
+      load_a_tile(ra0);
+    }
+    if constexpr (!X) lds_barrier();
+    int bp = 0, k = 0;   // bp = k % 3
+    for (; k + 3 < nt; k += 2) {   // steady state: steps k, k+1 have successors and filter tiles k+2, k+3 exist
+      const int bp1 = bp == 2 ? 0 : bp + 1, bp2 = bp1 == 2 ? 0 : bp1 + 1;
+      valu_phase(yes, k, ra0, ra1);
+      mfma_phase(yes, k, bp, bp2);
+      valu_phase(yes, k + 1, ra1, ra0);
+      mfma_phase(yes, k + 1, bp1, bp);
+      bp = bp2;
+    }
+    // up to 3 steps left (k is even here); run-time conditions are fine now.  Straight-line on purpose: a loop with the
+    // staging sets swapped per parity makes the optimiser select between POINTERS to them and keeps both in scratch.
+    auto tail_step = [&](int kk, int bpar, int bpar_dma, const f32x4 (&ra)[A_R], f32x4 (&ran)[A_R]) __attribute__((always_inline)) {
+      if (kk + 1 < nt) load_a_tile(ran);
+      store_a_tile(ra);
+      lds_barrier();
+      Bcur = &BsG[bpar][0][0];
+      limb_products32<NPROD>(acc, load_a, load_b);
+      if constexpr (X)
+        if (kk + 2 < nt) dma_b_tile(bpar_dma);
+      lds_barrier();
+    };
+    if (k < nt) {
+      const int bp1 = bp == 2 ? 0 : bp + 1, bp2 = bp1 == 2 ? 0 : bp1 + 1;
+      tail_step(k, bp, bp2, ra0, ra1);
+      if (k + 1 < nt) {
+        tail_step(k + 1, bp1, bp, ra1, ra0);
+        if (k + 2 < nt) tail_step(k + 2, bp2, bp1, ra0, ra1);
+      }
+    }
+    if constexpr (X) lds_barrier();
+  };
+  if (grp == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+
+  // D^T layout of the 32x32 accumulator: lane l holds pixel row l & 31 and, in registers 4g .. 4g+3, the four consecutive
+  // output channels 8g + 4 (l >> 5) .. +3 of its 32-channel block: one 16-byte store per register quad
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * WTM + i * 32 + l31;
+    if (m >= M) continue;
+    const int ox = m % ph.OWp;
+    const int t2 = m / ph.OWp;
+    const int oy = t2 % ph.OHp;
+    const int nb = t2 / ph.OHp;
+    float* yrow = (SPLITK ? a.ws + (size_t)zsplit * a.y_total : a.y) +
+                  ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * WTN + j * 32 + g * 8 + lh * 4;
+        if (n < N) {
+          float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          if constexpr (!SPLITK) {
+            if (a.bias) {
+              const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);
+              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            }
+            if (a.accumulate) {
+              const float4 o = *reinterpret_cast<const float4*>(yrow + n);
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+          }
+          *reinterpret_cast<float4*>(yrow + n) = v;
+        }
+      }
+  }
+}
+
+bool conv_x3_eligible(const ConvArgs& a) {
+  return a.wgt_bf && a.limbs == 3 && a.C % BKX == 0 && a.N > 16 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.y_ps % 4 == 0 &&
+         a.wbf_plane % 8 == 0 && (((uintptr_t)a.x & 15) == 0) &&
+         (((uintptr_t)a.y & 15) == 0) && (((uintptr_t)a.wgt_bf & 15) == 0) && (!a.bias || (((uintptr_t)a.bias & 15) == 0));
+}
+
+static int x3_nprod() {
+  static const int n = [] {
+    const char* e = getenv("EG_X3_PRODUCTS");
+    const int v = e ? atoi(e) : 6;
+    return (v == 8 || v == 9) ? v : 6;
+  }();
+  return n;
+}
+
+template <int BM, int BN, int WTM, int WTN, int NPROD>
+static void conv_x3_launch(const ConvArgs& a, int maxM, hipStream_t s) {
+  if (a.ksplit > 1) {
+    dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase * a.ksplit);
+    hipLaunchKernelGGL((conv_gemm_x3_kernel<BM, BN, WTM, WTN, true, NPROD>), grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid((maxM + BM - 1) / BM, (a.N + BN - 1) / BN, a.nphase);
+    hipLaunchKernelGGL((conv_gemm_x3_kernel<BM, BN, WTM, WTN, false, NPROD>), grid, dim3(256), 0, s, a);
+  }
+}
+
+const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s) {
+  const int np = x3_nprod();
+  static const int pipe = getenv("EG_X3_PIPE") ? atoi(getenv("EG_X3_PIPE")) : 2;
+  if (big_tile && pipe == 2 && np == 6 && a.x_bytes && a.wbf_bytes) {
+    const int zs = a.ksplit > 1 ? a.ksplit : 1;
+    dim3 grid((maxM + 255) / 256, (a.N + 127) / 128, a.nphase * zs);
+    static const bool timing = getenv("EG_X3_TIMING") != nullptr;
+    if (a.reflect) {
+      if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3pp_kernel<true, 6, true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((conv_gemm_x3pp_kernel<false, 6, true>), grid, dim3(512), 0, s, a);
+    } else {
+      if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3pp_kernel<true, 6, false>), grid, dim3(512), 0, s, a);
+      else if (timing && a.ws) hipLaunchKernelGGL((conv_gemm_x3pp_kernel<false, 6, false, true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((conv_gemm_x3pp_kernel<false, 6, false>), grid, dim3(512), 0, s, a);
+    }
+    return a.ksplit > 1 ? "conv_gemm_x3pp<2x128,128,splitk>" : "conv_gemm_x3pp<2x128,128>";
+  }
+  if (big_tile) {
+    if (np == 9) conv_x3_launch<128, 128, 64, 64, 9>(a, maxM, s);
+    else if (np == 8) conv_x3_launch<128, 128, 64, 64, 8>(a, maxM, s);
+    else conv_x3_launch<128, 128, 64, 64, 6>(a, maxM, s);
+    return a.ksplit > 1 ? "conv_gemm_x3<128,128,splitk>" : "conv_gemm_x3<128,128>";
+  }
+  if (np == 9) conv_x3_launch<64, 64, 32, 32, 9>(a, maxM, s);
+  else if (np == 8) conv_x3_launch<64, 64, 32, 32, 8>(a, maxM, s);
+  else conv_x3_launch<64, 64, 32, 32, 6>(a, maxM, s);
+  return a.ksplit > 1 ? "conv_gemm_x3<64,64,splitk>" : "conv_gemm_x3<64,64>";
+}
+
+// =============================================================================================
+// three-limb bf16 filter planes, K-step-major: src [T][R][Cc] fp32 -> out[plane][T][K/32][Nrows][32] bf16 with
+// (Nrows, K) = (R, Cc) ("as stored": the contracted index is the source's fast one) or (Cc, R) (transposed)
+// =============================================================================================
+__global__ void split_bf16x3_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int R, int Cc,
+                                    int transposed, size_t plane) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const float* src = in + (size_t)t * R * Cc;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < Cc) ? src[(size_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  // output rows n, contracted k; this block holds a 32 x 32 patch
+  const int Nrows = transposed ? Cc : R, K = transposed ? R : Cc;
+  const int nb0 = transposed ? c0 : r0, kb0 = transposed ? r0 : c0;   // kb0 is a multiple of 32: one K chunk
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int n = nb0 + i, k = kb0 + threadIdx.x;
+    if (n < Nrows && k < K) {
+      const float v = transposed ? tile[threadIdx.x][i] : tile[i][threadIdx.x];
+      unsigned p0, p1, p2;
+      split_pair(v, 0.f, p0, p1, p2);
+      const size_t o = (((size_t)t * (K / 32) + kb0 / 32) * Nrows + n) * 32 + threadIdx.x;
+      out[o] = (unsigned short)(p0 & 0xffffu);
+      out[o + plane] = (unsigned short)(p1 & 0xffffu);
+      out[o + 2 * plane] = (unsigned short)(p2 & 0xffffu);
+    }
+  }
+}
+void launch_split_bf16x3(const float* in, unsigned short* out, int T, int R, int Cc, int transposed, size_t plane,
+                         hipStream_t s) {
+  dim3 grid((Cc + 31) / 32, (R + 31) / 32, T);
+  hipLaunchKernelGGL(split_bf16x3_kernel, grid, dim3(32, 8), 0, s, in, out, R, Cc, transposed, plane);
+}
+
+}  // namespace eg

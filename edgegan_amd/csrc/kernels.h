@@ -27,6 +27,10 @@ struct ConvArgs {
   const unsigned short* wgt_bf;  // optional bf16 filter, element (tap wt, n, c) at wgt_bf[wt*wbf_ts + n*ldwbf + c]:
   long long wbf_ts;              // when set and the shape qualifies the contraction runs on the bf16 MFMA
   int ldwbf;
+  int limbs;                     // 3: wgt_bf holds the three bf16 limb planes of the fp32 filter (plane stride wbf_plane
+  long long wbf_plane;           //    elements) and the contraction runs as exact-product limb MFMAs (k_gemm_x3.hip)
+  int x3_tile;                   //    tile family chosen by conv_pick_ksplit for the limb kernels: 1 = 2x128x128 ping-pong, 2 = 64x64
+  unsigned x_bytes, wbf_bytes;   //    extents of x and of the limb planes (buffer-load bounds; 0 = unknown / >= 2 GB)
   float* y;          // [NB][OHf][OWf] pixels, y_ps floats per pixel
   int NB, IH, IW, C, x_ps;
   int OHf, OWf, N, y_ps;
@@ -46,7 +50,7 @@ struct ConvArgs {
 
 // flops (2*M*N*K summed over phases) are returned for the profiler.
 double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_name);
-int conv_pick_ksplit(const ConvArgs& a);
+int conv_pick_ksplit(ConvArgs& a);   // also sets a.x3_tile for limb-mode launches
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[wt(tap)][c][n] = sum_m X[pix_in(m,tap)][c] * dY[m][n], m over NB*OH*OW
@@ -67,6 +71,7 @@ struct WgradArgs {
   int accumulate;    // 1: dw += result
   int nsplit;
   int bf16;          // 1: round both operands to bf16 and use the bf16 MFMA (fp32 accumulate)
+  int limbs;         // 3: fp32 result from three-limb bf16 operand splits on the bf16 MFMA (k_gemm_x3.hip)
 };
 int wgrad_pick_splits(const WgradArgs& a);
 size_t wgrad_workspace_floats(const WgradArgs& a);
@@ -78,6 +83,15 @@ const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hi
 const char* launch_wgrad_bf16(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s);
 void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);
 void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int R, int Cc, hipStream_t s);
+
+// fp32-via-three-bf16-limbs kernels (k_gemm_x3.hip)
+bool conv_x3_eligible(const ConvArgs& a);
+const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s);
+const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s);
+// src [T][R][Cc] fp32 -> three bf16 limb planes, K-step-major [plane][T][K/32][Nrows][32]; (Nrows, K) = (R, Cc), or (Cc, R)
+// when transposed; K % 32 == 0
+void launch_split_bf16x3(const float* in, unsigned short* out, int T, int R, int Cc, int transposed, size_t plane,
+                         hipStream_t s);
 
 // Phase-merged filter of a stride-2 layer with 3 image channels: the 4 sub-pixel phases of a transposed convolution
 // (or of a stride-2 convolution's input gradient) become 12 output channels n = (py*2+px)*3 + ch of ONE 3x3 stride-1

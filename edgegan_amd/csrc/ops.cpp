@@ -222,6 +222,22 @@ static void run_merged_phases(Ctx& c, const float* x, int NB, int IH, int IW, in
 // compute_dtype bf16: hand the conv a bf16 copy of the filter with the contracted index contiguous.  `transposed`
 // selects the per-tap transpose [T][Cc][R] (contracted index = R) or the stored layout [T][R][Cc] (contracted = Cc).
 static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
+  if (c.cfg.x3) {   // three limb planes instead of one rounded copy (k_gemm_x3.hip)
+    if (a.C % 32 != 0 || a.N <= 16 || a.N % 4 != 0) return;
+    const size_t n = (size_t)w->T * w->R * w->Cc;
+    unsigned short*& slot = transposed ? w->wlT : w->wl;
+    if (!slot) {
+      slot = reinterpret_cast<unsigned short*>(c.arena.allocf((3 * n + 1) / 2));
+      launch_split_bf16x3(w->w, slot, w->T, w->R, w->Cc, transposed ? 1 : 0, n, c.stream);
+    }
+    a.wgt_bf = slot;
+    a.wbf_ts = (long long)a.C * a.N;
+    a.ldwbf = a.C;
+    a.limbs = 3;
+    a.wbf_plane = (long long)n;
+    a.wbf_bytes = 6 * n < (1ull << 31) ? (unsigned)(6 * n) : 0u;
+    return;
+  }
   if (!c.cfg.bf16 || a.C % 32 != 0 || a.N <= 16 || a.N % 4 != 0) return;
   unsigned short*& slot = transposed ? w->wbT : w->wb;
   if (!slot) {
@@ -238,6 +254,10 @@ static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
 // launch one implicit-GEMM conv; layers too small to fill the chip with output tiles split K over blocks
 static void run_conv(Ctx& c, ConvArgs& a) {
   a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
+  {
+    const size_t xb = (size_t)a.NB * a.IH * a.IW * a.x_ps * sizeof(float);
+    a.x_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
+  }
   a.ksplit = conv_pick_ksplit(a);
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
   static const bool shadow_exp = getenv("EG_BF16_SHADOW_EXPERIMENT") != nullptr;
@@ -248,8 +268,24 @@ static void run_conv(Ctx& c, ConvArgs& a) {
     a.x_bf = xb;
   }
   const char* nm;
+  static const bool x3_timing = getenv("EG_X3_TIMING") != nullptr;   // experiment: per-phase s_memtime stamps of block 0
+  if (x3_timing && a.limbs == 3 && a.ksplit <= 1) {
+    a.ws = c.arena.allocf(512);
+    EG_HIP(hipMemsetAsync(a.ws, 0, 2048, c.stream));
+  }
   ProfScope ps(c);
   const double fl = launch_conv_gemm(a, c.stream, &nm);
+  if (x3_timing && a.limbs == 3 && a.ksplit <= 1 && a.ws) {
+    long long h[128];
+    EG_HIP(hipStreamSynchronize(c.stream));
+    EG_HIP(hipMemcpy(h, a.ws, sizeof h, hipMemcpyDeviceToHost));
+    for (int g = 0; g < 2; ++g)
+      for (int k = 0; k < 4; ++k) {
+        const long long* t = h + g * 64 + k * 8;
+        fprintf(stderr, "X3T grp%d k%d t0=%lld | valu_phase=%lld bar=%lld mfma=%lld bar=%lld\n", g, k, t[0] - h[0], t[1] - t[0],
+                t[2] - t[1], t[3] - t[2], t[4] - t[3]);
+      }
+  }
   if (c.prof_on) {
     int maxM = 0, taps = 0;
     for (int p = 0; p < a.nphase; ++p) {
