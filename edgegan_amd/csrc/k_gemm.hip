@@ -885,8 +885,19 @@ static int pick_balanced_splits(long long tiles, long long target_blocks, long l
   return (int)s0;
 }
 
+static bool wgrad_x3(const WgradArgs& a) {
+  return a.limbs == 3 && a.C >= 128 && a.N >= 128 && a.C % 4 == 0 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.dy_ps % 4 == 0 &&
+         a.x_bytes != 0 && a.dy_bytes != 0 && a.x_bytes <= (1u << 30) && a.dy_bytes <= (1u << 30) &&
+         (((uintptr_t)a.x | (uintptr_t)a.dy) & 15) == 0 && a.ldw % 4 == 0 && a.w_ts % 4 == 0;
+}
+
 int wgrad_pick_splits(const WgradArgs& a) {
   const long long M = (long long)a.NB * a.OH * a.OW;
+  if (wgrad_x3(a)) {   // ping-pong blocks: two (tap, 128-channel) units x 128 output channels, one block per CU
+    const long long units = (long long)a.KH * a.KW * ((a.C + 127) / 128);
+    const long long tiles = ((units + 1) / 2) * ((a.N + 127) / 128);
+    return pick_balanced_splits(tiles, 512, std::min(256LL, (M + 255) / 256));
+  }
   if (wgrad_flatm(a)) {
     const long long tiles = (long long)((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64);
     return pick_balanced_splits(tiles, 2048, std::min(1024LL, (M + 511) / 512));
@@ -918,7 +929,9 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
                    (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0) && (a.ldw % 4 == 0) &&
                    (a.w_ts % 4 == 0) && (((uintptr_t)out & 15) == 0);
   const char* nm;
-  if (a.bf16 && vec && !wgrad_flatm(a)) {
+  if (wgrad_x3(a) && (((uintptr_t)out & 15) == 0)) {
+    nm = launch_wgrad_x3(a, out, dense, true, s);
+  } else if (a.bf16 && vec && !wgrad_flatm(a)) {
     nm = launch_wgrad_bf16(a, out, dense, wgrad_big(a), s);
   } else if (wgrad_flatm(a)) {
     dim3 grid(((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64), a.nsplit);

@@ -705,6 +705,252 @@ const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipS
 }
 
 // =============================================================================================
+// wgrad_x3pp_kernel: dW[tap][c][n] = sum_m X[pix_in(m,tap)][c] * dY[m][n] with both operands split into limbs in the
+// kernel.  The contraction runs over pixels, the SLOW index of both NHWC operands, so the transpose happens in the
+// register -> LDS store: a thread owns 4 channels x 2 consecutive pixels of a K step (32 pixels), splits the two
+// pixels of each channel as one packed pair (split_pair: limb dword = {pixel 2q, pixel 2q+1}) and writes 3 x 4 dwords
+// to the channel rows of the three limb planes (lane / store order as in k_gemm_bf16.hip: every ds_write_b32 hits 32
+// distinct banks; global loads stay whole 128-byte lines: 8 lanes x 16 bytes of one pixel).
+// Ping-pong as in conv_gemm_x3pp_kernel: 512 threads = groups X and Y, each owning one (tap, 128-channel block) unit of
+// the gathered operand with its own LDS image; the dY tile (same pixels, same 128 output channels for both units) is
+// shared and double-buffered by K-step parity, each group splitting one half of its rows -- X the half of step k in its
+// VALU phase k (slot 2k), Y the half of step k+1 in its VALU phase k (slot 2k+1), i.e. always at least one barrier
+// before the first reader (X, slot 2k+1 / 2k+3) and after the last reader of the buffer's previous tenant.
+// =============================================================================================
+template <int NPROD>
+__global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
+  constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64;
+  __shared__ __attribute__((aligned(16))) unsigned short AsG[2][3][BM * ROWX];   // per group: [c][pixel]
+  __shared__ __attribute__((aligned(16))) unsigned short BsG[2][3][BN * ROWX];   // per K-step parity: [n][pixel]
+  __shared__ unsigned poffG[2][2][256];   // per group: gathered-pixel byte offsets, 256 pixels (8 K steps) per half
+
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  const int wm = wave >> 1, wn = wave & 1;
+  unsigned short (&As)[3][BM * ROWX] = AsG[grp];
+  unsigned (&poff)[2][256] = poffG[grp];
+  const int C = a.C, N = a.N, IH = a.IH, IW = a.IW;
+  const int T = a.KH * a.KW;
+  const int ctiles = (C + BM - 1) / BM, ntn = (N + BN - 1) / BN, units = T * ctiles;
+  const int unit = ((int)blockIdx.x / ntn) * 2 + grp;
+  const bool uvalid = unit < units;                      // an idle group still splits its half of dY and keeps the barriers
+  const int tap = uvalid ? unit / ctiles : 0;
+  const int c0 = (uvalid ? unit % ctiles : 0) * BM, n0 = ((int)blockIdx.x % ntn) * BN;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int M = a.NB * a.OH * a.OW;
+  int chunk = (M + a.nsplit - 1) / a.nsplit;
+  chunk = (chunk + BKX - 1) / BKX * BKX;
+  const int p_lo = (int)blockIdx.y * chunk;
+  const int p_hi = min(M, p_lo + chunk);
+  const int nt = p_hi > p_lo ? (p_hi - p_lo + BKX - 1) / BKX : 0;
+
+  // unit = (pixel pair mp of the K step, channel quad cq): a half wave is 8 consecutive quads (one 128-byte line of
+  // a pixel) x 4 pixel pairs of ONE 8-pixel chunk
+  const int cq8 = tid & 7, mpl = (tid >> 3) & 3, rest = tid >> 5;
+  const int kch = rest & 3;
+  const int mp = kch * 4 + mpl;
+  const int cqb = (rest >> 2) * 8 + cq8;          // A: quads cqb, cqb + 16; B: quad cqb + 16 * grp
+  const int ex = cq8 & 1;                          // odd quads store their 4 rows in the order 1,0,3,2
+  const unsigned exmask = 0u - (unsigned)ex;
+  const int st_col = (kch ^ (((-(cq8 & 3)) & 3) ^ (cq8 >> 2))) * 4 + mpl;   // dword column, swizzled (swz(4*cq))
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  unsigned a_coff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = c0 + (cqb + 16 * i) * 4;
+    a_coff[i] = (uvalid && c < C) ? (unsigned)(c * 4) : 0x40000000u;   // (extents are < 1 GB: launch_wgrad)
+  }
+  const int bn = n0 + (cqb + 16 * grp) * 4;
+  const unsigned b_noff = bn < N ? (unsigned)(bn * 4) : 0x40000000u;
+
+  auto decode_block = [&](int blk) __attribute__((always_inline)) {
+    const int m = p_lo + blk * 256 + tid;
+    unsigned off = 0x80000000u;
+    if (m < p_hi) {
+      const int ox = m % a.OW;
+      const int t2 = m / a.OW;
+      const int oy = t2 % a.OH;
+      const int nb = t2 / a.OH;
+      int iy = oy * a.S + kh - a.pad, ix = ox * a.S + kw - a.pad;
+      if (a.reflect) {
+        iy = reflect_x(iy, IH);
+        ix = reflect_x(ix, IW);
+      }
+      if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) off = (unsigned)(((nb * IH + iy) * IW + ix) * a.x_ps * 4);
+    }
+    poff[blk & 1][tid] = off;
+  };
+  f32x4 ra0[2][2], ra1[2][2], rb0[2], rb1[2];
+  auto load_a = [&](int t, f32x4 (&ra)[2][2]) __attribute__((always_inline)) {
+    const unsigned* po = &poff[(t >> 3) & 1][(t & 7) * 32 + 2 * mp];
+    const unsigned o0 = po[0], o1 = po[1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, o0 + a_coff[i], 0, 0));
+      ra[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, o1 + a_coff[i], 0, 0));
+    }
+  };
+  auto load_b = [&](int t, f32x4 (&rb)[2]) __attribute__((always_inline)) {
+    const int m = p_lo + t * BKX + 2 * mp;
+    const unsigned r0 = m < p_hi ? (unsigned)(m * a.dy_ps * 4) : 0x80000000u;
+    const unsigned r1 = m + 1 < p_hi ? (unsigned)((m + 1) * a.dy_ps * 4) : 0x80000000u;
+    rb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r0 + b_noff, 0, 0));
+    rb[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r1 + b_noff, 0, 0));
+  };
+  // 4 channels x 2 pixels -> 3 planes x 4 packed dwords into rows 4*cq + (j ^ ex), j = 0..3
+  auto store_unit = [&](unsigned short (&P)[3][BM * ROWX], int cq, const f32x4& lo, const f32x4& hi) __attribute__((always_inline)) {
+    unsigned l0[4], l1[4], l2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair(lo[j], hi[j], l0[j], l1[j], l2[j]);
+    const int o = (4 * cq) * (ROWX / 2) + st_col;
+    auto put = [&](unsigned short* plane, const unsigned (&p)[4]) __attribute__((always_inline)) {
+      // instruction j writes channel j ^ ex to row 4*cq + (j ^ ex): branch-free swap of the packed pairs
+      const unsigned s01 = (p[0] ^ p[1]) & exmask, s23 = (p[2] ^ p[3]) & exmask;
+      unsigned* q = reinterpret_cast<unsigned*>(plane) + o;
+      q[(0 ^ ex) * (ROWX / 2)] = p[0] ^ s01;
+      q[(1 ^ ex) * (ROWX / 2)] = p[1] ^ s01;
+      q[(2 ^ ex) * (ROWX / 2)] = p[2] ^ s23;
+      q[(3 ^ ex) * (ROWX / 2)] = p[3] ^ s23;
+    };
+    put(P[0], l0);
+    put(P[1], l1);
+    put(P[2], l2);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int fsw = swz(l31);
+  const unsigned short* Bcur = &BsG[0][0][0];
+  auto frag_a = [&](int p, bf16x8 (&f)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        f[i][kk] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * WTM + i * 32 + l31) * ROWX + ((kk * 2 + lh) ^ fsw) * 8]);
+  };
+  auto frag_b = [&](int p, bf16x8 (&f)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        f[j][kk] = *reinterpret_cast<const bf16x8*>(Bcur + p * (BN * ROWX) + (wn * WTN + j * 32 + l31) * ROWX + ((kk * 2 + lh) ^ fsw) * 8);
+  };
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  const int nblk = (nt + 7) / 8;
+
+  auto run = [&](auto GRP) __attribute__((always_inline)) {
+    constexpr int LEAD = decltype(GRP)::value;   // X stages its dY half of step k in VALU phase k, Y that of step k + 1
+    // one VALU phase: requests for the next tiles first, then split + store; RT = run-time guards (tail only)
+    auto valu_phase = [&](auto RT, int k, const f32x4 (&ra)[2][2], f32x4 (&ran)[2][2], const f32x4 (&rb)[2], f32x4 (&rbn)[2])
+                          __attribute__((always_inline)) {
+      constexpr bool rt = decltype(RT)::value;
+      if (!rt || k + 1 < nt) load_a(k + 1, ran);
+      if (!rt || k + 1 + LEAD < nt) load_b(k + 1 + LEAD, rbn);
+      if constexpr (!rt) __builtin_amdgcn_sched_barrier(0);
+      if ((k & 7) == 2 && (k >> 3) + 1 < nblk) decode_block((k >> 3) + 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) store_unit(As, cqb + 16 * i, ra[i][0], ra[i][1]);
+      if (!rt || k + LEAD < nt) store_unit(BsG[(k + LEAD) & 1], cqb + 16 * LEAD, rb[0], rb[1]);
+    };
+    auto mfma_phase = [&](int k) __attribute__((always_inline)) {
+      lds_barrier();
+      Bcur = &BsG[k & 1][0][0];
+      limb_products32<NPROD>(acc, frag_a, frag_b);
+      lds_barrier();
+    };
+    constexpr std::true_type guarded{};
+    constexpr std::false_type steady{};
+    // prologue: X holds A(0), B(0); Y holds A(0), B(1) and has already stored its half of B(0) (in its idle slot 0)
+    if (nt > 0) {
+      decode_block(0);
+      lds_barrier();           // both groups: the offset tables are per group, but the barrier is block-wide
+      load_a(0, ra0);
+      if constexpr (LEAD == 0) {
+        load_b(0, rb0);
+      } else {
+        load_b(0, rb0);
+        if (nt > 1) load_b(1, rb1);
+        store_unit(BsG[0], cqb + 16, rb0[0], rb0[1]);
+        lds_barrier();         // Y's idle slot 0
+      }
+    }
+    // staging sets: A(k) in ra[k & 1]; X: B(k) in rb[k & 1]; Y: B(k + 1) in rb[(k + 1) & 1]
+    int k = 0;
+    for (; k + 3 < nt; k += 2) {
+      if constexpr (LEAD == 0) {
+        valu_phase(steady, k, ra0, ra1, rb0, rb1);
+        mfma_phase(k);
+        valu_phase(steady, k + 1, ra1, ra0, rb1, rb0);
+        mfma_phase(k + 1);
+      } else {
+        valu_phase(steady, k, ra0, ra1, rb1, rb0);
+        mfma_phase(k);
+        valu_phase(steady, k + 1, ra1, ra0, rb0, rb1);
+        mfma_phase(k + 1);
+      }
+    }
+    if (k < nt) {   // up to 3 steps left (k even), straight-line with run-time guards
+      if constexpr (LEAD == 0) valu_phase(guarded, k, ra0, ra1, rb0, rb1);
+      else valu_phase(guarded, k, ra0, ra1, rb1, rb0);
+      mfma_phase(k);
+      if (k + 1 < nt) {
+        if constexpr (LEAD == 0) valu_phase(guarded, k + 1, ra1, ra0, rb1, rb0);
+        else valu_phase(guarded, k + 1, ra1, ra0, rb0, rb1);
+        mfma_phase(k + 1);
+        if (k + 2 < nt) {
+          if constexpr (LEAD == 0) valu_phase(guarded, k + 2, ra0, ra1, rb0, rb1);
+          else valu_phase(guarded, k + 2, ra0, ra1, rb1, rb0);
+          mfma_phase(k + 2);
+        }
+      }
+    }
+    if constexpr (LEAD == 0)
+      if (nt > 0) lds_barrier();   // X's idle last slot
+  };
+  if (grp == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+
+  // lane l holds filter row c = .. + (l & 31) and, in registers 4g .. 4g+3, output channels 8g + 4 (l >> 5) .. +3
+  if (!uvalid) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = c0 + wm * WTM + i * 32 + l31;
+    if (c >= C) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * WTN + j * 32 + g * 8 + lh * 4;
+        if (n >= N) continue;
+        float* q = dense_out ? out + (((size_t)blockIdx.y * T + tap) * C + c) * N + n
+                             : out + (size_t)tap * a.w_ts + (size_t)c * a.ldw + n;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (!dense_out && a.accumulate) {
+          const float4 o = *reinterpret_cast<const float4*>(q);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(q) = v;
+      }
+  }
+}
+
+const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s) {
+  (void)big_tile;
+  const int units = a.KH * a.KW * ((a.C + 127) / 128), ntn = (a.N + 127) / 128;
+  dim3 grid(((units + 1) / 2) * ntn, a.nsplit);
+  hipLaunchKernelGGL((wgrad_x3pp_kernel<6>), grid, dim3(512), 0, s, a, out, dense);
+  return "wgrad_x3pp<2x128,128>";
+}
+
+// =============================================================================================
 // three-limb bf16 filter planes, K-step-major: src [T][R][Cc] fp32 -> out[plane][T][K/32][Nrows][32] bf16 with
 // (Nrows, K) = (R, Cc) ("as stored": the contracted index is the source's fast one) or (Cc, R) (transposed)
 // =============================================================================================

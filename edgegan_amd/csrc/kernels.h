@@ -72,6 +72,7 @@ struct WgradArgs {
   int nsplit;
   int bf16;          // 1: round both operands to bf16 and use the bf16 MFMA (fp32 accumulate)
   int limbs;         // 3: fp32 result from three-limb bf16 operand splits on the bf16 MFMA (k_gemm_x3.hip)
+  unsigned x_bytes, dy_bytes;   // extents of x / dy for the limb kernel's buffer loads (0 = unknown or >= 2 GB)
 };
 int wgrad_pick_splits(const WgradArgs& a);
 size_t wgrad_workspace_floats(const WgradArgs& a);

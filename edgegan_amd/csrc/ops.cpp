@@ -415,6 +415,12 @@ static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, c
   g.reflect = reflect;
   g.accumulate = *w->g_set ? 1 : 0;
   g.bf16 = c.cfg.bf16 ? 1 : 0;
+  if (c.cfg.x3) {
+    g.limbs = 3;
+    const size_t xb = (size_t)NB * IH * IW * C * sizeof(float), yb = (size_t)NB * OH * OW * N * sizeof(float);
+    g.x_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
+    g.dy_bytes = yb < (1ull << 31) ? (unsigned)yb : 0u;
+  }
   g.nsplit = wgrad_pick_splits(g);
   const size_t wsf = wgrad_workspace_floats(g);
   g.ws = wsf ? c.arena.allocf(wsf) : nullptr;
