@@ -342,7 +342,7 @@ static int pick_x3(ConvArgs& a) {
   const double out_bytes = 4.0 * (double)maxM * a.nphase * a.N;
   double best = 1e300;
   int best_ks = 1, best_tile = 2;
-  for (int tile = pp_ok ? 1 : 2; tile <= 2; ++tile)
+  for (int tile = pp_ok ? 1 : 2; tile <= (a.limbs == 1 ? 1 : 2); ++tile)
     for (int ks = 1; ks <= 8; ++ks) {
       if (ks > 1 && nk / ks < 4) break;
       const long long blocks = (tile == 1 ? tpp : t64) * ks;
@@ -362,7 +362,7 @@ static int pick_x3(ConvArgs& a) {
 
 int conv_pick_ksplit(ConvArgs& a) {
   if (a.N <= 16 || a.C % 32 != 0 || a.N % 4 != 0) return 1;
-  if (a.limbs == 3 && a.wgt_bf) return pick_x3(a);
+  if ((a.limbs == 3 || a.limbs == 1) && a.wgt_bf) return pick_x3(a);
   int maxM = 0, minTiles = 1 << 30;
   for (int p = 0; p < a.nphase; ++p) {
     maxM = std::max(maxM, a.NB * a.ph[p].OHp * a.ph[p].OWp);
@@ -885,8 +885,9 @@ static int pick_balanced_splits(long long tiles, long long target_blocks, long l
   return (int)s0;
 }
 
-static bool wgrad_x3(const WgradArgs& a) {
-  return a.limbs == 3 && a.C >= 128 && a.N >= 128 && a.C % 4 == 0 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.dy_ps % 4 == 0 &&
+static bool wgrad_x3(const WgradArgs& a) {   // (limbs == 1: the same kernel with one plane = bf16-rounded operands)
+  static const bool bf16_pp = !(getenv("EG_BF16_PP") && atoi(getenv("EG_BF16_PP")) == 0);
+  return (a.limbs == 3 || (a.limbs == 1 && bf16_pp)) && a.C >= 128 && a.N >= 128 && a.C % 4 == 0 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.dy_ps % 4 == 0 &&
          a.x_bytes != 0 && a.dy_bytes != 0 && a.x_bytes <= (1u << 30) && a.dy_bytes <= (1u << 30) &&
          (((uintptr_t)a.x | (uintptr_t)a.dy) & 15) == 0 && a.ldw % 4 == 0 && a.w_ts % 4 == 0;
 }

@@ -138,6 +138,13 @@ __device__ __forceinline__ void limb_products32(f32x16 (&acc)[2][2], LA load_a, 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
   };
   bf16x8 b0[2][2], b1[2][2];
+  if constexpr (NPROD == 1) {   // one plane: the operands ROUNDED to bf16 (compute_dtype bf16)
+    bf16x8 a0[2][2];
+    load_a(0, a0);
+    load_b(0, b0);
+    mm(a0, b0);
+    return;
+  }
   {
     bf16x8 a0[2][2];
     load_a(0, a0);
@@ -373,13 +380,14 @@ template <bool SPLITK, int NPROD, bool REFLECT, bool TIMING = false>
 __global__ __launch_bounds__(512, 1) void conv_gemm_x3pp_kernel(const ConvArgs a) {
   constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64;
   constexpr int MI = WTM / 16, NJ = WTN / 16;
-  __shared__ __attribute__((aligned(16))) unsigned short AsG[2][3][BM * ROWX];   // per group
-  __shared__ __attribute__((aligned(16))) unsigned short BsG[3][3][BN * ROWX];   // per K step mod 3
+  constexpr int NL = NPROD == 1 ? 1 : 3;   // limb planes (1: operands rounded to bf16, the compute_dtype bf16 arithmetic)
+  __shared__ __attribute__((aligned(16))) unsigned short AsG[2][NL][BM * ROWX];   // per group
+  __shared__ __attribute__((aligned(16))) unsigned short BsG[3][NL][BN * ROWX];   // per K step mod 3
 
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);   // uniform
   const int wm = wave >> 1, wn = wave & 1;
-  unsigned short (&As)[3][BM * ROWX] = AsG[grp];
+  unsigned short (&As)[NL][BM * ROWX] = AsG[grp];
   const int zphase = SPLITK ? (int)blockIdx.z / a.ksplit : (int)blockIdx.z;
   const int zsplit = SPLITK ? (int)blockIdx.z - zphase * a.ksplit : 0;
   const ConvPhase ph = a.ph[zphase];
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3pp_kernel(const ConvArgs a
   auto dma_b_tile = [&](int par) __attribute__((always_inline)) {   // filter tile -> BsG[par], 6 x 1 KB per wave
     const int wsoff = (((ph.kh0 + kx_ty * a.kst) * a.KW + (ph.kw0 + kx_tx * a.kst)) * cpt + kx_cc) * wtile;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NL; ++p)
 #pragma unroll
       for (int i = 0; i < B_V; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (__attribute__((address_space(3))) void*)&BsG[par][p][(i * 64 + wave * 16) * ROWX],
@@ -497,13 +505,17 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3pp_kernel(const ConvArgs a
   auto store_a_tile = [&](const f32x4 (&ra)[A_R]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < A_R; ++j) {
-      unsigned p0a, p1a, p2a, p0b, p1b, p2b;
-      split_pair(ra[j][0], ra[j][1], p0a, p1a, p2a);
-      split_pair(ra[j][2], ra[j][3], p0b, p1b, p2b);
       const int o = (j * 32 + ar) * ROWX + ast;
-      *reinterpret_cast<u32x2*>(&As[0][o]) = (u32x2){p0a, p0b};
-      *reinterpret_cast<u32x2*>(&As[1][o]) = (u32x2){p1a, p1b};
-      *reinterpret_cast<u32x2*>(&As[2][o]) = (u32x2){p2a, p2b};
+      if constexpr (NL == 1) {
+        *reinterpret_cast<u32x2*>(&As[0][o]) = (u32x2){pack2(ra[j][0], ra[j][1]), pack2(ra[j][2], ra[j][3])};
+      } else {
+        unsigned p0a, p1a, p2a, p0b, p1b, p2b;
+        split_pair(ra[j][0], ra[j][1], p0a, p1a, p2a);
+        split_pair(ra[j][2], ra[j][3], p0b, p1b, p2b);
+        *reinterpret_cast<u32x2*>(&As[0][o]) = (u32x2){p0a, p0b};
+        *reinterpret_cast<u32x2*>(&As[NL > 1 ? 1 : 0][o]) = (u32x2){p1a, p1b};
+        *reinterpret_cast<u32x2*>(&As[NL > 1 ? 2 : 0][o]) = (u32x2){p2a, p2b};
+      }
     }
   };
   f32x16 acc[2][2];
@@ -650,6 +662,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3pp_kernel(const ConvArgs a
 }
 
 bool conv_x3_eligible(const ConvArgs& a) {
+  if (a.limbs == 1)   // one plane (bf16-rounded operands): only the ping-pong kernel has that form
+    return a.wgt_bf && a.x3_tile == 1 && a.C % BKX == 0 && a.N >= 128 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.y_ps % 4 == 0 &&
+           a.x_bytes && a.wbf_bytes && (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.y & 15) == 0) &&
+           (((uintptr_t)a.wgt_bf & 15) == 0) && (!a.bias || (((uintptr_t)a.bias & 15) == 0));
   return a.wgt_bf && a.limbs == 3 && a.C % BKX == 0 && a.N > 16 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.y_ps % 4 == 0 &&
          a.wbf_plane % 8 == 0 && (((uintptr_t)a.x & 15) == 0) &&
          (((uintptr_t)a.y & 15) == 0) && (((uintptr_t)a.wgt_bf & 15) == 0) && (!a.bias || (((uintptr_t)a.bias & 15) == 0));
@@ -678,6 +694,18 @@ static void conv_x3_launch(const ConvArgs& a, int maxM, hipStream_t s) {
 const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s) {
   const int np = x3_nprod();
   static const int pipe = getenv("EG_X3_PIPE") ? atoi(getenv("EG_X3_PIPE")) : 2;
+  if (a.limbs == 1) {
+    const int zs = a.ksplit > 1 ? a.ksplit : 1;
+    dim3 grid((maxM + 255) / 256, (a.N + 127) / 128, a.nphase * zs);
+    if (a.reflect) {
+      if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3pp_kernel<true, 1, true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((conv_gemm_x3pp_kernel<false, 1, true>), grid, dim3(512), 0, s, a);
+    } else {
+      if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3pp_kernel<true, 1, false>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((conv_gemm_x3pp_kernel<false, 1, false>), grid, dim3(512), 0, s, a);
+    }
+    return a.ksplit > 1 ? "conv_gemm_bf16pp<2x128,128,splitk>" : "conv_gemm_bf16pp<2x128,128>";
+  }
   if (big_tile && pipe == 2 && np == 6 && a.x_bytes && a.wbf_bytes) {
     const int zs = a.ksplit > 1 ? a.ksplit : 1;
     dim3 grid((maxM + 255) / 256, (a.N + 127) / 128, a.nphase * zs);
@@ -720,14 +748,15 @@ const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipS
 template <int NPROD>
 __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
   constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64;
-  __shared__ __attribute__((aligned(16))) unsigned short AsG[2][3][BM * ROWX];   // per group: [c][pixel]
-  __shared__ __attribute__((aligned(16))) unsigned short BsG[2][3][BN * ROWX];   // per K-step parity: [n][pixel]
+  constexpr int NL = NPROD == 1 ? 1 : 3;
+  __shared__ __attribute__((aligned(16))) unsigned short AsG[2][NL][BM * ROWX];   // per group: [c][pixel]
+  __shared__ __attribute__((aligned(16))) unsigned short BsG[2][NL][BN * ROWX];   // per K-step parity: [n][pixel]
   __shared__ unsigned poffG[2][2][256];   // per group: gathered-pixel byte offsets, 256 pixels (8 K steps) per half
 
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
   const int wm = wave >> 1, wn = wave & 1;
-  unsigned short (&As)[3][BM * ROWX] = AsG[grp];
+  unsigned short (&As)[NL][BM * ROWX] = AsG[grp];
   unsigned (&poff)[2][256] = poffG[grp];
   const int C = a.C, N = a.N, IH = a.IH, IW = a.IW;
   const int T = a.KH * a.KW;
@@ -800,10 +829,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
     rb[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r1 + b_noff, 0, 0));
   };
   // 4 channels x 2 pixels -> 3 planes x 4 packed dwords into rows 4*cq + (j ^ ex), j = 0..3
-  auto store_unit = [&](unsigned short (&P)[3][BM * ROWX], int cq, const f32x4& lo, const f32x4& hi) __attribute__((always_inline)) {
+  auto store_unit = [&](unsigned short (&P)[NL][BM * ROWX], int cq, const f32x4& lo, const f32x4& hi) __attribute__((always_inline)) {
     unsigned l0[4], l1[4], l2[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split_pair(lo[j], hi[j], l0[j], l1[j], l2[j]);
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (NL == 1) l0[j] = pack2(lo[j], hi[j]);
+      else split_pair(lo[j], hi[j], l0[j], l1[j], l2[j]);
+    }
     const int o = (4 * cq) * (ROWX / 2) + st_col;
     auto put = [&](unsigned short* plane, const unsigned (&p)[4]) __attribute__((always_inline)) {
       // instruction j writes channel j ^ ex to row 4*cq + (j ^ ex): branch-free swap of the packed pairs
@@ -815,8 +847,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
       q[(3 ^ ex) * (ROWX / 2)] = p[3] ^ s23;
     };
     put(P[0], l0);
-    put(P[1], l1);
-    put(P[2], l2);
+    if constexpr (NL > 1) {
+      put(P[NL > 1 ? 1 : 0], l1);
+      put(P[NL > 1 ? 2 : 0], l2);
+    }
   };
 
   f32x16 acc[2][2];
@@ -946,6 +980,10 @@ const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_
   (void)big_tile;
   const int units = a.KH * a.KW * ((a.C + 127) / 128), ntn = (a.N + 127) / 128;
   dim3 grid(((units + 1) / 2) * ntn, a.nsplit);
+  if (a.limbs == 1) {
+    hipLaunchKernelGGL((wgrad_x3pp_kernel<1>), grid, dim3(512), 0, s, a, out, dense);
+    return "wgrad_bf16pp<2x128,128>";
+  }
   hipLaunchKernelGGL((wgrad_x3pp_kernel<6>), grid, dim3(512), 0, s, a, out, dense);
   return "wgrad_x3pp<2x128,128>";
 }
@@ -955,7 +993,7 @@ const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_
 // (Nrows, K) = (R, Cc) ("as stored": the contracted index is the source's fast one) or (Cc, R) (transposed)
 // =============================================================================================
 __global__ void split_bf16x3_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int R, int Cc,
-                                    int transposed, size_t plane) {
+                                    int transposed, size_t plane, int nplanes) {
   __shared__ float tile[32][33];
   const int t = blockIdx.z;
   const float* src = in + (size_t)t * R * Cc;
@@ -976,15 +1014,17 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ in, unsigned short
       split_pair(v, 0.f, p0, p1, p2);
       const size_t o = (((size_t)t * (K / 32) + kb0 / 32) * Nrows + n) * 32 + threadIdx.x;
       out[o] = (unsigned short)(p0 & 0xffffu);
-      out[o + plane] = (unsigned short)(p1 & 0xffffu);
-      out[o + 2 * plane] = (unsigned short)(p2 & 0xffffu);
+      if (nplanes == 3) {
+        out[o + plane] = (unsigned short)(p1 & 0xffffu);
+        out[o + 2 * plane] = (unsigned short)(p2 & 0xffffu);
+      }
     }
   }
 }
 void launch_split_bf16x3(const float* in, unsigned short* out, int T, int R, int Cc, int transposed, size_t plane,
-                         hipStream_t s) {
+                         int nplanes, hipStream_t s) {
   dim3 grid((Cc + 31) / 32, (R + 31) / 32, T);
-  hipLaunchKernelGGL(split_bf16x3_kernel, grid, dim3(32, 8), 0, s, in, out, R, Cc, transposed, plane);
+  hipLaunchKernelGGL(split_bf16x3_kernel, grid, dim3(32, 8), 0, s, in, out, R, Cc, transposed, plane, nplanes);
 }
 
 }  // namespace eg

@@ -92,7 +92,7 @@ const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_
 // src [T][R][Cc] fp32 -> three bf16 limb planes, K-step-major [plane][T][K/32][Nrows][32]; (Nrows, K) = (R, Cc), or (Cc, R)
 // when transposed; K % 32 == 0
 void launch_split_bf16x3(const float* in, unsigned short* out, int T, int R, int Cc, int transposed, size_t plane,
-                         hipStream_t s);
+                         int nplanes /* 3, or 1: the first limb only = the value rounded to bf16 */, hipStream_t s);
 
 // Phase-merged filter of a stride-2 layer with 3 image channels: the 4 sub-pixel phases of a transposed convolution
 // (or of a stride-2 convolution's input gradient) become 12 output channels n = (py*2+px)*3 + ch of ONE 3x3 stride-1

@@ -228,7 +228,7 @@ static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
     unsigned short*& slot = transposed ? w->wlT : w->wl;
     if (!slot) {
       slot = reinterpret_cast<unsigned short*>(c.arena.allocf((3 * n + 1) / 2));
-      launch_split_bf16x3(w->w, slot, w->T, w->R, w->Cc, transposed ? 1 : 0, n, c.stream);
+      launch_split_bf16x3(w->w, slot, w->T, w->R, w->Cc, transposed ? 1 : 0, n, 3, c.stream);
     }
     a.wgt_bf = slot;
     a.wbf_ts = (long long)a.C * a.N;
@@ -239,6 +239,26 @@ static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
     return;
   }
   if (!c.cfg.bf16 || a.C % 32 != 0 || a.N <= 16 || a.N % 4 != 0) return;
+  // >= 128 output channels: the ping-pong kernel in its one-plane form (same arithmetic: both operands rounded to
+  // bf16, fp32 accumulation), filter as ONE K-step-major plane; narrower layers keep the 64x64 bf16 kernel
+  static const bool bf16_pp = !(getenv("EG_BF16_PP") && atoi(getenv("EG_BF16_PP")) == 0);
+  const size_t xbytes = (size_t)a.NB * a.IH * a.IW * a.x_ps * sizeof(float);
+  if (bf16_pp && a.N >= 128 && xbytes < (1ull << 31) && a.x_ps % 4 == 0 && a.y_ps % 4 == 0) {
+    const size_t n = (size_t)w->T * w->R * w->Cc;
+    unsigned short*& slot = transposed ? w->wlT : w->wl;
+    if (!slot) {
+      slot = reinterpret_cast<unsigned short*>(c.arena.allocf((n + 1) / 2));
+      launch_split_bf16x3(w->w, slot, w->T, w->R, w->Cc, transposed ? 1 : 0, n, 1, c.stream);
+    }
+    a.wgt_bf = slot;
+    a.wbf_ts = (long long)a.C * a.N;
+    a.ldwbf = a.C;
+    a.limbs = 1;
+    a.wbf_plane = (long long)n;
+    a.wbf_bytes = 2 * n < (1ull << 31) ? (unsigned)(2 * n) : 0u;
+    if (a.wbf_bytes) return;
+    a.limbs = 0;
+  }
   unsigned short*& slot = transposed ? w->wbT : w->wb;
   if (!slot) {
     const size_t n = (size_t)w->T * w->R * w->Cc;
@@ -415,8 +435,8 @@ static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, c
   g.reflect = reflect;
   g.accumulate = *w->g_set ? 1 : 0;
   g.bf16 = c.cfg.bf16 ? 1 : 0;
-  if (c.cfg.x3) {
-    g.limbs = 3;
+  if (c.cfg.x3 || c.cfg.bf16) {
+    g.limbs = c.cfg.x3 ? 3 : 1;
     const size_t xb = (size_t)NB * IH * IW * C * sizeof(float), yb = (size_t)NB * OH * OW * N * sizeof(float);
     g.x_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
     g.dy_bytes = yb < (1ull << 31) ? (unsigned)yb : 0u;

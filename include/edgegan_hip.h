@@ -42,9 +42,13 @@ typedef struct eg_config {
   float learning_rate; /* train.py:18                                   */
   float joint_dweight, image_dweight, edge_dweight; /* train.py:68-73   */
   int device;          /* train.py:14 --gpu                             */
-  int compute_dtype;   /* no reference flag: 0 = fp32 everywhere (the reference's arithmetic), 1 = the dense
-                          conv/deconv contractions take bf16-rounded operands on the bf16 MFMA with fp32
-                          accumulation; storage, norms, losses and RMSProp stay fp32 (BASELINE configs 2,4,5) */
+  int compute_dtype;   /* no reference flag.  0 = fp32 everywhere (the reference's arithmetic), dense contractions on
+                          the exact-fp32 MFMA instruction; 2 = the same fp32 arithmetic with every fp32 operand of a dense
+                          conv / deconv / filter-gradient contraction split EXACTLY into three bf16 limbs and the
+                          product formed from 6 exact limb products on the bf16 MFMA, fp32 accumulation (an fp32
+                          implementation: held to the fp32 tolerances, ~1.35x faster -- DESIGN.md 3.4); 1 = the
+                          contractions take bf16-ROUNDED operands on the bf16 MFMA with fp32 accumulation; storage,
+                          norms, losses and RMSProp stay fp32 in every mode (BASELINE configs 2,4,5) */
 } eg_config;
 
 int eg_default_config(eg_config* cfg);
