@@ -166,7 +166,7 @@ int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long 
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
   ctx->c.sn_valid = false;
   ctx->c.gen_cache_valid[0] = ctx->c.gen_cache_valid[1] = false;
-  for (auto& p : ctx->c.params) p->wT_valid = p->wM_valid = false;
+  for (auto& p : ctx->c.params) p->invalidate_derived();
   EG_API_END(ctx)
 }
 

@@ -129,6 +129,24 @@ struct Tensor {
 };
 using T = Tensor*;
 
+// Derived bf16 copy of a filter that outlives a sub-step.  It is built lazily on whichever lane's stream first needs it;
+// `ready` is recorded behind the build and every OTHER stream waits for it before its first read (lanes run
+// concurrently: ops.cpp limb_planes).
+struct LimbCache {
+  unsigned short* buf = nullptr;
+  bool valid = false;
+  int planes = 0;
+  hipEvent_t ready = nullptr;
+  hipStream_t built_on = nullptr;
+  unsigned waited = 0;   // bit per lane that has already ordered itself behind `ready`
+  void release() {
+    if (buf) (void)hipFree(buf);
+    if (ready) (void)hipEventDestroy(ready);
+    buf = nullptr;
+    ready = nullptr;
+  }
+};
+
 // A model variable (TF variable of SURVEY Appendix C).  w/g/ms/mom point into the owning
 // network group's flat buffers (one all-reduce + one RMSProp launch per group).
 struct Param {
@@ -153,6 +171,9 @@ struct Param {
   // phase-merged 3x3 form of a stride-2 filter with 3 image channels (ops.cpp: merged_filter), same life cycle as wT
   float* wM = nullptr;
   bool wM_valid = false;
+  // bf16 limb planes of a filter (k_gemm_x3.hip), K-step-major, [0] as stored / [1] per-tap transposed; same life cycle
+  LimbCache wL[2];
+  void invalidate_derived() { wT_valid = wM_valid = wL[0].valid = wL[1].valid = false; }
 };
 
 struct Ctx;

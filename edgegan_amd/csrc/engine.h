@@ -31,6 +31,8 @@ struct NetGroup {
   size_t n_live = 0, n_train = 0, n_total = 0;
 };
 
+struct SNWeight;
+
 // Effective weights of one conv/deconv/linear for the current sub-step.
 struct WRef {
   const float* w = nullptr;  // [T][R][Cc]
@@ -39,6 +41,7 @@ struct WRef {
   bool want_grad = false;
   const float* wT = nullptr; // per-tap transpose [T][Cc][R] (built lazily, cached per sub-step)
   Param* param = nullptr;    // set when the weights ARE a variable (enables the persistent transpose cache)
+  SNWeight* sn = nullptr;    // set when the weights are a spectral-norm W/sigma (persistent derived copies live there)
   unsigned short* wb = nullptr;   // bf16 copy, same layout      (compute_dtype bf16; lazily, per sub-step)
   unsigned short* wbT = nullptr;  // bf16 copy, per-tap transposed
   unsigned short* wl = nullptr;   // three bf16 limb planes, same layout   (compute_dtype f32x3; lazily, per sub-step)
@@ -55,6 +58,7 @@ struct SNWeight {
         *scal = nullptr;
   bool dWbar_set = false;
   bool wT_valid = false;
+  LimbCache wL[2];   // limb planes of Wbar (as stored / transposed), rebuilt when Wbar is
   int K = 0, Co = 0, T = 1;
 };
 

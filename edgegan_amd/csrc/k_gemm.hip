@@ -418,7 +418,13 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     a.ksplit = 1;   // only the fully vectorised kernels have a split-K form
   const long long blocks128 = (long long)((maxM + 127) / 128) * ((a.N + 127) / 128) * a.nphase;
   const char* nm;
-  if (a.N <= 16) {
+  if (!a.wgt && !(a.N > 16 && (conv_x3_eligible(a) || conv_bf16_eligible(a)))) {
+    fprintf(stderr, "edgegan_hip: conv launch without an fp32 filter that no limb / bf16 kernel accepts (N=%d C=%d)\n", a.N, a.C);
+    abort();
+  }
+  if (conv_scatter_eligible(a)) {
+    nm = launch_conv_scatter(a, s);
+  } else if (a.N <= 16) {
     if ((long long)((maxM + 255) / 256) * a.nphase >= 256)
       nm = conv_dispatch<256, 16, 64, 16>(a, maxM, avec, bvec, s, "conv_gemm<256,16,vec>", "conv_gemm<256,16,avec>",
                                           "conv_gemm<256,16,flat>");
@@ -887,7 +893,9 @@ static int pick_balanced_splits(long long tiles, long long target_blocks, long l
 
 static bool wgrad_x3(const WgradArgs& a) {   // (limbs == 1: the same kernel with one plane = bf16-rounded operands)
   static const bool bf16_pp = !(getenv("EG_BF16_PP") && atoi(getenv("EG_BF16_PP")) == 0);
-  return (a.limbs == 3 || (a.limbs == 1 && bf16_pp)) && a.C >= 128 && a.N >= 128 && a.C % 4 == 0 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.dy_ps % 4 == 0 &&
+  // C == 64: two taps per 128-row tile (k_gemm_x3.hip), worth it when there are at least two taps
+  const bool c_ok = a.C >= 128 || (a.C == 64 && a.KH * a.KW >= 2);
+  return (a.limbs == 3 || (a.limbs == 1 && bf16_pp)) && c_ok && a.N >= 128 && a.C % 4 == 0 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.dy_ps % 4 == 0 &&
          a.x_bytes != 0 && a.dy_bytes != 0 && a.x_bytes <= (1u << 30) && a.dy_bytes <= (1u << 30) &&
          (((uintptr_t)a.x | (uintptr_t)a.dy) & 15) == 0 && a.ldw % 4 == 0 && a.w_ts % 4 == 0;
 }
@@ -895,7 +903,7 @@ static bool wgrad_x3(const WgradArgs& a) {   // (limbs == 1: the same kernel wit
 int wgrad_pick_splits(const WgradArgs& a) {
   const long long M = (long long)a.NB * a.OH * a.OW;
   if (wgrad_x3(a)) {   // ping-pong blocks: two (tap, 128-channel) units x 128 output channels, one block per CU
-    const long long units = (long long)a.KH * a.KW * ((a.C + 127) / 128);
+    const long long units = a.C == 64 ? (a.KH * a.KW + 1) / 2 : (long long)a.KH * a.KW * ((a.C + 127) / 128);
     const long long tiles = ((units + 1) / 2) * ((a.N + 127) / 128);
     return pick_balanced_splits(tiles, 512, std::min(256LL, (M + 255) / 256));
   }

@@ -751,21 +751,27 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
   constexpr int NL = NPROD == 1 ? 1 : 3;
   __shared__ __attribute__((aligned(16))) unsigned short AsG[2][NL][BM * ROWX];   // per group: [c][pixel]
   __shared__ __attribute__((aligned(16))) unsigned short BsG[2][NL][BN * ROWX];   // per K-step parity: [n][pixel]
-  __shared__ unsigned poffG[2][2][256];   // per group: gathered-pixel byte offsets, 256 pixels (8 K steps) per half
+  // per group, per 256-pixel block parity (8 K steps), per row half of the unit: gathered-pixel byte offsets.  The two
+  // halves (rows 0-63 / 64-127 of the A tile) belong to the same tap when C >= 128 and to two consecutive taps when
+  // C == 64 (a unit is then taps 2u, 2u+1 x all 64 channels: no half-empty tiles for the 64-channel layers)
+  __shared__ unsigned poffG[2][2][2][256];
 
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
   const int wm = wave >> 1, wn = wave & 1;
   unsigned short (&As)[NL][BM * ROWX] = AsG[grp];
-  unsigned (&poff)[2][256] = poffG[grp];
+  unsigned (&poff)[2][2][256] = poffG[grp];
   const int C = a.C, N = a.N, IH = a.IH, IW = a.IW;
   const int T = a.KH * a.KW;
-  const int ctiles = (C + BM - 1) / BM, ntn = (N + BN - 1) / BN, units = T * ctiles;
+  const bool two_taps = C == 64;
+  const int ctiles = (C + BM - 1) / BM, ntn = (N + BN - 1) / BN, units = two_taps ? (T + 1) / 2 : T * ctiles;
   const int unit = ((int)blockIdx.x / ntn) * 2 + grp;
   const bool uvalid = unit < units;                      // an idle group still splits its half of dY and keeps the barriers
-  const int tap = uvalid ? unit / ctiles : 0;
-  const int c0 = (uvalid ? unit % ctiles : 0) * BM, n0 = ((int)blockIdx.x % ntn) * BN;
-  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int tap = uvalid ? (two_taps ? 2 * unit : unit / ctiles) : 0;
+  const int tap1 = two_taps ? tap + 1 : tap;             // tap of the tile's upper row half (may be == T: an empty half)
+  const int c0 = (uvalid && !two_taps ? unit % ctiles : 0) * BM, n0 = ((int)blockIdx.x % ntn) * BN;
+  const int khh[2] = {tap / a.KW, tap1 / a.KW};
+  const int kwh[2] = {tap - khh[0] * a.KW, tap1 - khh[1] * a.KW};
   const int M = a.NB * a.OH * a.OW;
   int chunk = (M + a.nsplit - 1) / a.nsplit;
   chunk = (chunk + BKX - 1) / BKX * BKX;
@@ -788,35 +794,40 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
   unsigned a_coff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int c = c0 + (cqb + 16 * i) * 4;
-    a_coff[i] = (uvalid && c < C) ? (unsigned)(c * 4) : 0x40000000u;   // (extents are < 1 GB: launch_wgrad)
+    const int c = two_taps ? cqb * 4 : c0 + (cqb + 16 * i) * 4;
+    const bool ok = two_taps ? (i == 0 ? tap : tap1) < T : c < C;
+    a_coff[i] = (uvalid && ok) ? (unsigned)(c * 4) : 0x40000000u;   // (extents are < 1 GB: launch_wgrad)
   }
   const int bn = n0 + (cqb + 16 * grp) * 4;
   const unsigned b_noff = bn < N ? (unsigned)(bn * 4) : 0x40000000u;
 
   auto decode_block = [&](int blk) __attribute__((always_inline)) {
     const int m = p_lo + blk * 256 + tid;
-    unsigned off = 0x80000000u;
+    unsigned off[2] = {0x80000000u, 0x80000000u};
     if (m < p_hi) {
       const int ox = m % a.OW;
       const int t2 = m / a.OW;
       const int oy = t2 % a.OH;
       const int nb = t2 / a.OH;
-      int iy = oy * a.S + kh - a.pad, ix = ox * a.S + kw - a.pad;
-      if (a.reflect) {
-        iy = reflect_x(iy, IH);
-        ix = reflect_x(ix, IW);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int iy = oy * a.S + khh[h] - a.pad, ix = ox * a.S + kwh[h] - a.pad;
+        if (a.reflect) {
+          iy = reflect_x(iy, IH);
+          ix = reflect_x(ix, IW);
+        }
+        if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) off[h] = (unsigned)(((nb * IH + iy) * IW + ix) * a.x_ps * 4);
       }
-      if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) off = (unsigned)(((nb * IH + iy) * IW + ix) * a.x_ps * 4);
     }
-    poff[blk & 1][tid] = off;
+    poff[blk & 1][0][tid] = off[0];
+    poff[blk & 1][1][tid] = off[1];
   };
   f32x4 ra0[2][2], ra1[2][2], rb0[2], rb1[2];
   auto load_a = [&](int t, f32x4 (&ra)[2][2]) __attribute__((always_inline)) {
-    const unsigned* po = &poff[(t >> 3) & 1][(t & 7) * 32 + 2 * mp];
-    const unsigned o0 = po[0], o1 = po[1];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      const unsigned* po = &poff[(t >> 3) & 1][i][(t & 7) * 32 + 2 * mp];
+      const unsigned o0 = po[0], o1 = po[1];
       ra[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, o0 + a_coff[i], 0, 0));
       ra[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, o1 + a_coff[i], 0, 0));
     }
@@ -956,16 +967,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
   if (!uvalid) return;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int c = c0 + wm * WTM + i * 32 + l31;
-    if (c >= C) continue;
+    // the wave's 64 rows are one half of the tile: in the two-tap form that half is a tap of its own
+    const int c = two_taps ? i * 32 + l31 : c0 + wm * WTM + i * 32 + l31;
+    const int otap = two_taps ? tap + wm : tap;
+    if (c >= C || otap >= T) continue;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * WTN + j * 32 + g * 8 + lh * 4;
         if (n >= N) continue;
-        float* q = dense_out ? out + (((size_t)blockIdx.y * T + tap) * C + c) * N + n
-                             : out + (size_t)tap * a.w_ts + (size_t)c * a.ldw + n;
+        float* q = dense_out ? out + (((size_t)blockIdx.y * T + otap) * C + c) * N + n
+                             : out + (size_t)otap * a.w_ts + (size_t)c * a.ldw + n;
         float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         if (!dense_out && a.accumulate) {
           const float4 o = *reinterpret_cast<const float4*>(q);
@@ -978,7 +991,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
 
 const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s) {
   (void)big_tile;
-  const int units = a.KH * a.KW * ((a.C + 127) / 128), ntn = (a.N + 127) / 128;
+  const int units = a.C == 64 ? (a.KH * a.KW + 1) / 2 : a.KH * a.KW * ((a.C + 127) / 128), ntn = (a.N + 127) / 128;
   dim3 grid(((units + 1) / 2) * ntn, a.nsplit);
   if (a.limbs == 1) {
     hipLaunchKernelGGL((wgrad_x3pp_kernel<1>), grid, dim3(512), 0, s, a, out, dense);

@@ -1,0 +1,258 @@
+// Kernels for the thin layers of the EdgeGAN stack on gfx950: contractions with <= 12 output channels (input gradients
+// towards the 3-channel image / the classifier's 8-channel stem, the phase-merged 3-channel transposed convolution) or
+// <= 8 input channels.  These layers are HBM-class: a few FLOPs per byte, so what matters is that every
+// operand byte is read from HBM/L2 ONCE, in whole 128-byte lines, and that no MFMA work is spent on structural padding.
+//
+//   conv_scatter_kernel : 3x3 stride-1 convolution with N <= 12 output channels and C % 32 == 0 input channels,
+//                         written as ONE dense product over the INPUT pixels followed by a col2im in LDS:
+//                             P[pix][tap*N + n] = sum_c X[pix][c] * W[tap][c][n]          (M = pixels, N' = 9N, K = C)
+//                             Y[oy][ox][n]      = b[n] + sum_tap P[(oy,ox) + d(tap)][tap*N + n]
+//                         X is read exactly once, straight from global memory into the MFMA operand registers (whole
+//                         128-byte lines, no LDS staging); the gather form re-reads it 9 times through L2 and pads N to
+//                         16 per tap (N = 3: 81 % padding; here 27 -> 32 columns: 16 %).
+//                         conv.py:13-36 / 278-285 input gradients, conv.py:49-53 (deconv2d, phase-merged) forward.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace eg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_scatter_kernel<NT>: NT = 16-column tiles of the product (NP = 16 NT >= 9 N).
+//
+// Block = one image x a strip of S output rows, 256 threads = 4 waves.  The strip's input rows [lo, hi) (the strip plus
+// one halo row each side, clipped to the image) are processed in rounds of R rows (R W >= 64 pixels): a wave owns the
+// 16-pixel tiles wave, wave + 4, ... of the round, runs the K loop over all C channels for its tile with the 16x16x4 fp32
+// MFMA (exact fp32 products, fp32 accumulation), and writes the tile's NP columns to a ring of 2R + 2 product rows in LDS.
+// One barrier per round; after it the output rows whose three product rows are complete are summed from the ring
+// (9 N LDS reads per output pixel) and stored -- while faster waves already multiply the next round (their writes go to
+// ring rows the emit does not read).
+//
+// MFMA operands: lane (p = l & 15, g = l >> 4) loads channels [32 ks + 8 g, + 8) of pixel p as two float4 (a wave-level
+// load pair = 16 pixels x one whole 128-byte line); MFMA j = 0..7 of the K step takes element j, i.e. contracts channels
+// 32 ks + 8 g' + j over g' = 0..3.  The filter image in LDS is laid out to match: Wl[c / 8][col][c % 8], so the same lane
+// reads its 8 B-operands of a column tile with two ds_read_b128.  Operands are swapped (D^T = B^T A^T): lane l ends up
+// with columns 16 ct + 4 g .. + 3 of pixel p -> one ds_write_b128 per tile and column tile.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void conv_scatter_kernel(const ConvArgs a, int S, int R, int lw) {
+  constexpr int NP = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = a.C, N = a.N, H = a.IH, W = a.IW;
+  float* Wl = smem;                        // [C / 8][NP][8]
+  float* Pr = smem + (size_t)C * NP;       // [(2R + 2) rows][W][NP]
+  const int ring = 2 * R + 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int strips = (H + S - 1) / S;
+  const int nb = (int)blockIdx.x / strips, ya = ((int)blockIdx.x % strips) * S;
+  const int yb = min(H, ya + S);
+  const ConvPhase ph = a.ph[0];
+  const int D = a.D;                       // +1: input pixel = out + tap - 1; -1: out - tap + 1 (offy == offx == -D)
+
+  // ---- filter -> LDS, columns (tap, n), zero padded to NP -------------------------------------------------------------
+  for (int i = tid; i < C * NP; i += 256) {
+    const int c = i / NP, col = i - c * NP;
+    float v = 0.f;
+    if (col < 9 * N) {
+      const int tap = col / N, n = col - tap * N;
+      const int ty = tap / 3, tx = tap - 3 * ty;
+      const long long wt = (long long)((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * a.w_ts;
+      v = a.wgt[wt + (size_t)c * a.ldw + n];
+    }
+    Wl[((size_t)(c >> 3) * NP + col) * 8 + (c & 7)] = v;
+  }
+
+  const int lo = max(0, ya - 1), hi = min(H, yb + 1);
+  const int rounds = (hi - lo + R - 1) / R;
+  const int tiles = (R * W) >> 4;          // 16-pixel tiles per round (R W % 64 == 0)
+  const int tpw = tiles >> 2;              // tiles per wave and round
+  const int KS = C >> 5;                   // K steps of 32 channels
+  const int p15 = lane & 15, g = lane >> 4;
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+
+  // this lane's pixel of tile j in round k: byte offset of its channel group, or out of range (-> zeros)
+  auto pix_off = [&](int k, int j) -> unsigned {
+    const int idx = ((wave + 4 * j) << 4) + p15;
+    const int row = lo + k * R + (idx >> lw), col = idx & (W - 1);
+    if (k >= rounds || row >= hi) return 0x80000000u;
+    return (unsigned)((((nb * H + row) * W + col) * a.x_ps + 8 * g) * 4);
+  };
+  // flat sequence of this wave's work items (round, tile, K step); the operand loads run PD items ahead
+  constexpr int PD = 4;
+  f32x4 ra[PD][2];
+  const int items = rounds * tpw * KS;
+  int ld_k = 0, ld_j = 0, ld_ks = 0;
+  unsigned ld_off = pix_off(0, 0);
+  auto issue = [&](f32x4 (&r)[2]) __attribute__((always_inline)) {
+    r[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, ld_off, ld_ks * 128, 0));
+    r[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, ld_off, ld_ks * 128 + 16, 0));
+    if (++ld_ks == KS) {
+      ld_ks = 0;
+      if (++ld_j == tpw) {
+        ld_j = 0;
+        ++ld_k;
+      }
+      ld_off = pix_off(ld_k, ld_j);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < PD; ++i) issue(ra[i]);   // (items past the end resolve to out-of-range offsets: zeros, no faults)
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();   // filter image complete
+
+  const float* wl_lane = Wl + ((size_t)g * NP + p15) * 8;
+  int cur_k = 0, cur_j = 0, cur_ks = 0;
+  int emitted = ya;   // output rows [ya, emitted) are stored
+
+  auto emit_rows = [&](int k) {
+    // product rows < pr are complete
+    const int pr = min(hi, lo + (k + 1) * R);
+    const int e_now = pr >= hi ? yb : max(ya, pr - 1);
+    const int cnt = (e_now - emitted) * W * N;
+    for (int e = tid; e < cnt; e += 256) {
+      const int n = e % N, q = e / N;
+      const int ox = q & (W - 1), oy = emitted + (q >> lw);
+      float v = 0.f;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const int iy = oy + (ty - 1) * D;
+        if (iy < 0 || iy >= H) continue;
+        const float* prow = Pr + (size_t)(iy % ring) * W * NP;
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const int ix = ox + (tx - 1) * D;
+          if (ix < 0 || ix >= W) continue;
+          v += prow[ix * NP + (ty * 3 + tx) * N + n];
+        }
+      }
+      float* qy;
+      if (a.shuf) {   // 12 channels -> 2x2 output pixels of 3 channels (phase-merged stride-2 layer)
+        const int p = n / 3, ch = n - 3 * p;
+        qy = a.y + ((size_t)(nb * a.OHf + 2 * oy + (p >> 1)) * a.OWf + 2 * ox + (p & 1)) * a.y_ps + ch;
+        if (a.bias) v += a.bias[ch];
+      } else {
+        qy = a.y + ((size_t)(nb * a.OHf + oy) * a.OWf + ox) * a.y_ps + n;
+        if (a.bias) v += a.bias[n];
+      }
+      if (a.accumulate) v += *qy;
+      *qy = v;
+    }
+    emitted = e_now;
+  };
+
+  for (int it = 0; it < items; it += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      if (it + u < items) {
+        // consume the staged operand of item it + u, then re-issue its registers for item it + u + PD
+        const f32x4 a0 = ra[u][0], a1 = ra[u][1];
+        issue(ra[u]);
+        const float* wk = wl_lane + (size_t)cur_ks * 4 * NP * 8;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(wk + t * 16 * 8);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(wk + t * 16 * 8 + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j], a0[j], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j], a1[j], acc[t], 0, 0, 0);
+        }
+        if (++cur_ks == KS) {   // tile complete: its NP columns -> ring
+          cur_ks = 0;
+          const int idx = ((wave + 4 * cur_j) << 4) + p15;
+          const int row = lo + cur_k * R + (idx >> lw), col = idx & (W - 1);
+          if (row < hi) {
+            float* dst = Pr + ((size_t)(row % ring) * W + col) * NP + 4 * g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(dst + 16 * t) = acc[t];
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (++cur_j == tpw) {
+            cur_j = 0;
+            __syncthreads();
+            emit_rows(cur_k);
+            ++cur_k;
+          }
+        }
+      }
+    }
+  }
+}
+
+static int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+static bool scatter_geometry(const ConvArgs& a, int* S, int* R, size_t* lds) {
+  const int W = a.IW, H = a.IH;
+  if (W < 4 || (W & (W - 1)) != 0) return false;
+  int r = std::max(1, 64 / W);
+  if (r > H || (H % r) != 0) return false;
+  if ((r * W) % 64 != 0) return false;
+  const int NP = ((9 * a.N + 15) / 16) * 16;
+  // strips: at least ~256 blocks when the batch alone does not give them, strip height a multiple of R
+  int strips = std::max(1, (256 + a.NB - 1) / a.NB);
+  strips = std::min(strips, H / r);
+  int s = (H + strips - 1) / strips;
+  s = (s + r - 1) / r * r;
+  *S = s;
+  *R = r;
+  *lds = ((size_t)a.C * NP + (size_t)(2 * r + 2) * W * NP) * sizeof(float);
+  return *lds <= 150 * 1024;
+}
+
+bool conv_scatter_eligible(const ConvArgs& a) {
+  static const bool off = getenv("EG_NO_SCATTER") != nullptr;
+  if (off || !a.wgt || a.nphase != 1 || a.N > 12 || a.C % 32 != 0 || a.C < 32) return false;
+  const ConvPhase& p = a.ph[0];
+  if (p.Ty != 3 || p.Tx != 3 || a.kst != 1 || a.S != 1 || a.reflect) return false;
+  if (!(a.D == 1 || a.D == -1) || p.offy != -a.D || p.offx != -a.D) return false;
+  if (p.OHp != a.IH || p.OWp != a.IW || p.ophy != 0 || p.ophx != 0) return false;
+  if (a.shuf ? (a.N != 12 || a.OHf != 2 * a.IH || a.OWf != 2 * a.IW) : (a.os != 1 || a.OHf != a.IH || a.OWf != a.IW)) return false;
+  if (a.x_ps % 4 != 0 || (((uintptr_t)a.x) & 15) != 0 || a.x_bytes == 0) return false;
+  int S, R;
+  size_t lds;
+  return scatter_geometry(a, &S, &R, &lds);
+}
+
+template <int NT>
+static void scatter_launch(const ConvArgs& a, int S, int R, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_scatter_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  const int strips = (a.IH + S - 1) / S;
+  hipLaunchKernelGGL((conv_scatter_kernel<NT>), dim3(a.NB * strips), dim3(256), lds, s, a, S, R, ilog2(a.IW));
+}
+
+const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s) {
+  int S, R;
+  size_t lds;
+  scatter_geometry(a, &S, &R, &lds);
+  const int NT = (9 * a.N + 15) / 16;
+  switch (NT) {
+    case 1: scatter_launch<1>(a, S, R, lds, s); break;
+    case 2: scatter_launch<2>(a, S, R, lds, s); break;
+    case 3: scatter_launch<3>(a, S, R, lds, s); break;
+    case 4: scatter_launch<4>(a, S, R, lds, s); break;
+    case 5: scatter_launch<5>(a, S, R, lds, s); break;
+    case 6: scatter_launch<6>(a, S, R, lds, s); break;
+    default: scatter_launch<7>(a, S, R, lds, s); break;
+  }
+  return "conv_scatter<3x3,N<=12>";
+}
+
+}  // namespace eg

@@ -78,6 +78,11 @@ int wgrad_pick_splits(const WgradArgs& a);
 size_t wgrad_workspace_floats(const WgradArgs& a);
 double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name);
 
+// thin-layer kernels (k_thin.hip): 3x3 stride-1 convolution with <= 12 output channels as one product over the input
+// pixels + col2im in LDS
+bool conv_scatter_eligible(const ConvArgs& a);
+const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s);
+
 // bf16-operand kernels (k_gemm_bf16.hip); the tile choice is made by launch_conv_gemm / launch_wgrad
 bool conv_bf16_eligible(const ConvArgs& a);
 const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s);

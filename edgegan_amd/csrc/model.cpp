@@ -436,7 +436,7 @@ static void apply_group(Ctx& c, int group) {
   NetGroup& g = c.groups[group];
   if (group == G_G1) c.gen_cache_valid[0] = false;
   if (group == G_G2) c.gen_cache_valid[1] = false;
-  for (Param* p : g.params) p->wT_valid = p->wM_valid = false;
+  for (Param* p : g.params) p->invalidate_derived();
   for (Param* p : g.params)
     if (p->trainable && !p->dead) EG_CHECK(p->g_set, "variable %s received no gradient", p->name.c_str());
   if (c.nccl_comm) {

@@ -113,6 +113,7 @@ WRef* wref_sn(Ctx& c, Param* p) {
   c.wrefs.emplace_back();
   WRef* w = &c.wrefs.back();
   w->w = s.Wbar;
+  w->sn = &s;
   w->g = s.dWbar;
   w->g_set = &s.dWbar_set;
   w->want_grad = p->want_grad;
@@ -221,16 +222,55 @@ static void run_merged_phases(Ctx& c, const float* x, int NB, int IH, int IW, in
 
 // compute_dtype bf16: hand the conv a bf16 copy of the filter with the contracted index contiguous.  `transposed`
 // selects the per-tap transpose [T][Cc][R] (contracted index = R) or the stored layout [T][R][Cc] (contracted = Cc).
+// bf16 limb planes (3: f32x3 mode, 1: the value rounded to bf16) of a filter in the orientation a launch needs.  Network
+// variables and spectral-norm weights keep them until the weights change (a discriminator's filters are read in its own
+// sub-step, then unchanged in sub-steps 5 and 7); ad-hoc weights (filter slices) get per-sub-step copies in the arena.
+static unsigned short* limb_planes(Ctx& c, WRef* w, bool transposed, int nplanes) {
+  const size_t n = (size_t)w->T * w->R * w->Cc;
+  const int o = transposed ? 1 : 0;
+  LimbCache* lc = nullptr;
+  if (w->param && w->param->cache_T)
+    lc = &w->param->wL[o];
+  else if (w->sn)
+    lc = &w->sn->wL[o];
+  if (lc) {
+    if (lc->buf && lc->planes != nplanes) {
+      (void)hipFree(lc->buf);
+      lc->buf = nullptr;
+    }
+    if (!lc->buf) {
+      EG_HIP(hipMalloc(&lc->buf, (size_t)nplanes * n * sizeof(unsigned short)));
+      lc->planes = nplanes;
+      lc->valid = false;
+    }
+    if (!lc->ready) EG_HIP(hipEventCreateWithFlags(&lc->ready, hipEventDisableTiming));
+    if (!lc->valid) {
+      launch_split_bf16x3(w->w, lc->buf, w->T, w->R, w->Cc, o, n, nplanes, c.stream);
+      EG_HIP(hipEventRecord(lc->ready, c.stream));
+      lc->built_on = c.stream;
+      lc->waited = 0;
+      lc->valid = true;
+    } else if (lc->built_on != c.stream && !(lc->waited & (1u << c.cur_lane))) {
+      // built on another lane's stream: this lane's reads go behind the build (later reads on this lane follow in
+      // stream order)
+      EG_HIP(hipStreamWaitEvent(c.stream, lc->ready, 0));
+      lc->waited |= 1u << c.cur_lane;
+    }
+    return lc->buf;
+  }
+  unsigned short*& tmp = transposed ? w->wlT : w->wl;
+  if (!tmp) {
+    tmp = reinterpret_cast<unsigned short*>(c.arena.allocf(((size_t)nplanes * n + 1) / 2));
+    launch_split_bf16x3(w->w, tmp, w->T, w->R, w->Cc, o, n, nplanes, c.stream);
+  }
+  return tmp;
+}
+
 static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
   if (c.cfg.x3) {   // three limb planes instead of one rounded copy (k_gemm_x3.hip)
     if (a.C % 32 != 0 || a.N <= 16 || a.N % 4 != 0) return;
     const size_t n = (size_t)w->T * w->R * w->Cc;
-    unsigned short*& slot = transposed ? w->wlT : w->wl;
-    if (!slot) {
-      slot = reinterpret_cast<unsigned short*>(c.arena.allocf((3 * n + 1) / 2));
-      launch_split_bf16x3(w->w, slot, w->T, w->R, w->Cc, transposed ? 1 : 0, n, 3, c.stream);
-    }
-    a.wgt_bf = slot;
+    a.wgt_bf = limb_planes(c, w, transposed, 3);
     a.wbf_ts = (long long)a.C * a.N;
     a.ldwbf = a.C;
     a.limbs = 3;
@@ -245,12 +285,7 @@ static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
   const size_t xbytes = (size_t)a.NB * a.IH * a.IW * a.x_ps * sizeof(float);
   if (bf16_pp && a.N >= 128 && xbytes < (1ull << 31) && a.x_ps % 4 == 0 && a.y_ps % 4 == 0) {
     const size_t n = (size_t)w->T * w->R * w->Cc;
-    unsigned short*& slot = transposed ? w->wlT : w->wl;
-    if (!slot) {
-      slot = reinterpret_cast<unsigned short*>(c.arena.allocf((n + 1) / 2));
-      launch_split_bf16x3(w->w, slot, w->T, w->R, w->Cc, transposed ? 1 : 0, n, 1, c.stream);
-    }
-    a.wgt_bf = slot;
+    a.wgt_bf = limb_planes(c, w, transposed, 1);
     a.wbf_ts = (long long)a.C * a.N;
     a.ldwbf = a.C;
     a.limbs = 1;
@@ -331,7 +366,10 @@ static void same_pad(int n, int k, int s, int* out, int* before) {
 // ---------------------------------------------------------------------------------------------
 static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, int pt, int pl) {
   const int Cin = x->c, N = y->c;
-  const float* wT = wref_transposed(c, w);  // [T][N][Cin]
+  // [T][N][Cin] for the fp32 kernels; the limb / bf16 kernels take their own copies of the filter as stored
+  // (a.wgt stays null then: launch_conv_gemm refuses to run an fp32 kernel without its filter)
+  const bool limb_path = (c.cfg.x3 || c.cfg.bf16) && N % 32 == 0 && Cin > 16 && Cin % 4 == 0;
+  const float* wT = limb_path ? nullptr : wref_transposed(c, w);
   if (c.prof_on) c.cur_label = w->name + " dgrad";
   ConvArgs a{};
   a.x = y->g;
@@ -1057,7 +1095,7 @@ void sn_prepare(Ctx& c) {
   if (count == 0) return;
   if (!c.sn_valid) {  // the classifier's weights only change in sub-step 4: sub-steps 5 and 7 share one W/sigma
     launch_sn_fwd(c.sn_table, count, c.sn_maxK, c.sn_maxCo, c.stream);
-    for (auto& s : c.sn) s.wT_valid = false;
+    for (auto& s : c.sn) s.wT_valid = s.wL[0].valid = s.wL[1].valid = false;
     c.sn_valid = true;
   }
   bool want = false;
@@ -1090,6 +1128,7 @@ Ctx::~Ctx() {
     {
       if (p->wT) (void)hipFree(p->wT);
       if (p->wM) (void)hipFree(p->wM);
+      for (int o = 0; o < 2; ++o) p->wL[o].release();
     }
   (void)hipFree(inf_in);
   (void)hipFree(inf_edge);
@@ -1105,6 +1144,7 @@ Ctx::~Ctx() {
   for (auto& s : sn) {
     (void)hipFree(s.Wbar);
     (void)hipFree(s.WbarT);
+    for (int o = 0; o < 2; ++o) s.wL[o].release();
     (void)hipFree(s.dWbar);
     (void)hipFree(s.t);
     (void)hipFree(s.sv);

@@ -69,6 +69,12 @@ CONV_CASES = [
     ('g_lin_0-like linear 114->256', 4, 1, 1, 114, 256, 1, 1, 0, True),
     ('FC8-like linear 512->100', 4, 1, 1, 512, 100, 1, 1, 0, True),
     ('fc-like linear 768->14 (flat N)', 4, 1, 1, 768, 14, 1, 1, 0, True),
+    # thin layers at the extents that select the dedicated kernels (k_thin.hip): several strips per image with halo
+    # rows, one-row rounds (W = 64), whole-image blocks (8x8), the 3-channel image rows of the MRU units
+    ('cls Conv_1 3x3 C8->128 64x64 (strips)', 1, 64, 64, 8, 128, 3, 1, 0, True),
+    ('cls mru Conv 3x3 C3->128 32x32 (image rows)', 2, 32, 32, 3, 128, 3, 1, 0, True),
+    ('cls mru Conv 3x3 C3->512 8x8', 3, 8, 8, 3, 512, 3, 1, 0, False),
+    ('d_conv_0-like 4x4s2 C3->64 64x128', 1, 64, 128, 3, 64, 4, 2, 0, False),
 ]
 
 
