@@ -23,15 +23,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------------------
-// conv_scatter_kernel<NT>: NT = 16-column tiles of the product (NP = 16 NT >= 9 N).
+// conv_scatter_kernel<N>: N output channels, NT = ceil(9 N / 16) 16-column tiles of the product (NP = 16 NT).
 //
-// Block = one image x a strip of S output rows, 256 threads = 4 waves.  The strip's input rows [lo, hi) (the strip plus
-// one halo row each side, clipped to the image) are processed in rounds of R rows (R W >= 64 pixels): a wave owns the
-// 16-pixel tiles wave, wave + 4, ... of the round, runs the K loop over all C channels for its tile with the 16x16x4 fp32
-// MFMA (exact fp32 products, fp32 accumulation), and writes the tile's NP columns to a ring of 2R + 2 product rows in LDS.
-// One barrier per round; after it the output rows whose three product rows are complete are summed from the ring
-// (9 N LDS reads per output pixel) and stored -- while faster waves already multiply the next round (their writes go to
-// ring rows the emit does not read).
+// Block = one image x a strip of S output rows; 512 threads = 4 product waves + 4 output waves.  The strip's input rows
+// [lo, hi) (the strip plus one halo row each side, clipped to the image) are processed in rounds of R rows (R W >= 64
+// pixels, a multiple of 64).  A product wave owns the 16-pixel tiles wave, wave + 4, ... of the round, runs the K loop over
+// all C channels for its tile with the 16x16x4 fp32 MFMA (exact fp32 products, fp32 accumulation) and writes the tile's NP
+// columns to a ring of 2R + 2 product rows in LDS.  One barrier per round.  During round k the output waves sum the
+// output rows that round k - 1 completed from the ring (9 taps x N per pixel, float4 reads when N % 4 == 0) and store
+// them: the col2im runs beside the MFMAs on the same SIMDs instead of between them (ring rows written in round k are
+// never the ones read for round k - 1: see the index argument at emit_rows).
 //
 // MFMA operands: lane (p = l & 15, g = l >> 4) loads channels [32 ks + 8 g, + 8) of pixel p as two float4 (a wave-level
 // load pair = 16 pixels x one whole 128-byte line); MFMA j = 0..7 of the K step takes element j, i.e. contracts channels
@@ -39,36 +40,168 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // reads its 8 B-operands of a column tile with two ds_read_b128.  Operands are swapped (D^T = B^T A^T): lane l ends up
 // with columns 16 ct + 4 g .. + 3 of pixel p -> one ds_write_b128 per tile and column tile.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void conv_scatter_kernel(const ConvArgs a, int S, int R, int lw) {
+template <int N>
+__global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int S, int R, int lw) {
+  constexpr int NT = (9 * N + 15) / 16;
   constexpr int NP = NT * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int C = a.C, N = a.N, H = a.IH, W = a.IW;
+  const int C = a.C, H = a.IH, W = a.IW;
   float* Wl = smem;                        // [C / 8][NP][8]
   float* Pr = smem + (size_t)C * NP;       // [(2R + 2) rows][W][NP]
   const int ring = 2 * R + 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) == 0;
   const int strips = (H + S - 1) / S;
   const int nb = (int)blockIdx.x / strips, ya = ((int)blockIdx.x % strips) * S;
   const int yb = min(H, ya + S);
   const ConvPhase ph = a.ph[0];
   const int D = a.D;                       // +1: input pixel = out + tap - 1; -1: out - tap + 1 (offy == offx == -D)
 
-  // ---- filter -> LDS, columns (tap, n), zero padded to NP -------------------------------------------------------------
-  for (int i = tid; i < C * NP; i += 256) {
-    const int c = i / NP, col = i - c * NP;
-    float v = 0.f;
-    if (col < 9 * N) {
-      const int tap = col / N, n = col - tap * N;
-      const int ty = tap / 3, tx = tap - 3 * ty;
-      const long long wt = (long long)((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * a.w_ts;
-      v = a.wgt[wt + (size_t)c * a.ldw + n];
+  // ---- filter -> LDS, columns (tap, n), zero padded to NP: linear (coalesced) reads, 8 per thread in flight -----------
+  {
+    const int CN = C * N, total = 9 * CN;
+    for (int base = 0; base < total; base += 512 * 8) {
+      float v[8];
+      int dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * 512 + (int)threadIdx.x;
+        v[u] = 0.f;
+        dst[u] = -1;
+        if (i < total) {
+          const int tap = i / CN, r = i - tap * CN;
+          const int c = r / N, n = r - c * N;
+          const int ty = tap / 3, tx = tap - 3 * ty;
+          const long long wt = (long long)((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * a.w_ts;
+          v[u] = a.wgt[wt + (size_t)c * a.ldw + n];
+          dst[u] = ((c >> 3) * NP + tap * N + n) * 8 + (c & 7);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] >= 0) Wl[dst[u]] = v[u];
     }
-    Wl[((size_t)(c >> 3) * NP + col) * 8 + (c & 7)] = v;
+    constexpr int PADC = NP - 9 * N;
+    if constexpr (PADC > 0)
+      for (int i = threadIdx.x; i < C * PADC; i += 512) {
+        const int c = i / PADC, col = 9 * N + (i - c * PADC);
+        Wl[((c >> 3) * NP + col) * 8 + (c & 7)] = 0.f;
+      }
   }
 
   const int lo = max(0, ya - 1), hi = min(H, yb + 1);
   const int rounds = (hi - lo + R - 1) / R;
+
+  // Output rows [from, to) from the ring.  Called for round k - 1 while round k is being multiplied: it reads product
+  // rows >= lo + (k-1) R - 2; round k writes rows [lo + kR, lo + (k+1) R), whose ring slots last held rows
+  // [lo + (k-1) R - R - 2, lo + (k-1) R - 3]: disjoint.
+  auto emit_rows = [&](int from, int to) {
+    for (int oy = from; oy < to; ++oy) {
+      int slot[3];
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const int iy = oy + (ty - 1) * D;
+        slot[ty] = (iy < 0 || iy >= H) ? -1 : iy % ring;
+      }
+      if constexpr (N % 4 == 0) {
+        constexpr int NQ = N / 4;
+        for (int t = tid; t < W * NQ; t += 256) {
+          const int ox = t / NQ, q4 = t - ox * NQ;
+          // branch-free: out-of-image taps read a clamped address and are multiplied by 0 (all 9 reads in flight at once)
+          f32x4 pv[9];
+          bool keep[9];
+#pragma unroll
+          for (int ty = 0; ty < 3; ++ty) {
+            const float* prow = Pr + (size_t)(slot[ty] < 0 ? 0 : slot[ty]) * W * NP + 4 * q4;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+              const int ix = ox + (tx - 1) * D;
+              const bool ok = slot[ty] >= 0 && ix >= 0 && ix < W;
+              const int ixc = min(max(ix, 0), W - 1);
+              pv[ty * 3 + tx] = *reinterpret_cast<const f32x4*>(prow + ixc * NP + (ty * 3 + tx) * N);
+              keep[ty * 3 + tx] = ok;
+            }
+          }
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {   // (select, not multiply: an unwritten ring row may hold NaN bit patterns)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += keep[q] ? pv[q][j] : 0.f;
+          }
+          if (a.shuf) {   // 12 channels -> 2x2 output pixels of 3 channels (phase-merged stride-2 layer)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int n = 4 * q4 + j, p = n / 3, ch = n - 3 * p;
+              float* qy = a.y + ((size_t)(nb * a.OHf + 2 * oy + (p >> 1)) * a.OWf + 2 * ox + (p & 1)) * a.y_ps + ch;
+              float r = v[j];
+              if (a.bias) r += a.bias[ch];
+              if (a.accumulate) r += *qy;
+              *qy = r;
+            }
+          } else {
+            float* qy = a.y + ((size_t)(nb * a.OHf + oy) * a.OWf + ox) * a.y_ps + 4 * q4;
+            if (a.bias) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] += a.bias[4 * q4 + j];
+            }
+            if ((a.y_ps & 3) == 0 && (((uintptr_t)a.y) & 15) == 0) {
+              if (a.accumulate) v += *reinterpret_cast<const f32x4*>(qy);
+              *reinterpret_cast<f32x4*>(qy) = v;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) qy[j] = a.accumulate ? qy[j] + v[j] : v[j];
+            }
+          }
+        }
+      } else {
+        for (int ox = tid; ox < W; ox += 256) {
+          float v[N];
+#pragma unroll
+          for (int n = 0; n < N; ++n) v[n] = 0.f;
+#pragma unroll
+          for (int ty = 0; ty < 3; ++ty) {
+            if (slot[ty] < 0) continue;
+            const float* prow = Pr + (size_t)slot[ty] * W * NP;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+              const int ix = ox + (tx - 1) * D;
+              if (ix < 0 || ix >= W) continue;
+#pragma unroll
+              for (int n = 0; n < N; ++n) v[n] += prow[ix * NP + (ty * 3 + tx) * N + n];
+            }
+          }
+          float* qy = a.y + ((size_t)(nb * a.OHf + oy) * a.OWf + ox) * a.y_ps;
+#pragma unroll
+          for (int n = 0; n < N; ++n) {
+            float r = v[n];
+            if (a.bias) r += a.bias[n];
+            if (a.accumulate) r += qy[n];
+            qy[n] = r;
+          }
+        }
+      }
+    }
+  };
+  // output rows complete once product rows < pr are: all of the strip after the last round, else rows < pr - 1
+  auto rows_done = [&](int k) { const int pr = min(hi, lo + (k + 1) * R); return pr >= hi ? yb : max(ya, pr - 1); };
+
+  // round barrier: LDS traffic only -- the operand prefetch (global loads several items ahead) stays in flight across it,
+  // which __syncthreads() would drain (s_waitcnt vmcnt(0)) once per round
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  if (!producer) {
+    // ---- output waves: round k's barrier releases the rows round k completed -------------------------------------------
+    __syncthreads();   // filter image (not read here, but the barrier count must match the product waves')
+    int emitted = ya;
+    for (int k = 0; k < rounds; ++k) {
+      lds_barrier();
+      const int e_now = rows_done(k);
+      emit_rows(emitted, e_now);
+      emitted = e_now;
+    }
+    return;
+  }
+
+  // ---- product waves --------------------------------------------------------------------------------------------------
   const int tiles = (R * W) >> 4;          // 16-pixel tiles per round (R W % 64 == 0)
   const int tpw = tiles >> 2;              // tiles per wave and round
   const int KS = C >> 5;                   // K steps of 32 channels
@@ -110,44 +243,15 @@ __global__ __launch_bounds__(256) void conv_scatter_kernel(const ConvArgs a, int
 
   const float* wl_lane = Wl + ((size_t)g * NP + p15) * 8;
   int cur_k = 0, cur_j = 0, cur_ks = 0;
-  int emitted = ya;   // output rows [ya, emitted) are stored
-
-  auto emit_rows = [&](int k) {
-    // product rows < pr are complete
-    const int pr = min(hi, lo + (k + 1) * R);
-    const int e_now = pr >= hi ? yb : max(ya, pr - 1);
-    const int cnt = (e_now - emitted) * W * N;
-    for (int e = tid; e < cnt; e += 256) {
-      const int n = e % N, q = e / N;
-      const int ox = q & (W - 1), oy = emitted + (q >> lw);
-      float v = 0.f;
+  f32x4 bb[2][NT][2];   // filter fragments of the current / the next item (double buffered by item parity; PD is even)
+  auto load_b = [&](f32x4 (&b)[NT][2], int ks) __attribute__((always_inline)) {
+    const float* wk = wl_lane + (size_t)ks * 4 * NP * 8;
 #pragma unroll
-      for (int ty = 0; ty < 3; ++ty) {
-        const int iy = oy + (ty - 1) * D;
-        if (iy < 0 || iy >= H) continue;
-        const float* prow = Pr + (size_t)(iy % ring) * W * NP;
+    for (int t = 0; t < NT; ++t) b[t][0] = *reinterpret_cast<const f32x4*>(wk + t * 16 * 8);
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-          const int ix = ox + (tx - 1) * D;
-          if (ix < 0 || ix >= W) continue;
-          v += prow[ix * NP + (ty * 3 + tx) * N + n];
-        }
-      }
-      float* qy;
-      if (a.shuf) {   // 12 channels -> 2x2 output pixels of 3 channels (phase-merged stride-2 layer)
-        const int p = n / 3, ch = n - 3 * p;
-        qy = a.y + ((size_t)(nb * a.OHf + 2 * oy + (p >> 1)) * a.OWf + 2 * ox + (p & 1)) * a.y_ps + ch;
-        if (a.bias) v += a.bias[ch];
-      } else {
-        qy = a.y + ((size_t)(nb * a.OHf + oy) * a.OWf + ox) * a.y_ps + n;
-        if (a.bias) v += a.bias[n];
-      }
-      if (a.accumulate) v += *qy;
-      *qy = v;
-    }
-    emitted = e_now;
+    for (int t = 0; t < NT; ++t) b[t][1] = *reinterpret_cast<const f32x4*>(wk + t * 16 * 8 + 4);
   };
-
+  load_b(bb[0], 0);
   for (int it = 0; it < items; it += PD) {
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
@@ -155,16 +259,19 @@ __global__ __launch_bounds__(256) void conv_scatter_kernel(const ConvArgs a, int
         // consume the staged operand of item it + u, then re-issue its registers for item it + u + PD
         const f32x4 a0 = ra[u][0], a1 = ra[u][1];
         issue(ra[u]);
-        const float* wk = wl_lane + (size_t)cur_ks * 4 * NP * 8;
+        // this item's filter fragments were requested one item ago; request the next item's before multiplying
+        const int nks = cur_ks + 1 == KS ? 0 : cur_ks + 1;
+        load_b(bb[(u + 1) & 1], nks);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(wk + t * 16 * 8);
-          const f32x4 b1 = *reinterpret_cast<const f32x4*>(wk + t * 16 * 8 + 4);
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j], a0[j], acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[u & 1][t][0][j], a0[j], acc[t], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j], a1[j], acc[t], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[u & 1][t][1][j], a1[j], acc[t], 0, 0, 0);
         if (++cur_ks == KS) {   // tile complete: its NP columns -> ring
           cur_ks = 0;
           const int idx = ((wave + 4 * cur_j) << 4) + p15;
@@ -178,8 +285,7 @@ __global__ __launch_bounds__(256) void conv_scatter_kernel(const ConvArgs a, int
           for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (++cur_j == tpw) {
             cur_j = 0;
-            __syncthreads();
-            emit_rows(cur_k);
+            lds_barrier();
             ++cur_k;
           }
         }
@@ -214,7 +320,7 @@ static bool scatter_geometry(const ConvArgs& a, int* S, int* R, size_t* lds) {
 
 bool conv_scatter_eligible(const ConvArgs& a) {
   static const bool off = getenv("EG_NO_SCATTER") != nullptr;
-  if (off || !a.wgt || a.nphase != 1 || a.N > 12 || a.C % 32 != 0 || a.C < 32) return false;
+  if (off || !a.wgt || a.nphase != 1 || !(a.N == 3 || a.N == 4 || a.N == 8 || a.N == 12) || a.C % 32 != 0 || a.C < 32) return false;
   const ConvPhase& p = a.ph[0];
   if (p.Ty != 3 || p.Tx != 3 || a.kst != 1 || a.S != 1 || a.reflect) return false;
   if (!(a.D == 1 || a.D == -1) || p.offy != -a.D || p.offx != -a.D) return false;
@@ -226,31 +332,27 @@ bool conv_scatter_eligible(const ConvArgs& a) {
   return scatter_geometry(a, &S, &R, &lds);
 }
 
-template <int NT>
+template <int N>
 static void scatter_launch(const ConvArgs& a, int S, int R, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_scatter_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_scatter_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr_set = true;
   }
   const int strips = (a.IH + S - 1) / S;
-  hipLaunchKernelGGL((conv_scatter_kernel<NT>), dim3(a.NB * strips), dim3(256), lds, s, a, S, R, ilog2(a.IW));
+  hipLaunchKernelGGL((conv_scatter_kernel<N>), dim3(a.NB * strips), dim3(512), lds, s, a, S, R, ilog2(a.IW));
 }
 
 const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s) {
   int S, R;
   size_t lds;
   scatter_geometry(a, &S, &R, &lds);
-  const int NT = (9 * a.N + 15) / 16;
-  switch (NT) {
-    case 1: scatter_launch<1>(a, S, R, lds, s); break;
-    case 2: scatter_launch<2>(a, S, R, lds, s); break;
+  switch (a.N) {
     case 3: scatter_launch<3>(a, S, R, lds, s); break;
     case 4: scatter_launch<4>(a, S, R, lds, s); break;
-    case 5: scatter_launch<5>(a, S, R, lds, s); break;
-    case 6: scatter_launch<6>(a, S, R, lds, s); break;
-    default: scatter_launch<7>(a, S, R, lds, s); break;
+    case 8: scatter_launch<8>(a, S, R, lds, s); break;
+    default: scatter_launch<12>(a, S, R, lds, s); break;
   }
   return "conv_scatter<3x3,N<=12>";
 }
