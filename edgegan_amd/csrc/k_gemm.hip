@@ -424,6 +424,8 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
   }
   if (conv_scatter_eligible(a)) {
     nm = launch_conv_scatter(a, s);
+  } else if (conv_smallc_eligible(a)) {
+    nm = launch_conv_smallc(a, s);
   } else if (a.N <= 16) {
     if ((long long)((maxM + 255) / 256) * a.nphase >= 256)
       nm = conv_dispatch<256, 16, 64, 16>(a, maxM, avec, bvec, s, "conv_gemm<256,16,vec>", "conv_gemm<256,16,avec>",

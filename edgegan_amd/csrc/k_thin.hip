@@ -357,4 +357,309 @@ const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s) {
   return "conv_scatter<3x3,N<=12>";
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_smallc_kernel<NT>: convolution with few input channels (the 3-channel image, the classifier's 8-channel stem):
+// K = taps x C is tiny (27 ... 392), the layer is bound by writing its output.  The gather form's flat-K path loads every
+// operand element with its own scalar global load; here a block stages the input ROWS its 512 output pixels need in LDS
+// with linear 16-byte loads (north_star: "LDS-staged input tiles and coalesced HBM reads"), keeps the whole filter
+// [K][16 NT] in LDS, and builds the MFMA operands from LDS: no im2col buffer, every global byte read once per block.
+//
+// Block tile = one image x 512 (or 128) consecutive output pixels (sub-tiles of 128; a wave owns 2 x 16 pixels) x 16 NT
+// output channels.  K is padded to a multiple of 16 and contracted in the order of the fragment layout: lane (p, q) of
+// MFMA j in K group kg multiplies element k = 16 kg + 4 q + j, so the filter image [k / 4][n][k % 4] gives a lane its 4
+// B operands of a column tile as one ds_read_b128; A operands are single LDS reads at staged[(iy - ylo) IW + ix][c]
+// through a per-k offset table (taps outside the image: predicated to zero = SAME padding).
+// conv.py:13-36 (conv2d forward, SAME), conv.py:278-285 (conv2d2), and the stride-2 convolution that is the input
+// gradient of g_dconv_4 (conv.py:49-53).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, int K, int K16, int tiles_per_img, int subs) {
+  constexpr int BN = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Bl = smem;                                          // [K16 / 4][BN][4]
+  int2* kt = reinterpret_cast<int2*>(Bl + (size_t)K16 * BN); // [K16] {packed (dy, dx) or -1, LDS offset (dy IW + dx) C + c}
+  int* wsrc = reinterpret_cast<int*>(kt + K16);              // [K16] filter element offset of (k, n = 0)
+  float* Bias = reinterpret_cast<float*>(wsrc + K16);        // [BN] (zeros without a bias)
+  float* Xs = Bias + BN;                                     // staged input rows [ylo, yhi] of the image
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p15 = lane & 15, kq = lane >> 4;
+  const ConvPhase ph = a.ph[0];
+  const int C = a.C, N = a.N, IH = a.IH, IW = a.IW, OWp = ph.OWp, npix = ph.OHp * ph.OWp;
+  const int n0 = (int)blockIdx.y * BN;
+
+  // ---- tap table ---------------------------------------------------------------------------------------------------
+  for (int k = tid; k < K16; k += 256) {
+    int2 e = {-1, 0};
+    int ws = 0;
+    if (k < K) {
+      const int tap = k / C, c = k - tap * C;
+      const int ty = tap / ph.Tx, tx = tap - ty * ph.Tx;
+      const int dy = ty * a.D + ph.offy, dx = tx * a.D + ph.offx;
+      e.x = ((dy + 512) << 16) | (dx + 512);
+      e.y = (dy * IW + dx) * C + c;
+      ws = (int)(((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * a.w_ts + (long long)c * a.ldw);
+    }
+    kt[k] = e;
+    wsrc[k] = ws;
+  }
+  for (int n = tid; n < BN; n += 256) Bias[n] = (a.bias && n0 + n < N) ? a.bias[n0 + n] : 0.f;
+  __syncthreads();
+  // ---- filter -> LDS, once per block (the block then walks over pixel tiles): n fastest (coalesced), 8 loads per thread
+  // in flight; K padding rows are zero -----------------------------------------------------------------------------------
+  if (BN >= 64 && n0 + BN <= N && (a.ldw & 3) == 0 && (a.w_ts & 3) == 0 && (((uintptr_t)a.wgt) & 15) == 0) {
+    // whole 16-byte loads along n (a filter row of BN floats is contiguous), scattered to the [k / 4][n][k % 4] image
+    constexpr int Q = BN / 4;
+    const int total = K16 * Q;
+    for (int base = 0; base < total; base += 256 * 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + tid;
+        const int k = i / Q, n4 = i - k * Q;
+        v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < total && k < K) v[u] = *reinterpret_cast<const f32x4*>(a.wgt + (size_t)wsrc[k] + n0 + 4 * n4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + tid;
+        const int k = i / Q, n4 = i - k * Q;
+        if (i < total) {
+          float* d = Bl + ((k >> 2) * BN + 4 * n4) * 4 + (k & 3);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d[4 * r] = v[u][r];
+        }
+      }
+    }
+  } else {
+    const int total = K16 * BN;
+    for (int base = 0; base < total; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * 256 + tid;
+        const int k = i / BN, n = i - k * BN;   // BN is a power of two
+        v[u] = (i < total && k < K && n0 + n < N) ? a.wgt[(size_t)wsrc[k] + n0 + n] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * 256 + tid;
+        const int k = i / BN, n = i - k * BN;
+        if (i < total) Bl[((k >> 2) * BN + n) * 4 + (k & 3)] = v[u];
+      }
+    }
+  }
+  const int dy_lo = min(ph.offy, (ph.Ty - 1) * a.D + ph.offy), dy_hi = max(ph.offy, (ph.Ty - 1) * a.D + ph.offy);
+  const float* bl_lane = Bl + ((size_t)kq * BN + p15) * 4;
+  const int total_tiles = a.NB * tiles_per_img;
+
+  // The rows of the NEXT tile are fetched into registers before the current tile is multiplied and stored, and written to
+  // LDS after it: the fetch latency runs under the MFMAs, and (vmcnt is one in-order counter for loads and stores on
+  // gfx9) waiting for those loads does not wait for the output stores issued after them.  Round barriers are LDS-only.
+  constexpr int PF = 5;   // 16-byte registers per thread: tiles stage <= 20 KB of rows (smallc_geometry)
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  f32x4 pf[PF];
+  int pf_n4 = 0;
+  auto tile_rows = [&](int tile, int* nb_, int* q_lo_, int* q_hi_, int* ylo_) __attribute__((always_inline)) {
+    const int nb = tile / tiles_per_img, q_lo = (tile - nb * tiles_per_img) * subs * 128;
+    const int q_hi = min(q_lo + subs * 128, npix) - 1;
+    const int ylo = max(0, (q_lo / OWp) * a.S + dy_lo), yhi = min(IH - 1, (q_hi / OWp) * a.S + dy_hi);
+    *nb_ = nb; *q_lo_ = q_lo; *q_hi_ = q_hi; *ylo_ = ylo;
+    return max(0, yhi - ylo + 1) * IW * C >> 2;   // 16-byte units
+  };
+  auto prefetch = [&](int tile) __attribute__((always_inline)) {
+    pf_n4 = 0;
+    if (tile >= total_tiles) return;
+    int nb, q_lo, q_hi, ylo;
+    pf_n4 = tile_rows(tile, &nb, &q_lo, &q_hi, &ylo);
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.x + ((size_t)nb * IH + ylo) * IW * C);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i = u * 256 + tid;
+      if (i < pf_n4) pf[u] = src[i];
+    }
+  };
+  prefetch(blockIdx.x);
+  __syncthreads();   // filter image complete
+
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    int nb, q_lo, q_hi, ylo;
+    tile_rows(tile, &nb, &q_lo, &q_hi, &ylo);
+    lds_barrier();   // the previous tile's rows are no longer read
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i = u * 256 + tid;
+      if (i < pf_n4) reinterpret_cast<f32x4*>(Xs)[i] = pf[u];
+    }
+    lds_barrier();
+    prefetch(tile + gridDim.x);
+
+    for (int sub = 0; sub < subs; ++sub) {
+      const int qb = q_lo + sub * 128 + wave * 32;
+      if (qb > q_hi) break;
+      int oyS[2], oxS[2], base[2];
+      bool pv[2];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        const int q = qb + pt * 16 + p15;
+        pv[pt] = q <= q_hi;
+        const int oy = q / OWp, ox = q - oy * OWp;
+        oyS[pt] = oy * a.S;
+        oxS[pt] = ox * a.S;
+        base[pt] = ((oyS[pt] - ylo) * IW + oxS[pt]) * C;
+      }
+      f32x4 acc[2][NT];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[pt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // A operands of K group kg: table entry -> predicate + staged-row address -> LDS read.  They are requested one group
+      // ahead (av0 / av1 alternate), so the two dependent LDS round trips run under the previous group's MFMAs.
+      auto load_av = [&](int kg, float (&av)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int2 e = kt[kg * 16 + kq * 4 + j];
+          const int dy = (e.x >> 16) - 512, dx = (e.x & 0xffff) - 512;
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            const bool ok = pv[pt] && e.x >= 0 && (unsigned)(oyS[pt] + dy) < (unsigned)IH && (unsigned)(oxS[pt] + dx) < (unsigned)IW;
+            const float v = Xs[ok ? base[pt] + e.y : 0];
+            av[pt][j] = ok ? v : 0.f;
+          }
+        }
+      };
+      auto mfma_group = [&](int kg, const float (&av)[2][4]) __attribute__((always_inline)) {
+        const float* bk = bl_lane + (size_t)kg * 4 * BN * 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(bk + t * 16 * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) acc[pt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], av[pt][j], acc[pt][t], 0, 0, 0);
+        }
+      };
+      const int nkg = K16 / 16;
+      float av0[2][4], av1[2][4];
+      load_av(0, av0);
+      int kg = 0;
+      for (; kg + 1 < nkg; kg += 2) {
+        load_av(kg + 1, av1);
+        mfma_group(kg, av0);
+        if (kg + 2 < nkg) load_av(kg + 2, av0);
+        mfma_group(kg + 1, av1);
+      }
+      if (kg < nkg) mfma_group(kg, av0);
+      // epilogue: lane holds pixel p15, channels 16 t + 4 kq .. + 3.  All loads (the bias from LDS, the old output when
+      // accumulating) are issued before the first store: vmcnt is one in-order counter, a load issued after a store would
+      // wait for that store's round trip.
+      const bool vec_out = (a.y_ps & 3) == 0 && (((uintptr_t)a.y) & 15) == 0 && (N & 3) == 0;
+      float* yrow[2];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        const int q = qb + pt * 16 + p15;
+        const int oy = q / OWp, ox = q - oy * OWp;
+        yrow[pt] = a.y + ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int nl = t * 16 + kq * 4;
+          acc[pt][t] += *reinterpret_cast<const f32x4*>(Bias + nl);
+          if (a.accumulate && pv[pt]) {
+            if (vec_out) {
+              if (n0 + nl < N) acc[pt][t] += *reinterpret_cast<const f32x4*>(yrow[pt] + n0 + nl);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (n0 + nl + r < N) acc[pt][t][r] += yrow[pt][n0 + nl + r];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        if (!pv[pt]) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int n = n0 + t * 16 + kq * 4;
+          if (vec_out) {
+            if (n < N) *reinterpret_cast<f32x4*>(yrow[pt] + n) = acc[pt][t];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < N) yrow[pt][n + r] = acc[pt][t][r];
+          }
+        }
+      }
+    }
+  }
+}
+
+static bool smallc_geometry(const ConvArgs& a, int* K, int* K16, int* nt, int* tiles, int* subs, size_t* lds) {
+  const ConvPhase& p = a.ph[0];
+  *K = p.Ty * p.Tx * a.C;
+  *K16 = (*K + 15) / 16 * 16;
+  const int n16 = (a.N + 15) / 16;
+  *nt = n16 >= 8 ? 8 : (n16 >= 4 ? 4 : (n16 >= 2 ? 2 : 1));
+  const int npix = p.OHp * p.OWp;
+  // a block's tile = subs x 128 output pixels of one image: the largest of 512 / 256 / 128 whose input rows fit the
+  // 20 KB register prefetch (5 x 16 bytes per thread) and that leaves the ~512 resident blocks >= 4 tiles each
+  const int ny = (a.N + *nt * 16 - 1) / (*nt * 16);
+  int xs_floats = 0;
+  *subs = 0;
+  for (int sb = 4; sb >= 1; sb >>= 1) {
+    const int tpx = sb * 128;
+    const int orows = std::min(p.OHp, (tpx + p.OWp - 1) / p.OWp + 1);
+    const int rows = std::min(a.IH, (orows - 1) * a.S + p.Ty + 1);
+    xs_floats = rows * a.IW * a.C;
+    const bool enough_tiles = (long long)a.NB * ((npix + tpx - 1) / tpx) * ny >= 2048;
+    if (xs_floats <= 5 * 1024 && (enough_tiles || sb == 1)) {
+      *subs = sb;
+      break;
+    }
+  }
+  if (*subs == 0) return false;
+  *tiles = (npix + *subs * 128 - 1) / (*subs * 128);
+  *lds = ((size_t)*K16 * (*nt * 16) + 3 * (size_t)*K16 + (size_t)(*nt * 16) + (size_t)xs_floats) * sizeof(float);
+  return *lds <= 80 * 1024;
+}
+
+bool conv_smallc_eligible(const ConvArgs& a) {
+  static const bool off = getenv("EG_NO_SMALLC") != nullptr;
+  if (off || !a.wgt || a.nphase != 1 || a.C > 8 || a.x_ps != a.C || a.reflect || a.shuf || a.ksplit > 1) return false;
+  const ConvPhase& p = a.ph[0];
+  if (!(a.D == 1 || a.D == -1) || a.S < 1 || a.S > 2) return false;
+  if (p.Ty > 8 || p.Tx > 8) return false;
+  if ((a.IW * a.C) % 4 != 0 || (((uintptr_t)a.x) & 15) != 0) return false;   // rows are staged in 16-byte units
+  if ((long long)a.NB * a.IH * a.IW * a.C >= (1ll << 31) || (long long)p.Ty * p.Tx * a.w_ts >= (1ll << 31)) return false;
+  int K, K16, nt, tiles, subs;
+  size_t lds;
+  return smallc_geometry(a, &K, &K16, &nt, &tiles, &subs, &lds);
+}
+
+template <int NT>
+static void smallc_launch(const ConvArgs& a, int K, int K16, int tiles, int subs, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallc_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024);
+    attr_set = true;
+  }
+  // persistent blocks: the filter is staged once per block, which then walks over (image, 512-pixel tile) pairs
+  const int ny = (a.N + NT * 16 - 1) / (NT * 16);
+  dim3 grid(std::min(a.NB * tiles, std::max(1, 512 / ny)), ny);
+  hipLaunchKernelGGL((conv_smallc_kernel<NT>), grid, dim3(256), lds, s, a, K, K16, tiles, subs);
+}
+
+const char* launch_conv_smallc(const ConvArgs& a, hipStream_t s) {
+  int K, K16, nt, tiles, subs;
+  size_t lds;
+  smallc_geometry(a, &K, &K16, &nt, &tiles, &subs, &lds);
+  switch (nt) {
+    case 1: smallc_launch<1>(a, K, K16, tiles, subs, lds, s); break;
+    case 2: smallc_launch<2>(a, K, K16, tiles, subs, lds, s); break;
+    case 4: smallc_launch<4>(a, K, K16, tiles, subs, lds, s); break;
+    default: smallc_launch<8>(a, K, K16, tiles, subs, lds, s); break;
+  }
+  return "conv_smallc<C<=8>";
+}
+
 }  // namespace eg

@@ -82,6 +82,9 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
 // pixels + col2im in LDS
 bool conv_scatter_eligible(const ConvArgs& a);
 const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s);
+// convolution with <= 8 input channels: input rows and the whole filter staged in LDS, MFMA operands built from LDS
+bool conv_smallc_eligible(const ConvArgs& a);
+const char* launch_conv_smallc(const ConvArgs& a, hipStream_t s);
 
 // bf16-operand kernels (k_gemm_bf16.hip); the tile choice is made by launch_conv_gemm / launch_wgrad
 bool conv_bf16_eligible(const ConvArgs& a);
