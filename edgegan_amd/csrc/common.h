@@ -181,12 +181,15 @@ struct Ctx;
 // Tape of backward closures; run in reverse.
 struct Tape {
   std::vector<std::function<void()>> ops;
+  std::function<void()> after;   // runs when a backward pass ends (the engine flushes its queued reductions here)
   void push(std::function<void()> f) { ops.push_back(std::move(f)); }
   void backward() {
     for (size_t i = ops.size(); i-- > 0;) ops[i]();
+    if (after) after();
   }
   void backward_range(size_t lo, size_t hi) {
     for (size_t i = hi; i-- > lo;) ops[i]();
+    if (after) after();
   }
   void clear() { ops.clear(); }
 };

@@ -87,6 +87,8 @@ struct Ctx {
   std::string last_error;
 
   // per-step state
+  std::vector<RedDesc> deferred;   // queued second-stage reductions (ops.cpp: defer_reduction / flush_deferred)
+  bool defer_on = true;            // EG_DEFER_REDUCE=0: every reduction launches on the spot
   std::deque<Tensor> tensors;
   std::deque<WRef> wrefs;
   std::map<const void*, WRef*> wref_cache;
@@ -176,6 +178,7 @@ T new_tensor(Ctx& c, int n, int h, int w, int ch, bool needs_grad, bool alloc = 
 T wrap_tensor(Ctx& c, float* data, int n, int h, int w, int ch);
 float* grad_acc(Ctx& c, T t, int* acc);   // returns t->g; *acc = 1 if it already holds a value
 void reset_step(Ctx& c);                  // arena + tape + tensor list (start of a sub-step)
+void flush_deferred(Ctx& c);              // runs the queued second-stage reductions on the current stream
 void reset_grads(Ctx& c);                 // forget every activation / weight gradient (keeps buffers)
 void set_want_grad(Ctx& c, int group, bool on);
 

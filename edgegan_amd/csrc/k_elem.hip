@@ -199,7 +199,8 @@ static int col_sum_row_blocks(size_t R) {
   return nrb > CS_RB ? CS_RB : (nrb < 1 ? 1 : (int)nrb);
 }
 size_t col_sum_scratch_floats(size_t R, int C) { return (size_t)col_sum_row_blocks(R) * C; }
-void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C, float* scratch, hipStream_t s) {
+size_t col_sum_partial_floats(size_t R, int C) { return col_sum_scratch_floats(R, C); }
+int launch_col_sum_stage1(const float* dy, size_t R, int C, float* scratch, hipStream_t s) {
   const int nrb = col_sum_row_blocks(R);
   if (C % 32 == 0 && (((uintptr_t)dy & 15) == 0))
     hipLaunchKernelGGL(col_sum_stage1_v, dim3(C / 32, nrb), dim3(256), 0, s, dy, scratch, R, C);
@@ -207,6 +208,10 @@ void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C,
     hipLaunchKernelGGL(col_sum_stage1_narrow, dim3(nrb), dim3(256), 0, s, dy, scratch, R, C);
   else
     hipLaunchKernelGGL(col_sum_stage1, dim3((C + 63) / 64, nrb), dim3(256), 0, s, dy, scratch, R, C);
+  return nrb;
+}
+void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C, float* scratch, hipStream_t s) {
+  const int nrb = launch_col_sum_stage1(dy, R, C, scratch, s);
   hipLaunchKernelGGL(col_sum_stage2, dim3((C + 63) / 64), dim3(256), 0, s, scratch, db, accumulate, C, nrb);
 }
 

@@ -823,13 +823,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // float4 form (N % 4 == 0): 64 element quads x 4 split lanes per block; lane l sums splits l, l+4, ... with 4
 // independent loads in flight, the 4 lane totals are added in lane order -> deterministic, 16-byte coalesced.
-__global__ __launch_bounds__(256) void wgrad_reduce_v_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                             int T, int C, int N, long long w_ts, int ldw, int nsplit,
-                                                             int accumulate) {
-  __shared__ float4 red[4][64];
+__device__ __forceinline__ void wgrad_reduce_v_body(float4 (&red)[4][64], unsigned block, const float* __restrict__ ws,
+                                                    float* __restrict__ dw, int T, int C, int N, long long w_ts, int ldw,
+                                                    int nsplit, int accumulate) {
   const size_t total4 = (size_t)T * C * N / 4;
   const int e = threadIdx.x & 63, l = threadIdx.x >> 6;
-  const size_t i4 = (size_t)blockIdx.x * 64 + e;
+  const size_t i4 = (size_t)block * 64 + e;
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
   if (i4 < total4) {
     const float4* p = reinterpret_cast<const float4*>(ws) + i4;
@@ -866,6 +865,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_v_kernel(const float* __rest
     }
     *q = t;
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_v_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                             int T, int C, int N, long long w_ts, int ldw, int nsplit,
+                                                             int accumulate) {
+  __shared__ float4 red[4][64];
+  wgrad_reduce_v_body(red, blockIdx.x, ws, dw, T, C, N, w_ts, ldw, nsplit, accumulate);
+}
+
+// One launch for a batch of queued second-stage reductions (kernels.h: RedBatch).  A block finds its descriptor from the
+// block-offset table and runs that reduction's ordinary block body.
+__global__ __launch_bounds__(256) void reduce_batch_kernel(const RedBatch b) {
+  __shared__ float4 red[4][64];
+  int i = 0;
+  while (i + 1 < b.count && blockIdx.x >= b.start[i + 1]) ++i;   // uniform
+  const RedDesc& d = b.d[i];
+  const unsigned block = blockIdx.x - b.start[i];
+  if (d.kind == 0) {
+    wgrad_reduce_v_body(red, block, d.src, d.dst, d.T, d.C, d.N, d.w_ts, d.ldw, d.n, d.accumulate);
+  } else {   // col_sum_stage2 (k_elem.hip): 64 columns per block, 4 row lanes
+    float* r = reinterpret_cast<float*>(&red[0][0]);
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = (int)block * 64 + cx;
+    float s = 0.f;
+    if (c < d.C)
+      for (int q = py; q < d.n; q += 4) s += d.src[(size_t)q * d.C + c];
+    r[py * 64 + cx] = s;
+    __syncthreads();
+    if (py == 0 && c < d.C) {
+      const float t = (r[cx] + r[64 + cx]) + (r[128 + cx] + r[192 + cx]);
+      d.dst[c] = d.accumulate ? d.dst[c] + t : t;
+    }
+  }
+}
+unsigned red_desc_blocks(const RedDesc& d) {
+  if (d.kind == 0) return (unsigned)(((size_t)d.T * d.C * d.N / 4 + 63) / 64);
+  return (unsigned)((d.C + 63) / 64);
+}
+void launch_reduce_batch(const RedBatch& b, hipStream_t s) {
+  if (b.count == 0) return;
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3(b.start[b.count]), dim3(256), 0, s, b);
 }
 
 static bool wgrad_big(const WgradArgs& a) { return a.C >= 128 && a.N >= 128; }
@@ -959,7 +999,9 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
     const size_t total = (size_t)a.KH * a.KW * a.C * a.N;
     const bool rv = (a.N % 4 == 0) && (a.ldw % 4 == 0) && (a.w_ts % 4 == 0) && (((uintptr_t)a.dw & 15) == 0) &&
                     (((uintptr_t)a.ws & 15) == 0);
-    if (rv)
+    if (rv && a.defer_reduce)
+      const_cast<WgradArgs&>(a).reduce_deferred = 1;
+    else if (rv)
       hipLaunchKernelGGL(wgrad_reduce_v_kernel, dim3((unsigned)((total / 4 + 63) / 64)), dim3(256), 0, s, a.ws, a.dw,
                          a.KH * a.KW, a.C, a.N, a.w_ts, a.ldw, a.nsplit, a.accumulate);
     else

@@ -372,7 +372,7 @@ const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s) {
 // conv.py:13-36 (conv2d forward, SAME), conv.py:278-285 (conv2d2), and the stride-2 convolution that is the input
 // gradient of g_dconv_4 (conv.py:49-53).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int PT>
 __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, int K, int K16, int tiles_per_img, int subs) {
   constexpr int BN = NT * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -455,13 +455,13 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
   // The rows of the NEXT tile are fetched into registers before the current tile is multiplied and stored, and written to
   // LDS after it: the fetch latency runs under the MFMAs, and (vmcnt is one in-order counter for loads and stores on
   // gfx9) waiting for those loads does not wait for the output stores issued after them.  Round barriers are LDS-only.
-  constexpr int PF = 5;   // 16-byte registers per thread: tiles stage <= 20 KB of rows (smallc_geometry)
+  constexpr int PF = 6;   // 16-byte registers per thread: tiles stage <= 24 KB of rows (smallc_geometry)
   auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   f32x4 pf[PF];
   int pf_n4 = 0;
   auto tile_rows = [&](int tile, int* nb_, int* q_lo_, int* q_hi_, int* ylo_) __attribute__((always_inline)) {
-    const int nb = tile / tiles_per_img, q_lo = (tile - nb * tiles_per_img) * subs * 128;
-    const int q_hi = min(q_lo + subs * 128, npix) - 1;
+    const int nb = tile / tiles_per_img, q_lo = (tile - nb * tiles_per_img) * subs * (64 * PT);
+    const int q_hi = min(q_lo + subs * (64 * PT), npix) - 1;
     const int ylo = max(0, (q_lo / OWp) * a.S + dy_lo), yhi = min(IH - 1, (q_hi / OWp) * a.S + dy_hi);
     *nb_ = nb; *q_lo_ = q_lo; *q_hi_ = q_hi; *ylo_ = ylo;
     return max(0, yhi - ylo + 1) * IW * C >> 2;   // 16-byte units
@@ -494,12 +494,12 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
     prefetch(tile + gridDim.x);
 
     for (int sub = 0; sub < subs; ++sub) {
-      const int qb = q_lo + sub * 128 + wave * 32;
+      const int qb = q_lo + sub * (64 * PT) + wave * (16 * PT);
       if (qb > q_hi) break;
-      int oyS[2], oxS[2], base[2];
-      bool pv[2];
+      int oyS[PT], oxS[PT], base[PT];
+      bool pv[PT];
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
+      for (int pt = 0; pt < PT; ++pt) {
         const int q = qb + pt * 16 + p15;
         pv[pt] = q <= q_hi;
         const int oy = q / OWp, ox = q - oy * OWp;
@@ -507,27 +507,27 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
         oxS[pt] = ox * a.S;
         base[pt] = ((oyS[pt] - ylo) * IW + oxS[pt]) * C;
       }
-      f32x4 acc[2][NT];
+      f32x4 acc[PT][NT];
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[pt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // A operands of K group kg: table entry -> predicate + staged-row address -> LDS read.  They are requested one group
       // ahead (av0 / av1 alternate), so the two dependent LDS round trips run under the previous group's MFMAs.
-      auto load_av = [&](int kg, float (&av)[2][4]) __attribute__((always_inline)) {
+      auto load_av = [&](int kg, float (&av)[PT][4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int2 e = kt[kg * 16 + kq * 4 + j];
           const int dy = (e.x >> 16) - 512, dx = (e.x & 0xffff) - 512;
 #pragma unroll
-          for (int pt = 0; pt < 2; ++pt) {
+          for (int pt = 0; pt < PT; ++pt) {
             const bool ok = pv[pt] && e.x >= 0 && (unsigned)(oyS[pt] + dy) < (unsigned)IH && (unsigned)(oxS[pt] + dx) < (unsigned)IW;
             const float v = Xs[ok ? base[pt] + e.y : 0];
             av[pt][j] = ok ? v : 0.f;
           }
         }
       };
-      auto mfma_group = [&](int kg, const float (&av)[2][4]) __attribute__((always_inline)) {
+      auto mfma_group = [&](int kg, const float (&av)[PT][4]) __attribute__((always_inline)) {
         const float* bk = bl_lane + (size_t)kg * 4 * BN * 4;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -535,11 +535,11 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt) acc[pt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], av[pt][j], acc[pt][t], 0, 0, 0);
+            for (int pt = 0; pt < PT; ++pt) acc[pt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], av[pt][j], acc[pt][t], 0, 0, 0);
         }
       };
       const int nkg = K16 / 16;
-      float av0[2][4], av1[2][4];
+      float av0[PT][4], av1[PT][4];
       load_av(0, av0);
       int kg = 0;
       for (; kg + 1 < nkg; kg += 2) {
@@ -553,9 +553,9 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
       // accumulating) are issued before the first store: vmcnt is one in-order counter, a load issued after a store would
       // wait for that store's round trip.
       const bool vec_out = (a.y_ps & 3) == 0 && (((uintptr_t)a.y) & 15) == 0 && (N & 3) == 0;
-      float* yrow[2];
+      float* yrow[PT];
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
+      for (int pt = 0; pt < PT; ++pt) {
         const int q = qb + pt * 16 + p15;
         const int oy = q / OWp, ox = q - oy * OWp;
         yrow[pt] = a.y + ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
         }
       }
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
+      for (int pt = 0; pt < PT; ++pt) {
         if (!pv[pt]) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -600,24 +600,24 @@ static bool smallc_geometry(const ConvArgs& a, int* K, int* K16, int* nt, int* t
   const int n16 = (a.N + 15) / 16;
   *nt = n16 >= 8 ? 8 : (n16 >= 4 ? 4 : (n16 >= 2 ? 2 : 1));
   const int npix = p.OHp * p.OWp;
-  // a block's tile = subs x 128 output pixels of one image: the largest of 512 / 256 / 128 whose input rows fit the
-  // 20 KB register prefetch (5 x 16 bytes per thread) and that leaves the ~512 resident blocks >= 4 tiles each
+  // a block's tile = subs x 128 output pixels of one image: 512 or 256 (a wave owns 4 x 16 pixels of a 256-pixel sub-tile) whose input rows fit
+  // the 24 KB register prefetch (6 x 16 bytes per thread) and that leaves the ~512 resident blocks >= 4 tiles each
   const int ny = (a.N + *nt * 16 - 1) / (*nt * 16);
   int xs_floats = 0;
   *subs = 0;
-  for (int sb = 4; sb >= 1; sb >>= 1) {
-    const int tpx = sb * 128;
+  for (int sb = 2; sb >= 1; sb >>= 1) {
+    const int tpx = sb * 256;
     const int orows = std::min(p.OHp, (tpx + p.OWp - 1) / p.OWp + 1);
     const int rows = std::min(a.IH, (orows - 1) * a.S + p.Ty + 1);
     xs_floats = rows * a.IW * a.C;
     const bool enough_tiles = (long long)a.NB * ((npix + tpx - 1) / tpx) * ny >= 2048;
-    if (xs_floats <= 5 * 1024 && (enough_tiles || sb == 1)) {
+    if (xs_floats <= 6 * 1024 && (enough_tiles || sb == 1)) {
       *subs = sb;
       break;
     }
   }
   if (*subs == 0) return false;
-  *tiles = (npix + *subs * 128 - 1) / (*subs * 128);
+  *tiles = (npix + *subs * 256 - 1) / (*subs * 256);
   *lds = ((size_t)*K16 * (*nt * 16) + 3 * (size_t)*K16 + (size_t)(*nt * 16) + (size_t)xs_floats) * sizeof(float);
   return *lds <= 80 * 1024;
 }
@@ -639,14 +639,14 @@ template <int NT>
 static void smallc_launch(const ConvArgs& a, int K, int K16, int tiles, int subs, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallc_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallc_kernel<NT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               80 * 1024);
     attr_set = true;
   }
   // persistent blocks: the filter is staged once per block, which then walks over (image, 512-pixel tile) pairs
   const int ny = (a.N + NT * 16 - 1) / (NT * 16);
   dim3 grid(std::min(a.NB * tiles, std::max(1, 512 / ny)), ny);
-  hipLaunchKernelGGL((conv_smallc_kernel<NT>), grid, dim3(256), lds, s, a, K, K16, tiles, subs);
+  hipLaunchKernelGGL((conv_smallc_kernel<NT, 4>), grid, dim3(256), lds, s, a, K, K16, tiles, subs);
 }
 
 const char* launch_conv_smallc(const ConvArgs& a, hipStream_t s) {

@@ -73,6 +73,9 @@ struct WgradArgs {
   int bf16;          // 1: round both operands to bf16 and use the bf16 MFMA (fp32 accumulate)
   int limbs;         // 3: fp32 result from three-limb bf16 operand splits on the bf16 MFMA (k_gemm_x3.hip)
   unsigned x_bytes, dy_bytes;   // extents of x / dy for the limb kernel's buffer loads (0 = unknown or >= 2 GB)
+  int defer_reduce;  // 1: the caller runs the second-stage reduction of the split partials itself (launch_wgrad sets
+                     //    reduce_deferred when it left the reduction out: the float4 form applies)
+  int reduce_deferred;
 };
 int wgrad_pick_splits(const WgradArgs& a);
 size_t wgrad_workspace_floats(const WgradArgs& a);
@@ -85,6 +88,30 @@ const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s);
 // convolution with <= 8 input channels: input rows and the whole filter staged in LDS, MFMA operands built from LDS
 bool conv_smallc_eligible(const ConvArgs& a);
 const char* launch_conv_smallc(const ConvArgs& a, hipStream_t s);
+
+// Second stages of the split reductions (filter gradients: sum of the pixel-split partial slabs; bias gradients: sum of
+// the row-block partials) are tiny launches, ~150 per iteration; they are queued and run as ONE launch per batch
+// (ops.cpp: flush_deferred).  Same arithmetic and summation order as wgrad_reduce_v_kernel / col_sum_stage2.
+struct RedDesc {
+  const float* src;
+  float* dst;
+  int kind;          // 0: filter-gradient slabs (float4 form), 1: bias-gradient row blocks
+  int T, C, N;       // kind 0: taps, channels, outputs; kind 1: C = columns
+  long long w_ts;
+  int ldw;
+  int n;             // kind 0: nsplit, kind 1: row blocks
+  int accumulate;
+};
+constexpr int kRedBatch = 24;
+struct RedBatch {
+  int count;
+  unsigned start[kRedBatch + 1];   // first block of each descriptor
+  RedDesc d[kRedBatch];
+};
+unsigned red_desc_blocks(const RedDesc& d);
+void launch_reduce_batch(const RedBatch& b, hipStream_t s);
+size_t col_sum_partial_floats(size_t R, int C);
+int launch_col_sum_stage1(const float* dy, size_t R, int C, float* part, hipStream_t s);   // returns the row blocks
 
 // bf16-operand kernels (k_gemm_bf16.hip); the tile choice is made by launch_conv_gemm / launch_wgrad
 bool conv_bf16_eligible(const ConvArgs& a);

@@ -259,6 +259,9 @@ void build_context(Ctx& c) {
     c.lanes_mask = atoi(e);
     c.lanes_on = c.lanes_mask != 0;
   }
+  if (const char* e = getenv("EG_DEFER_REDUCE")) c.defer_on = atoi(e) != 0;
+  Ctx* cp = &c;
+  c.tape.after = [cp]() { flush_deferred(*cp); };
 }
 
 void use_lane(Ctx& c, int lane) {
@@ -391,6 +394,7 @@ T classifier_forward(Ctx& c, T x) {
       c.tape.push([=]() {  // runs after both partial wgrads (pushed before them)
         Ctx& c = *cp;
         if (!c.param_grad_enabled || !*f_h || !*f_x) return;
+        flush_deferred(c);   // the two partial filter gradients are reduced before their columns are copied
         launch_copy_cols(g_h, full->g, 9, 1, hidden, ct, 0, hidden, 1, 0, c.stream);
         launch_copy_cols(g_x, full->g, 9, 1, 3, ct, hidden, hidden, 1, 0, c.stream);
         *full->g_set = true;

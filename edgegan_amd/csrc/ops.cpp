@@ -57,6 +57,33 @@ T wrap_tensor(Ctx& c, float* data, int n, int h, int w, int ch) {
   t->d = data;
   return t;
 }
+// Second-stage reductions (kernels.h: RedBatch) are queued and run one launch per batch.  Everything that READS a
+// gradient a queued reduction writes calls flush_deferred first: the end of a backward pass (Tape::after), the gate
+// filter's column copy, the spectral-norm backward, and a second reduction into the same buffer (summation order kept).
+void flush_deferred(Ctx& c) {
+  if (c.deferred.empty()) return;
+  RedBatch b{};
+  b.count = (int)c.deferred.size();
+  unsigned at = 0;
+  for (int i = 0; i < b.count; ++i) {
+    b.d[i] = c.deferred[i];
+    b.start[i] = at;
+    at += red_desc_blocks(b.d[i]);
+  }
+  b.start[b.count] = at;
+  launch_reduce_batch(b, c.stream);
+  c.deferred.clear();
+}
+static void defer_reduction(Ctx& c, const RedDesc& d) {
+  for (const RedDesc& q : c.deferred)
+    if (q.dst == d.dst) {
+      flush_deferred(c);
+      break;
+    }
+  c.deferred.push_back(d);
+  if ((int)c.deferred.size() == kRedBatch) flush_deferred(c);
+}
+
 float* grad_acc(Ctx& c, T t, int* acc) {
   if (!t->g) t->g = c.arena.allocf(t->numel());
   *acc = t->g_set ? 1 : 0;
@@ -73,6 +100,7 @@ void reset_grads(Ctx& c) {
   for (auto& s : c.sn) s.dWbar_set = false;
 }
 void reset_step(Ctx& c) {
+  flush_deferred(c);   // (empty unless a caller skipped its backward pass)
   c.arena.reset();
   c.tape.clear();
   c.tensors.clear();
@@ -482,10 +510,18 @@ static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, c
   g.nsplit = wgrad_pick_splits(g);
   const size_t wsf = wgrad_workspace_floats(g);
   g.ws = wsf ? c.arena.allocf(wsf) : nullptr;
+  g.defer_reduce = c.defer_on ? 1 : 0;
+  for (const RedDesc& q : c.deferred)   // a queued reduction into this filter's gradient comes first (summation order)
+    if (q.dst == g.dw) {
+      flush_deferred(c);
+      break;
+    }
   const char* nm;
   if (c.prof_on) c.cur_label = w->name + " wgrad";
   ProfScope ps(c);
   const double fl = launch_wgrad(g, c.stream, &nm);
+  if (g.reduce_deferred)
+    defer_reduction(c, RedDesc{g.ws, g.dw, 0, k * k, C, N, g.w_ts, g.ldw, g.nsplit, g.accumulate});
   if (c.prof_on) {
     char buf[96];
     snprintf(buf, sizeof buf, "%d,%d,%d,%d,1,%d", NB * OH * OW, N, C, k * k, g.nsplit);
@@ -495,6 +531,13 @@ static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, c
 }
 
 static void bias_grad(Ctx& c, Param* b, const float* dy, size_t rows, int C) {
+  if (c.defer_on) {   // row-block partials now (into the arena: they outlive this call), their sum with the next batch
+    float* part = c.arena.allocf(col_sum_partial_floats(rows, C));
+    const int nrb = launch_col_sum_stage1(dy, rows, C, part, c.stream);
+    defer_reduction(c, RedDesc{part, b->g, 1, 0, C, 0, 0, 0, nrb, b->g_set ? 1 : 0});
+    b->g_set = true;
+    return;
+  }
   if (c.scratch_floats < col_sum_scratch_floats(rows, C)) fail(1, "scratch too small for bias grad");
   launch_col_sum(dy, b->g, b->g_set ? 1 : 0, rows, C, c.scratch, c.stream);
   b->g_set = true;
@@ -1106,6 +1149,7 @@ void sn_prepare(Ctx& c) {
       Ctx& c = *cp;
       if (!c.param_grad_enabled) return;
       for (auto& s : c.sn) EG_CHECK(s.dWbar_set, "SN weight %s received no gradient", s.W->name.c_str());
+      flush_deferred(c);   // dWbar of every SN weight is complete before sigma's backward reads it
       launch_sn_bwd(c.sn_table, (int)c.sn.size(), c.sn_maxK, c.sn_maxCo, c.stream);
       for (auto& s : c.sn) s.W->g_set = true;
     });
