@@ -87,6 +87,7 @@ struct Ctx {
   std::string last_error;
 
   // per-step state
+  std::map<const float*, unsigned short*> bf_copies;   // bf16 copies of activations made this sub-step (ops.cpp: run_conv)
   std::vector<RedDesc> deferred;   // queued second-stage reductions (ops.cpp: defer_reduction / flush_deferred)
   bool defer_on = true;            // EG_DEFER_REDUCE=0: every reduction launches on the spot
   std::deque<Tensor> tensors;

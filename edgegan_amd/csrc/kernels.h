@@ -22,6 +22,7 @@ struct ConvPhase {
 struct ConvArgs {
   const float* x;    // [NB][IH][IW] pixels, x_ps floats per pixel, C channels used
   const unsigned short* x_bf;   // optional bf16 copy of x (same pixel pitch, in elements): read by the bf16 kernels
+  int x_is_activation;          // x is a forward activation (written once per sub-step): its bf16 copy may be kept and reused
   const float* wgt;  // element (tap wt, c, n) at wgt[wt*w_ts + c*ldw + n]
   const float* bias; // [N] or null
   const unsigned short* wgt_bf;  // optional bf16 filter, element (tap wt, n, c) at wgt_bf[wt*wbf_ts + n*ldwbf + c]:
@@ -119,6 +120,10 @@ const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hi
 const char* launch_wgrad_bf16(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s);
 void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);
 void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int R, int Cc, hipStream_t s);
+
+// DMA-fed bf16 kernel (k_gemm_dma.hip): activation read from its bf16 copy a.x_bf, filter from the one-plane K-step-major image
+bool conv_dma_eligible(const ConvArgs& a);
+const char* launch_conv_gemm_dma(const ConvArgs& a, int maxM, hipStream_t s);
 
 // fp32-via-three-bf16-limbs kernels (k_gemm_x3.hip)
 bool conv_x3_eligible(const ConvArgs& a);

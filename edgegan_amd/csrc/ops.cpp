@@ -101,6 +101,7 @@ void reset_grads(Ctx& c) {
 }
 void reset_step(Ctx& c) {
   flush_deferred(c);   // (empty unless a caller skipped its backward pass)
+  c.bf_copies.clear();
   c.arena.reset();
   c.tape.clear();
   c.tensors.clear();
@@ -343,6 +344,23 @@ static void run_conv(Ctx& c, ConvArgs& a) {
   }
   a.ksplit = conv_pick_ksplit(a);
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
+  // bf16 mode, one-plane filter: the DMA kernel reads the activation from a bf16 copy (made once per tensor and sub-step:
+  // a forward activation is read again by nothing that changes it, a gradient is final when its producer's backward runs)
+  static const bool dma_on = getenv("EG_NO_DMA") == nullptr;
+  if (dma_on && a.limbs == 1 && a.wgt_bf && !a.x_bf && a.x_ps == a.C && a.C % 32 == 0 && a.N >= 128 && !a.reflect && a.x_bytes) {
+    // a forward activation is written once per sub-step: its copy is kept for the other convolutions that read it;
+    // gradient buffers are rewritten by later backward passes of the same sub-step (gradient penalty): converted per use
+    const size_t n = (size_t)a.NB * a.IH * a.IW * a.x_ps;
+    auto it = a.x_is_activation ? c.bf_copies.find(a.x) : c.bf_copies.end();
+    if (it == c.bf_copies.end()) {
+      unsigned short* xb = reinterpret_cast<unsigned short*>(c.arena.allocf((n + 1) / 2));
+      launch_cvt_bf16(a.x, xb, n, c.stream);
+      a.x_bf = xb;
+      if (a.x_is_activation) c.bf_copies.emplace(a.x, xb);
+    } else {
+      a.x_bf = it->second;
+    }
+  }
   static const bool shadow_exp = getenv("EG_BF16_SHADOW_EXPERIMENT") != nullptr;
   if (shadow_exp && a.wgt_bf && !a.x_bf && a.x_ps == a.C && a.C % 32 == 0 && a.N > 16) {
     const size_t n = (size_t)a.NB * a.IH * a.IW * a.x_ps;
@@ -560,6 +578,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   EG_CHECK(y->n == x->n && y->h == OH && y->w == OW && y->c == N, "conv2d output shape");
   ConvArgs a{};
   a.x = x->d;
+  a.x_is_activation = 1;
   a.wgt = w->w;
   a.bias = bias ? bias->w : nullptr;
   a.y = y->d;
@@ -622,6 +641,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
   const float* wT = merged ? nullptr : wref_transposed(c, w);  // [25][Cin][Cout]
   ConvArgs a{};
   a.x = x->d;
+  a.x_is_activation = 1;
   a.wgt = wT;
   a.bias = bias ? bias->w : nullptr;
   a.y = y->d;
