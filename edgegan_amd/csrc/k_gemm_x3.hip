@@ -694,6 +694,7 @@ static void conv_x3_launch(const ConvArgs& a, int maxM, hipStream_t s) {
 const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s) {
   const int np = x3_nprod();
   static const int pipe = getenv("EG_X3_PIPE") ? atoi(getenv("EG_X3_PIPE")) : 2;
+  if ((a.limbs == 1 || (big_tile && np == 6)) && conv_x3h_eligible(a)) return launch_conv_gemm_x3h(a, s);
   if (a.limbs == 1 && conv_dma_eligible(a)) return launch_conv_gemm_dma(a, maxM, s);
   if (a.limbs == 1) {
     const int zs = a.ksplit > 1 ? a.ksplit : 1;

@@ -125,6 +125,10 @@ void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int 
 bool conv_dma_eligible(const ConvArgs& a);
 const char* launch_conv_gemm_dma(const ConvArgs& a, int maxM, hipStream_t s);
 
+// halo-staged limb / bf16 kernel for stride-1 layers (k_gemm_x3h.hip)
+bool conv_x3h_eligible(const ConvArgs& a);
+const char* launch_conv_gemm_x3h(const ConvArgs& a, hipStream_t s);
+
 // fp32-via-three-bf16-limbs kernels (k_gemm_x3.hip)
 bool conv_x3_eligible(const ConvArgs& a);
 const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s);

@@ -346,7 +346,8 @@ static void run_conv(Ctx& c, ConvArgs& a) {
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
   // bf16 mode, one-plane filter: the DMA kernel reads the activation from a bf16 copy (made once per tensor and sub-step:
   // a forward activation is read again by nothing that changes it, a gradient is final when its producer's backward runs)
-  static const bool dma_on = getenv("EG_NO_DMA") == nullptr;
+  // (opt-in, EG_BF16_DMA=1: with fp32 activation storage the conversion passes cost what the kernel gains)
+  static const bool dma_on = getenv("EG_BF16_DMA") != nullptr && atoi(getenv("EG_BF16_DMA")) != 0;
   if (dma_on && a.limbs == 1 && a.wgt_bf && !a.x_bf && a.x_ps == a.C && a.C % 32 == 0 && a.N >= 128 && !a.reflect && a.x_bytes) {
     // a forward activation is written once per sub-step: its copy is kept for the other convolutions that read it;
     // gradient buffers are rewritten by later backward passes of the same sub-step (gradient penalty): converted per use

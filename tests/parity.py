@@ -75,6 +75,12 @@ CONV_CASES = [
     ('cls mru Conv 3x3 C3->128 32x32 (image rows)', 2, 32, 32, 3, 128, 3, 1, 0, True),
     ('cls mru Conv 3x3 C3->512 8x8', 3, 8, 8, 3, 512, 3, 1, 0, False),
     ('d_conv_0-like 4x4s2 C3->64 64x128', 1, 64, 128, 3, 64, 4, 2, 0, False),
+    # stride-1 layers with >= 128 output channels: the halo-staged kernel (k_gemm_x3h.hip) in the f32x3 / bf16 modes --
+    # one 16x16 tile per image, 2x2 tiles per image, 4 images per tile, and the 2x2-tap phases of a stride-2 input gradient
+    ('cls Conv_2 3x3 C128->128 16x16', 2, 16, 16, 128, 128, 3, 1, 0, True),
+    ('cls 3x3 C256->128 32x32 (2x2 tiles)', 1, 32, 32, 256, 128, 3, 1, 0, False),
+    ('cls Conv_2 3x3 C64->256 8x8 (4 images per tile)', 4, 8, 8, 64, 256, 3, 1, 0, True),
+    ('d_conv_3-like 4x4s2 C128->256 (dgrad phases)', 4, 16, 16, 128, 256, 4, 2, 0, False),
 ]
 
 
@@ -130,7 +136,8 @@ def check_conv(net: ea.EdgeGAN, case, seed=0, bf16=False):
 
 
 DECONV_CASES = [('g_dconv_1-like 512->256', 2, 4, 4, 512, 256), ('g_dconv_3-like 128->64', 2, 8, 8, 128, 64),
-                ('g_dconv_4-like 64->3', 2, 16, 16, 64, 3), ('odd C 24->20', 1, 4, 8, 24, 20)]
+                ('g_dconv_4-like 64->3', 2, 16, 16, 64, 3), ('odd C 24->20', 1, 4, 8, 24, 20),
+                ('g_dconv_2-like 256->128 8x8 (halo phases)', 4, 8, 8, 256, 128)]
 
 
 def check_deconv(net, case, seed=1, bf16=False):
