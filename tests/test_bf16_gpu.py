@@ -53,7 +53,19 @@ def test_bf16_substeps_14_classes():
     net = ea.EdgeGAN(cfg, values)
     rows = parity.substep_checks(net, values, ea.synthetic_batch(cfg), grad_tol=0.1, bf16=True, loss_tol=1e-2)
     assert len(rows) > 400
-    _assert(rows)
+    # A scalar PReLU slope's gradient is a cancelling sum over every element of its layer; where it is < 1 % of the
+    # sub-step's largest gradient, the bf16 noise of the other 99 % lands on it in ABSOLUTE terms (measured: the unit-2
+    # `Conv_1` slope, |g| = 9e-3 gmax, deviates by 0.12 - 0.16 of itself depending on the contraction kernels' summation
+    # order, i.e. by 1.4e-3 gmax, while full-size variables deviate by up to 0.05 gmax).  Such scalars are judged by
+    # their absolute error against 5e-3 of the sub-step's largest gradient (the same rule as tests/test_x3_gpu.py).
+    judged = []
+    for name, err, tol in rows:
+        if err > tol and 'prelu/param' in name and '|g|/gmax' in name:
+            frac = float(name.split('|g|/gmax')[1].strip(' ]'))
+            judged.append((name + ' (absolute: err * |g|/gmax vs 5e-3)', err * max(frac, 1e-5), 5e-3))
+        else:
+            judged.append((name, err, tol))
+    _assert(judged)
     net.close()
 
 
@@ -126,3 +138,26 @@ def test_bf16_full_size_gradients_track_fp32(shape):
     n32.close(); n16.close()
     bad = {kv: e for kv, e in worst.items() if e > (0.7 if kv[0] == 6 else 0.25)}
     assert not bad, (bad, worst)
+
+
+def test_bf16_dma_kernel_opt_in():
+    """The DMA-fed bf16 convolution kernel (k_gemm_dma.hip, EG_BF16_DMA=1: activation read from a bf16 copy, both tiles
+    global -> LDS) is not on the default path (with fp32 activation storage its conversion passes cost
+    what it gains); it stays covered: the conv / deconv op cases under the switch, against the emulating oracle at the
+    fp32-accumulation tolerances.  EG_NO_HALO=1 keeps the halo kernel from taking the same layers first."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys; sys.path[:0] = [%r, %r, %r]\n'
+            'import edgegan_amd as ea, parity\n'
+            'net = ea.EdgeGAN(ea.Config(batch_size=2, compute_dtype="bf16"))\n'
+            'rows = []\n'
+            'for c in parity.CONV_CASES: rows += parity.check_conv(net, c, bf16=True)\n'
+            'for c in parity.DECONV_CASES: rows += parity.check_deconv(net, c, bf16=True)\n'
+            'bad = [r for r in rows if not r[1] <= r[2]]\n'
+            'assert not bad, parity.format_rows(bad)\n'
+            'print("rows", len(rows))\n') % (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests'))
+    env = dict(os.environ, EG_BF16_DMA='1', EG_NO_HALO='1')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
