@@ -874,6 +874,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_v_kernel(const float* __rest
   wgrad_reduce_v_body(red, blockIdx.x, ws, dw, T, C, N, w_ts, ldw, nsplit, accumulate);
 }
 
+constexpr int kWideSplits = 64;
 // One launch for a batch of queued second-stage reductions (kernels.h: RedBatch).  A block finds its descriptor from the
 // block-offset table and runs that reduction's ordinary block body.
 __global__ __launch_bounds__(256) void reduce_batch_kernel(const RedBatch b) {
@@ -882,7 +883,49 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const RedBatch b) {
   while (i + 1 < b.count && blockIdx.x >= b.start[i + 1]) ++i;   // uniform
   const RedDesc& d = b.d[i];
   const unsigned block = blockIdx.x - b.start[i];
-  if (d.kind == 0) {
+  if (d.kind == 0 && d.n >= kWideSplits) {
+    // many slabs, few elements (the 3- / 8-channel layers: up to 757 slabs of a 48 x 64 filter): 16 split lanes x 16
+    // element quads per block, so a lane's chain of dependent loads is nsplit / 16 long instead of nsplit / 4
+    const int e = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const size_t total4 = (size_t)d.T * d.C * d.N / 4;
+    const size_t i4 = (size_t)block * 16 + e;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (i4 < total4) {
+      const float4* p = reinterpret_cast<const float4*>(d.src) + i4;
+      int z = l;
+      for (; z + 16 < d.n; z += 32) {
+        const float4 a0 = p[(size_t)z * total4], a1 = p[(size_t)(z + 16) * total4];
+        s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+        s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+      }
+      if (z < d.n) {
+        const float4 a0 = p[(size_t)z * total4];
+        s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+      }
+    }
+    float4* r16 = &red[0][0];   // [16 lanes][16 quads]
+    r16[l * 16 + e] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (l == 0 && i4 < total4) {
+      float4 t = r16[e];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) {
+        const float4 v = r16[q * 16 + e];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      const size_t i = i4 * 4;
+      const int n = (int)(i % d.N);
+      const size_t t2 = i / d.N;
+      const int c = (int)(t2 % d.C);
+      const int tp = (int)(t2 / d.C);
+      float4* q = reinterpret_cast<float4*>(d.dst + (size_t)tp * d.w_ts + (size_t)c * d.ldw + n);
+      if (d.accumulate) {
+        const float4 o = *q;
+        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+      }
+      *q = t;
+    }
+  } else if (d.kind == 0) {
     wgrad_reduce_v_body(red, block, d.src, d.dst, d.T, d.C, d.N, d.w_ts, d.ldw, d.n, d.accumulate);
   } else {   // col_sum_stage2 (k_elem.hip): 64 columns per block, 4 row lanes
     float* r = reinterpret_cast<float*>(&red[0][0]);
@@ -900,6 +943,7 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const RedBatch b) {
   }
 }
 unsigned red_desc_blocks(const RedDesc& d) {
+  if (d.kind == 0 && d.n >= kWideSplits) return (unsigned)(((size_t)d.T * d.C * d.N / 4 + 15) / 16);
   if (d.kind == 0) return (unsigned)(((size_t)d.T * d.C * d.N / 4 + 63) / 64);
   return (unsigned)((d.C + 63) / 64);
 }
