@@ -63,10 +63,13 @@ struct HaloGeom {
   int tiles_x, tiles_y;    // tiles per image
 };
 
-template <int NPROD, bool SPLITK>
+template <int NPROD, bool SPLITK, int BN>
 __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a, const HaloGeom g) {
   constexpr int NL = NPROD == 1 ? 1 : 3;
-  constexpr int BN = 128, NSB = 3;
+  constexpr int NSB = 3;
+  constexpr int MI = BN / 64;                 // 32-row accumulator blocks per wave: wave tile 64 x 64 (BN = 128: waves 4 x 2)
+                                              // or 32 x 64 (BN = 64, layers with 64 .. 127 output channels: waves 8 x 1)
+  constexpr int WROWS = 32 * MI;
   constexpr int NBI = NL;                     // filter DMA instructions per wave and K step (one per plane)
   constexpr int APL = HRMAX * 64;             // bytes of one halo plane
   constexpr int BPL = BN * 64;                // bytes of one filter plane of a ring slot
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7: two waves per SIMD
-  const int wm = wave >> 1, wn = wave & 1;                      // wave tile: rows wm*64 .. +63, columns wn*64 .. +63
+  const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
+  const bool issuer = wave < BN / 16;         // waves that carry a share of the filter DMA (16 rows per instruction)
   const int zphase = SPLITK ? (int)blockIdx.z / a.ksplit : (int)blockIdx.z;
   const int zsplit = SPLITK ? (int)blockIdx.z - zphase * a.ksplit : 0;
   const ConvPhase ph = a.ph[zphase];
@@ -156,10 +160,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   int rq_cc = cc_lo, rq_ty = 0, rq_tx = 0, rq_slot = 0;   // next filter tile to request
   auto request_b = [&]() __attribute__((always_inline)) {
     const int wsoff = (((ph.kh0 + rq_ty * a.kst) * a.KW + (ph.kw0 + rq_tx * a.kst)) * cpt + rq_cc) * wtile;
+    if (issuer) {
 #pragma unroll
-    for (int p = 0; p < NL; ++p)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (__attribute__((address_space(3))) void*)&Bs[rq_slot][p][(wave * 16) * 32], 16, woff,
-                                               wsoff + p * plane_bytes, 0, 0);
+      for (int p = 0; p < NL; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (__attribute__((address_space(3))) void*)&Bs[rq_slot][p][(wave * 16) * 32], 16, woff,
+                                                 wsoff + p * plane_bytes, 0, 0);
+    }
     rq_slot = rq_slot == NSB - 1 ? 0 : rq_slot + 1;
     rq_tx += 1;
     const bool wx = rq_tx == ph.Tx;
@@ -172,10 +178,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
 
   // ---- fragments --------------------------------------------------------------------------------------------------------
   const int l31 = lane & 31, lh = lane >> 5;
-  int base_row[2];
+  int base_row[MI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wm * 64 + i * 32 + l31;
+  for (int i = 0; i < MI; ++i) {
+    const int r = wm * WROWS + i * 32 + l31;
     const int ti = r >> (g.lTW + g.lTH), py = (r >> g.lTW) & (TH - 1), px = r & (TW - 1);
     base_row[i] = ti * HPI + py * HW + px;
   }
@@ -183,9 +189,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   const unsigned bs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&Bs[0][0][0];
   const unsigned b_frag = ((wn * 64 + l31) * 32 + ((lh ^ swz_h(l31)) * 8)) * 2;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -196,19 +202,20 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   // ordering that matters is the explicit vmcnt wait + barrier of every K step.
 #define EG_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define EG_WAIT4(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]))
+#define EG_WAIT2(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0][0]), "+v"(f[0][1]))
   // one limb product: 8 MFMAs of the wave's 2 x 2 accumulators over the K step's two 16-wide halves
-  auto mm = [&](const bf16x8 (&af)[2][2], const bf16x8 (&bf)[2][2]) __attribute__((always_inline)) {
+  auto mm = [&](const bf16x8 (&af)[MI][2], const bf16x8 (&bf)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
   };
-  auto read_a = [&](bf16x8 (&f)[2][2], const unsigned (&aa)[2], auto PL) __attribute__((always_inline)) {
+  auto read_a = [&](bf16x8 (&f)[MI][2], const unsigned (&aa)[MI], auto PL) __attribute__((always_inline)) {
     constexpr int off = decltype(PL)::value * APL;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
       EG_DSR(f[i][0], aa[i], off);
       EG_DSR(f[i][1], aa[i] ^ 32u, off);
     }
@@ -221,10 +228,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   constexpr std::integral_constant<int, 1> P1{};
   constexpr std::integral_constant<int, 2> P2{};
   // fragment addresses of a tap: halo row of the lane's output pixel + the tap's row offset, chunk swizzled by that row
-  auto tap_addr = [&](int ty, int tx, unsigned (&aa)[2]) __attribute__((always_inline)) {
+  auto tap_addr = [&](int ty, int tx, unsigned (&aa)[MI]) __attribute__((always_inline)) {
     const int toff = (ty * D + ph.offy - dminy) * HW + (tx * D + ph.offx - dminx);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int row = base_row[i] + toff;
       aa[i] = ah_base + row * 64 + ((lh ^ swz_h(row)) * 16);
     }
@@ -241,22 +248,25 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
     // ---- chunk start: the previous chunk's fragment reads are done (barrier), its successor's halo is in registers --------
     asm volatile("s_barrier" ::: "memory");
     // everything older than the two filter requests in flight has landed (the halo loads were issued >= 2 K steps ago)
-    if (nt - k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBI) : "memory");
+    // (a wave without a share of the filter DMA has only halo loads outstanding: it waits for all of them)
+    if (!issuer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (nt - k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBI) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");
     store_halo();
     if (has_next) load_halo(cc_lo + c + 1);
-    unsigned aa[2];
+    unsigned aa[MI];
     tap_addr(0, 0, aa);
     int ty = 0, tx = 0;
     for (int t = 0; t < ntaps; ++t, ++k) {
       // filter tile k has landed when only the requests issued after it are outstanding: tile k+1, and for the first two
       // taps of a chunk the next chunk's halo loads (issued at the chunk start, after the requests of tiles k, k+1)
-      if (k + 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!issuer) {
+      } else if (k + 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (t < 2 && has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI + NA) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // halo stores + every wave's share of tile k visible
       const unsigned bb = bs_base + slot * (NL * BPL) + b_frag;
-      bf16x8 a0[2][2], b0[2][2];
+      bf16x8 a0[MI][2], b0[2][2];
       read_a(a0, aa, P0);
       read_b(b0, bb, P0);
       // next tap's position: its address arithmetic and the filter request issue under the first product's MFMAs
@@ -265,33 +275,40 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
       tx = wx ? 0 : tx;
       ty += wx ? 1 : 0;
       if constexpr (NPROD == 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0][0]), "+v"(a0[0][1]), "+v"(a0[1][0]), "+v"(a0[1][1]), "+v"(b0[0][0]),
-                     "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]));
+        if constexpr (MI == 2) EG_WAIT4(0, a0);
+        else EG_WAIT2(0, a0);
+        EG_WAIT4(0, b0);
         mm(a0, b0);
         if (k + 2 < nt) request_b();
         tap_addr(ty, tx, aa);
       } else {
-        bf16x8 b1[2][2], b2[2][2], a1[2][2], a2[2][2];
+        // LDS reads return in order: a0 (2 MI), b0 (4), b1 (4), b2 (4), then a1 (2 MI), then a2 (2 MI)
+        bf16x8 b1[2][2], b2[2][2], a1[MI][2], a2[MI][2];
         read_b(b1, bb, P1);
         read_b(b2, bb, P2);
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[0][0]), "+v"(a0[0][1]), "+v"(a0[1][0]), "+v"(a0[1][1]), "+v"(b0[0][0]),
-                     "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]));
+        if constexpr (MI == 2) EG_WAIT4(8, a0);
+        else EG_WAIT2(8, a0);
+        EG_WAIT4(8, b0);
         read_a(a1, aa, P1);
         mm(a0, b0);
         if (k + 2 < nt) request_b();
         __builtin_amdgcn_sched_barrier(0);
-        EG_WAIT4(8, b1);
+        if constexpr (MI == 2) EG_WAIT4(8, b1);
+        else EG_WAIT4(6, b1);
         mm(a0, b1);
-        EG_WAIT4(4, b2);
+        if constexpr (MI == 2) EG_WAIT4(4, b2);
+        else EG_WAIT4(2, b2);
         mm(a0, b2);
         __builtin_amdgcn_sched_barrier(0);
-        EG_WAIT4(0, a1);
+        if constexpr (MI == 2) EG_WAIT4(0, a1);
+        else EG_WAIT2(0, a1);
         read_a(a2, aa, P2);
         mm(a1, b0);
         tap_addr(ty, tx, aa);   // (all reads through the current addresses are issued)
         mm(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        EG_WAIT4(0, a2);
+        if constexpr (MI == 2) EG_WAIT4(0, a2);
+        else EG_WAIT2(0, a2);
         mm(a2, b0);
       }
       slot = slot == NSB - 1 ? 0 : slot + 1;
@@ -299,12 +316,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   }
 #undef EG_DSR
 #undef EG_WAIT4
+#undef EG_WAIT2
 
   // D^T layout of the 32x32 accumulator: lane l holds pixel row l & 31 and, in registers 4q .. 4q+3, the four consecutive
   // output channels 8q + 4 (l >> 5) .. +3 of its 32-channel block: one 16-byte store per register quad
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wm * 64 + i * 32 + l31;
+  for (int i = 0; i < MI; ++i) {
+    const int r = wm * WROWS + i * 32 + l31;
     const int ti = r >> (g.lTW + g.lTH), py = (r >> g.lTW) & (TH - 1), px = r & (TW - 1);
     const int nb = img0 + ti, oy = oy0 + py, ox = ox0 + px;
     float* yrow = (SPLITK ? a.ws + (size_t)zsplit * a.y_total : a.y) +
@@ -365,7 +383,7 @@ static bool x3h_geometry(const ConvArgs& a, HaloGeom* g) {
 bool conv_x3h_eligible(const ConvArgs& a) {
   static const bool off = getenv("EG_NO_HALO") != nullptr;
   if (off || !a.wgt_bf || !(a.limbs == 3 || a.limbs == 1) || a.shuf) return false;
-  if (a.S != 1 || !(a.D == 1 || a.D == -1) || a.C % 32 != 0 || a.N < 128 || a.N % 4 != 0) return false;
+  if (a.S != 1 || !(a.D == 1 || a.D == -1) || a.C % 32 != 0 || a.N < 64 || a.N % 4 != 0) return false;
   if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || !a.x_bytes || !a.wbf_bytes || a.wbf_plane % 8 != 0) return false;
   if ((((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.wgt_bf) & 15) != 0 || (a.bias && (((uintptr_t)a.bias) & 15) != 0)) return false;
   if (a.ksplit > 1 && a.ksplit > a.C / 32) return false;
@@ -373,19 +391,26 @@ bool conv_x3h_eligible(const ConvArgs& a) {
   return x3h_geometry(a, &g);
 }
 
+template <int BN>
+static const char* x3h_launch(const ConvArgs& a, const HaloGeom& g, hipStream_t s) {
+  const int zs = a.ksplit > 1 ? a.ksplit : 1;
+  dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, (a.N + BN - 1) / BN, a.nphase * zs);
+  if (a.limbs == 1) {
+    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, true, BN>), grid, dim3(512), 0, s, a, g);
+    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, false, BN>), grid, dim3(512), 0, s, a, g);
+    return BN == 128 ? (a.ksplit > 1 ? "conv_gemm_bf16h<256,128,splitk>" : "conv_gemm_bf16h<256,128>")
+                     : (a.ksplit > 1 ? "conv_gemm_bf16h<256,64,splitk>" : "conv_gemm_bf16h<256,64>");
+  }
+  if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, true, BN>), grid, dim3(512), 0, s, a, g);
+  else hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, false, BN>), grid, dim3(512), 0, s, a, g);
+  return BN == 128 ? (a.ksplit > 1 ? "conv_gemm_x3h<256,128,splitk>" : "conv_gemm_x3h<256,128>")
+                   : (a.ksplit > 1 ? "conv_gemm_x3h<256,64,splitk>" : "conv_gemm_x3h<256,64>");
+}
+
 const char* launch_conv_gemm_x3h(const ConvArgs& a, hipStream_t s) {
   HaloGeom g;
   x3h_geometry(a, &g);
-  const int zs = a.ksplit > 1 ? a.ksplit : 1;
-  dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, (a.N + 127) / 128, a.nphase * zs);
-  if (a.limbs == 1) {
-    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, true>), grid, dim3(512), 0, s, a, g);
-    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, false>), grid, dim3(512), 0, s, a, g);
-    return a.ksplit > 1 ? "conv_gemm_bf16h<256,128,splitk>" : "conv_gemm_bf16h<256,128>";
-  }
-  if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, true>), grid, dim3(512), 0, s, a, g);
-  else hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, false>), grid, dim3(512), 0, s, a, g);
-  return a.ksplit > 1 ? "conv_gemm_x3h<256,128,splitk>" : "conv_gemm_x3h<256,128>";
+  return a.N >= 128 ? x3h_launch<128>(a, g, s) : x3h_launch<64>(a, g, s);
 }
 
 }  // namespace eg

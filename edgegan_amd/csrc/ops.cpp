@@ -343,6 +343,21 @@ static void run_conv(Ctx& c, ConvArgs& a) {
     a.x_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
   }
   a.ksplit = conv_pick_ksplit(a);
+  // Stride-1 layers with >= 128 output channels that the cost model sent to the 64x64 limb kernel (too few pixels for the
+  // ping-pong kernel's 256-row blocks) still fit the halo-staged kernel (k_gemm_x3h.hip) when its 256-pixel tiles x K
+  // splits over the channel chunks give every CU a block: 168-186 vs 111-139 TFLOP/s on the discriminators' conv3 / conv4
+  // input gradients and the encoder's residual convolutions.
+  static const bool halo_small = getenv("EG_NO_HALO_SMALL") == nullptr;
+  if (halo_small && a.limbs == 3 && a.x3_tile == 2 && a.N >= 64 && a.S == 1) {
+    const ConvArgs keep = a;
+    const int bn = a.N >= 128 ? 128 : 64;
+    const long long blocks = (long long)((a.NB * a.ph[0].OHp * a.ph[0].OWp + 255) / 256) * ((a.N + bn - 1) / bn) * a.nphase;
+    int ks = (int)std::min<long long>(8, std::max<long long>(1, (256 + blocks - 1) / blocks));
+    ks = std::min(ks, a.C / 32);
+    a.x3_tile = 1;
+    a.ksplit = ks;
+    if (blocks * ks < 128 || !conv_x3h_eligible(a)) a = keep;
+  }
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
   // bf16 mode, one-plane filter: the DMA kernel reads the activation from a bf16 copy (made once per tensor and sub-step:
   // a forward activation is read again by nothing that changes it, a gradient is final when its producer's backward runs)

@@ -81,6 +81,8 @@ CONV_CASES = [
     ('cls 3x3 C256->128 32x32 (2x2 tiles)', 1, 32, 32, 256, 128, 3, 1, 0, False),
     ('cls Conv_2 3x3 C64->256 8x8 (4 images per tile)', 4, 8, 8, 64, 256, 3, 1, 0, True),
     ('d_conv_3-like 4x4s2 C128->256 (dgrad phases)', 4, 16, 16, 128, 256, 4, 2, 0, False),
+    # ... and its 64-output-channel form (32 x 64 wave tiles): d_conv_1's input gradient at an extent that fills the CUs
+    ('d_conv_1-like 4x4s2 C64->128 64x64 (dgrad to 64 channels)', 8, 64, 64, 64, 128, 4, 2, 0, False),
 ]
 
 
@@ -137,7 +139,8 @@ def check_conv(net: ea.EdgeGAN, case, seed=0, bf16=False):
 
 DECONV_CASES = [('g_dconv_1-like 512->256', 2, 4, 4, 512, 256), ('g_dconv_3-like 128->64', 2, 8, 8, 128, 64),
                 ('g_dconv_4-like 64->3', 2, 16, 16, 64, 3), ('odd C 24->20', 1, 4, 8, 24, 20),
-                ('g_dconv_2-like 256->128 8x8 (halo phases)', 4, 8, 8, 256, 128)]
+                ('g_dconv_2-like 256->128 8x8 (halo phases)', 4, 8, 8, 256, 128),
+                ('g_dconv_3-like 128->64 32x32 (halo, 64 channels)', 8, 32, 32, 128, 64)]
 
 
 def check_deconv(net, case, seed=1, bf16=False):
