@@ -189,7 +189,8 @@ const float* wref_transposed(Ctx& c, WRef* w);
 
 enum PadMode { PAD_SAME = 0, PAD_REFLECT = 1 };
 // y = conv(x, w) (+ bias); with accumulate_into the result is added to an existing output (split-input convs)
-T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into = nullptr);
+T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into = nullptr,
+         int fused_act = 0 /* ACT_RELU / ACT_LRELU applied by the conv where its kernel can (else by act()) */);
 T deconv2d(Ctx& c, T x, WRef* w /*[25][Cout][Cin]*/, Param* bias, int cout);
 T linear(Ctx& c, T x, WRef* w /*[1][in][out]*/, Param* bias);
 T linear1(Ctx& c, T x, Param* w /*[K][1]*/, Param* bias /*nullable*/);

@@ -563,6 +563,13 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
         for (int t = 0; t < NT; ++t) {
           const int nl = t * 16 + kq * 4;
           acc[pt][t] += *reinterpret_cast<const f32x4*>(Bias + nl);
+          if (a.act == 1) {   // ReLU / LeakyReLU(0.2) fused behind the bias (conv_block of d_conv_0, the encoder stem)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[pt][t][r] = fmaxf(acc[pt][t][r], 0.f);
+          } else if (a.act == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[pt][t][r] = fmaxf(acc[pt][t][r], 0.2f * acc[pt][t][r]);
+          }
           if (a.accumulate && pv[pt]) {
             if (vec_out) {
               if (n0 + nl < N) acc[pt][t] += *reinterpret_cast<const f32x4*>(yrow[pt] + n0 + nl);

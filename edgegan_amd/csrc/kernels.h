@@ -40,6 +40,7 @@ struct ConvArgs {
   int ldw;
   int reflect;       // 1: out-of-range input index is mirrored (tf.pad REFLECT), 0: contributes zero
   int accumulate;    // 1: y += result
+  int act;           // fused activation of the output (Act enum; only the small-C kernel applies it: ops.cpp conv2d)
   int shuf;          // 1 (N == 12, tiles <*,16> only): channel n = (py*2+px)*3 + ch is stored to output pixel
                      //    (2*oy+py, 2*ox+px), channel ch of a [NB][OHf][OWf][y_ps] image; bias is indexed by ch
   int ksplit;        // > 1: K is split over ksplit blocks writing partial slabs to ws, reduced afterwards

@@ -306,10 +306,12 @@ T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_o
   const int ch[5] = {cfg.c_dim, df, df * 2, df * 4, df * 8};
   for (int i = 0; i < 4; ++i) {
     WRef* w = wref_param(c, P(c, p + "/" + kDiscNames[i] + "/conv2d/w"), 16, ch[i], ch[i + 1]);
-    T pre = conv2d(c, x, w, nullptr, 4, 2, PAD_SAME);
+    // (first block: conv + LeakyReLU, fused where the small-C kernel runs the conv; `pre` is then the activated output,
+    //  which is all the tangent pass and the backward need of it)
+    T pre = conv2d(c, x, w, nullptr, 4, 2, PAD_SAME, nullptr, (i == 0 && !tangent_of) ? ACT_LRELU : 0);
     T out, st = nullptr;
     if (!tangent_of) {
-      out = (i == 0) ? act(c, pre, ACT_LRELU) : in_act(c, pre, ACT_LRELU, &st);
+      out = (i == 0) ? pre : in_act(c, pre, ACT_LRELU, &st);
       if (save) {
         save->pre[i] = pre;
         save->out[i] = out;
@@ -328,8 +330,7 @@ T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_o
 T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out) {
   const Config& cfg = c.cfg;
   T E = conv2d(c, x, wref_param(c, P(c, "E/e_resnet_64_0/conv2d/w"), 16, cfg.c_dim, 64),
-               P(c, "E/e_resnet_64_0/conv2d/b"), 4, 2, PAD_SAME);
-  E = act(c, E, ACT_RELU);
+               P(c, "E/e_resnet_64_0/conv2d/b"), 4, 2, PAD_SAME, nullptr, ACT_RELU);
   int cin = 64, i = 1;
   for (int n : encoder_filters(cfg)) {
     const std::string b = "E/e_resnet_" + std::to_string(n) + "_" + std::to_string(i++);
@@ -704,7 +705,8 @@ void train_step(Ctx& c) {
   {
     // the classifier sub-step is the longest of the four and the one whose gradient exchange (69 MB under data
     // parallelism) sub-step 5 waits for: enqueue it first so its all-reduce runs under the discriminator sub-steps
-    if (cls) {
+    static const bool exp4 = getenv("EG_EXP_OVERLAP4") != nullptr;   // TIMING EXPERIMENT ONLY (racy): sub-step 4 under 5-7
+    if (cls && !exp4) {
       use_lane(c, 3);
       run_substep(c, 4, true);
       use_lane(c, 0);
@@ -732,6 +734,13 @@ void train_step(Ctx& c) {
   for (int i = 1; i < 4; ++i) EG_HIP(hipEventRecord(c.lanes[i].done, c.lanes[i].stream));
   }
   // ---- phase B: generators against all four ----------------------------------------------------------------
+  if (conc_a && cls && getenv("EG_EXP_OVERLAP4")) {
+    EG_HIP(hipEventRecord(c.ev_fork, c.lanes[0].stream));
+    EG_HIP(hipStreamWaitEvent(c.lanes[3].stream, c.ev_fork, 0));
+    use_lane(c, 3);
+    run_substep(c, 4, true);
+    use_lane(c, 0);
+  }
   if (conc_a) {
     hipEvent_t ev[G_COUNT] = {};
     ev[G_DP2] = c.lanes[1].done;
@@ -767,6 +776,10 @@ void train_step(Ctx& c) {
     run_substep(c, 7, true, &o7);
   }
   join(2);
+  if (getenv("EG_EXP_OVERLAP4")) {
+    EG_HIP(hipEventRecord(c.lanes[3].done, c.lanes[3].stream));
+    EG_HIP(hipStreamWaitEvent(c.lanes[0].stream, c.lanes[3].done, 0));
+  }
   ++c.step_count;
 }
 

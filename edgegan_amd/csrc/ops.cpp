@@ -577,7 +577,7 @@ static void bias_grad(Ctx& c, Param* b, const float* dy, size_t rows, int C) {
   b->g_set = true;
 }
 
-T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into) {
+T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into, int fused_act) {
   const int Cin = x->c, N = w->Cc;
   EG_CHECK(w->T == k * k && w->R == Cin, "conv2d weight shape: T=%d R=%d vs k=%d Cin=%d", w->T, w->R, k, Cin);
   int OH, OW, pt, pl;
@@ -619,6 +619,15 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   a.nphase = 1;
   a.ph[0] = ConvPhase{OH, OW, 0, 0, k, k, 0, 0, -pt, -pl};
   attach_bf16(c, a, w, true);    // rows = Cout, contracted = Cin
+  // conv + ReLU / LeakyReLU in one pass where the small-C kernel runs the layer (its epilogue applies the activation; the
+  // backward turns dL/d(out) into dL/d(pre) in place from the OUTPUT's sign, like act()): d_conv_0, the encoder stem
+  bool fused = false;
+  if (fused_act == ACT_RELU || fused_act == ACT_LRELU) {
+    static const bool fuse_on = getenv("EG_NO_FUSED_ACT") == nullptr;
+    a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
+    fused = fuse_on && !accumulate_into && !conv_scatter_eligible(a) && conv_smallc_eligible(a);
+    if (fused) a.act = fused_act;
+  }
   if (c.prof_on) c.cur_label = w->name + " fwd";
   run_conv(c, a);
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
@@ -629,6 +638,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     c.tape.push([=]() {
       Ctx& c = *cp;
       if (!y->g_set) return;
+      if (fused) launch_act_bwd(y->d, y->g, y->g, 0, y->numel(), fused_act, c.stream);   // in place: g *= act'(out)
       if (c.param_grad_enabled) {
         if (w->want_grad)
           conv_wgrad(c, x->d, x->n, x->h, x->w, Cin, y->g, OH, OW, N, w, k, stride, pt, pad == PAD_REFLECT);
@@ -637,6 +647,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
       if (x->needs_grad) conv_dgrad(c, x, y, w, k, stride, pad, pt, pl);
     });
   }
+  if (fused_act && !fused) return act(c, y, fused_act);
   return y;
 }
 
