@@ -34,6 +34,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef EG_X3H_DBG
+#define EG_X3H_DBG 0   // timing experiments (wrong results): 1 no per-step barrier, 2 no halo store, 4 no filter DMA, 8 no MFMA, 16 A reads from row 0
+#endif
 namespace {
 constexpr int HRMAX = 400;   // halo rows (pixels) per block: 18 x 18 = 324, 4 x (10 x 10) = 400
 constexpr int NA = 7;        // 16-byte staging loads per thread and chunk: 7 x 512 / 8 = 448 >= HRMAX rows x 8 quads
@@ -61,9 +64,10 @@ __device__ __forceinline__ int reflect_h(int i, int n) {
 struct HaloGeom {
   int lTW, lTH, TI;        // tile = TI images x 2^lTH rows x 2^lTW columns = 256 output pixels
   int tiles_x, tiles_y;    // tiles per image
+  int pitch;               // LDS row pitch of a halo row: 20 for 16-wide tiles (conflict-free layout), 0 = dense rows
 };
 
-template <int NPROD, bool SPLITK, int BN>
+template <int NPROD, bool SPLITK, int BN, bool SW16>
 __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a, const HaloGeom g) {
   constexpr int NL = NPROD == 1 ? 1 : 3;
   constexpr int NSB = 3;
@@ -93,17 +97,25 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   const int n0 = blockIdx.y * BN;
   // halo geometry of this phase (stride 1): input pixel of output (oy, ox), tap (ty, tx) = (oy + ty D + offy, ox + tx D + offx)
   const int dminy = min(ph.offy, (ph.Ty - 1) * D + ph.offy), dminx = min(ph.offx, (ph.Tx - 1) * D + ph.offx);
-  const int HH = TH + ph.Ty - 1, HW = TW + ph.Tx - 1, HPI = HH * HW, HR = g.TI * HPI;
+  const int HH = TH + ph.Ty - 1, HW = TW + ph.Tx - 1, HU = g.TI * HH * HW;   // HU staged halo pixels
+  // LDS image: pixel (ti, hy, hx) lives in row ti HPI + hy HWP + hx.  16-wide tiles: pitch 20 (a multiple of 4, so a row's
+  // bank quarter is hx mod 4) with the 16-byte chunk swizzled by (hx >> 2) & 3 -- the four rows of a ds_read_b128 lane
+  // group that share a bank quarter are hx = h, h + 12 (one tile row) and h + 4, h + 8 (the next one): four different
+  // swizzles for every tap offset, i.e. conflict-free fragment reads.  Narrower tiles keep the dense rows / row swizzle.
+  constexpr bool sw16 = SW16;
+  const int HWP = sw16 ? 20 : HW, HPI = HH * HWP;
 
   // ---- staging: thread -> (halo row, channel quad) units u = tid + 512 j; global byte offsets are per block constants ---
   const int c4 = tid & 7;
   unsigned goff[NA];
+  int srow[NA];    // LDS row of the unit (-1: none), bits 16..17: its chunk swizzle
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    const int row = (tid + 512 * j) >> 3;
+    const int u = (tid + 512 * j) >> 3;
     unsigned off = 0x80000000u;
-    if (row < HR) {
-      const int ti = row / HPI, rem = row - ti * HPI;
+    srow[j] = -1;
+    if (u < HU) {
+      const int ti = u / (HH * HW), rem = u - ti * (HH * HW);
       const int hy = rem / HW, hx = rem - hy * HW;
       int iy = oy0 + dminy + hy, ix = ox0 + dminx + hx;
       if (a.reflect) {
@@ -112,6 +124,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
       }
       if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW)
         off = (unsigned)(((((img0 + ti) * IH + iy) * IW + ix) * a.x_ps + c4 * 4) * 4);
+      const int row = ti * HPI + hy * HWP + hx;
+      srow[j] = row | ((sw16 ? (hx >> 2) & 3 : swz_h(row)) << 16);
     }
     goff[j] = off;
   }
@@ -125,11 +139,11 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
       ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, goff[j], cc * 128, 0));
   };
   auto store_halo = [&]() __attribute__((always_inline)) {
+    if constexpr ((EG_X3H_DBG & 2) != 0) return;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const int row = (tid + 512 * j) >> 3;
-      if (row < HR) {
-        const int o = row * 32 + (((c4 >> 1) ^ swz_h(row)) * 8) + (c4 & 1) * 4;
+      if (srow[j] >= 0) {
+        const int o = (srow[j] & 0xffff) * 32 + (((c4 >> 1) ^ (srow[j] >> 16)) * 8) + (c4 & 1) * 4;
         if constexpr (NL == 1) {
           *reinterpret_cast<u32x2*>(&Ah[0][o]) = (u32x2){pack2h(ra[j][0], ra[j][1]), pack2h(ra[j][2], ra[j][3])};
         } else {
@@ -160,7 +174,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   int rq_cc = cc_lo, rq_ty = 0, rq_tx = 0, rq_slot = 0;   // next filter tile to request
   auto request_b = [&]() __attribute__((always_inline)) {
     const int wsoff = (((ph.kh0 + rq_ty * a.kst) * a.KW + (ph.kw0 + rq_tx * a.kst)) * cpt + rq_cc) * wtile;
-    if (issuer) {
+    if (issuer && (EG_X3H_DBG & 4) == 0) {
 #pragma unroll
       for (int p = 0; p < NL; ++p)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (__attribute__((address_space(3))) void*)&Bs[rq_slot][p][(wave * 16) * 32], 16, woff,
@@ -178,12 +192,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
 
   // ---- fragments --------------------------------------------------------------------------------------------------------
   const int l31 = lane & 31, lh = lane >> 5;
-  int base_row[MI];
+  int base_row[MI], base_px[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int r = wm * WROWS + i * 32 + l31;
     const int ti = r >> (g.lTW + g.lTH), py = (r >> g.lTW) & (TH - 1), px = r & (TW - 1);
-    base_row[i] = ti * HPI + py * HW + px;
+    base_row[i] = ti * HPI + py * HWP + px;
+    base_px[i] = px;
   }
   const unsigned ah_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&Ah[0][0];
   const unsigned bs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&Bs[0][0][0];
@@ -210,7 +225,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          if constexpr ((EG_X3H_DBG & 8) != 0) asm volatile("" : "+v"(acc[i][j]) : "v"(bf[j][kk]), "v"(af[i][kk]));
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+        }
   };
   auto read_a = [&](bf16x8 (&f)[MI][2], const unsigned (&aa)[MI], auto PL) __attribute__((always_inline)) {
     constexpr int off = decltype(PL)::value * APL;
@@ -229,11 +247,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   constexpr std::integral_constant<int, 2> P2{};
   // fragment addresses of a tap: halo row of the lane's output pixel + the tap's row offset, chunk swizzled by that row
   auto tap_addr = [&](int ty, int tx, unsigned (&aa)[MI]) __attribute__((always_inline)) {
-    const int toff = (ty * D + ph.offy - dminy) * HW + (tx * D + ph.offx - dminx);
+    const int dxx = tx * D + ph.offx - dminx;
+    const int toff = (ty * D + ph.offy - dminy) * HWP + dxx;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const int row = base_row[i] + toff;
-      aa[i] = ah_base + row * 64 + ((lh ^ swz_h(row)) * 16);
+      const int row = (EG_X3H_DBG & 16) ? (lane & 31) : base_row[i] + toff;
+      const int sw = sw16 ? ((base_px[i] + dxx) >> 2) & 3 : swz_h(row);
+      aa[i] = ah_base + row * 64 + ((lh ^ sw) * 16);
     }
   };
 
@@ -255,6 +275,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
     store_halo();
     if (has_next) load_halo(cc_lo + c + 1);
     unsigned aa[MI];
+    bf16x8 a0[MI][2];
     tap_addr(0, 0, aa);
     int ty = 0, tx = 0;
     for (int t = 0; t < ntaps; ++t, ++k) {
@@ -264,10 +285,14 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
       } else if (k + 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (t < 2 && has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI + NA) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // halo stores + every wave's share of tile k visible
+      if constexpr ((EG_X3H_DBG & 1) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // halo stores + every wave's share of tile k visible
       const unsigned bb = bs_base + slot * (NL * BPL) + b_frag;
-      bf16x8 a0[MI][2], b0[2][2];
-      read_a(a0, aa, P0);
+      bf16x8 b0[2][2];
+      // the first plane of the gathered operand: read here for the first tap of a chunk (the halo image was just stored),
+      // otherwise it was requested under the previous tap's last products (the image does not change within a chunk) and
+      // has landed (the lgkmcnt(0) of the barrier above)
+      if (t == 0) read_a(a0, aa, P0);
       read_b(b0, bb, P0);
       // next tap's position: its address arithmetic and the filter request issue under the first product's MFMAs
       tx += 1;
@@ -281,8 +306,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
         mm(a0, b0);
         if (k + 2 < nt) request_b();
         tap_addr(ty, tx, aa);
+        read_a(a0, aa, P0);
       } else {
-        // LDS reads return in order: a0 (2 MI), b0 (4), b1 (4), b2 (4), then a1 (2 MI), then a2 (2 MI)
+        // LDS reads return in order: [a0 (2 MI)], b0 (4), b1 (4), b2 (4), then a1 (2 MI), then a2 (2 MI), then the next a0
         bf16x8 b1[2][2], b2[2][2], a1[MI][2], a2[MI][2];
         read_b(b1, bb, P1);
         read_b(b2, bb, P2);
@@ -290,6 +316,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
         else EG_WAIT2(8, a0);
         EG_WAIT4(8, b0);
         read_a(a1, aa, P1);
+        __builtin_amdgcn_sched_barrier(0);
         mm(a0, b0);
         if (k + 2 < nt) request_b();
         __builtin_amdgcn_sched_barrier(0);
@@ -303,12 +330,15 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
         if constexpr (MI == 2) EG_WAIT4(0, a1);
         else EG_WAIT2(0, a1);
         read_a(a2, aa, P2);
-        mm(a1, b0);
         tap_addr(ty, tx, aa);   // (all reads through the current addresses are issued)
+        read_a(a0, aa, P0);     // next tap's first plane (a0's last use was the third product); after the last tap of a
+                                // chunk it fetches stale rows that the re-read at t == 0 replaces
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a1, b0);
         mm(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MI == 2) EG_WAIT4(0, a2);
-        else EG_WAIT2(0, a2);
+        if constexpr (MI == 2) EG_WAIT4(4, a2);
+        else EG_WAIT2(2, a2);
         mm(a2, b0);
       }
       slot = slot == NSB - 1 ? 0 : slot + 1;
@@ -366,6 +396,10 @@ static bool x3h_geometry(const ConvArgs& a, HaloGeom* g) {
   if ((TH & (TH - 1)) != 0 || OH % TH != 0 || OW % TW != 0) return false;
   const int TI = 256 / (TW * TH);
   if (TI * TW * TH != 256 || a.NB % TI != 0) return false;
+  static const bool dense = getenv("EG_X3H_DENSE") != nullptr;   // A/B switch: dense halo rows / row swizzle everywhere
+  g->pitch = TW == 16 && !dense ? 20 : 0;
+  for (int p = 0; p < a.nphase; ++p)
+    if (TI * (TH + a.ph[p].Ty - 1) * 20 > HRMAX) g->pitch = 0;
   for (int p = 0; p < a.nphase; ++p) {
     const ConvPhase& ph = a.ph[p];
     const int nt = ph.Ty * ph.Tx;
@@ -396,13 +430,23 @@ static const char* x3h_launch(const ConvArgs& a, const HaloGeom& g, hipStream_t 
   const int zs = a.ksplit > 1 ? a.ksplit : 1;
   dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, (a.N + BN - 1) / BN, a.nphase * zs);
   if (a.limbs == 1) {
-    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, true, BN>), grid, dim3(512), 0, s, a, g);
-    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, false, BN>), grid, dim3(512), 0, s, a, g);
+    if (g.pitch) {
+      if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, true, BN, true>), grid, dim3(512), 0, s, a, g);
+      else hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, false, BN, true>), grid, dim3(512), 0, s, a, g);
+    } else {
+      if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, true, BN, false>), grid, dim3(512), 0, s, a, g);
+      else hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, false, BN, false>), grid, dim3(512), 0, s, a, g);
+    }
     return BN == 128 ? (a.ksplit > 1 ? "conv_gemm_bf16h<256,128,splitk>" : "conv_gemm_bf16h<256,128>")
                      : (a.ksplit > 1 ? "conv_gemm_bf16h<256,64,splitk>" : "conv_gemm_bf16h<256,64>");
   }
-  if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, true, BN>), grid, dim3(512), 0, s, a, g);
-  else hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, false, BN>), grid, dim3(512), 0, s, a, g);
+  if (g.pitch) {
+    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, true, BN, true>), grid, dim3(512), 0, s, a, g);
+    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, false, BN, true>), grid, dim3(512), 0, s, a, g);
+  } else {
+    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, true, BN, false>), grid, dim3(512), 0, s, a, g);
+    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, false, BN, false>), grid, dim3(512), 0, s, a, g);
+  }
   return BN == 128 ? (a.ksplit > 1 ? "conv_gemm_x3h<256,128,splitk>" : "conv_gemm_x3h<256,128>")
                    : (a.ksplit > 1 ? "conv_gemm_x3h<256,64,splitk>" : "conv_gemm_x3h<256,64>");
 }
