@@ -35,9 +35,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef EG_X3H_DBG
-#define EG_X3H_DBG 0   // timing experiments (wrong results): 1 no per-step barrier, 2 no halo store, 4 no filter DMA, 8 no MFMA, 16 A reads from row 0
+#define EG_X3H_DBG 0   // timing experiments (wrong results): 1 no per-step barrier, 2 no halo store, 4 no filter DMA, 8 no MFMA, 16 A reads from row 0, 32 no fragment reads
 #endif
 namespace {
+typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void mfma_acc(f32x16_& c, const bf16x8_& x, const bf16x8_& y) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+}
 constexpr int HRMAX = 400;   // halo rows (pixels) per block: 18 x 18 = 324, 4 x (10 x 10) = 400
 constexpr int NA = 7;        // 16-byte staging loads per thread and chunk: 7 x 512 / 8 = 448 >= HRMAX rows x 8 quads
 
@@ -215,7 +220,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   // Fragment reads as inline assembly: the compiler guards ordinary LDS loads against the filter DMA still in flight
   // ("may alias") with s_waitcnt vmcnt(0), which would wait for the requests issued a moment ago and undo the ring; the
   // ordering that matters is the explicit vmcnt wait + barrier of every K step.
+#if (EG_X3H_DBG & 32)   // no fragment reads: the registers keep whatever they hold ("+v": no new value, ordering kept)
+#define EG_DSR(dst, addr, off) asm volatile("" : "+v"(dst) : "v"(addr), "n"(off))
+#elif (EG_X3H_DBG & 64)   // half of the fragment reads (every instruction reading the odd 16-byte chunk) dropped
+#define EG_DSR(dst, addr, off) do { if (__builtin_constant_p(off) && ((off) % 4096) >= 2048) asm volatile("" : "+v"(dst) : "v"(addr), "n"(off)); else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off)); } while (0)
+#else
 #define EG_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#endif
 #define EG_WAIT4(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]))
 #define EG_WAIT2(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0][0]), "+v"(f[0][1]))
   // one limb product: 8 MFMAs of the wave's 2 x 2 accumulators over the K step's two 16-wide halves
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if constexpr ((EG_X3H_DBG & 8) != 0) asm volatile("" : "+v"(acc[i][j]) : "v"(bf[j][kk]), "v"(af[i][kk]));
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+          else mfma_acc(acc[i][j], bf[j][kk], af[i][kk]);
         }
   };
   auto read_a = [&](bf16x8 (&f)[MI][2], const unsigned (&aa)[MI], auto PL) __attribute__((always_inline)) {
@@ -243,8 +254,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
     EG_DSR(f[0][0], bb, off); EG_DSR(f[0][1], bb ^ 32u, off); EG_DSR(f[1][0], bb, off + 2048); EG_DSR(f[1][1], bb ^ 32u, off + 2048);
   };
   constexpr std::integral_constant<int, 0> P0{};
-  constexpr std::integral_constant<int, 1> P1{};
-  constexpr std::integral_constant<int, 2> P2{};
+  [[maybe_unused]] constexpr std::integral_constant<int, 1> P1{};
+  [[maybe_unused]] constexpr std::integral_constant<int, 2> P2{};
   // fragment addresses of a tap: halo row of the lane's output pixel + the tap's row offset, chunk swizzled by that row
   auto tap_addr = [&](int ty, int tx, unsigned (&aa)[MI]) __attribute__((always_inline)) {
     const int dxx = tx * D + ph.offx - dminx;
@@ -257,93 +268,129 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
     }
   };
 
+  // K step k = (chunk c, tap t).  Filter tile k+2 is requested in step k; tile k+1 has landed and is visible to every wave
+  // at the barrier of step k (each wave waits for its share before it), so step k also fetches the first filter plane of
+  // step k+1, and -- the halo image being constant within a chunk -- the first halo plane of the next tap: a step
+  // opens with its first product's operands already in registers, and the other five products' planes return under it.
+  // Product order a0b0, a1b0, a2b0 | (b0 free: next b0) | a0b1, a0b2 | (a0 free: next a0) | a1b1.
+#define EG_TOP(a, b) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) :: "memory")
+#define EG_TOP_NB(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) :: "memory")
+  bf16x8 a0[MI][2], b0[2][2];
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every issue arbitration otherwise (+0.5 %)
   if (nt > 0) {
     load_halo(cc_lo);
     request_b();
     if (nt > 1) request_b();
+    // filter tile 0 (outstanding, oldest first: halo, tile 0, tile 1)
+    if (!issuer) {
+    } else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    read_b(b0, bs_base + b_frag, P0);
   }
   int k = 0, slot = 0;
   for (int c = 0; c < ncc; ++c) {
     const bool has_next = c + 1 < ncc;
     // ---- chunk start: the previous chunk's fragment reads are done (barrier), its successor's halo is in registers --------
-    asm volatile("s_barrier" ::: "memory");
-    // everything older than the two filter requests in flight has landed (the halo loads were issued >= 2 K steps ago)
-    // (a wave without a share of the filter DMA has only halo loads outstanding: it waits for all of them)
-    if (!issuer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (nt - k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBI) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the halo loads are older than the newest filter request (tile k+1, issued in the previous chunk's last step)
+    if (!issuer || k + 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");
     store_halo();
     if (has_next) load_halo(cc_lo + c + 1);
     unsigned aa[MI];
-    bf16x8 a0[MI][2];
     tap_addr(0, 0, aa);
     int ty = 0, tx = 0;
     for (int t = 0; t < ntaps; ++t, ++k) {
-      // filter tile k has landed when only the requests issued after it are outstanding: tile k+1, and for the first two
-      // taps of a chunk the next chunk's halo loads (issued at the chunk start, after the requests of tiles k, k+1)
+      // tile k+1 has landed: it is the newest request except, in a chunk's first step, for the next chunk's halo loads
       if (!issuer) {
-      } else if (k + 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (t < 2 && has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI + NA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");
-      if constexpr ((EG_X3H_DBG & 1) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // halo stores + every wave's share of tile k visible
+      } else if (t == 0 && has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // halo stores + every wave's share of tile k+1 visible, all reads of tile k-1 done; a0 / b0 have landed
+      if constexpr ((EG_X3H_DBG & 1) != 0) EG_TOP_NB(a0, b0);
+      else EG_TOP(a0, b0);
       const unsigned bb = bs_base + slot * (NL * BPL) + b_frag;
-      bf16x8 b0[2][2];
-      // the first plane of the gathered operand: read here for the first tap of a chunk (the halo image was just stored),
-      // otherwise it was requested under the previous tap's last products (the image does not change within a chunk) and
-      // has landed (the lgkmcnt(0) of the barrier above)
-      if (t == 0) read_a(a0, aa, P0);
-      read_b(b0, bb, P0);
-      // next tap's position: its address arithmetic and the filter request issue under the first product's MFMAs
+      const int nslot = slot == NSB - 1 ? 0 : slot + 1;
+      const unsigned bbn = bs_base + nslot * (NL * BPL) + b_frag;
+      if (t == 0) {   // first tap of a chunk: the halo image was just stored
+        read_a(a0, aa, P0);
+        if constexpr (MI == 2) EG_WAIT4(0, a0);
+        else EG_WAIT2(0, a0);
+      }
+      // next tap's position
       tx += 1;
       const bool wx = tx == ph.Tx;
       tx = wx ? 0 : tx;
       ty += wx ? 1 : 0;
       if constexpr (NPROD == 1) {
-        if constexpr (MI == 2) EG_WAIT4(0, a0);
-        else EG_WAIT2(0, a0);
-        EG_WAIT4(0, b0);
         mm(a0, b0);
         if (k + 2 < nt) request_b();
+        __builtin_amdgcn_sched_barrier(0);
         tap_addr(ty, tx, aa);
-        read_a(a0, aa, P0);
+        read_a(a0, aa, P0);      // (after a chunk's last tap: stale rows, replaced by the re-read at t == 0)
+        read_b(b0, bbn, P0);
       } else {
-        // LDS reads return in order: [a0 (2 MI)], b0 (4), b1 (4), b2 (4), then a1 (2 MI), then a2 (2 MI), then the next a0
+        // LDS reads return in order: a1 (2 MI), a2 (2 MI), b1 (4), b2 (4), then the next b0 (4), then the next a0 (2 MI)
         bf16x8 b1[2][2], b2[2][2], a1[MI][2], a2[MI][2];
-        read_b(b1, bb, P1);
-        read_b(b2, bb, P2);
-        if constexpr (MI == 2) EG_WAIT4(8, a0);
-        else EG_WAIT2(8, a0);
-        EG_WAIT4(8, b0);
-        read_a(a1, aa, P1);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(a0, b0);
+        // the first product's MFMAs with the step's 12 / 16 fragment reads dealt out between them: eight waves issuing
+        // their reads in one burst fill the LDS queue, and an in-order wave cannot issue the MFMA behind a blocked read
+        {
+          constexpr int NM = 4 * MI;   // MFMAs of a product
+#pragma unroll
+          for (int n = 0; n < NM; ++n) {
+            const int kk = n / (2 * MI), i = (n / 2) % MI, j = n % 2;
+            mfma_acc(acc[i][j], b0[j][kk], a0[i][kk]);
+            if constexpr (MI == 2) {
+              if (n == 0) { EG_DSR(a1[0][0], aa[0], 1 * APL); EG_DSR(a1[0][1], aa[0] ^ 32u, 1 * APL); }
+              if (n == 1) { EG_DSR(a1[1][0], aa[1], 1 * APL); EG_DSR(a1[1][1], aa[1] ^ 32u, 1 * APL); }
+              if (n == 2) { EG_DSR(a2[0][0], aa[0], 2 * APL); EG_DSR(a2[0][1], aa[0] ^ 32u, 2 * APL); }
+              if (n == 3) { EG_DSR(a2[1][0], aa[1], 2 * APL); EG_DSR(a2[1][1], aa[1] ^ 32u, 2 * APL); }
+              if (n == 4) { EG_DSR(b1[0][0], bb, 1 * BPL); EG_DSR(b1[0][1], bb ^ 32u, 1 * BPL); }
+              if (n == 5) { EG_DSR(b1[1][0], bb, 1 * BPL + 2048); EG_DSR(b1[1][1], bb ^ 32u, 1 * BPL + 2048); }
+              if (n == 6) { EG_DSR(b2[0][0], bb, 2 * BPL); EG_DSR(b2[0][1], bb ^ 32u, 2 * BPL); }
+              if (n == 7) { EG_DSR(b2[1][0], bb, 2 * BPL + 2048); EG_DSR(b2[1][1], bb ^ 32u, 2 * BPL + 2048); }
+            } else {
+              if (n == 0) { EG_DSR(a1[0][0], aa[0], 1 * APL); EG_DSR(a1[0][1], aa[0] ^ 32u, 1 * APL); EG_DSR(a2[0][0], aa[0], 2 * APL); EG_DSR(a2[0][1], aa[0] ^ 32u, 2 * APL); }
+              if (n == 1) { EG_DSR(b1[0][0], bb, 1 * BPL); EG_DSR(b1[0][1], bb ^ 32u, 1 * BPL); EG_DSR(b1[1][0], bb, 1 * BPL + 2048); EG_DSR(b1[1][1], bb ^ 32u, 1 * BPL + 2048); }
+              if (n == 2) { EG_DSR(b2[0][0], bb, 2 * BPL); EG_DSR(b2[0][1], bb ^ 32u, 2 * BPL); }
+              if (n == 3) { EG_DSR(b2[1][0], bb, 2 * BPL + 2048); EG_DSR(b2[1][1], bb ^ 32u, 2 * BPL + 2048); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         if (k + 2 < nt) request_b();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MI == 2) EG_WAIT4(8, b1);
-        else EG_WAIT4(6, b1);
+        if constexpr (MI == 2) EG_WAIT4(12, a1);
+        else EG_WAIT2(10, a1);
+        mm(a1, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MI == 2) EG_WAIT4(8, a2);
+        else EG_WAIT2(8, a2);
+        mm(a2, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(b0, bbn, P0);     // tile k+1 (after the last step: a stale slot, never used)
+        __builtin_amdgcn_sched_barrier(0);
+        EG_WAIT4(8, b1);
         mm(a0, b1);
-        if constexpr (MI == 2) EG_WAIT4(4, b2);
-        else EG_WAIT4(2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        EG_WAIT4(4, b2);
         mm(a0, b2);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MI == 2) EG_WAIT4(0, a1);
-        else EG_WAIT2(0, a1);
-        read_a(a2, aa, P2);
-        tap_addr(ty, tx, aa);   // (all reads through the current addresses are issued)
-        read_a(a0, aa, P0);     // next tap's first plane (a0's last use was the third product); after the last tap of a
-                                // chunk it fetches stale rows that the re-read at t == 0 replaces
+        tap_addr(ty, tx, aa);
+        read_a(a0, aa, P0);      // (after a chunk's last tap: stale rows, replaced by the re-read at t == 0)
         __builtin_amdgcn_sched_barrier(0);
-        mm(a1, b0);
         mm(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MI == 2) EG_WAIT4(4, a2);
-        else EG_WAIT2(2, a2);
-        mm(a2, b0);
       }
-      slot = slot == NSB - 1 ? 0 : slot + 1;
+      slot = nslot;
     }
   }
+  // the last step's look-ahead reads still target a0 / b0: they land before anything else may use those registers
+  if (nt > 0) {
+    EG_TOP_NB(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef EG_TOP
+#undef EG_TOP_NB
 #undef EG_DSR
 #undef EG_WAIT4
 #undef EG_WAIT2
