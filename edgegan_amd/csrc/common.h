@@ -139,6 +139,10 @@ struct LimbCache {
   hipEvent_t ready = nullptr;
   hipStream_t built_on = nullptr;
   unsigned waited = 0;   // bit per lane that has already ordered itself behind `ready`
+  // what the planes are built from (set at the first build): the batched rebuild (ops.cpp: limb_planes) refreshes every
+  // stale cache of the same domain (network group / the spectral-norm weights) in one launch
+  const float* src = nullptr;
+  int T = 0, R = 0, Cc = 0, o = 0, domain = -1;
   void release() {
     if (buf) (void)hipFree(buf);
     if (ready) (void)hipEventDestroy(ready);

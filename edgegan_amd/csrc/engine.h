@@ -102,6 +102,7 @@ struct Ctx {
 
   // spectral norm
   std::vector<SNWeight> sn;
+  std::vector<LimbCache*> limb_caches;   // every persistent limb-plane cache built so far (ops.cpp: limb_planes)
   std::map<Param*, int> sn_index;
   SNDesc* sn_table = nullptr;
   int sn_maxK = 0, sn_maxCo = 0;

@@ -997,7 +997,10 @@ int wgrad_pick_splits(const WgradArgs& a) {
   }
   if (wgrad_flatm(a)) {
     const long long tiles = (long long)((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64);
-    return pick_balanced_splits(tiles, 2048, std::min(1024LL, (M + 511) / 512));
+    // latency-bound (one gather round trip per 32-pixel step, prefetch distance 1): eight resident blocks per CU hide it
+    static const int fl_chunk = getenv("EG_FLATM_CHUNK") ? atoi(getenv("EG_FLATM_CHUNK")) : 128;
+    static const int fl_blocks = getenv("EG_FLATM_BLOCKS") ? atoi(getenv("EG_FLATM_BLOCKS")) : 2048;
+    return pick_balanced_splits(tiles, fl_blocks, std::min(2048LL, (M + fl_chunk - 1) / fl_chunk));
   }
   const int bm = wgrad_big(a) ? 128 : 64;
   const long long tiles = (long long)((a.C + bm - 1) / bm) * ((a.N + bm - 1) / bm) * a.KH * a.KW;

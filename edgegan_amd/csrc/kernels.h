@@ -138,6 +138,20 @@ const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_
 // when transposed; K % 32 == 0
 void launch_split_bf16x3(const float* in, unsigned short* out, int T, int R, int Cc, int transposed, size_t plane,
                          int nplanes /* 3, or 1: the first limb only = the value rounded to bf16 */, hipStream_t s);
+// the same for up to kSplitMax filters in one launch (all stale limb-plane caches of a network group)
+constexpr int kSplitMax = 40;
+struct SplitDesc {
+  const float* in;
+  unsigned short* out;
+  unsigned long long plane;
+  int R, Cc, T, transposed, nplanes, gx, gy, pad_;
+};
+struct SplitBatch {
+  int count;
+  unsigned start[kSplitMax + 1];
+  SplitDesc d[kSplitMax];
+};
+void launch_split_bf16x3_batch(const SplitBatch& b, hipStream_t s);
 
 // Phase-merged filter of a stride-2 layer with 3 image channels: the 4 sub-pixel phases of a transposed convolution
 // (or of a stride-2 convolution's input gradient) become 12 output channels n = (py*2+px)*3 + ch of ONE 3x3 stride-1

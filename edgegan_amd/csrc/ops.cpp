@@ -273,12 +273,55 @@ static unsigned short* limb_planes(Ctx& c, WRef* w, bool transposed, int nplanes
       lc->valid = false;
     }
     if (!lc->ready) EG_HIP(hipEventCreateWithFlags(&lc->ready, hipEventDisableTiming));
+    if (!lc->src) {   // first build: remember the source and find the domain (the variable's network group / SN weights)
+      lc->src = w->w;
+      lc->T = w->T;
+      lc->R = w->R;
+      lc->Cc = w->Cc;
+      lc->o = o;
+      lc->domain = G_COUNT;
+      if (!w->sn)
+        for (int g = 0; g < G_COUNT; ++g)
+          if (c.groups[g].w && w->w >= c.groups[g].w && w->w < c.groups[g].w + c.groups[g].n_total) lc->domain = g;
+      c.limb_caches.push_back(lc);
+    }
     if (!lc->valid) {
-      launch_split_bf16x3(w->w, lc->buf, w->T, w->R, w->Cc, o, n, nplanes, c.stream);
-      EG_HIP(hipEventRecord(lc->ready, c.stream));
-      lc->built_on = c.stream;
-      lc->waited = 0;
-      lc->valid = true;
+      // every stale cache of the domain goes into the same launch: the domain's weights changed together (one RMSProp
+      // launch per group / one sn_prepare) and are final until the next update
+      static const bool batch_on = getenv("EG_NO_SPLIT_BATCH") == nullptr;
+      SplitBatch b;
+      b.count = 0;
+      b.start[0] = 0;
+      std::vector<LimbCache*> built;
+      auto flush = [&]() {
+        launch_split_bf16x3_batch(b, c.stream);
+        b.count = 0;
+        b.start[0] = 0;
+      };
+      for (LimbCache* q : c.limb_caches) {
+        if (q != lc && (!batch_on || q->valid || !q->buf || q->domain != lc->domain || q->planes != nplanes)) continue;
+        SplitDesc& d = b.d[b.count];
+        d.in = q->src;
+        d.out = q->buf;
+        d.plane = (unsigned long long)q->T * q->R * q->Cc;
+        d.R = q->R;
+        d.Cc = q->Cc;
+        d.T = q->T;
+        d.transposed = q->o;
+        d.nplanes = q->planes;
+        d.gx = (q->Cc + 31) / 32;
+        d.gy = (q->R + 31) / 32;
+        b.start[b.count + 1] = b.start[b.count] + (unsigned)(d.gx * d.gy * q->T);
+        ++b.count;
+        if (!q->ready) EG_HIP(hipEventCreateWithFlags(&q->ready, hipEventDisableTiming));
+        q->built_on = c.stream;
+        q->waited = 0;
+        q->valid = true;
+        built.push_back(q);
+        if (b.count == kSplitMax) flush();
+      }
+      flush();
+      for (LimbCache* q : built) EG_HIP(hipEventRecord(q->ready, c.stream));
     } else if (lc->built_on != c.stream && !(lc->waited & (1u << c.cur_lane))) {
       // built on another lane's stream: this lane's reads go behind the build (later reads on this lane follow in
       // stream order)
