@@ -181,60 +181,6 @@ __device__ __forceinline__ void limb_products32(f32x16 (&acc)[2][2], LA load_a, 
 }
 
 
-// The six limb products of one K step with the fragment reads placed by hand (the compiler's own placement re-used
-// fragment registers and issued three of the six planes' reads directly in front of their first MFMA: three exposed LDS
-// round trips per 48-MFMA phase).  aa / bb: LDS byte address of the lane's plane-0 fragment of row block 0, K half 0;
-// K half 1 = address ^ 32, row block 1 = + 2048, plane p = + p * PA / p * PB.  Reads return in order: a0 b0 | b1 b2 a1 | a2.
-template <int PA, int PB>
-__device__ __forceinline__ void limb_products6_lds(f32x16 (&acc)[2][2], unsigned aa, unsigned bb) {
-#define EG_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define EG_WAIT4(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]))
-  const unsigned aax = aa ^ 32u, bbx = bb ^ 32u;
-  bf16x8 a0[2][2], a1[2][2], b0[2][2], b1[2][2], b2[2][2];
-  auto mm = [&](const bf16x8 (&af)[2][2], const bf16x8 (&bf)[2][2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
-  };
-  EG_DSR(a0[0][0], aa, 0); EG_DSR(a0[0][1], aax, 0); EG_DSR(a0[1][0], aa, 2048); EG_DSR(a0[1][1], aax, 2048);
-  EG_DSR(b0[0][0], bb, 0); EG_DSR(b0[0][1], bbx, 0); EG_DSR(b0[1][0], bb, 2048); EG_DSR(b0[1][1], bbx, 2048);
-  EG_WAIT4(0, a0);
-  EG_WAIT4(0, b0);
-#pragma unroll
-  for (int n = 0; n < 8; ++n) {   // first product, the next three planes' reads dealt out between its MFMAs
-    const int kk = n / 4, i = (n / 2) % 2, j = n % 2;
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[j][kk], a0[i][kk], acc[i][j], 0, 0, 0);
-    if (n == 0) { EG_DSR(b1[0][0], bb, PB); EG_DSR(b1[0][1], bbx, PB); }
-    if (n == 1) { EG_DSR(b1[1][0], bb, PB + 2048); EG_DSR(b1[1][1], bbx, PB + 2048); }
-    if (n == 2) { EG_DSR(b2[0][0], bb, 2 * PB); EG_DSR(b2[0][1], bbx, 2 * PB); }
-    if (n == 3) { EG_DSR(b2[1][0], bb, 2 * PB + 2048); EG_DSR(b2[1][1], bbx, 2 * PB + 2048); }
-    if (n == 4) { EG_DSR(a1[0][0], aa, PA); EG_DSR(a1[0][1], aax, PA); }
-    if (n == 5) { EG_DSR(a1[1][0], aa, PA + 2048); EG_DSR(a1[1][1], aax, PA + 2048); }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  EG_WAIT4(8, b1);
-  mm(a0, b1);
-  __builtin_amdgcn_sched_barrier(0);
-  EG_WAIT4(4, b2);
-  mm(a0, b2);
-  __builtin_amdgcn_sched_barrier(0);
-  // a0's last use is issued: its registers take the third plane of the gathered operand
-  EG_DSR(a0[0][0], aa, 2 * PA); EG_DSR(a0[0][1], aax, 2 * PA); EG_DSR(a0[1][0], aa, 2 * PA + 2048); EG_DSR(a0[1][1], aax, 2 * PA + 2048);
-  __builtin_amdgcn_sched_barrier(0);
-  EG_WAIT4(4, a1);
-  mm(a1, b0);
-  mm(a1, b1);
-  __builtin_amdgcn_sched_barrier(0);
-  EG_WAIT4(0, a0);
-  mm(a0, b0);
-#undef EG_DSR
-#undef EG_WAIT4
-}
-
 }  // namespace
 
 // =============================================================================================
@@ -947,9 +893,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
   };
   auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   const int nblk = (nt + 7) / 8;
-  // LDS byte addresses of the lane's plane-0 fragments (row block 0, K half 0) for the hand-placed reads
-  const unsigned a_frag_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&As[0][(wm * WTM + l31) * ROWX + (lh ^ fsw) * 8];
-  const unsigned b_frag_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&BsG[0][0][(wn * WTN + l31) * ROWX + (lh ^ fsw) * 8];
 
   auto run = [&](auto GRP) __attribute__((always_inline)) {
     constexpr int LEAD = decltype(GRP)::value;   // X stages its dY half of step k in VALU phase k, Y that of step k + 1
@@ -968,11 +911,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
     auto mfma_phase = [&](int k) __attribute__((always_inline)) {
       lds_barrier();
       Bcur = &BsG[k & 1][0][0];
-      if constexpr (NPROD == 6) {
-        limb_products6_lds<BM * ROWX * 2, BN * ROWX * 2>(acc, a_frag_addr, b_frag_addr + (unsigned)(k & 1) * (unsigned)(NL * BN * ROWX * 2));
-      } else {
-        limb_products32<NPROD>(acc, frag_a, frag_b);
-      }
+      limb_products32<NPROD>(acc, frag_a, frag_b);
       lds_barrier();
     };
     constexpr std::true_type guarded{};
