@@ -34,6 +34,21 @@ def pmc_traffic(kernel_label):
     passes, gfx950 x2 read correction -- tools/pmc_summary.py).  None if there is no matching row."""
     import csv
     import re
+    # halo-staged kernels (round 2): per-kernel table derived by tools/pmc_derive.py from the round's PMC passes
+    mh = re.match(r'conv_gemm_(x3h|bf16h)<256,(\d+)(,splitk)?>', kernel_label)
+    upath = os.path.join(ROOT, 'profiles', 'pmc_utilisation_latest.csv')
+    if mh and os.path.exists(upath):
+        want = (6 if mh.group(1) == 'x3h' else 1, 'true' if mh.group(3) else 'false', mh.group(2))
+        best = None
+        with open(upath) as f:
+            for r in csv.DictReader(f):
+                mk = re.match(r'conv_gemm_x3h_kernel<(\d+), (true|false)(?:, (\d+))?', r['kernel'])
+                if not mk or (int(mk.group(1)), mk.group(2)) != want[:2] or (mk.group(3) and mk.group(3) != want[2]):
+                    continue
+                if best is None or int(r['launches']) > int(best['launches']):
+                    best = r
+        if best:
+            return float(best['hbm_read_bytes_per_launch(2xFETCH_SIZE)']) + float(best['hbm_write_bytes_per_launch'])
     path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic_latest.csv')
     m = re.match(r'(\w+)<(\d+),(\d+)(?:,(\w+))?(?:,(splitk))?>', kernel_label)
     if not m or not os.path.exists(path):
@@ -305,7 +320,7 @@ def main():
                     'algorithmic_tflops': round(alg, 2),
                     'algorithmic_frac_of_fp32_mfma_peak': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                     'traffic': pmc_traffic(dom['name']) if (args.height, args.width, args.batch) == (64, 128, 64) else None,
-                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.csv)',
+                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes FETCH_SIZE x 2 + WRITE_SIZE, profiles/pmc_utilisation_latest.csv)',
                     'kernel': dom['name'],
                     'measured': 'HIP events, sub-steps serialised (EG_LANES=0 semantics) so that kernels do not overlap',
                     'launches_per_step': dom['launches'] / args.profile_steps,

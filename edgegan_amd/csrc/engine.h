@@ -133,8 +133,8 @@ struct Ctx {
   Lane lanes[kLanes];
   int cur_lane = 0;
   bool lanes_on = true;
-  int lanes_mask = 3;
-  hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr;
+  int lanes_mask = 7;
+  hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr, ev_branch = nullptr;
 
   // inference staging buffers (host <-> device hand-over of eg_infer), grown on demand and kept
   float *inf_in = nullptr, *inf_edge = nullptr, *inf_image = nullptr, *inf_eps = nullptr;
@@ -252,6 +252,9 @@ struct SubOpts {
   // sub-step 5 right behind the concurrent sub-steps 1-4: instead of waiting for all of them up front, wait for a
   // network's update (event of the lane that trained it) only where that network is first used
   const hipEvent_t* wait_for_group = nullptr;  // [G_COUNT], null entries = no wait
+  // sub-steps 5 / 7: the four critics' forward + input-gradient passes are independent given G1(z), G2(z); run each on the
+  // lane that trained that network (D: 0, D_patch2: 1, D_patch3: 2, classifier: 3), join before the generators' backward
+  bool branch_lanes = false;
 };
 void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts = nullptr);
 void train_step(Ctx& c);

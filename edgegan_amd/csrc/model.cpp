@@ -255,7 +255,8 @@ void build_context(Ctx& c) {
   EG_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_gen, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_g1fwd, hipEventDisableTiming));
-  if (const char* e = getenv("EG_LANES")) {   // 0 = one stream; bit 0 = sub-steps 1-4 concurrent, bit 1 = 6/7 concurrent
+  EG_HIP(hipEventCreateWithFlags(&c.ev_branch, hipEventDisableTiming));
+  if (const char* e = getenv("EG_LANES")) {   // 0 = one stream; bit 0 = sub-steps 1-4 concurrent, bit 1 = 6/7 concurrent, bit 2 = the critics of 5 / 7 on four lanes
     c.lanes_mask = atoi(e);
     c.lanes_on = c.lanes_mask != 0;
   }
@@ -606,30 +607,65 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       T edge = generator_forward(c, G_G1, zin, bn1);
       T image = generator_forward(c, G_G2, zin, bn2);
       T joint = concat_w(c, edge, image);
+      T r_edge = resize(c, edge, cfg.dis_size), r_image = resize(c, image, cfg.dis_size);
+      // The four critics are independent given the generator outputs (each writes the gradient of its OWN input tensor;
+      // `image`'s gradient gets the classifier's contributions first, then -- after the join -- the resize's and the
+      // concat's, the order of the single-stream sweep).  With branch lanes each runs forward and backward on the lane that
+      // trained it, directly behind that sub-step; the generators' backward waits for all four.
+      const bool bl = opts && opts->branch_lanes && c.cur_lane == 0;
+      const size_t m0 = c.tape.ops.size();
+      if (bl) EG_HIP(hipEventRecord(c.ev_branch, c.stream));
+      auto enter = [&](int lane) {
+        if (!bl || lane == 0) return;
+        use_lane(c, lane);
+        c.arena.reset();   // (this lane's previous sub-step is fully enqueued; stream order protects its memory)
+        EG_HIP(hipStreamWaitEvent(c.stream, c.ev_branch, 0));
+      };
       await_group(G_D);
       T dj = disc_forward(c, G_D, joint, nullptr, nullptr);
-      T r_edge = resize(c, edge, cfg.dis_size), r_image = resize(c, image, cfg.dis_size);
+      launch_mean_neg(dj->d, c.d_losses + L_JOINT_G, B, c.stream);
+      seed_grad(c, dj);
+      launch_fill(dj->g, -cfg.joint_dweight / B, B, c.stream);
+      const size_t m1 = c.tape.ops.size();
+      enter(2);
       await_group(G_DP3);
       T de = disc_forward(c, G_DP3, r_edge, nullptr, nullptr);
+      launch_mean_neg(de->d, c.d_losses + L_EDGE_G, B, c.stream);
+      seed_grad(c, de);
+      launch_fill(de->g, -cfg.edge_dweight / B, B, c.stream);
+      const size_t m2 = c.tape.ops.size();
+      enter(1);
       await_group(G_DP2);
       T di = disc_forward(c, G_DP2, r_image, nullptr, nullptr);
-      launch_mean_neg(dj->d, c.d_losses + L_JOINT_G, B, c.stream);
-      launch_mean_neg(de->d, c.d_losses + L_EDGE_G, B, c.stream);
       launch_mean_neg(di->d, c.d_losses + L_IMAGE_G, B, c.stream);
-      seed_grad(c, dj);
-      seed_grad(c, de);
       seed_grad(c, di);
-      launch_fill(dj->g, -cfg.joint_dweight / B, B, c.stream);
-      launch_fill(de->g, -cfg.edge_dweight / B, B, c.stream);
       launch_fill(di->g, -cfg.image_dweight / B, B, c.stream);
+      const size_t m3 = c.tape.ops.size();
       if (cfg.multiclasses()) {
+        enter(3);
         await_group(G_D2);
         T lf = classifier_forward(c, image);
         seed_grad(c, lf);
         launch_acgan_loss(lf->d, c.d_z + cfg.z_dim, cfg.z_dim + 1, c.d_losses + L_CLS_G, lf->g, B, cfg.num_classes,
                           1, c.scratch, c.stream);
       }
-      c.tape.backward();
+      const size_t m4 = c.tape.ops.size();
+      if (!bl) {
+        c.tape.backward();
+      } else {
+        auto sweep = [&](int lane, size_t lo, size_t hi) {
+          use_lane(c, lane);
+          c.tape.backward_range(lo, hi);
+          if (lane != 0) EG_HIP(hipEventRecord(c.lanes[lane].done, c.stream));
+        };
+        if (m4 > m3) sweep(3, m3, m4);
+        sweep(1, m2, m3);
+        sweep(2, m1, m2);
+        sweep(0, m0, m1);
+        for (int i = 1; i < 4; ++i)
+          if (i != 3 || m4 > m3) EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[i].done, 0));
+        c.tape.backward_range(0, m0);
+      }
       if (apply) {
         before_apply();
         apply_group(c, G_G1);
@@ -748,14 +784,19 @@ void train_step(Ctx& c) {
     ev[G_D2] = c.lanes[3].done;
     SubOpts o5;
     o5.wait_for_group = ev;
+    o5.branch_lanes = (c.lanes_mask & 4) != 0;
     run_substep(c, 5, true, &o5);
   } else {
-    run_substep(c, 5, true);
+    SubOpts o5;
+    o5.branch_lanes = (c.lanes_mask & 4) != 0;
+    run_substep(c, 5, true, &o5);
   }
   // ---- phase C: encoder (reads G1) next to the second generator step (updates G1 at its end) -----------------
   if (!conc_c) {
     run_substep(c, 6, true);
-    run_substep(c, 7, true);
+    SubOpts o7;
+    o7.branch_lanes = (c.lanes_mask & 4) != 0;
+    run_substep(c, 7, true, &o7);
     ++c.step_count;
     return;
   }
@@ -772,6 +813,7 @@ void train_step(Ctx& c) {
     o7.bn_times_g1 = 2;
     o7.bn_times_g2 = 1;
     o7.wait_before_apply = c.ev_g1fwd;
+    o7.branch_lanes = (c.lanes_mask & 4) != 0;
     use_lane(c, 0);
     run_substep(c, 7, true, &o7);
   }
