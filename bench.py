@@ -299,12 +299,14 @@ def main():
     # profiler is on, train_step runs its sub-steps one after another on one stream (a kernel is measured in isolation;
     # the timed region above overlaps independent sub-steps on several streams, which stretches individual kernels)
     roof = None
-    if rank == 0 and args.profile_steps > 0:
+    if args.profile_steps > 0:
+        # EVERY rank runs the profiled iterations: under data parallelism a training iteration issues the groups'
+        # all-reduces, and a collective that only rank 0 enqueued would pair with the other ranks' next one
         net.profile_begin()
         for _ in range(args.profile_steps):
             net.train_step()
         prof = net.profile_end()
-        ks = prof['kernels']
+        ks = prof['kernels'] if rank == 0 else None
         if ks:
             dom = max(ks, key=lambda k: k['ms'])
             tot_ms = sum(k['ms'] for k in ks)
