@@ -20,6 +20,13 @@ typedef const char* (*fn_errstr)(int);
 
 void* load_lib(Ctx& c) {
   if (c.nccl_lib) return c.nccl_lib;
+  // EG_RCCL_LIB: bind this library instead (a site's own RCCL build; the gpu tests' loop-back stand-in that lets
+  // several ranks share ONE device, tests/shim/loopback_rccl.cpp) -- no fallback when it is set and does not load
+  if (const char* forced = getenv("EG_RCCL_LIB")) {
+    c.nccl_lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (c.nccl_lib) return c.nccl_lib;
+    fail(3, "cannot load EG_RCCL_LIB=%s: %s", forced, dlerror());
+  }
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
     c.nccl_lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);

@@ -54,19 +54,10 @@ __device__ __forceinline__ float lo_fh(unsigned p) { return __builtin_bit_cast(f
 __device__ __forceinline__ float hi_fh(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 // (x, y) -> packed limb pairs p0, p1, p2 with x = lo(p0) + lo(p1) + lo(p2) exactly (k_gemm_x3.hip: split_pair)
 __device__ __forceinline__ void split_pair_h(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
-#ifdef EG_X3H_PKSUB   // residuals as packed subtractions (v_pk_add_f32): the halo split runs with no MFMAs beside it
-  const f32x2 v = {x, y};
-  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  const f32x2 r = v - (f32x2){lo_fh(p0), hi_fh(p0)};
-  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-  const f32x2 r2 = r - (f32x2){lo_fh(p1), hi_fh(p1)};
-  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-#else
   p0 = pack2h(x, y);
   const float rx = x - lo_fh(p0), ry = y - hi_fh(p0);
   p1 = pack2h(rx, ry);
   p2 = pack2h(rx - lo_fh(p1), ry - hi_fh(p1));
-#endif
 }
 __device__ __forceinline__ int swz_h(int row) { return ((-((row >> 2) & 3)) & 3) ^ ((row >> 4) & 1); }
 __device__ __forceinline__ int reflect_h(int i, int n) {

@@ -1,0 +1,42 @@
+"""One data-parallel rank of tests/test_dp_gpu.py (run as a subprocess): an engine on device 0 with its own shard of
+the batch, the communicator bound through edgegan_amd.rendezvous (the product's bring-up), then either one
+discriminator sub-step or whole training iterations; every variable and RMSProp slot goes to <out>/rank<r>.npz.
+
+usage: dp_worker.py <rank> <world> <out_dir> <mode>      mode: substep1 | iterations"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+import edgegan_amd as ea
+from edgegan_amd import rendezvous
+
+
+def main():
+    rank, world, out, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    cfg = ea.Config(batch_size=2)
+    values = ea.init_variables(cfg, 0)                      # the same weights on every rank
+    net = ea.EdgeGAN(cfg, values)
+    rendezvous.init_data_parallel(net, rank, world)
+    batch = ea.synthetic_batch(cfg, seed=4321, rank=rank)   # its own shard
+    net.upload_batch(**batch)
+    if mode == 'substep1':
+        net.substep(1, apply=True)
+    else:
+        net.train_step()
+        net.train_step()
+    net.sync()
+    net.comm_barrier()
+    mx = net.comm_reduce_scalars([float(rank)], 'max')[0]   # the scalar path bench.py takes its max-over-ranks with
+    assert mx == world - 1, mx
+    np.savez(os.path.join(out, f'rank{rank}.npz'), **net.get_variables(slots=True))
+    losses = net.losses()
+    assert all(np.isfinite(v) for v in losses.values()), losses
+    net.close()
+
+
+if __name__ == '__main__':
+    main()

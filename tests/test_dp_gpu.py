@@ -1,0 +1,126 @@
+"""The engine's MULTI-RANK path on the GPU: edgegan_amd/csrc/model.cpp:apply_group (event-ordered all-reduce +
+RMSProp(1/nranks) on the side stream), comm.cpp:comm_wait_groups, comm_reduce_scalars, rendezvous.py and bench.py's
+N > 1 flow -- with two ranks sharing the box's ONE device.  The real RCCL refuses two ranks on one device
+(ncclCommInitRank -> ncclInvalidUsage; measured), so the ranks bind tests/shim/loopback_rccl.cpp through
+EG_RCCL_LIB: same five entry points, the reduction done over a shared mapping in rank order, and a check that
+every rank is in the SAME collective (a collective only one rank enqueues fails instead of hanging).  What this
+does not cover is RCCL's own transport over xGMI (the single-rank test in test_step_gpu.py runs the real library).
+
+Reference semantics: pure data parallelism over the 7 sub-steps of edgegan/models/edgegan.py:109-130 -- each rank
+differentiates its shard, the group's gradient is averaged, every replica applies the same RMSProp update
+(SURVEY.md 8e)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import edgegan_amd as ea
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM_SRC = os.path.join(ROOT, 'tests', 'shim', 'loopback_rccl.cpp')
+SHIM = os.path.join(ROOT, 'tests', 'shim', 'libloopback_rccl.so')
+
+
+@pytest.fixture(scope='module')
+def shim(built_lib):
+    if not os.path.exists(SHIM) or os.path.getmtime(SHIM) < os.path.getmtime(SHIM_SRC):
+        import __graft_entry__ as ge
+        ge.build_test_shim()
+    return SHIM
+
+
+def _replicated(name):
+    """BatchNorm moving statistics follow each rank's own shard (no exchange: they are not optimised variables; rank 0's
+    copy is the one a checkpoint keeps) -- everything else must be bit-identical on every replica."""
+    return 'moving_' not in name
+
+
+def _env(shim, tmp, key, **extra):
+    env = dict(os.environ, EG_RCCL_LIB=shim, EG_RDZV_DIR=str(tmp), EG_RDZV_KEY=key, EG_LOOPBACK_TIMEOUT_S='240')
+    env.update(extra)
+    return env
+
+
+def _run_ranks(shim, tmp, mode, key, world=2, **extra):
+    out = tmp / key
+    out.mkdir()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), str(r), str(world), str(out), mode],
+                              env=_env(shim, tmp, key, **extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f'rank {r} failed:\n{logs[r][-3000:]}'
+    return [dict(np.load(out / f'rank{r}.npz')) for r in range(world)]
+
+
+def test_two_ranks_average_the_shard_gradients_before_rmsprop(shim, tmp_path):
+    """Sub-step 1 (joint discriminator) on two ranks == RMSProp of the MEAN of the two shard gradients, the gradients
+    taken from a communicator-free engine at the same weights; other groups' variables untouched; replicas identical."""
+    ranks = _run_ranks(shim, tmp_path, 'substep1', 'ss1')
+    for k in filter(_replicated, ranks[0]):
+        assert np.array_equal(ranks[0][k], ranks[1][k]), f'replicas differ in {k}'
+    cfg = ea.Config(batch_size=2)
+    values = ea.init_variables(cfg, 0)
+    net = ea.EdgeGAN(cfg, values)
+    names = [s.name for s in net.specs if s.trainable and s.name.startswith('D/')]
+    assert names
+    shard_grads = []
+    for r in range(2):
+        # the alpha rows a rank draws for itself are part of its shard: dp_worker passes the batch's own alpha
+        net.upload_batch(**ea.synthetic_batch(cfg, seed=4321, rank=r))
+        net.substep(1, apply=False)
+        shard_grads.append({n: net.get_variable(n + '/grad', values[n].shape).astype(np.float64) for n in names})
+    net.close()
+    lr = cfg.learning_rate
+    worst = 0.0
+    for n in names:
+        g = 0.5 * (shard_grads[0][n] + shard_grads[1][n])
+        ms = 1.0 + (g * g - 1.0) * 0.1                        # tf RMSProp: slot starts at 1, decay 0.9
+        step = lr * g / np.sqrt(ms + 1e-10)
+        got_step = values[n].astype(np.float64) - ranks[0][n].astype(np.float64)
+        scale = np.abs(step).max() + 1e-30
+        worst = max(worst, float(np.abs(got_step - step).max() / scale))
+        np.testing.assert_allclose(ranks[0][n + '/RMSProp'], ms, rtol=2e-6, atol=0)
+        # one shard alone would give a different update: the test can tell mean from "rank 0's gradient"
+    assert worst < 2e-4, worst    # fp32 weights: w - step rounds at 2^-24 |w|, |step| ~ lr
+    for s in net.specs:
+        if not s.name.startswith('D/') and _replicated(s.name):
+            assert np.array_equal(ranks[0][s.name], np.asarray(values[s.name], dtype=np.float32).reshape(ranks[0][s.name].shape)), s.name
+    g0, g1 = shard_grads[0][names[0]], shard_grads[1][names[0]]
+    assert np.abs(g0 - g1).max() > 1e-3 * np.abs(g0).max(), 'the two shards must differ for this test to mean anything'
+
+
+def test_two_rank_iterations_lanes_equal_one_stream_and_replicas_stay_identical(shim, tmp_path):
+    """Two whole iterations (7 sub-steps, 9 all-reduces each) on two ranks: both replicas bit-identical, and the
+    concurrent-lane schedule bit-identical to the one-stream schedule (comm_wait_groups with lanes + DP)."""
+    lanes = _run_ranks(shim, tmp_path, 'iterations', 'lanes')
+    serial = _run_ranks(shim, tmp_path, 'iterations', 'serial', EG_LANES='0')
+    for k in lanes[0]:
+        if _replicated(k):
+            assert np.array_equal(lanes[0][k], lanes[1][k]), f'replicas differ in {k}'
+        assert np.array_equal(lanes[0][k], serial[0][k]), f'lanes vs one stream differ in {k}'
+        assert np.isfinite(lanes[0][k]).all(), k
+    values = ea.init_variables(ea.Config(batch_size=2), 0)
+    moved = [k for k in values if not np.array_equal(lanes[0][k].reshape(-1), np.asarray(values[k], np.float32).reshape(-1))]
+    assert len(moved) > 100, len(moved)
+
+
+def test_bench_two_ranks_end_to_end(shim, tmp_path):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per process), both ranks on
+    device 0: rendezvous, barriers, the profiled iterations on every rank, max-over-ranks, ONE JSON line from rank 0."""
+    env = _env(shim, tmp_path, 'bench', EG_FORCE_DEVICE='0')
+    env.pop('EG_RDZV_KEY')         # the launcher-derived key (parent pid + MASTER_PORT) is what the driver's run uses
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '8']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 16 and out['scaling'] == 'weak'
+    assert out['losses_finite'] and out['value'] > 0 and out['roofline'] and out['roofline']['frac'] < 1
+    assert 'cpu_baseline' not in out      # rank 0 at N = 1 only
