@@ -63,6 +63,8 @@ def main(argv=None):
     F.check_supported(fl)
     rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', fl.gpu if world == 1 else rank))
+    if 'EG_FORCE_DEVICE' in os.environ:      # test hook (as in bench.py): several ranks on one GPU
+        local = int(os.environ['EG_FORCE_DEVICE'])
     if rank == 0:
         print({k: v for k, v in vars(fl).items()})
         for d in (fl.outputsroot, fl.checkpoint_dir, fl.logdir):

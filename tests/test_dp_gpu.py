@@ -124,3 +124,31 @@ def test_bench_two_ranks_end_to_end(shim, tmp_path):
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 16 and out['scaling'] == 'weak'
     assert out['losses_finite'] and out['value'] > 0 and out['roofline'] and out['roofline']['frac'] < 1
     assert 'cpu_baseline' not in out      # rank 0 at N = 1 only
+
+
+def test_training_command_line_two_ranks(shim, tmp_path):
+    """python -m edgegan_amd.train under torch.distributed.run with two ranks: one shared shuffle seed, the batches of an
+    epoch partitioned over the ranks (4 batches -> 2 iterations per rank), rank 0 prints and writes the checkpoint
+    (edgegan/train.py + edgegan.py:425-489 as a data-parallel loop, SURVEY.md 8e / ADVICE r1)."""
+    from PIL import Image
+    from edgegan_amd import tf_bundle
+    rng = np.random.RandomState(0)
+    root = tmp_path / 'data'
+    for c in (0, 5):
+        os.makedirs(root / 'class14' / 'train' / str(c))
+        for i in range(4):
+            Image.fromarray(rng.randint(0, 256, size=(64, 128, 3)).astype(np.uint8)).save(
+                root / 'class14' / 'train' / str(c) / f'{i}.png')
+    env = _env(shim, tmp_path, 'train', EG_FORCE_DEVICE='0', PYTHONPATH=ROOT)
+    env.pop('EG_RDZV_KEY')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29534', '-m', 'edgegan_amd.train', '--name=dp', f'--dataroot={root}', '--batch_size=2', '--epoch=1',
+           '--save_checkpoint_frequency=3']
+    p = subprocess.run(cmd, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    progress = [l for l in p.stdout.splitlines() if l.startswith('Epoch:')]
+    assert len(progress) == 2 and '/   2]' in progress[0], p.stdout[-2000:]          # 8 images / batch 2 / 2 ranks; rank 0 only
+    ck = tmp_path / 'outputs' / 'dp' / 'checkpoints'
+    # counter starts at 1, +1 per iteration; saved when counter % 3 == 2 (edgegan.py:487-489) -> after rank 0's 1st iteration
+    assert (ck / 'EdgeGAN-Model-2.index').exists(), sorted(x.name for x in ck.glob('*'))
+    assert tf_bundle.read_checkpoint_state(str(ck))[0] == 'EdgeGAN-Model-2'
