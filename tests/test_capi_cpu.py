@@ -76,3 +76,18 @@ def test_synthetic_batch_contract():
     b2 = ea.synthetic_batch(cfg)
     assert all(np.array_equal(b[k], b2[k]) for k in b)
     assert not np.array_equal(ea.synthetic_batch(cfg, rank=1)['z'], b['z'])
+
+
+def test_loopback_rccl_stand_in_builds_and_exports_what_the_engine_binds(built_lib):
+    """tests/shim/loopback_rccl.cpp (what tests/test_dp_gpu.py binds through EG_RCCL_LIB) must offer every RCCL entry
+    point edgegan_amd/csrc/comm.cpp resolves by name -- checked against the dlsym strings in comm.cpp itself."""
+    import __graft_entry__ as ge
+    so = os.path.join(ROOT, 'tests', 'shim', 'libloopback_rccl.so')
+    if not os.path.exists(so):
+        ge.build_test_shim()
+    bound = sorted(set(re.findall(r'"(nccl[A-Za-z]+)"', open(os.path.join(ROOT, 'edgegan_amd', 'csrc', 'comm.cpp')).read())))
+    assert bound == ['ncclAllReduce', 'ncclCommDestroy', 'ncclCommInitRank', 'ncclGetErrorString', 'ncclGetUniqueId'], bound
+    lib = ctypes.CDLL(so)
+    assert all(hasattr(lib, s) for s in bound)
+    lib.ncclGetErrorString.restype = ctypes.c_char_p
+    assert b'invalid usage' in lib.ncclGetErrorString(5)
