@@ -86,6 +86,29 @@ def test_inference_matches_oracle():
     net.close()
 
 
+def test_inference_shares_the_encoder_trunk_without_changing_a_bit(monkeypatch):
+    """The reference's two runs (E -> G1, E -> G2; edgegan.py:606-609) each evaluate the encoder; the engine evaluates
+    the trunk once and applies each run's eps in z = mu + eps exp(log sigma) (model.cpp:infer).  The edge output may
+    depend on eps2[0] only, the image output on eps2[1] only, and both must equal -- bit for bit -- what a call that
+    gives BOTH runs that eps produces; the two-lane schedule must equal the one-stream one."""
+    cfg = ea.Config(batch_size=4)
+    values = ea.init_variables(cfg, 5)
+    imgs = np.random.RandomState(11).uniform(-1, 1, size=(4, 64, 128, 3)).astype(np.float32)
+    cls = np.array([0, 3, 7, 13], dtype=np.int32)
+    outs = {}
+    for lanes in ('7', '0'):
+        monkeypatch.setenv('EG_LANES', lanes)
+        net = ea.EdgeGAN(cfg, values)
+        outs[lanes] = {k: net.infer(imgs, cls, eps2=list(k)) for k in ((0.4, -1.1), (0.4, 0.4), (-1.1, -1.1), (0.4, 2.0))}
+        net.close()
+    for lanes, o in outs.items():
+        assert np.array_equal(o[(0.4, -1.1)][0], o[(0.4, 0.4)][0]) and np.array_equal(o[(0.4, -1.1)][0], o[(0.4, 2.0)][0])
+        assert np.array_equal(o[(0.4, -1.1)][1], o[(-1.1, -1.1)][1])
+        assert not np.array_equal(o[(0.4, -1.1)][1], o[(0.4, 2.0)][1])          # eps does reach the image run
+    for k in outs['7']:
+        assert np.array_equal(outs['7'][k][0], outs['0'][k][0]) and np.array_equal(outs['7'][k][1], outs['0'][k][1])
+
+
 def test_train_step_equals_sequential_substeps_and_is_deterministic():
     cfg = ea.Config(batch_size=2)
     values = ea.init_variables(cfg, 0)
