@@ -665,6 +665,54 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_v(const float* __restrict__ x
   }
 }
 
+// The same kernel with the thread's rows held in registers between the three passes (R <= 32 NI): the generator's
+// BatchNorm sits on a chain of small launches (R = 16 B rows of 512 channels, 16 blocks), where the loop form pays the
+// global-load latency 3 x R / 32 times in sequence.  Same per-thread summation order => the same bits as bn_relu_fwd_v.
+template <int NI>
+__global__ __launch_bounds__(256) void bn_relu_fwd_vr(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ out,
+                                                      float* __restrict__ stats, int R, int C, float eps) {
+  __shared__ float4 red[4 * 8];
+  const int cq = threadIdx.x % 8, pl = threadIdx.x / 8;
+  const int c = (blockIdx.x * 8 + cq) * 4;
+  float4 v[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int p = pl + 32 * i;
+    v[i] = p < R ? ld4(x + (size_t)p * C + c) : f4_zero();
+  }
+  float4 s[1] = {f4_zero()};
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (pl + 32 * i < R) { s[0].x += v[i].x; s[0].y += v[i].y; s[0].z += v[i].z; s[0].w += v[i].w; }
+  cq_reduce<1, 8>(s, red);
+  const float4 mean = make_float4(s[0].x / R, s[0].y / R, s[0].z / R, s[0].w / R);
+  float4 q[1] = {f4_zero()};
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (pl + 32 * i < R) {
+      const float a = v[i].x - mean.x, b = v[i].y - mean.y, d = v[i].z - mean.z, e = v[i].w - mean.w;
+      q[0].x += a * a; q[0].y += b * b; q[0].z += d * d; q[0].w += e * e;
+    }
+  cq_reduce<1, 8>(q, red);
+  const float4 var = make_float4(q[0].x / R, q[0].y / R, q[0].z / R, q[0].w / R);
+  const float4 g = ld4(gamma + c), b = ld4(beta + c);
+  const float4 sc = make_float4(g.x / sqrtf(var.x + eps), g.y / sqrtf(var.y + eps), g.z / sqrtf(var.z + eps),
+                                g.w / sqrtf(var.w + eps));
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int p = pl + 32 * i;
+    if (p < R)
+      st4(out + (size_t)p * C + c,
+          make_float4(fmaxf((v[i].x - mean.x) * sc.x + b.x, 0.f), fmaxf((v[i].y - mean.y) * sc.y + b.y, 0.f),
+                      fmaxf((v[i].z - mean.z) * sc.z + b.z, 0.f), fmaxf((v[i].w - mean.w) * sc.w + b.w, 0.f)));
+  }
+  if (pl == 0) {
+    st4(stats + c, mean);
+    st4(stats + C + c, var);
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_relu_bwd_v(const float* __restrict__ x, const float* __restrict__ out,
                                                      const float* __restrict__ dout, const float* __restrict__ gamma,
                                                      const float* __restrict__ stats, float* __restrict__ dx, int acc_dx,
@@ -677,31 +725,57 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_v(const float* __restrict__ x
   const float4 rs = make_float4(1.f / sqrtf(var.x + eps), 1.f / sqrtf(var.y + eps), 1.f / sqrtf(var.z + eps),
                                 1.f / sqrtf(var.w + eps));
   float4 s[2] = {f4_zero(), f4_zero()};
-  for (int p = pl; p < R; p += 32) {
-    const size_t i = (size_t)p * C + c;
-    const float4 o = ld4(out + i), d = ld4(dout + i), v = ld4(x + i);
-    const float e0 = o.x > 0.f ? d.x : 0.f, e1 = o.y > 0.f ? d.y : 0.f, e2 = o.z > 0.f ? d.z : 0.f,
-                e3 = o.w > 0.f ? d.w : 0.f;
-    s[0].x += e0; s[0].y += e1; s[0].z += e2; s[0].w += e3;
-    s[1].x += e0 * (v.x - mean.x) * rs.x; s[1].y += e1 * (v.y - mean.y) * rs.y;
-    s[1].z += e2 * (v.z - mean.z) * rs.z; s[1].w += e3 * (v.w - mean.w) * rs.w;
+  constexpr int U = 4;   // rows whose loads are in flight together (the sums keep the row order of the plain loop)
+  for (int p0 = pl; p0 < R; p0 += 32 * U) {
+    float4 o[U], d[U], v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + 32 * u;
+      if (p < R) {
+        const size_t i = (size_t)p * C + c;
+        o[u] = ld4(out + i); d[u] = ld4(dout + i); v[u] = ld4(x + i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (p0 + 32 * u >= R) break;
+      const float e0 = o[u].x > 0.f ? d[u].x : 0.f, e1 = o[u].y > 0.f ? d[u].y : 0.f, e2 = o[u].z > 0.f ? d[u].z : 0.f,
+                  e3 = o[u].w > 0.f ? d[u].w : 0.f;
+      s[0].x += e0; s[0].y += e1; s[0].z += e2; s[0].w += e3;
+      s[1].x += e0 * (v[u].x - mean.x) * rs.x; s[1].y += e1 * (v[u].y - mean.y) * rs.y;
+      s[1].z += e2 * (v[u].z - mean.z) * rs.z; s[1].w += e3 * (v[u].w - mean.w) * rs.w;
+    }
   }
   cq_reduce<2, 8>(s, red);
   const float4 g = ld4(gamma + c);
   const float4 me = make_float4(s[0].x / R, s[0].y / R, s[0].z / R, s[0].w / R);
   const float4 mex = make_float4(s[1].x / R, s[1].y / R, s[1].z / R, s[1].w / R);
   if (dx)
-    for (int p = pl; p < R; p += 32) {
-      const size_t i = (size_t)p * C + c;
-      const float4 o = ld4(out + i), d = ld4(dout + i), v = ld4(x + i);
-      const float e0 = o.x > 0.f ? d.x : 0.f, e1 = o.y > 0.f ? d.y : 0.f, e2 = o.z > 0.f ? d.z : 0.f,
-                  e3 = o.w > 0.f ? d.w : 0.f;
-      float4 r = make_float4(g.x * rs.x * (e0 - me.x - (v.x - mean.x) * rs.x * mex.x),
-                             g.y * rs.y * (e1 - me.y - (v.y - mean.y) * rs.y * mex.y),
-                             g.z * rs.z * (e2 - me.z - (v.z - mean.z) * rs.z * mex.z),
-                             g.w * rs.w * (e3 - me.w - (v.w - mean.w) * rs.w * mex.w));
-      if (acc_dx) { const float4 t = ld4(dx + i); r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
-      st4(dx + i, r);
+    for (int p0 = pl; p0 < R; p0 += 32 * U) {
+      float4 o[U], d[U], v[U], t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = p0 + 32 * u;
+        t[u] = f4_zero();
+        if (p < R) {
+          const size_t i = (size_t)p * C + c;
+          o[u] = ld4(out + i); d[u] = ld4(dout + i); v[u] = ld4(x + i);
+          if (acc_dx) t[u] = ld4(dx + i);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = p0 + 32 * u;
+        if (p >= R) break;
+        const float e0 = o[u].x > 0.f ? d[u].x : 0.f, e1 = o[u].y > 0.f ? d[u].y : 0.f, e2 = o[u].z > 0.f ? d[u].z : 0.f,
+                    e3 = o[u].w > 0.f ? d[u].w : 0.f;
+        float4 r = make_float4(g.x * rs.x * (e0 - me.x - (v[u].x - mean.x) * rs.x * mex.x),
+                               g.y * rs.y * (e1 - me.y - (v[u].y - mean.y) * rs.y * mex.y),
+                               g.z * rs.z * (e2 - me.z - (v[u].z - mean.z) * rs.z * mex.z),
+                               g.w * rs.w * (e3 - me.w - (v[u].w - mean.w) * rs.w * mex.w));
+        if (acc_dx) { r.x += t[u].x; r.y += t[u].y; r.z += t[u].z; r.w += t[u].w; }
+        st4(dx + (size_t)p * C + c, r);
+      }
     }
   if (pl == 0) {
     if (dgamma) {
@@ -720,7 +794,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_v(const float* __restrict__ x
 void launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats, int R,
                         int C, float eps, hipStream_t s) {
   if (C % 32 == 0) {
-    hipLaunchKernelGGL(bn_relu_fwd_v, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
+    if (R <= 32 * 4)
+      hipLaunchKernelGGL(bn_relu_fwd_vr<4>, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
+    else if (R <= 32 * 32)
+      hipLaunchKernelGGL(bn_relu_fwd_vr<32>, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
+    else
+      hipLaunchKernelGGL(bn_relu_fwd_v, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
     return;
   }
   hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
