@@ -124,6 +124,11 @@ struct Tensor {
   int n = 0, h = 1, w = 1, c = 0;
   bool needs_grad = false;
   bool g_set = false;
+  // forward-only convolution outputs left as their K-split slabs for the InstanceNorm pass that is their only reader
+  // (ops.cpp: conv2d / deconv2d with Ctx::feeds_in, in_act): d is then NOT written
+  const float* slabs = nullptr;
+  const float* slab_bias = nullptr;
+  int nslab = 0;
   size_t numel() const { return (size_t)n * h * w * c; }
   size_t pixels() const { return (size_t)n * h * w; }
 };

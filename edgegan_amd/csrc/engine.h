@@ -97,6 +97,9 @@ struct Ctx {
   bool sn_prepared = false;   // tape entry for the SN backward pushed in this sub-step
   bool sn_valid = false;      // Wbar buffers match the current D2 weights (persists across sub-steps)
   bool param_grad_enabled = true;
+  // set by a caller right before a conv2d / deconv2d whose ONLY reader is in_act: a forward-only K-split launch then
+  // leaves its slabs for the InstanceNorm load pass (consumed, i.e. reset, by that convolution)
+  bool feeds_in = false;
   float* scratch = nullptr;  // persistent reduction scratch
   size_t scratch_floats = 0;
 

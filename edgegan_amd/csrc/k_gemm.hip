@@ -459,7 +459,7 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
                                          a.ksplit > 1 ? "conv_gemm<64,64,vec,splitk>" : "conv_gemm<64,64,vec>",
                                          "conv_gemm<64,64,avec>", "conv_gemm<64,64,flat>");
   }
-  if (a.ksplit > 1) {
+  if (a.ksplit > 1 && !a.keep_slabs) {
     const size_t total4 = a.y_total / 4;   // split-K requires N % 4 == 0 and a 16-byte aligned, y_ps % 4 == 0 output
     size_t blocks = (total4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;

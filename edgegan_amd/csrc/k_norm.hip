@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void in_fwd_v(const float* __restrict__ x, flo
 // variance and for the apply pass; at 128 KB per block those re-reads miss L2)
 template <int NP, int CQ>
 __global__ __launch_bounds__(256) void in_fwd_vr(const float* __restrict__ x, float* __restrict__ out,
-                                                 float* __restrict__ stats, int HW, int C, int act) {
+                                                 float* __restrict__ stats, int HW, int C, int act, int nslab,
+                                                 size_t slab_stride, const float* __restrict__ slab_bias) {
   constexpr int PL = 256 / CQ;   // CQ = 4 for the 32x32 layers: 16 channels per block -> twice the blocks, half the registers
   __shared__ float4 red[4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -244,7 +245,19 @@ __global__ __launch_bounds__(256) void in_fwd_vr(const float* __restrict__ x, fl
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int p = pl + i * PL;
-    xv[i] = p < HW ? ld4(xp + (size_t)p * C) : f4_zero();
+    if (nslab > 1) {   // an un-summed K-split convolution output: bias + slabs in conv_split_reduce's order
+      float4 v = f4_zero();
+      if (p < HW) {
+        if (slab_bias) v = ld4(slab_bias + c);
+        for (int k = 0; k < nslab; ++k) {
+          const float4 q = ld4(xp + (size_t)k * slab_stride + (size_t)p * C);
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+      }
+      xv[i] = v;
+    } else {
+      xv[i] = p < HW ? ld4(xp + (size_t)p * C) : f4_zero();
+    }
     s[0].x += xv[i].x; s[0].y += xv[i].y; s[0].z += xv[i].z; s[0].w += xv[i].w;
   }
   cq_reduce<1, CQ>(s, red);
@@ -386,16 +399,18 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
   }
 }
 
-void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s) {
+void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s, int nslab,
+                   size_t slab_stride, const float* slab_bias) {
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
-    if (HW <= 64) hipLaunchKernelGGL((in_fwd_vr<2, 8>), grid, dim3(256), 0, s, x, out, stats, HW, C, act);
-    else if (HW <= 128) hipLaunchKernelGGL((in_fwd_vr<4, 8>), grid, dim3(256), 0, s, x, out, stats, HW, C, act);
-    else if (HW <= 256) hipLaunchKernelGGL((in_fwd_vr<8, 8>), grid, dim3(256), 0, s, x, out, stats, HW, C, act);
-    else if (HW <= 512) hipLaunchKernelGGL((in_fwd_vr<16, 8>), grid, dim3(256), 0, s, x, out, stats, HW, C, act);
-    else if (HW <= 1024)
-      hipLaunchKernelGGL((in_fwd_vr<16, 4>), dim3(NB, C / 16), dim3(256), 0, s, x, out, stats, HW, C, act);
+#define EG_IN_FWD(NP, CQ, G) hipLaunchKernelGGL((in_fwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, HW, C, act, nslab, slab_stride, slab_bias)
+    if (HW <= 64) EG_IN_FWD(2, 8, grid);
+    else if (HW <= 128) EG_IN_FWD(4, 8, grid);
+    else if (HW <= 256) EG_IN_FWD(8, 8, grid);
+    else if (HW <= 512) EG_IN_FWD(16, 8, grid);
+    else if (HW <= 1024) EG_IN_FWD(16, 4, dim3(NB, C / 16));
     else hipLaunchKernelGGL(in_fwd_v<8>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+#undef EG_IN_FWD
     return;
   }
 

@@ -48,6 +48,7 @@ struct ConvArgs {
   size_t y_total;    // NB*OHf*OWf*y_ps
   int nphase;
   ConvPhase ph[4];
+  int keep_slabs;   // K-split launches: leave the slabs in ws (no conv_split_reduce); the caller's consumer sums them
 };
 
 // flops (2*M*N*K summed over phases) are returned for the profiler.
@@ -170,7 +171,10 @@ void launch_tap_transpose(const float* in, float* out, int T, int R, int Cc, con
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
 
 // InstanceNorm (x-mean)/(sqrt(var)+1e-5) + act, per (n,c) over H*W. stats[n][c] = {mean, sigma}.
-void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s);
+// nslab > 1: x is the first of nslab K-split slabs (slab_stride floats apart) of a convolution output that was never
+// summed; the load pass forms bias + slab 0 + slab 1 + ... in conv_split_reduce's order (C % 32 == 0, HW <= 1024 only)
+void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s,
+                   int nslab = 0, size_t slab_stride = 0, const float* slab_bias = nullptr);
 // dx (+)= J * (dout * act'(out))   (J = IN Jacobian, symmetric)
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
                    int accumulate, int NB, int HW, int C, int act, hipStream_t s);

@@ -291,6 +291,7 @@ T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out) {
   const int ch[5] = {gf * 8, gf * 4, gf * 2, gf, cfg.c_dim};
   for (int i = 1; i <= 4; ++i) {
     const std::string b = p + "/g_dconv_" + std::to_string(i) + "/deconv2d/";
+    c.feeds_in = i < 4;   // deconv_block: the InstanceNorm is the transposed convolution's only reader
     x = deconv2d(c, x, wref_param(c, P(c, b + "w"), 25, ch[i], ch[i - 1]), P(c, b + "b"), ch[i]);
     if (i < 4) x = in_act(c, x, ACT_RELU);
   }
@@ -335,9 +336,11 @@ T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out) {
   int cin = 64, i = 1;
   for (int n : encoder_filters(cfg)) {
     const std::string b = "E/e_resnet_" + std::to_string(n) + "_" + std::to_string(i++);
+    c.feeds_in = true;   // residual: both 3x3 convolutions are read by their InstanceNorm alone
     T o1 = conv2d(c, E, wref_param(c, P(c, b + "/res1/conv2d/w"), 9, cin, n), P(c, b + "/res1/conv2d/b"), 3, 1,
                   PAD_REFLECT);
     o1 = in_act(c, o1, ACT_RELU);
+    c.feeds_in = true;
     T o2 = conv2d(c, o1, wref_param(c, P(c, b + "/res2/conv2d/w"), 9, n, n), P(c, b + "/res2/conv2d/b"), 3, 1,
                   PAD_REFLECT);
     o2 = in_act(c, o2, ACT_NONE);

@@ -672,8 +672,19 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     if (fused) a.act = fused_act;
   }
   if (c.prof_on) c.cur_label = w->name + " fwd";
-  run_conv(c, a);
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
+  // forward-only convolution read by an InstanceNorm alone (Ctx::feeds_in): a K-split launch keeps its slabs, the
+  // norm's load pass sums them (bias + slabs in conv_split_reduce's order: same bits, one launch and one round trip less)
+  static const bool slab_fusion = getenv("EG_NO_SLAB_IN") == nullptr;
+  const bool slabs_ok = c.feeds_in && slab_fusion && !need && !accumulate_into && !fused_act && N % 32 == 0 && OH * OW <= 1024;
+  c.feeds_in = false;
+  a.keep_slabs = slabs_ok ? 1 : 0;
+  run_conv(c, a);
+  if (slabs_ok && a.ksplit > 1) {
+    y->slabs = a.ws;
+    y->nslab = a.ksplit;
+    y->slab_bias = a.bias;
+  }
   if (need) {
     y->needs_grad = true;
     Ctx* cp = &c;
@@ -740,8 +751,17 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
     }
   attach_bf16(c, a, w, false);   // filter [25][Cout][Cin]: rows = Cout, contracted = Cin as stored
   if (c.prof_on) c.cur_label = w->name + " fwd";
-  if (!merged) run_conv(c, a);
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
+  static const bool slab_fusion = getenv("EG_NO_SLAB_IN") == nullptr;
+  const bool slabs_ok = c.feeds_in && slab_fusion && !need && !merged && cout % 32 == 0 && OH * OW <= 1024;   // see conv2d
+  c.feeds_in = false;
+  a.keep_slabs = slabs_ok ? 1 : 0;
+  if (!merged) run_conv(c, a);
+  if (slabs_ok && a.ksplit > 1) {
+    y->slabs = a.ws;
+    y->nslab = a.ksplit;
+    y->slab_bias = a.bias;
+  }
   if (need) {
     y->needs_grad = true;
     Ctx* cp = &c;
@@ -844,7 +864,11 @@ T in_act(Ctx& c, T x, int a, T* stats_out) {
   T out = new_tensor(c, x->n, x->h, x->w, x->c, x->needs_grad);
   T st = new_tensor(c, x->n, 1, 1, 2 * x->c, false);
   const int HW = x->h * x->w;
-  launch_in_fwd(x->d, out->d, st->d, x->n, HW, x->c, a, c.stream);
+  EG_CHECK(x->nslab <= 1 || (x->c % 32 == 0 && HW <= 1024), "in_act: slab input needs C %% 32 == 0 and HW <= 1024");
+  if (x->nslab > 1)   // a forward-only K-split convolution output that was left as slabs for this pass (conv2d)
+    launch_in_fwd(x->slabs, out->d, st->d, x->n, HW, x->c, a, c.stream, x->nslab, x->numel(), x->slab_bias);
+  else
+    launch_in_fwd(x->d, out->d, st->d, x->n, HW, x->c, a, c.stream);
   if (stats_out) *stats_out = st;
   if (x->needs_grad) {
     Ctx* cp = &c;
