@@ -916,7 +916,7 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
   T z0 = encoder_forward(c, left, d_eps2, &mu, &ls);
   const bool two = c.lanes_on && !c.prof_on;
   if (two) {
-    warm_transposes(c, G_G2);   // lazily built filter images are filled on the stream that will read them ...
+    warm_transposes(c, G_G2);   // G2's lazily built transposed filters: filled here, on lane 0, before lane 1 forks off and reads them
     EG_HIP(hipEventRecord(c.ev_fork, c.stream));
   }
   for (int run = 0; run < 2; ++run) {
