@@ -2,7 +2,7 @@
 the batch, the communicator bound through edgegan_amd.rendezvous (the product's bring-up), then either one
 discriminator sub-step or whole training iterations; every variable and RMSProp slot goes to <out>/rank<r>.npz.
 
-usage: dp_worker.py <rank> <world> <out_dir> <mode>      mode: substep1 | iterations"""
+usage: dp_worker.py <rank> <world> <out_dir> <mode>      mode: substep1 | iterations | mismatch"""
 import os
 import sys
 
@@ -23,6 +23,14 @@ def main():
     rendezvous.init_data_parallel(net, rank, world)
     batch = ea.synthetic_batch(cfg, seed=4321, rank=rank)   # its own shard
     net.upload_batch(**batch)
+    if mode == 'mismatch':      # the ranks disagree on the collective: the stand-in must report it on every rank, not hang
+        try:
+            net.comm_reduce_scalars([1.0] * (2 if rank == 0 else 1))
+        except ea.EdgeGANLibError as e:
+            assert 'invalid usage' in str(e), str(e)
+            np.savez(os.path.join(out, f'rank{rank}.npz'), reported=np.ones(1))
+            return
+        raise SystemExit('mismatched collective was not reported')
     if mode == 'substep1':
         net.substep(1, apply=True)
     else:

@@ -109,6 +109,13 @@ def test_two_rank_iterations_lanes_equal_one_stream_and_replicas_stay_identical(
     assert len(moved) > 100, len(moved)
 
 
+def test_stand_in_reports_a_collective_the_ranks_disagree_on(shim, tmp_path):
+    """What makes the two-rank tests above meaningful as a guard for bench.py / train.py: a collective that the ranks do
+    not enqueue alike (round 2's bench bug: profiled iterations on rank 0 only) is an error on every rank, not a hang."""
+    ranks = _run_ranks(shim, tmp_path, 'mismatch', 'mismatch')
+    assert all('reported' in r for r in ranks)
+
+
 def test_bench_two_ranks_end_to_end(shim, tmp_path):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per process), both ranks on
     device 0: rendezvous, barriers, the profiled iterations on every rank, max-over-ranks, ONE JSON line from rank 0."""
