@@ -100,6 +100,9 @@ struct Ctx {
   // set by a caller right before a conv2d / deconv2d whose ONLY reader is in_act: a forward-only K-split launch then
   // leaves its slabs for the InstanceNorm load pass (consumed, i.e. reset, by that convolution)
   bool feeds_in = false;
+  // inference only (set inside infer()): a residual block's 1x1 shortcut convolution runs on lane 1 beside the block's
+  // two 3x3 convolutions on lane 0 -- the encoder trunk is ONE chain of small launches otherwise
+  bool infer_lanes = false;
   float* scratch = nullptr;  // persistent reduction scratch
   size_t scratch_floats = 0;
 

@@ -336,6 +336,7 @@ T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out) {
   int cin = 64, i = 1;
   for (int n : encoder_filters(cfg)) {
     const std::string b = "E/e_resnet_" + std::to_string(n) + "_" + std::to_string(i++);
+    if (c.infer_lanes) EG_HIP(hipEventRecord(c.ev_fork, c.stream));   // the block's input is complete here
     c.feeds_in = true;   // residual: both 3x3 convolutions are read by their InstanceNorm alone
     T o1 = conv2d(c, E, wref_param(c, P(c, b + "/res1/conv2d/w"), 9, cin, n), P(c, b + "/res1/conv2d/b"), 3, 1,
                   PAD_REFLECT);
@@ -344,8 +345,17 @@ T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out) {
     T o2 = conv2d(c, o1, wref_param(c, P(c, b + "/res2/conv2d/w"), 9, n, n), P(c, b + "/res2/conv2d/b"), 3, 1,
                   PAD_REFLECT);
     o2 = in_act(c, o2, ACT_NONE);
+    if (c.infer_lanes) {
+      use_lane(c, 1);
+      EG_HIP(hipStreamWaitEvent(c.stream, c.ev_fork, 0));
+    }
     T sc = conv2d(c, E, wref_param(c, P(c, b + "/shortcut/conv2d/w"), 1, cin, n), P(c, b + "/shortcut/conv2d/b"),
                   1, 1, PAD_REFLECT);
+    if (c.infer_lanes) {
+      EG_HIP(hipEventRecord(c.lanes[1].done, c.stream));
+      use_lane(c, 0);
+      EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[1].done, 0));
+    }
     E = pool2(c, add(c, sc, o2, true));
     cin = n;
   }
@@ -913,8 +923,16 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
   T images = wrap_tensor(c, const_cast<float*>(d_images), NB, cfg.H, cfg.W, cfg.c_dim);
   T left = slice_w(c, images, 0, cfg.W / 2);
   T mu = nullptr, ls = nullptr;
-  T z0 = encoder_forward(c, left, d_eps2, &mu, &ls);
   const bool two = c.lanes_on && !c.prof_on;
+  static const bool sc_lane = getenv("EG_NO_INFER_SC_LANE") == nullptr;
+  if (two && sc_lane) {   // lane 1 hosts the residual shortcuts of the trunk, then G2's chain (its arena: one reset per call)
+    use_lane(c, 1);
+    c.arena.reset();      // (lane 1's previous work is fully enqueued; stream order protects its memory)
+    use_lane(c, 0);
+    c.infer_lanes = true;
+  }
+  T z0 = encoder_forward(c, left, d_eps2, &mu, &ls);
+  c.infer_lanes = false;
   if (two) {
     warm_transposes(c, G_G2);   // G2's lazily built transposed filters: filled here, on lane 0, before lane 1 forks off and reads them
     EG_HIP(hipEventRecord(c.ev_fork, c.stream));
@@ -922,7 +940,7 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
   for (int run = 0; run < 2; ++run) {
     if (two && run == 1) {
       use_lane(c, 1);
-      c.arena.reset();   // (lane 1's previous work is fully enqueued; stream order protects its memory)
+      if (!sc_lane) c.arena.reset();   // (lane 1's previous work is fully enqueued; stream order protects its memory)
       EG_HIP(hipStreamWaitEvent(c.stream, c.ev_fork, 0));
     }
     T z = run == 0 ? z0 : reparam(c, mu, ls, d_eps2 + 1);
