@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = 93.551 - 2 * 0.3263
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (never the 2:1-sparse figure)
+PMC_SET = 'r02g'                # the profile set profiles/pmc_utilisation_latest.csv was derived from (tools/gpu_round_profile.sh)
 X3_LIMB_PRODUCTS = 6            # limb products issued per fp32 product in f32x3 mode (edgegan_amd/csrc/k_gemm_x3.hip)
 
 
@@ -102,30 +103,43 @@ def _oracle_iteration(cfg_kwargs, batch, threads, substeps=None):
 
 
 def cpu_baseline(cfg_kwargs, batch_all=64, batch_one=2):
-    """the CPU restatement of the identical iteration (`kind: port` -- the reference's TF-1.14 CPU
-    path cannot exist on this box), timed on this host: (a) one full iteration (7 sub-steps) at the bench batch
-    (config-3 shapes) with the BEST thread count of a short sweep at batch 16 -- torch-CPU does not scale to all 128
-    hardware threads on these conv shapes (measured: 16 threads 9.5 images/s, 128 threads 1.1), so "all cores" would
-    understate the CPU; `cores` is the thread count actually used -- and (b) ONE core on a bounded sample (a full
-    iteration at batch `batch_one`).  torch-CPU fp32, NOT the reference's TensorFlow."""
+    """the CPU restatement of the identical iteration (`kind: port`, torch-CPU -- the reference's
+    TF-1.14 CPU path cannot exist on this box), timed on this host's cores:
+      (a) `value`: one full iteration (7 sub-steps) at the bench batch (configs[2] shapes) with the BEST thread count of a
+          short sweep at batch 16 -- torch-CPU does not scale to all hardware threads on these conv shapes, so "all
+          cores" alone would understate the CPU; `cores` is the thread count actually used;
+      (b) `all_cores`: the same iteration at batch 16 on EVERY hardware thread of the box (printed although it is worse);
+      (c) `single_core`: ONE thread, a full iteration at batch `batch_one`;
+      (d) `config0_single_class_b4`: BASELINE configs[0]'s shape (single-class, batch 4: the reference's own CPU-runnable
+          case) at the best thread count.
+    torch-CPU fp32, NOT the reference's TensorFlow."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch
     ncpu = torch.get_num_threads()
+    hw = os.cpu_count() or ncpu
     _oracle_iteration(cfg_kwargs, 2, min(ncpu, 16), ['e_optim'])          # untimed: thread pool / allocator warm-up
-    sweep = {th: round(16 / _oracle_iteration(cfg_kwargs, 16, th), 2) for th in (8, 16, 32, 64) if th <= ncpu} or \
+    sweep = {th: round(16 / _oracle_iteration(cfg_kwargs, 16, th), 2) for th in (8, 16, 32, 64) if th <= hw} or \
         {ncpu: 0.0}
     best = max(sweep, key=sweep.get)
+    dt_allc = _oracle_iteration(cfg_kwargs, 16, hw) if hw not in sweep else 16 / max(sweep[hw], 1e-9)
     dt_all = _oracle_iteration(cfg_kwargs, batch_all, best)
     dt_one = _oracle_iteration(cfg_kwargs, batch_one, 1)
+    dt_c0 = _oracle_iteration(dict(cfg_kwargs, num_classes=0), 4, best)
     torch.set_num_threads(ncpu)
     return {'value': round(batch_all / dt_all, 3), 'unit': 'images/s', 'cores': best, 'kind': 'port',
-            'cpu_model': cpu_model(), 'host_hardware_threads': os.cpu_count(),
+            'kind_detail': 'torch-CPU fp32 restatement (oracle/edgegan_oracle.py), not the reference\'s TensorFlow 1.14',
+            'cpu_model': cpu_model(), 'host_hardware_threads': hw,
             'sample': f'1 full iteration (7 sub-steps) at batch {batch_all} (BASELINE configs[2] shapes), torch-CPU fp32 '
                       f'oracle, {best} threads (best of the sweep), {dt_all:.1f} s',
             'thread_sweep_images_per_s_at_batch_16': sweep,
+            'all_cores': {'value': round(16 / dt_allc, 3), 'unit': 'images/s', 'cores': hw,
+                          'sample': f'1 full iteration at batch 16 on all {hw} hardware threads, {dt_allc:.1f} s'},
             'single_core': {'value': round(batch_one / dt_one, 4), 'unit': 'images/s', 'cores': 1,
-                            'sample': f'1 full iteration at batch {batch_one}, 1 thread, {dt_one:.1f} s'}}
+                            'sample': f'1 full iteration at batch {batch_one}, 1 thread, {dt_one:.1f} s'},
+            'config0_single_class_b4': {'value': round(4 / dt_c0, 3), 'unit': 'images/s', 'cores': best,
+                                        'sample': f'BASELINE configs[0]: single-class 64x128, batch 4, 1 full iteration '
+                                                  f'(6 sub-steps: no classifier), {dt_c0:.1f} s'}}
 
 
 def alt_mode(ea, cfg_kwargs, values, batch, args):
@@ -322,7 +336,8 @@ def main():
                     'algorithmic_tflops': round(alg, 2),
                     'algorithmic_frac_of_fp32_mfma_peak': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                     'traffic': pmc_traffic(dom['name']) if (args.height, args.width, args.batch) == (64, 128, 64) else None,
-                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes FETCH_SIZE x 2 + WRITE_SIZE, profiles/pmc_utilisation_latest.csv)',
+                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes FETCH_SIZE x 2 + WRITE_SIZE)',
+                    'traffic_source': 'committed profile set ' + PMC_SET + ' (profiles/pmc_utilisation_latest.csv), not re-measured in this run',
                     'kernel': dom['name'],
                     'measured': 'HIP events, sub-steps serialised (EG_LANES=0 semantics) so that kernels do not overlap',
                     'launches_per_step': dom['launches'] / args.profile_steps,
@@ -334,6 +349,8 @@ def main():
                     'per_kernel': {k['name']: {'ms_per_step': round(k['ms'] / args.profile_steps, 3),
                                                'tflops': round(k['flops'] / (k['ms'] * 1e-3) / 1e12, 2)} for k in ks}}
     net.comm_barrier()
+    ci = net.comm_info()
+    iters_run = args.warmup + args.steps + (args.profile_steps if args.profile_steps > 0 else 0)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -342,14 +359,17 @@ def main():
             'metric': f'training images/sec (G+D step) at {args.height}x{args.width}, 14-class',
             'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.dtype == 'f32x3' else args.dtype, 'data': 'synthetic',
+            'dtype': args.dtype, 'data': 'synthetic',
             'arithmetic': {'f32x3': 'fp32 storage / accumulation / optimizer; each fp32 operand of a dense contraction is split '
                                     'EXACTLY into three bf16 limbs and the product is formed from 6 exact limb products on '
-                                    'v_mfma_f32_32x32x16_bf16 (dropped terms < 2^-23 of the product); thin layers, filter '
-                                    'gradients, norms, losses: fp32 instructions',
+                                    'v_mfma_f32_32x32x16_bf16 (dropped terms < 2^-23 of the product) -- forward, input-gradient AND '
+                                    'filter-gradient kernels; thin layers (<= 16 channels on either side), N=1 heads, norms, '
+                                    'activations, losses, RMSProp: fp32 instructions',
                            'f32': 'fp32 everywhere; dense contractions on v_mfma_f32_16x16x4_f32 (exact fp32 products)',
                            'bf16': 'operands of dense contractions ROUNDED to bf16, fp32 accumulation / storage'}[args.dtype],
-            'config': {'workload': ((('configs[2]: 14-class 64x128 fp32' if args.dtype in ('f32', 'f32x3') else
+            'config': {'workload': ((({'f32': 'configs[2]: 14-class 64x128 fp32 (exact-fp32 MFMA)',
+                                       'f32x3': 'configs[2]: 14-class 64x128 fp32 (f32x3: fp32 results from exact bf16-limb products)'}[args.dtype]
+                                      if args.dtype in ('f32', 'f32x3') else
                                       'configs[3] arithmetic (bf16 MFMA operands, fp32 accumulate/storage): 14-class 64x128')
                                      if (args.height, args.width) == (64, 128) else
                                      f'configs[4] geometry: 14-class {args.height}x{args.width} {args.dtype}')) +
@@ -357,8 +377,15 @@ def main():
                                    f'(7 RMSProp sub-steps), batch {args.batch} per GPU', 'global_batch': args.batch * world,
                        'per_gpu_batch': args.batch, 'num_classes': args.classes, 'parallelism': f'dp{world}'},
             'algorithmic_tflops_per_gpu': round(gflop_per_image * value / world / 1e3, 2) if gflop_per_image else None,
-            'frac_of_fp32_mfma_peak': round(gflop_per_image * value / world / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)
+            'algorithmic_frac_of_fp32_mfma_peak': round(gflop_per_image * value / world / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)
             if gflop_per_image else None,
+            'algorithmic_frac_note': 'algorithmic fp32 FLOP/s of the whole iteration over the exact-fp32 MFMA peak (157.3 TF); in '
+                                     'f32x3 mode the work executes on the bf16 pipe, so this is a speed-up figure, not a utilisation',
+            'exchange': {'nranks': ci['nranks'], 'rccl_version': ci['rccl_version'], 'rccl_library': ci['rccl_library'],
+                         'allreduce_calls_per_step': round(ci['allreduce_calls'] / iters_run, 2) if world > 1 else 0,
+                         'allreduce_mbytes_per_step': round(ci['allreduce_bytes'] / iters_run / 1e6, 2) if world > 1 else 0.0,
+                         'what': 'one RCCL all-reduce (sum, fp32, in place) of the flat gradient buffer per optimised network '
+                                 'group and sub-step (G1+G2 in one call), on a side stream, averaged inside RMSProp'},
             'losses_finite': bool(finite), 'memory': net.memory_stats(),
             'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
             'roofline': roof,

@@ -40,7 +40,7 @@ static Config to_config(const eg_config* k) {
 #define EG_API_BEGIN try {
 // entry points that enqueue work: always start on lane 0 (the context's own stream; train_step ends there too, and
 // an error in the middle of a concurrent iteration may have left another lane active)
-#define EG_API_BEGIN_CTX(ctxp) try { use_lane((ctxp)->c, 0);
+#define EG_API_BEGIN_CTX(ctxp) try { use_lane((ctxp)->c, 0); (ctxp)->c.infer_lanes = false; (ctxp)->c.feeds_in = false;
 #define EG_API_END(ctxp)                                  \
   }                                                       \
   catch (const eg::Error& e) {                            \
@@ -262,6 +262,7 @@ static void infer_reserve(Ctx& c, int nb) {
   c.inf_in = c.inf_edge = c.inf_image = nullptr;
   c.inf_cls = nullptr;
   c.inf_cap = 0;
+  c.inf_nb = 0;   // nothing is resident any more: a failed allocation below must not leave eg_infer_run runnable
   EG_HIP(hipMalloc(&c.inf_in, in_n * 4));
   EG_HIP(hipMalloc(&c.inf_edge, out_n * 4));
   EG_HIP(hipMalloc(&c.inf_image, out_n * 4));
@@ -329,6 +330,15 @@ int eg_comm_unique_id(eg_ctx* ctx, char* out128) {
 int eg_comm_init(eg_ctx* ctx, const char* id128, int rank, int nranks) {
   EG_API_BEGIN
   comm_init(ctx->c, id128, rank, nranks);
+  EG_API_END(ctx)
+}
+
+int eg_comm_info(eg_ctx* ctx, int* nranks, int* rccl_version, char* libpath, int libpath_cap, long long* allreduce_calls,
+                 long long* allreduce_bytes) {
+  EG_API_BEGIN
+  EG_CHECK(nranks && rccl_version && allreduce_calls && allreduce_bytes, "null argument");
+  *nranks = ctx->c.nranks;
+  comm_info(ctx->c, rccl_version, libpath, libpath_cap, allreduce_calls, allreduce_bytes);
   EG_API_END(ctx)
 }
 

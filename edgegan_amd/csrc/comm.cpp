@@ -74,6 +74,8 @@ void comm_init(Ctx& c, const char* id128, int rank, int nranks) {
 
 void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream) {
   EG_CHECK(c.nccl_comm, "comm_allreduce without comm_init");
+  ++c.comm_calls;
+  c.comm_bytes += (long long)n * 4;
   // ncclFloat32 = 7, ncclSum = 0
   check(c, sym<fn_allreduce>(c, "ncclAllReduce")(buf, buf, n, 7, 0, c.nccl_comm, stream), "ncclAllReduce");
 }
@@ -103,6 +105,23 @@ void comm_reduce_scalars(Ctx& c, float* inout, int n, int op) {
 }
 
 void comm_wait_all(Ctx& c) { comm_wait_groups(c, ~0u); }
+
+// What the exchange of this context looks like from outside (bench.py prints it so that a scaling line is
+// self-describing): RCCL version code (ncclGetVersion), the file the bound library was mapped from, and the gradient
+// all-reduces / bytes enqueued so far.
+void comm_info(Ctx& c, int* version, char* libpath, int cap, long long* calls, long long* bytes) {
+  *version = 0;
+  if (libpath && cap > 0) libpath[0] = 0;
+  if (c.nccl_lib) {
+    typedef int (*fn_ver)(int*);
+    if (void* p = dlsym(c.nccl_lib, "ncclGetVersion")) (void)reinterpret_cast<fn_ver>(p)(version);
+    Dl_info di;
+    void* any = dlsym(c.nccl_lib, "ncclAllReduce");
+    if (any && dladdr(any, &di) && di.dli_fname && libpath && cap > 0) snprintf(libpath, cap, "%s", di.dli_fname);
+  }
+  *calls = c.comm_calls;
+  *bytes = c.comm_bytes;
+}
 
 void comm_destroy(Ctx& c) {
   if (c.comm_stream) {

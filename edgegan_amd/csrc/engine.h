@@ -29,6 +29,7 @@ struct NetGroup {
   std::vector<Param*> params;
   float *w = nullptr, *g = nullptr, *ms = nullptr, *mom = nullptr;
   size_t n_live = 0, n_train = 0, n_total = 0;
+  size_t n_train_hint = 0;   // G2 only: its trainable extent, known before G1's gradient buffer (which hosts G2's) is allocated
 };
 
 struct SNWeight;
@@ -87,7 +88,6 @@ struct Ctx {
   std::string last_error;
 
   // per-step state
-  std::map<const float*, unsigned short*> bf_copies;   // bf16 copies of activations made this sub-step (ops.cpp: run_conv)
   std::vector<RedDesc> deferred;   // queued second-stage reductions (ops.cpp: defer_reduction / flush_deferred)
   bool defer_on = true;            // EG_DEFER_REDUCE=0: every reduction launches on the spot
   std::deque<Tensor> tensors;
@@ -164,6 +164,7 @@ struct Ctx {
   hipEvent_t ev_ready[G_COUNT] = {}, ev_applied[G_COUNT] = {};
   bool pending[G_COUNT] = {};
   float* comm_scal = nullptr;   // device staging of comm_reduce_scalars
+  long long comm_calls = 0, comm_bytes = 0;   // gradient all-reduces enqueued / their payload (comm_info)
 
   ~Ctx();
 };
@@ -279,6 +280,7 @@ void comm_reduce_scalars(Ctx& c, float* inout, int n, int op);
 void use_lane(Ctx& c, int lane);                // model.cpp
 void comm_wait_groups(Ctx& c, unsigned mask);   // main stream waits for the pending updates of these groups
 void comm_wait_all(Ctx& c);
+void comm_info(Ctx& c, int* version, char* libpath, int cap, long long* calls, long long* bytes);
 void comm_destroy(Ctx& c);
 
 }  // namespace eg

@@ -466,7 +466,7 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.ws, a.y, a.bias,
                        (unsigned)total4, a.y_ps / 4, a.N / 4, a.ksplit, a.accumulate);
   }
-  static const bool trace = getenv("EG_TRACE_GEMM") != nullptr;   // shape log for offline tile/split tuning
+  static const bool trace = dbg_env("EG_TRACE_GEMM") != nullptr;   // shape log for offline tile/split tuning
   if (trace)
     fprintf(stderr, "EG_GEMM conv maxM=%d N=%d C=%d nphase=%d taps0=%d ksplit=%d kernel=%s gflop=%.3f\n", maxM, a.N, a.C,
             a.nphase, a.ph[0].Ty * a.ph[0].Tx, a.ksplit, nm, flops * 1e-9);
@@ -978,7 +978,7 @@ static int pick_balanced_splits(long long tiles, long long target_blocks, long l
 }
 
 static bool wgrad_x3(const WgradArgs& a) {   // (limbs == 1: the same kernel with one plane = bf16-rounded operands)
-  static const bool bf16_pp = !(getenv("EG_BF16_PP") && atoi(getenv("EG_BF16_PP")) == 0);
+  static const bool bf16_pp = !(dbg_env("EG_BF16_PP") && atoi(dbg_env("EG_BF16_PP")) == 0);
   // C == 64: two taps per 128-row tile (k_gemm_x3.hip), worth it when there are at least two taps
   const bool c_ok = a.C >= 128 || (a.C == 64 && a.KH * a.KW >= 2);
   return (a.limbs == 3 || (a.limbs == 1 && bf16_pp)) && c_ok && a.N >= 128 && a.C % 4 == 0 && a.N % 4 == 0 && a.x_ps % 4 == 0 && a.dy_ps % 4 == 0 &&
@@ -998,8 +998,8 @@ int wgrad_pick_splits(const WgradArgs& a) {
   if (wgrad_flatm(a)) {
     const long long tiles = (long long)((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64);
     // latency-bound (one gather round trip per 32-pixel step, prefetch distance 1): eight resident blocks per CU hide it
-    static const int fl_chunk = getenv("EG_FLATM_CHUNK") ? atoi(getenv("EG_FLATM_CHUNK")) : 128;
-    static const int fl_blocks = getenv("EG_FLATM_BLOCKS") ? atoi(getenv("EG_FLATM_BLOCKS")) : 2048;
+    static const int fl_chunk = dbg_env("EG_FLATM_CHUNK") ? atoi(dbg_env("EG_FLATM_CHUNK")) : 128;
+    static const int fl_blocks = dbg_env("EG_FLATM_BLOCKS") ? atoi(dbg_env("EG_FLATM_BLOCKS")) : 2048;
     return pick_balanced_splits(tiles, fl_blocks, std::min(2048LL, (M + fl_chunk - 1) / fl_chunk));
   }
   const int bm = wgrad_big(a) ? 128 : 64;
@@ -1057,7 +1057,7 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, a.ws, a.dw,
                          a.KH * a.KW, a.C, a.N, a.w_ts, a.ldw, a.nsplit, a.accumulate);
   }
-  static const bool trace = getenv("EG_TRACE_GEMM") != nullptr;
+  static const bool trace = dbg_env("EG_TRACE_GEMM") != nullptr;
   if (trace)
     fprintf(stderr, "EG_GEMM wgrad M=%d N=%d C=%d taps=%d nsplit=%d kernel=%s gflop=%.3f\n", a.NB * a.OH * a.OW, a.N, a.C,
             a.KH * a.KW, a.nsplit, nm, 2e-9 * a.NB * a.OH * a.OW * (double)a.N * a.C * a.KH * a.KW);

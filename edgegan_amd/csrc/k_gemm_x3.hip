@@ -674,7 +674,7 @@ bool conv_x3_eligible(const ConvArgs& a) {
 
 static int x3_nprod() {
   static const int n = [] {
-    const char* e = getenv("EG_X3_PRODUCTS");
+    const char* e = dbg_env("EG_X3_PRODUCTS");
     const int v = e ? atoi(e) : 6;
     return (v == 8 || v == 9) ? v : 6;
   }();
@@ -694,9 +694,8 @@ static void conv_x3_launch(const ConvArgs& a, int maxM, hipStream_t s) {
 
 const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s) {
   const int np = x3_nprod();
-  static const int pipe = getenv("EG_X3_PIPE") ? atoi(getenv("EG_X3_PIPE")) : 2;
+  static const int pipe = dbg_env("EG_X3_PIPE") ? atoi(dbg_env("EG_X3_PIPE")) : 2;
   if ((a.limbs == 1 || (big_tile && np == 6)) && conv_x3h_eligible(a)) return launch_conv_gemm_x3h(a, s);
-  if (a.limbs == 1 && conv_dma_eligible(a)) return launch_conv_gemm_dma(a, maxM, s);
   if (a.limbs == 1) {
     const int zs = a.ksplit > 1 ? a.ksplit : 1;
     dim3 grid((maxM + 255) / 256, (a.N + 127) / 128, a.nphase * zs);
@@ -712,7 +711,7 @@ const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipS
   if (big_tile && pipe == 2 && np == 6 && a.x_bytes && a.wbf_bytes) {
     const int zs = a.ksplit > 1 ? a.ksplit : 1;
     dim3 grid((maxM + 255) / 256, (a.N + 127) / 128, a.nphase * zs);
-    static const bool timing = getenv("EG_X3_TIMING") != nullptr;
+    static const bool timing = dbg_env("EG_X3_TIMING") != nullptr;
     if (a.reflect) {
       if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3pp_kernel<true, 6, true>), grid, dim3(512), 0, s, a);
       else hipLaunchKernelGGL((conv_gemm_x3pp_kernel<false, 6, true>), grid, dim3(512), 0, s, a);

@@ -443,7 +443,7 @@ static bool x3h_geometry(const ConvArgs& a, HaloGeom* g) {
   if ((TH & (TH - 1)) != 0 || OH % TH != 0 || OW % TW != 0) return false;
   const int TI = 256 / (TW * TH);
   if (TI * TW * TH != 256 || a.NB % TI != 0) return false;
-  static const bool dense = getenv("EG_X3H_DENSE") != nullptr;   // A/B switch: dense halo rows / row swizzle everywhere
+  static const bool dense = dbg_env("EG_X3H_DENSE") != nullptr;   // A/B switch: dense halo rows / row swizzle everywhere
   g->pitch = TW == 16 && !dense ? 20 : 0;
   for (int p = 0; p < a.nphase; ++p)
     if (TI * (TH + a.ph[p].Ty - 1) * 20 > HRMAX) g->pitch = 0;
@@ -462,7 +462,7 @@ static bool x3h_geometry(const ConvArgs& a, HaloGeom* g) {
 }
 
 bool conv_x3h_eligible(const ConvArgs& a) {
-  static const bool off = getenv("EG_NO_HALO") != nullptr;
+  static const bool off = dbg_env("EG_NO_HALO") != nullptr;
   if (off || !a.wgt_bf || !(a.limbs == 3 || a.limbs == 1) || a.shuf) return false;
   if (a.S != 1 || !(a.D == 1 || a.D == -1) || a.C % 32 != 0 || a.N < 64 || a.N % 4 != 0) return false;
   if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || !a.x_bytes || !a.wbf_bytes || a.wbf_plane % 8 != 0) return false;

@@ -319,7 +319,7 @@ static bool scatter_geometry(const ConvArgs& a, int* S, int* R, size_t* lds) {
 }
 
 bool conv_scatter_eligible(const ConvArgs& a) {
-  static const bool off = getenv("EG_NO_SCATTER") != nullptr;
+  static const bool off = dbg_env("EG_NO_SCATTER") != nullptr;
   if (off || !a.wgt || a.nphase != 1 || !(a.N == 3 || a.N == 4 || a.N == 8 || a.N == 12) || a.C % 32 != 0 || a.C < 32) return false;
   const ConvPhase& p = a.ph[0];
   if (p.Ty != 3 || p.Tx != 3 || a.kst != 1 || a.S != 1 || a.reflect) return false;
@@ -630,7 +630,7 @@ static bool smallc_geometry(const ConvArgs& a, int* K, int* K16, int* nt, int* t
 }
 
 bool conv_smallc_eligible(const ConvArgs& a) {
-  static const bool off = getenv("EG_NO_SMALLC") != nullptr;
+  static const bool off = dbg_env("EG_NO_SMALLC") != nullptr;
   if (off || !a.wgt || a.nphase != 1 || a.C > 8 || a.x_ps != a.C || a.reflect || a.shuf || a.ksplit > 1) return false;
   const ConvPhase& p = a.ph[0];
   if (!(a.D == 1 || a.D == -1) || a.S < 1 || a.S > 2) return false;

@@ -3,8 +3,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 
 namespace eg {
+
+// A/B and timing switches (EG_NO_*, EG_X3_*, EG_TRACE_GEMM, ...) exist only in builds made with -DEG_EXPERIMENTS
+// (make EXPERIMENTS=1 -> libedgegan_hip_exp.so, selected with EG_LIB_PATH by tools/gpu_ab*.py); the shipped library
+// ignores them.  Runtime options of the product proper -- EG_LANES, EG_DEFER_REDUCE, EG_RCCL_LIB -- read getenv directly.
+inline const char* dbg_env(const char* name) {
+#ifdef EG_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Tap-gather implicit GEMM (conv forward, conv input-gradient, transposed conv), NHWC fp32:
@@ -122,10 +136,6 @@ const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hi
 const char* launch_wgrad_bf16(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s);
 void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);
 void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int R, int Cc, hipStream_t s);
-
-// DMA-fed bf16 kernel (k_gemm_dma.hip): activation read from its bf16 copy a.x_bf, filter from the one-plane K-step-major image
-bool conv_dma_eligible(const ConvArgs& a);
-const char* launch_conv_gemm_dma(const ConvArgs& a, int maxM, hipStream_t s);
 
 // halo-staged limb / bf16 kernel for stride-1 layers (k_gemm_x3h.hip)
 bool conv_x3h_eligible(const ConvArgs& a);

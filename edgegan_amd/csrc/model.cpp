@@ -155,6 +155,12 @@ void build_context(Ctx& c) {
   }
   // flat layout per group: [live trainables | dead trainables | non-trainables], 64-float aligned slots
   auto align = [](size_t n) { return (n + 63) & ~(size_t)63; };
+  {  // G2's trainable extent, needed when G1's gradient buffer is allocated (same layout rule as the loop below)
+    size_t n = 0;
+    for (Param* p : c.groups[G_G2].params)
+      if (p->trainable) n += align(p->numel);
+    c.groups[G_G2].n_train_hint = n;
+  }
   for (int g = 0; g < G_COUNT; ++g) {
     NetGroup& ng = c.groups[g];
     if (ng.params.empty()) continue;
@@ -171,10 +177,19 @@ void build_context(Ctx& c) {
       if (pass == 1) ng.n_train = off;
     }
     ng.n_total = off;
+    EG_CHECK(g != G_G2 || ng.n_train == ng.n_train_hint, "G2 layout");
     EG_HIP(hipMalloc(&ng.w, ng.n_total * sizeof(float)));
     EG_HIP(hipMemsetAsync(ng.w, 0, ng.n_total * sizeof(float), c.stream));
     if (ng.n_train) {
-      EG_HIP(hipMalloc(&ng.g, ng.n_train * sizeof(float)));
+      // G1's and G2's gradients live in ONE allocation (G2's right behind G1's): sub-steps 5 / 7 optimise both, and
+      // under data parallelism they travel in one all-reduce (apply_generators)
+      if (g == G_G1) {
+        EG_HIP(hipMalloc(&ng.g, (ng.n_train + c.groups[G_G2].n_train_hint) * sizeof(float)));
+      } else if (g == G_G2) {
+        ng.g = c.groups[G_G1].g + c.groups[G_G1].n_train;
+      } else {
+        EG_HIP(hipMalloc(&ng.g, ng.n_train * sizeof(float)));
+      }
       EG_HIP(hipMalloc(&ng.ms, ng.n_train * sizeof(float)));
       EG_HIP(hipMalloc(&ng.mom, ng.n_train * sizeof(float)));
       EG_HIP(hipMemsetAsync(ng.g, 0, ng.n_train * sizeof(float), c.stream));
@@ -470,6 +485,33 @@ static void apply_group(Ctx& c, int group) {
   launch_rmsprop(g.w, g.g, g.ms, g.mom, g.n_live, c.cfg.lr, 1.f, c.stream);
 }
 
+// Sub-steps 5 / 7 optimise G1 and G2 together (quirk N9): their gradient buffers are adjacent, so under data parallelism
+// both travel in ONE all-reduce (2 x 5.25 M floats); RMSProp stays one launch per group (the weight buffers also hold
+// the BatchNorm moving statistics between the two live ranges).
+static void apply_generators(Ctx& c) {
+  if (!c.nccl_comm) {
+    apply_group(c, G_G1);
+    apply_group(c, G_G2);
+    return;
+  }
+  NetGroup &g1 = c.groups[G_G1], &g2 = c.groups[G_G2];
+  c.gen_cache_valid[0] = c.gen_cache_valid[1] = false;
+  for (NetGroup* g : {&g1, &g2})
+    for (Param* p : g->params) {
+      p->invalidate_derived();
+      if (p->trainable && !p->dead) EG_CHECK(p->g_set, "variable %s received no gradient", p->name.c_str());
+    }
+  EG_CHECK(g2.g == g1.g + g1.n_train, "generator gradient buffers are not adjacent");
+  EG_HIP(hipEventRecord(c.ev_ready[G_G1], c.stream));
+  EG_HIP(hipStreamWaitEvent(c.comm_stream, c.ev_ready[G_G1], 0));
+  comm_allreduce(c, g1.g, g1.n_train + g2.n_live, c.comm_stream);
+  launch_rmsprop(g1.w, g1.g, g1.ms, g1.mom, g1.n_live, c.cfg.lr, 1.f / c.nranks, c.comm_stream);
+  launch_rmsprop(g2.w, g2.g, g2.ms, g2.mom, g2.n_live, c.cfg.lr, 1.f / c.nranks, c.comm_stream);
+  EG_HIP(hipEventRecord(c.ev_applied[G_G1], c.comm_stream));
+  EG_HIP(hipEventRecord(c.ev_applied[G_G2], c.comm_stream));
+  c.pending[G_G1] = c.pending[G_G2] = true;
+}
+
 // WGAN-GP discriminator step (edgegan.py:278-309, functional.py:26-33, edgegan.py:32-42).
 // The penalty's second-order term is evaluated as reverse-over-forward: with g = d/dx sum_b[sigmoid(D)+D]
 // (quirk N10) and v = dL_gp/dg held constant, dL_gp/dtheta = d/dtheta <g, v> = d/dtheta JVP_v[sigmoid(D)+D],
@@ -672,6 +714,12 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
           if (lane != 0) EG_HIP(hipEventRecord(c.lanes[lane].done, c.stream));
         };
         if (m4 > m3) sweep(3, m3, m4);
+        // resize() is the identity when H == W/2 == dis_size: r_image IS image, so the image discriminator's input
+        // gradient accumulates into the buffer the classifier's sweep (lane 3) writes first -- order lane 1 behind it
+        if (m4 > m3 && r_image == image) {
+          use_lane(c, 1);
+          EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[3].done, 0));
+        }
         sweep(1, m2, m3);
         sweep(2, m1, m2);
         sweep(0, m0, m1);
@@ -681,8 +729,7 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       }
       if (apply) {
         before_apply();
-        apply_group(c, G_G1);
-        apply_group(c, G_G2);
+        apply_generators(c);
       }
     } break;
     case 6: {  // e_optim: L1 latent reconstruction through G1 (edgegan.py:275,337-342)
@@ -754,8 +801,7 @@ void train_step(Ctx& c) {
   {
     // the classifier sub-step is the longest of the four and the one whose gradient exchange (69 MB under data
     // parallelism) sub-step 5 waits for: enqueue it first so its all-reduce runs under the discriminator sub-steps
-    static const bool exp4 = getenv("EG_EXP_OVERLAP4") != nullptr;   // TIMING EXPERIMENT ONLY (racy): sub-step 4 under 5-7
-    if (cls && !exp4) {
+    if (cls) {
       use_lane(c, 3);
       run_substep(c, 4, true);
       use_lane(c, 0);
@@ -783,13 +829,6 @@ void train_step(Ctx& c) {
   for (int i = 1; i < 4; ++i) EG_HIP(hipEventRecord(c.lanes[i].done, c.lanes[i].stream));
   }
   // ---- phase B: generators against all four ----------------------------------------------------------------
-  if (conc_a && cls && getenv("EG_EXP_OVERLAP4")) {
-    EG_HIP(hipEventRecord(c.ev_fork, c.lanes[0].stream));
-    EG_HIP(hipStreamWaitEvent(c.lanes[3].stream, c.ev_fork, 0));
-    use_lane(c, 3);
-    run_substep(c, 4, true);
-    use_lane(c, 0);
-  }
   if (conc_a) {
     hipEvent_t ev[G_COUNT] = {};
     ev[G_DP2] = c.lanes[1].done;
@@ -831,10 +870,6 @@ void train_step(Ctx& c) {
     run_substep(c, 7, true, &o7);
   }
   join(2);
-  if (getenv("EG_EXP_OVERLAP4")) {
-    EG_HIP(hipEventRecord(c.lanes[3].done, c.lanes[3].stream));
-    EG_HIP(hipStreamWaitEvent(c.lanes[0].stream, c.lanes[3].done, 0));
-  }
   ++c.step_count;
 }
 
@@ -924,7 +959,7 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
   T left = slice_w(c, images, 0, cfg.W / 2);
   T mu = nullptr, ls = nullptr;
   const bool two = c.lanes_on && !c.prof_on;
-  static const bool sc_lane = getenv("EG_NO_INFER_SC_LANE") == nullptr;
+  static const bool sc_lane = dbg_env("EG_NO_INFER_SC_LANE") == nullptr;
   if (two && sc_lane) {   // lane 1 hosts the residual shortcuts of the trunk, then G2's chain (its arena: one reset per call)
     use_lane(c, 1);
     c.arena.reset();      // (lane 1's previous work is fully enqueued; stream order protects its memory)

@@ -101,7 +101,6 @@ void reset_grads(Ctx& c) {
 }
 void reset_step(Ctx& c) {
   flush_deferred(c);   // (empty unless a caller skipped its backward pass)
-  c.bf_copies.clear();
   c.arena.reset();
   c.tape.clear();
   c.tensors.clear();
@@ -288,7 +287,7 @@ static unsigned short* limb_planes(Ctx& c, WRef* w, bool transposed, int nplanes
     if (!lc->valid) {
       // every stale cache of the domain goes into the same launch: the domain's weights changed together (one RMSProp
       // launch per group / one sn_prepare) and are final until the next update
-      static const bool batch_on = getenv("EG_NO_SPLIT_BATCH") == nullptr;
+      static const bool batch_on = dbg_env("EG_NO_SPLIT_BATCH") == nullptr;
       SplitBatch b;
       b.count = 0;
       b.start[0] = 0;
@@ -353,7 +352,7 @@ static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
   if (!c.cfg.bf16 || a.C % 32 != 0 || a.N <= 16 || a.N % 4 != 0) return;
   // >= 128 output channels: the ping-pong kernel in its one-plane form (same arithmetic: both operands rounded to
   // bf16, fp32 accumulation), filter as ONE K-step-major plane; narrower layers keep the 64x64 bf16 kernel
-  static const bool bf16_pp = !(getenv("EG_BF16_PP") && atoi(getenv("EG_BF16_PP")) == 0);
+  static const bool bf16_pp = !(dbg_env("EG_BF16_PP") && atoi(dbg_env("EG_BF16_PP")) == 0);
   const size_t xbytes = (size_t)a.NB * a.IH * a.IW * a.x_ps * sizeof(float);
   if (bf16_pp && a.N >= 128 && xbytes < (1ull << 31) && a.x_ps % 4 == 0 && a.y_ps % 4 == 0) {
     const size_t n = (size_t)w->T * w->R * w->Cc;
@@ -390,7 +389,7 @@ static void run_conv(Ctx& c, ConvArgs& a) {
   // ping-pong kernel's 256-row blocks) still fit the halo-staged kernel (k_gemm_x3h.hip) when its 256-pixel tiles x K
   // splits over the channel chunks give every CU a block: 168-186 vs 111-139 TFLOP/s on the discriminators' conv3 / conv4
   // input gradients and the encoder's residual convolutions.
-  static const bool halo_small = getenv("EG_NO_HALO_SMALL") == nullptr;
+  static const bool halo_small = dbg_env("EG_NO_HALO_SMALL") == nullptr;
   if (halo_small && a.limbs == 3 && a.x3_tile == 2 && a.N >= 64 && a.S == 1) {
     const ConvArgs keep = a;
     const int bn = a.N >= 128 ? 128 : 64;
@@ -402,33 +401,8 @@ static void run_conv(Ctx& c, ConvArgs& a) {
     if (blocks * ks < 128 || !conv_x3h_eligible(a)) a = keep;
   }
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
-  // bf16 mode, one-plane filter: the DMA kernel reads the activation from a bf16 copy (made once per tensor and sub-step:
-  // a forward activation is read again by nothing that changes it, a gradient is final when its producer's backward runs)
-  // (opt-in, EG_BF16_DMA=1: with fp32 activation storage the conversion passes cost what the kernel gains)
-  static const bool dma_on = getenv("EG_BF16_DMA") != nullptr && atoi(getenv("EG_BF16_DMA")) != 0;
-  if (dma_on && a.limbs == 1 && a.wgt_bf && !a.x_bf && a.x_ps == a.C && a.C % 32 == 0 && a.N >= 128 && !a.reflect && a.x_bytes) {
-    // a forward activation is written once per sub-step: its copy is kept for the other convolutions that read it;
-    // gradient buffers are rewritten by later backward passes of the same sub-step (gradient penalty): converted per use
-    const size_t n = (size_t)a.NB * a.IH * a.IW * a.x_ps;
-    auto it = a.x_is_activation ? c.bf_copies.find(a.x) : c.bf_copies.end();
-    if (it == c.bf_copies.end()) {
-      unsigned short* xb = reinterpret_cast<unsigned short*>(c.arena.allocf((n + 1) / 2));
-      launch_cvt_bf16(a.x, xb, n, c.stream);
-      a.x_bf = xb;
-      if (a.x_is_activation) c.bf_copies.emplace(a.x, xb);
-    } else {
-      a.x_bf = it->second;
-    }
-  }
-  static const bool shadow_exp = getenv("EG_BF16_SHADOW_EXPERIMENT") != nullptr;
-  if (shadow_exp && a.wgt_bf && !a.x_bf && a.x_ps == a.C && a.C % 32 == 0 && a.N > 16) {
-    const size_t n = (size_t)a.NB * a.IH * a.IW * a.x_ps;
-    unsigned short* xb = reinterpret_cast<unsigned short*>(c.arena.allocf((n + 1) / 2));
-    launch_cvt_bf16(a.x, xb, n, c.stream);
-    a.x_bf = xb;
-  }
   const char* nm;
-  static const bool x3_timing = getenv("EG_X3_TIMING") != nullptr;   // experiment: per-phase s_memtime stamps of block 0
+  static const bool x3_timing = dbg_env("EG_X3_TIMING") != nullptr;   // experiment: per-phase s_memtime stamps of block 0
   if (x3_timing && a.limbs == 3 && a.ksplit <= 1) {
     a.ws = c.arena.allocf(512);
     EG_HIP(hipMemsetAsync(a.ws, 0, 2048, c.stream));
@@ -666,7 +640,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   // backward turns dL/d(out) into dL/d(pre) in place from the OUTPUT's sign, like act()): d_conv_0, the encoder stem
   bool fused = false;
   if (fused_act == ACT_RELU || fused_act == ACT_LRELU) {
-    static const bool fuse_on = getenv("EG_NO_FUSED_ACT") == nullptr;
+    static const bool fuse_on = dbg_env("EG_NO_FUSED_ACT") == nullptr;
     a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
     fused = fuse_on && !accumulate_into && !conv_scatter_eligible(a) && conv_smallc_eligible(a);
     if (fused) a.act = fused_act;
@@ -675,7 +649,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
   // forward-only convolution read by an InstanceNorm alone (Ctx::feeds_in): a K-split launch keeps its slabs, the
   // norm's load pass sums them (bias + slabs in conv_split_reduce's order: same bits, one launch and one round trip less)
-  static const bool slab_fusion = getenv("EG_NO_SLAB_IN") == nullptr;
+  static const bool slab_fusion = dbg_env("EG_NO_SLAB_IN") == nullptr;
   const bool slabs_ok = c.feeds_in && slab_fusion && !need && !accumulate_into && !fused_act && N % 32 == 0 && OH * OW <= 1024;
   c.feeds_in = false;
   a.keep_slabs = slabs_ok ? 1 : 0;
@@ -752,7 +726,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
   attach_bf16(c, a, w, false);   // filter [25][Cout][Cin]: rows = Cout, contracted = Cin as stored
   if (c.prof_on) c.cur_label = w->name + " fwd";
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
-  static const bool slab_fusion = getenv("EG_NO_SLAB_IN") == nullptr;
+  static const bool slab_fusion = dbg_env("EG_NO_SLAB_IN") == nullptr;
   const bool slabs_ok = c.feeds_in && slab_fusion && !need && !merged && cout % 32 == 0 && OH * OW <= 1024;   // see conv2d
   c.feeds_in = false;
   a.keep_slabs = slabs_ok ? 1 : 0;
@@ -1293,6 +1267,7 @@ Ctx::~Ctx() {
   (void)hipFree(inf_image);
   (void)hipFree(inf_eps);
   (void)hipFree(inf_cls);
+  groups[G_G2].g = nullptr;   // lives inside G1's allocation (model.cpp: build_context)
   for (auto& g : groups) {
     (void)hipFree(g.w);
     (void)hipFree(g.g);

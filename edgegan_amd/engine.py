@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -205,13 +206,33 @@ class EdgeGAN:
         return edge, image
 
     # -- data parallel ----------------------------------------------------------------------------
+    @staticmethod
+    def _locate_rccl():
+        """The library binds RCCL with dlopen("librccl.so.1") (csrc/comm.cpp).  Where the loader's search path has none
+        -- a host without /opt/rocm/lib on it -- point EG_RCCL_LIB at the copy PyTorch ships, found WITHOUT importing
+        torch (importing it would map a second HIP runtime into a process that does not otherwise need one)."""
+        if os.environ.get('EG_RCCL_LIB'):
+            return
+        import ctypes.util
+        import importlib.util
+        if ctypes.util.find_library('rccl') or any(os.path.exists(os.path.join(d, 'librccl.so.1')) for d in
+                                                   ['/opt/rocm/lib'] + os.environ.get('LD_LIBRARY_PATH', '').split(':') if d):
+            return
+        spec = importlib.util.find_spec('torch')
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'librccl.so')
+            if os.path.exists(cand):
+                os.environ['EG_RCCL_LIB'] = cand
+
     def comm_unique_id(self) -> bytes:
+        self._locate_rccl()
         buf = C.create_string_buffer(128)
         self._check(self._lib.eg_comm_unique_id(self._ctx, buf))
         return buf.raw
 
     def comm_init(self, unique_id: bytes, rank: int, nranks: int):
         assert len(unique_id) == 128
+        self._locate_rccl()
         self._check(self._lib.eg_comm_init(self._ctx, unique_id, rank, nranks))
         self.rank, self.nranks = rank, nranks
         self._rng_alpha = np.random.RandomState(6666 + 7919 * rank)
@@ -221,6 +242,16 @@ class EdgeGAN:
         a = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
         self._check(self._lib.eg_comm_reduce_scalars(self._ctx, fptr(a), a.size, {'sum': 0, 'max': 2, 'min': 3}[op]))
         return a
+
+    def comm_info(self) -> dict:
+        """Ranks, RCCL version / library path and the gradient all-reduces enqueued so far (count, bytes)."""
+        nr, ver, calls, nbytes = C.c_int(), C.c_int(), C.c_longlong(), C.c_longlong()
+        path = C.create_string_buffer(1024)
+        self._check(self._lib.eg_comm_info(self._ctx, C.byref(nr), C.byref(ver), path, len(path), C.byref(calls), C.byref(nbytes)))
+        v = ver.value
+        vs = None if v == 0 else (f'{v // 10000}.{v % 10000 // 100}.{v % 100}' if v >= 10000 else f'{v // 1000}.{v % 1000 // 100}.{v % 100}')
+        return {'nranks': nr.value, 'rccl_version': vs, 'rccl_library': path.value.decode() or None,
+                'allreduce_calls': calls.value, 'allreduce_bytes': nbytes.value}
 
     def comm_barrier(self):
         if self.nranks > 1:

@@ -134,6 +134,11 @@ int eg_comm_init(eg_ctx* ctx, const char* id128, int rank, int nranks);
 /* all-reduce of n <= 64 host floats over the ranks (op: 0 sum, 2 max, 3 min); returns when every rank has arrived,
  * i.e. it is also the host barrier of the data-parallel loop -- the host needs no other collective library */
 int eg_comm_reduce_scalars(eg_ctx* ctx, float* inout, int n, int op);
+/* introspection of the exchange (no reference counterpart): ranks, RCCL version code (ncclGetVersion, 0 before
+ * eg_comm_unique_id / eg_comm_init), the path the bound librccl was mapped from, and the gradient all-reduces enqueued so
+ * far with their payload in bytes -- bench.py prints them so that a multi-GPU line is self-describing */
+int eg_comm_info(eg_ctx* ctx, int* nranks, int* rccl_version, char* libpath, int libpath_cap, long long* allreduce_calls,
+                 long long* allreduce_bytes);
 
 /* ---- measurement -------------------------------------------------------------------------------
  * Between begin/end every GEMM-shaped launch is bracketed by HIP events on the engine's stream;

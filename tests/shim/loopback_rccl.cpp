@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE -- not part of the product.  A loop-back stand-in for the five RCCL entry points
 // edgegan_amd/csrc/comm.cpp binds by dlopen (ncclGetUniqueId, ncclCommInitRank, ncclAllReduce,
-// ncclCommDestroy, ncclGetErrorString), so that the engine's multi-rank path (apply_group: event-ordered
+// ncclCommDestroy, ncclGetErrorString, ncclGetVersion), so that the engine's multi-rank path (apply_group: event-ordered
 // all-reduce + RMSProp on the side stream, comm_wait_groups, comm_reduce_scalars, bench.py's barriers) can be
 // run with SEVERAL RANKS ON ONE GPU: the real RCCL refuses two ranks on one device (ncclInvalidUsage), and
 // the boxes the gpu tests run on have one.  Selected with EG_RCCL_LIB=<this .so> (comm.cpp: load_lib).
@@ -160,6 +160,11 @@ int ncclCommDestroy(void* comm) {
   if (c->rank == 0) unlink(c->path);   // the mapping lives until the last rank unmaps it
   munmap(c->h, c->bytes);
   delete c;
+  return 0;
+}
+
+int ncclGetVersion(int* v) {   // (comm_info: reported in bench.py's line; 0.0.1 marks the stand-in)
+  *v = 1;
   return 0;
 }
 

@@ -105,15 +105,17 @@ def test_bf16_train_step_is_deterministic_and_finite():
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
 
 
-@pytest.mark.parametrize('shape', [(64, 64, 128), (4, 256, 512)], ids=['configs3_b64_64x128', 'configs4_b4_256x512'])
+@pytest.mark.parametrize('shape', [(64, 64, 128), (16, 256, 512)], ids=['configs3_b64_64x128', 'configs4_b16_256x512'])
 def test_bf16_full_size_gradients_track_fp32(shape):
-    """BASELINE's full sizes (configs[3]: batch 64 at 64x128; configs[4]'s 256x512 geometry at batch 4), 14 classes:
-    every sub-step's gradients from the bf16 engine against the fp32 engine on the same weights and batch.  The
-    batch-2 tests above never reach the production shapes (128x128 tiles, tens of K steps per weight-gradient block,
-    84-way split reductions); a kernel bug there shows up as O(1) error, bf16 rounding as a few percent (the encoder
+    """BASELINE's full sizes AS WRITTEN (configs[3]: batch 64 per GPU at 64x128; configs[4]: batch 16 per GPU at 256x512),
+    14 classes, bf16: every sub-step's gradients from the bf16 engine against the fp32 engine (f32x3 arithmetic: fp32
+    results, tests/test_x3_gpu.py) on the same weights and batch; the bf16 sub-step is run twice and must reproduce itself
+    bit for bit; a whole bf16 training iteration on top must leave finite losses.  The batch-2 tests above never reach the
+    production shapes (256-pixel tiles, tens of K steps per weight-gradient block, 84-way split reductions, 2^31-byte
+    activation extents at 256x512); a kernel bug there shows up as O(1) error, bf16 rounding as a few percent (the encoder
     sub-step ~0.3, see the module docstring)."""
     B, H, W = shape
-    cfg32 = ea.Config(batch_size=B, height=H, width=W)
+    cfg32 = ea.Config(batch_size=B, height=H, width=W, compute_dtype='f32x3')
     cfg16 = ea.Config(batch_size=B, height=H, width=W, compute_dtype='bf16')
     values = ea.init_variables(cfg32, 0)
     batch = ea.synthetic_batch(cfg32)
@@ -131,33 +133,17 @@ def test_bf16_full_size_gradients_track_fp32(shape):
     for k in range(1, 8):
         n32.substep(k, apply=False)
         n16.substep(k, apply=False)
+        first = {vn: n16.get_variable(vn + '/grad') for vn in names[k]}
+        n16.substep(k, apply=False)
         for vn in names[k]:
             a, b = n16.get_variable(vn + '/grad'), n32.get_variable(vn + '/grad')
             assert np.all(np.isfinite(a))
+            assert np.array_equal(a, first[vn]), f'sub-step {k} {vn}: the bf16 engine does not reproduce itself'
             worst[(k, vn)] = parity.rel_l2(a, b)
-    n32.close(); n16.close()
+    n32.close()
+    n16.train_step()
+    losses = n16.losses()
+    n16.close()
+    assert all(np.isfinite(v) for v in losses.values()), losses
     bad = {kv: e for kv, e in worst.items() if e > (0.7 if kv[0] == 6 else 0.25)}
     assert not bad, (bad, worst)
-
-
-def test_bf16_dma_kernel_opt_in():
-    """The DMA-fed bf16 convolution kernel (k_gemm_dma.hip, EG_BF16_DMA=1: activation read from a bf16 copy, both tiles
-    global -> LDS) is not on the default path (with fp32 activation storage its conversion passes cost
-    what it gains); it stays covered: the conv / deconv op cases under the switch, against the emulating oracle at the
-    fp32-accumulation tolerances.  EG_NO_HALO=1 keeps the halo kernel from taking the same layers first."""
-    import os
-    import subprocess
-    import sys
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ('import sys; sys.path[:0] = [%r, %r, %r]\n'
-            'import edgegan_amd as ea, parity\n'
-            'net = ea.EdgeGAN(ea.Config(batch_size=2, compute_dtype="bf16"))\n'
-            'rows = []\n'
-            'for c in parity.CONV_CASES: rows += parity.check_conv(net, c, bf16=True)\n'
-            'for c in parity.DECONV_CASES: rows += parity.check_deconv(net, c, bf16=True)\n'
-            'bad = [r for r in rows if not r[1] <= r[2]]\n'
-            'assert not bad, parity.format_rows(bad)\n'
-            'print("rows", len(rows))\n') % (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests'))
-    env = dict(os.environ, EG_BF16_DMA='1', EG_NO_HALO='1')
-    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

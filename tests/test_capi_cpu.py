@@ -83,10 +83,11 @@ def test_loopback_rccl_stand_in_builds_and_exports_what_the_engine_binds(built_l
     point edgegan_amd/csrc/comm.cpp resolves by name -- checked against the dlsym strings in comm.cpp itself."""
     import __graft_entry__ as ge
     so = os.path.join(ROOT, 'tests', 'shim', 'libloopback_rccl.so')
-    if not os.path.exists(so):
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(ROOT, 'tests', 'shim', 'loopback_rccl.cpp')):
         ge.build_test_shim()
     bound = sorted(set(re.findall(r'"(nccl[A-Za-z]+)"', open(os.path.join(ROOT, 'edgegan_amd', 'csrc', 'comm.cpp')).read())))
-    assert bound == ['ncclAllReduce', 'ncclCommDestroy', 'ncclCommInitRank', 'ncclGetErrorString', 'ncclGetUniqueId'], bound
+    assert bound == ['ncclAllReduce', 'ncclCommDestroy', 'ncclCommInitRank', 'ncclGetErrorString', 'ncclGetUniqueId',
+                     'ncclGetVersion'], bound
     lib = ctypes.CDLL(so)
     assert all(hasattr(lib, s) for s in bound)
     lib.ncclGetErrorString.restype = ctypes.c_char_p

@@ -159,3 +159,57 @@ def test_training_command_line_two_ranks(shim, tmp_path):
     # counter starts at 1, +1 per iteration; saved when counter % 3 == 2 (edgegan.py:487-489) -> after rank 0's 1st iteration
     assert (ck / 'EdgeGAN-Model-2.index').exists(), sorted(x.name for x in ck.glob('*'))
     assert tf_bundle.read_checkpoint_state(str(ck))[0] == 'EdgeGAN-Model-2'
+
+
+def test_real_rccl_binds_in_a_process_that_never_imports_torch(tmp_path):
+    """`bench.py --gpus N` and `python -m edgegan_amd.train` do not import torch before eg_comm_init, so the library's own
+    dlopen search (csrc/comm.cpp: EG_RCCL_LIB, then librccl.so.1 / librccl.so / /opt/rocm/lib/librccl.so.1, with
+    engine.py's fallback to the copy PyTorch ships, located without importing it) has to find the REAL RCCL on the box.
+    A fresh interpreter -- no torch in sys.modules before or after -- creates an engine, brings up a one-rank communicator
+    on the real library, runs one data-parallel training iteration (all-reduces on the communication stream, averaging
+    RMSProp) plus a scalar reduction, and reports which librccl it bound.  With one rank the exchange is the identity, so
+    the iteration must reproduce the communicator-free one bit for bit (checked here against this process's engine)."""
+    code = ('import sys, json, os\n'
+            'sys.path.insert(0, %r)\n'
+            'import numpy as np\n'
+            'import edgegan_amd as ea\n'
+            'assert "torch" not in sys.modules\n'
+            'cfg = ea.Config(batch_size=2)\n'
+            'values = ea.init_variables(cfg, 0)\n'
+            'b = ea.synthetic_batch(cfg)\n'
+            'net = ea.EdgeGAN(cfg, values)\n'
+            'net.comm_init(net.comm_unique_id(), 0, 1)\n'
+            'net.upload_batch(**b)\n'
+            'net.train_step()\n'
+            'r = net.comm_reduce_scalars([1.5, 2.0], "max")\n'
+            'info = net.comm_info()\n'
+            'np.savez(%r, **net.get_variables(slots=True))\n'
+            'net.close()\n'
+            'assert "torch" not in sys.modules\n'
+            'print("INFO " + json.dumps(dict(info, reduced=[float(x) for x in r], env=os.environ.get("EG_RCCL_LIB"))))\n'
+            ) % (ROOT, str(tmp_path / 'dp.npz'))
+    env = {k: v for k, v in os.environ.items() if k not in ('EG_RCCL_LIB',)}
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    info = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('INFO ')][-1][5:])
+    assert info['nranks'] == 1 and info['reduced'] == [1.5, 2.0]
+    assert info['rccl_library'] and 'loopback' not in info['rccl_library'] and 'rccl' in info['rccl_library']
+    assert info['rccl_version'] is not None
+    # 7 gradient exchanges per iteration: D, D_patch2, D_patch3, D2, G1+G2 (one call), E, G1+G2 = 56.4 M floats
+    assert info['allreduce_calls'] == 7, info
+    cfg = ea.Config(batch_size=2)
+    specs = {s.name: s for s in ea.variable_specs(cfg)}
+    live = lambda g: sum(int(np.prod(s.shape, dtype=np.int64)) for s in specs.values() if s.name.split('/')[0] == g and s.trainable
+                         and not s.name.startswith('D2/Conv_1/'))
+    floats = live('D') + live('D_patch2') + live('D_patch3') + live('D2') + 2 * (live('G1') + live('G2')) + live('E')
+    # (each variable's slot in the flat buffer is rounded up to 64 floats, so the payload is slightly above the raw count)
+    assert floats * 4 <= info['allreduce_bytes'] <= floats * 4 * 1.001 + 4 * 64 * 400, (info, floats * 4)
+    print('bound RCCL:', info['rccl_library'], info['rccl_version'])
+    got = dict(np.load(tmp_path / 'dp.npz'))
+    net = ea.EdgeGAN(cfg, ea.init_variables(cfg, 0))
+    net.upload_batch(**ea.synthetic_batch(cfg))
+    net.train_step()
+    want = net.get_variables(slots=True)
+    net.close()
+    for k, v in want.items():
+        assert np.array_equal(v, got[k]), k

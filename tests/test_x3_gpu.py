@@ -6,7 +6,7 @@ held to the fp32 tests' OWN tolerances against the fp64 oracle (no emulation in 
     (measured <= 1.5e-6, the exact-fp32 MFMA kernels measure <= 1e-6 on the same cases);
   * network forwards at 5e-4, inference at 1e-4, the committed golden vectors;
   * the margin-selected fixtures (no activation within 3e-6 rms of a ReLU / PReLU kink) at relative L2 1e-4 on every
-    optimised variable of every sub-step, and BASELINE's full batch (B=64) sub-steps 1, 3, 5, 6 against fp64 autograd --
+    optimised variable of every sub-step, and BASELINE's full batch (B=64) sub-steps 1, 3, 4, 5, 6 against fp64 autograd --
     the tests of tests/test_tight_gpu.py, re-run here with the fp32 compute type mapped to f32x3 (EG_F32_MODE);
   * the ordinary sub-step tests at their relative-L2 1e-2 (kink flips allowed) tolerance.
 
@@ -87,7 +87,7 @@ def test_x3_substep_gradients_at_1e4_on_margin_selected_fixtures(name):
     test_tight_gpu.test_substep_gradients_at_1e4_on_margin_selected_fixtures(name)
 
 
-@pytest.mark.parametrize('name', ['d_optim', 'g_optim_u'])
+@pytest.mark.parametrize('name', test_tight_gpu.FULL_BATCH_SUBSTEPS)
 def test_x3_full_batch_substep_against_fp64_oracle(name):
     test_tight_gpu.test_full_batch_fp32_substep_against_fp64_oracle(name)
 
