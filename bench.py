@@ -229,6 +229,96 @@ def infer_bench(args, ea, np, rank, world, local):
     net.close()
 
 
+def loop_bench(args, ea, np, local):
+    """End-to-end throughput of the REAL training loop (edgegan/models/edgegan.py:456-489 as python -m edgegan_amd.train
+    runs it) beside the resident-batch number: PNG files on disk -> Dataset / Prefetcher (edgegan/utils/data/dataset.py:
+    58-69 semantics: decode, bytescale, resize, /127.5-1) -> host->device feed -> the 7 sub-steps -> per-iteration loss
+    read-back.  Measured in one process, same engine: (a) resident batch (what `value` of the default mode measures),
+    (b) the pipelined loop (update_model_async + losses one iteration late: what train.py does), (c) the synchronous
+    loop of round 2 (update_model, then losses(): a host<->device synchronisation per iteration), (d) the loader alone."""
+    import shutil
+    import tempfile
+    from PIL import Image
+    from edgegan_amd.data import Dataset, Prefetcher
+    K, W = args.steps, args.warmup
+    cfg = ea.Config(batch_size=args.batch, num_classes=args.classes, device=local, compute_dtype=args.dtype,
+                    height=args.height, width=args.width)
+    root = tempfile.mkdtemp(prefix='edgegan_loop_')
+    try:
+        rng = np.random.RandomState(0)
+        n_img = (K + W) * args.batch
+        ncls = max(args.classes, 1)
+        t0 = time.perf_counter()
+        for c in range(ncls):
+            d = os.path.join(root, 'synth', 'train', str(c)) if args.classes else os.path.join(root, 'synth', 'train')
+            os.makedirs(d, exist_ok=True)
+            for i in range((n_img + ncls - 1) // ncls):
+                # smooth random fields (photo-like compressibility), not white noise
+                low = rng.randint(0, 256, size=(args.height // 8, args.width // 8, 3)).astype(np.uint8)
+                Image.fromarray(low).resize((args.width, args.height), Image.BILINEAR).save(os.path.join(d, f'{c}_{i}.png'))
+        t_make = time.perf_counter() - t0
+        dcfg = {'input_height': args.height, 'input_width': args.width, 'output_height': args.height,
+                'output_width': args.width, 'crop': False, 'grayscale': False, 'z_dim': cfg.z_dim}
+        ds = Dataset(root, 'synth', float('inf'), args.batch, dcfg, args.classes or None, 'train')
+        ds.shuffle()
+        net = ea.EdgeGAN(cfg, ea.init_variables(cfg, 0))
+        order = list(range(K + W))
+        # (d) loader alone
+        t0 = time.perf_counter()
+        n = 0
+        for _ in Prefetcher(ds, order):
+            n += 1
+        loader_ips = n * args.batch / (time.perf_counter() - t0)
+        # (a) resident batch
+        b = ea.synthetic_batch(cfg, seed=1234)
+        net.upload_batch(b['images'], b['z'], b['alpha'], b['eps'])
+        for _ in range(W):
+            net.train_step()
+        net.sync()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            net.train_step()
+        net.sync()
+        resident = args.batch * K / (time.perf_counter() - t0)
+
+        def run(pipelined):
+            t0 = None
+            late = False
+            for it, (idx, images, z, _) in enumerate(Prefetcher(ds, order)):
+                if it == W:
+                    net.sync()
+                    t0 = time.perf_counter()
+                if pipelined:
+                    net.update_model_async(images, z)
+                    if late:
+                        l = net.losses_async(back=1)
+                    late = True
+                else:
+                    net.update_model(images, z)
+                    l = net.losses()
+                if it >= 1 or not pipelined:
+                    _ = '%.8f %.8f' % (2 * (l['joint_dis_dloss'] + l['image_dis_dloss'] + l['edge_dis_dloss']), l['edge_gloss'] + l['image_gloss'])
+            if pipelined:
+                l = net.losses_async(back=0)
+            net.sync()
+            return args.batch * K / (time.perf_counter() - t0), l
+        piped, l1 = run(True)
+        synced, l2 = run(False)
+        print(json.dumps({
+            'metric': f'training images/sec (G+D step) at {args.height}x{args.width}, 14-class -- END-TO-END LOOP', 'unit': 'images/s',
+            'value': round(piped, 2), 'n_gpus': 1, 'steps': K, 'warmup': W, 'dtype': args.dtype, 'data': 'synthetic PNG files on local disk',
+            'higher_is_better': True,
+            'config': {'workload': f'python -m edgegan_amd.train loop: PNG decode -> feed -> 7 sub-steps -> loss read-back, batch {args.batch}'},
+            'resident_batch_images_per_s': round(resident, 2), 'loop_pipelined_images_per_s': round(piped, 2),
+            'loop_synchronous_images_per_s': round(synced, 2), 'loader_alone_images_per_s': round(loader_ips, 1),
+            'loop_vs_resident': round(piped / resident, 4), 'decode_workers': Prefetcher(ds, []).workers,
+            'host_hardware_threads': os.cpu_count(), 'png_tree_seconds': round(t_make, 1),
+            'losses_finite': bool(all(np.isfinite(v) for v in l1.values()) and all(np.isfinite(v) for v in l2.values()))}))
+        net.close()
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -242,9 +332,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the side measurement of the exact-fp32-MFMA mode')
     ap.add_argument('--cpu-baseline-batch', type=int, default=64)
-    ap.add_argument('--mode', choices=['train', 'infer'], default='train',
+    ap.add_argument('--mode', choices=['train', 'infer', 'loop'], default='train',
                     help='train = BASELINE configs[2] (the headline metric); infer = configs[1]: single-class 64x128 bf16 '
-                         'generator-only inference (edgegan.test path E -> G1, E -> G2), batch 64, inputs resident in HBM')
+                         'generator-only inference (edgegan.test path E -> G1, E -> G2), batch 64, inputs resident in HBM; '
+                         'loop = the real training loop end to end (PNG files -> loader -> feed -> iteration -> loss read-back) '
+                         'beside the resident-batch number, one GPU')
     ap.add_argument('--dtype', choices=['f32x3', 'f32', 'bf16'], default='f32x3',
                     help="f32x3 (default) and f32 = BASELINE configs[2] (the headline metric) in fp32: f32x3 forms every fp32 "
                          "product of the dense contractions from exact bf16-limb products on the bf16 MFMA (fp32 accumulate), "
@@ -269,6 +361,10 @@ def main():
 
     if args.mode == 'infer':
         return infer_bench(args, ea, np, rank, world, local)
+    if args.mode == 'loop':
+        if '--steps' not in sys.argv:
+            args.steps = 50
+        return loop_bench(args, ea, np, local)
 
     cfg_kwargs = dict(batch_size=args.batch, num_classes=args.classes, device=local, compute_dtype=args.dtype,
                       height=args.height, width=args.width)

@@ -76,7 +76,7 @@ class _CEvalOutputs(C.Structure):
 
 EXPORTS = ['eg_default_config', 'eg_variable_count', 'eg_variable_info', 'eg_create', 'eg_destroy',
            'eg_last_error', 'eg_set_variable', 'eg_get_variable', 'eg_upload_batch', 'eg_substep',
-           'eg_train_step', 'eg_read_losses', 'eg_eval_losses', 'eg_infer', 'eg_infer_upload', 'eg_infer_run', 'eg_infer_download', 'eg_sync', 'eg_comm_unique_id', 'eg_comm_init',
+           'eg_train_step', 'eg_train_batch', 'eg_losses_wait', 'eg_read_losses', 'eg_eval_losses', 'eg_infer', 'eg_infer_upload', 'eg_infer_run', 'eg_infer_download', 'eg_sync', 'eg_comm_unique_id', 'eg_comm_init',
            'eg_comm_reduce_scalars', 'eg_comm_info',
            'eg_profile_begin', 'eg_profile_end', 'eg_profile_layers', 'eg_memory_stats', 'eg_test_op', 'eg_net_forward', 'eg_crc32c']
 
@@ -105,6 +105,8 @@ def load_library() -> C.CDLL:
     lib.eg_substep.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.eg_train_step.argtypes = [C.c_void_p]
     lib.eg_read_losses.argtypes = [C.c_void_p, fp]
+    lib.eg_train_batch.argtypes = [C.c_void_p, fp, fp, fp, fp]
+    lib.eg_losses_wait.argtypes = [C.c_void_p, C.c_int, fp]
     lib.eg_infer.argtypes = [C.c_void_p, fp, ip, C.c_int, fp, fp, fp]
     lib.eg_eval_losses.argtypes = [C.c_void_p, fp, C.c_float, C.c_int, C.POINTER(_CEvalOutputs)]
     lib.eg_infer_upload.argtypes = [C.c_void_p, fp, ip, C.c_int, fp]

@@ -121,6 +121,11 @@ struct Ctx {
   float* d_eval = nullptr;    // eval_losses: [16 losses | 6 x B discriminator logits | 3 x B alpha | 4 eps]
   int* d_classes = nullptr;
   long long step_count = 0;
+  // pipelined feed (capi.cpp: eg_train_batch / eg_losses_wait): two pinned host slots for the batch and for the losses
+  float* feed_host[2] = {nullptr, nullptr};
+  float* loss_host[2] = {nullptr, nullptr};
+  hipEvent_t feed_copied[2] = {nullptr, nullptr}, loss_ready[2] = {nullptr, nullptr};
+  long long feed_count = 0;
   // generator outputs of the D-phase (sub-steps 1-3 share G1(z), G2(z): G is frozen until sub-step 5)
   float* d_gen_cache[2] = {nullptr, nullptr};
   float* d_gen_bn[2] = {nullptr, nullptr};   // batch statistics of that forward, for the moving-average updates

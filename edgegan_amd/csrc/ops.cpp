@@ -1262,6 +1262,12 @@ Ctx::~Ctx() {
       if (p->wM) (void)hipFree(p->wM);
       for (int o = 0; o < 2; ++o) p->wL[o].release();
     }
+  for (int i = 0; i < 2; ++i) {
+    if (feed_host[i]) (void)hipHostFree(feed_host[i]);
+    if (loss_host[i]) (void)hipHostFree(loss_host[i]);
+    if (feed_copied[i]) (void)hipEventDestroy(feed_copied[i]);
+    if (loss_ready[i]) (void)hipEventDestroy(loss_ready[i]);
+  }
   (void)hipFree(inf_in);
   (void)hipFree(inf_edge);
   (void)hipFree(inf_image);

@@ -8,7 +8,6 @@ from __future__ import annotations
 
 import os
 import queue
-import threading
 from glob import glob
 from pathlib import Path
 from typing import Dict, List, Optional, Tuple
@@ -145,30 +144,32 @@ class Dataset:
 
 
 class Prefetcher:
-    """Decodes the next batches on worker threads while the GPU trains on the current one.  z is drawn on the
-    consumer side in batch order, so the np.random stream is the reference's (shuffle, then one draw per batch)."""
+    """Decodes the next batches on worker threads while the GPU trains on the current one: `workers` threads each decode
+    whole batches (PIL releases the GIL inside the PNG / JPEG decoders and the resize), results are handed out strictly in
+    batch order, at most `depth` batches ahead.  z is drawn on the consumer side in batch order, so the np.random stream
+    is the reference's (shuffle, then one draw per batch)."""
 
-    def __init__(self, dataset: Dataset, indices: List[int], depth: int = 3):
+    def __init__(self, dataset: Dataset, indices: List[int], depth: int = 6, workers: Optional[int] = None):
         self.ds, self.indices = dataset, list(indices)
-        self.q: 'queue.Queue' = queue.Queue(maxsize=depth)
-        self.t = threading.Thread(target=self._run, daemon=True)
-        self.t.start()
+        self.workers = workers if workers is not None else max(1, min(8, (os.cpu_count() or 2) - 1))
+        self.depth = max(depth, self.workers)
 
-    def _run(self):
-        try:
-            for idx in self.indices:
-                files = self.ds.filenames(idx)
-                self.q.put((idx, self.ds.load_images(files), files))
-            self.q.put(None)
-        except BaseException as e:      # surface decoding errors in the training thread
-            self.q.put(e)
+    def _load(self, idx):
+        files = self.ds.filenames(idx)
+        return idx, self.ds.load_images(files), files
 
     def __iter__(self):
-        while True:
-            item = self.q.get()
-            if item is None:
-                return
-            if isinstance(item, BaseException):
-                raise item
-            idx, images, files = item
-            yield idx, images, self.ds.draw_z(files), files
+        from concurrent.futures import ThreadPoolExecutor
+        pending: 'queue.deque' = __import__('collections').deque()
+        with ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix='edgegan-decode') as pool:
+            it = iter(self.indices)
+            for idx in it:
+                pending.append(pool.submit(self._load, idx))
+                if len(pending) >= self.depth:
+                    break
+            while pending:
+                idx, images, files = pending.popleft().result()      # decoding errors surface here, in the training thread
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append(pool.submit(self._load, nxt))
+                yield idx, images, self.ds.draw_z(files), files

@@ -84,8 +84,7 @@ class EdgeGAN:
         return out
 
     # -- training ---------------------------------------------------------------------------------
-    def upload_batch(self, images: np.ndarray, z: np.ndarray, alpha: Optional[np.ndarray] = None,
-                     eps: Optional[np.ndarray] = None):
+    def _feed(self, images, z, alpha, eps):
         cfg = self.config
         images = np.ascontiguousarray(images, dtype=np.float32)
         z = np.ascontiguousarray(z, dtype=np.float32)
@@ -100,7 +99,24 @@ class EdgeGAN:
         alpha = np.ascontiguousarray(alpha, dtype=np.float32)
         eps = np.ascontiguousarray(np.asarray(eps, dtype=np.float32).reshape(-1))
         assert alpha.shape == (3, cfg.batch_size) and eps.size >= 1
+        return images, z, alpha, eps
+
+    def upload_batch(self, images: np.ndarray, z: np.ndarray, alpha: Optional[np.ndarray] = None,
+                     eps: Optional[np.ndarray] = None):
+        images, z, alpha, eps = self._feed(images, z, alpha, eps)
         self._check(self._lib.eg_upload_batch(self._ctx, fptr(images), fptr(z), fptr(alpha), fptr(eps)))
+
+    def update_model_async(self, images: np.ndarray, z: np.ndarray, alpha=None, eps=None):
+        """update_model without any wait for the GPU: the feed goes through pinned host staging and is enqueued behind
+        the previous iteration (eg_train_batch).  Pair with losses_async(back=1) to report iteration k-1 while k runs."""
+        images, z, alpha, eps = self._feed(images, z, alpha, eps)
+        self._check(self._lib.eg_train_batch(self._ctx, fptr(images), fptr(z), fptr(alpha), fptr(eps)))
+
+    def losses_async(self, back: int = 0) -> Dict[str, float]:
+        """Losses of the latest (back=0) / the previous (back=1) update_model_async call; waits for that iteration only."""
+        out = np.zeros(12, dtype=np.float32)
+        self._check(self._lib.eg_losses_wait(self._ctx, int(back), fptr(out)))
+        return self._compose_losses(out)
 
     def substep(self, k: int, apply: bool = True):
         self._check(self._lib.eg_substep(self._ctx, int(k), 1 if apply else 0))

@@ -104,9 +104,25 @@ def main(argv=None):
                 base_order = list(dataset.data)
             dataset.data = [base_order[i] for i in epoch_permutation(len(base_order), shuffle_seed, epoch)]
         steps = len(dataset) // world
+        def report(it, counter_of_it, l):
+            """The host side of one iteration (edgegan.py:427-433,462-489): summaries, the printed line."""
+            discriminator_err = l['joint_dis_dloss'] + l['image_dis_dloss'] + l['edge_dis_dloss']
+            generator_err = l['edge_gloss'] + l['image_gloss']
+            if writer is not None:                                                   # edgegan.py:427-433,462
+                writer.add_scalars({t: l[t] for t in SCALAR_TAGS if t in l and (cfg.multiclasses or 'ac' not in t)},
+                                   counter_of_it)
+            if rank == 0:
+                print('Epoch: [%2d/%2d] [%4d/%4d] time: %4.4f, joint_dis_dloss: %.8f, joint_dis_gloss: %.8f'
+                      % (epoch, fl.epoch, it, steps, time.time() - start_time, 2 * discriminator_err, generator_err))
+
+        # Default path: iteration k is ENQUEUED (pinned-memory feed, no wait), then iteration k-1 is reported -- its losses
+        # were copied to the host behind it -- so decoding, printing and summary writing overlap the GPU's work and the
+        # GPU never waits for the host.  The printed / logged values and their order are unchanged.  An iteration after
+        # which a checkpoint is due is reported at once (the saved weights must be the ones right after that update).
+        late = None                      # (it, counter) of the enqueued, not yet reported iteration
         for it, (idx, images, z, _) in enumerate(Prefetcher(dataset, rank_batches(len(dataset), world, rank))):
-            net.update_model(images, z)                                              # edgegan.py:461
             if fl.reference_evaluation:      # the reference's observe-only runs: post-update weights, fresh draws, BN x6
+                net.update_model(images, z)                                          # edgegan.py:461
                 l = net.evaluate(bn_updates=6, tensors=writer is not None)           # edgegan.py:427-433,464-481
                 if writer is not None:
                     hist = {t: 0.5 * (1.0 + np.tanh(0.5 * l[k][i].astype(np.float64))) for t, (k, i) in HISTOGRAM_TAGS.items()}   # D = sigmoid(logits)
@@ -115,19 +131,23 @@ def main(argv=None):
                     imgs = {t: l[k] for t, k in IMAGE_TAGS.items()}
                     imgs['inputs'] = images
                     writer.add_images(imgs, counter)
-            else:                            # default: the values the sub-steps computed on their way (no extra passes)
-                l = net.losses()
-            discriminator_err = l['joint_dis_dloss'] + l['image_dis_dloss'] + l['edge_dis_dloss']
-            generator_err = l['edge_gloss'] + l['image_gloss']
-            if writer is not None:                                                   # edgegan.py:427-433,462
-                writer.add_scalars({t: l[t] for t in SCALAR_TAGS if t in l and (cfg.multiclasses or 'ac' not in t)},
-                                   counter)
-            counter += 1
-            if rank == 0:
-                print('Epoch: [%2d/%2d] [%4d/%4d] time: %4.4f, joint_dis_dloss: %.8f, joint_dis_gloss: %.8f'
-                      % (epoch, fl.epoch, it, steps, time.time() - start_time, 2 * discriminator_err, generator_err))
-                if np.mod(counter, fl.save_checkpoint_frequency) == 2:               # edgegan.py:487-489
+                report(it, counter, l)
+                counter += 1
+                if rank == 0 and np.mod(counter, fl.save_checkpoint_frequency) == 2:  # edgegan.py:487-489
                     checkpoint.save(net, fl.checkpoint_dir, counter)
+                continue
+            net.update_model_async(images, z)                                        # edgegan.py:461 (enqueue only)
+            if late is not None:
+                report(late[0], late[1], net.losses_async(back=1))
+            late = (it, counter)
+            counter += 1
+            if np.mod(counter, fl.save_checkpoint_frequency) == 2:                   # edgegan.py:487-489
+                report(late[0], late[1], net.losses_async(back=0))
+                late = None
+                if rank == 0:
+                    checkpoint.save(net, fl.checkpoint_dir, counter)
+        if late is not None:
+            report(late[0], late[1], net.losses_async(back=0))
     if writer is not None:
         writer.close()
     net.close()

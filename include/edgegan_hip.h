@@ -88,6 +88,14 @@ int eg_train_step(eg_ctx* ctx);
  * out[0..11] = joint wgan, joint gp, image wgan, image gp, edge wgan, edge gp, loss_d_ac,
  *              joint_dis_gloss, edge_dis_gloss, image_dis_gloss, loss_g_ac, zl_loss */
 int eg_read_losses(eg_ctx* ctx, float* out12);
+/* The loop of models/edgegan.py:456-486 (feed a batch, run the sub-steps, read the losses back) without a host<->device
+ * synchronisation per iteration: eg_train_batch = eg_upload_batch + eg_train_step with the feed staged through pinned
+ * host memory and enqueued behind the previous iteration (returns at once; the host buffers may be reused on return);
+ * eg_losses_wait(back, out12) returns the losses of the latest (back = 0) or the previous (back = 1) eg_train_batch,
+ * blocking only until that iteration has finished.  A loop that enqueues iteration k and then reports iteration k-1
+ * keeps the GPU busy while the host decodes, prints and writes summaries. */
+int eg_train_batch(eg_ctx* ctx, const float* images, const float* z, const float* alpha, const float* eps);
+int eg_losses_wait(eg_ctx* ctx, int back, float* out12);
 
 /* Post-update evaluation with the reference's semantics -- replaces the observe-only runs the reference issues AFTER
  * update_model: sess.run(d_sum), sess.run(g_sum) (models/edgegan.py:427-433) and the five evaluate() calls
