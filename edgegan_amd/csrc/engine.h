@@ -139,12 +139,19 @@ struct Ctx {
     hipStream_t stream = nullptr;
     float* scratch = nullptr;
     hipEvent_t done = nullptr;
+    // "leaf" stream of the lane: filter / bias gradients are leaves of the backward graph (nothing downstream in the
+    // sweep reads them), so they run here, beside the lane's dependent chain dgrad -> norm / activation backward -> dgrad
+    // whose HBM-bound kernels they overlap (ops.cpp: LeafScope); joined where their results are read (flush_deferred)
+    hipStream_t leaf = nullptr;
+    hipEvent_t leaf_in = nullptr, leaf_out = nullptr;
   };
   static constexpr int kLanes = 4;
   Lane lanes[kLanes];
   int cur_lane = 0;
   bool lanes_on = true;
-  int lanes_mask = 7;
+  int lanes_mask = 15;
+  bool leaf_on = true;      // EG_LANES bit 3
+  bool leaf_dirty = false;  // the active lane's leaf stream holds work the main stream has not ordered itself behind
   hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr, ev_branch = nullptr;
 
   // inference staging buffers (host <-> device hand-over of eg_infer), grown on demand and kept

@@ -266,15 +266,19 @@ void build_context(Ctx& c) {
       EG_HIP(hipMalloc(&c.lanes[i].scratch, c.scratch_floats * 4));
     }
     EG_HIP(hipEventCreateWithFlags(&c.lanes[i].done, hipEventDisableTiming));
+    EG_HIP(hipStreamCreateWithFlags(&c.lanes[i].leaf, hipStreamNonBlocking));
+    EG_HIP(hipEventCreateWithFlags(&c.lanes[i].leaf_in, hipEventDisableTiming));
+    EG_HIP(hipEventCreateWithFlags(&c.lanes[i].leaf_out, hipEventDisableTiming));
   }
   EG_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_gen, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_g1fwd, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_branch, hipEventDisableTiming));
-  if (const char* e = getenv("EG_LANES")) {   // 0 = one stream; bit 0 = sub-steps 1-4 concurrent, bit 1 = 6/7 concurrent, bit 2 = the critics of 5 / 7 on four lanes
+  if (const char* e = getenv("EG_LANES")) {   // 0 = one stream; bit 0 = sub-steps 1-4 concurrent, bit 1 = 6/7 concurrent, bit 2 = the critics of 5 / 7 on four lanes, bit 3 = filter / bias gradients on the lanes' leaf streams
     c.lanes_mask = atoi(e);
     c.lanes_on = c.lanes_mask != 0;
   }
+  c.leaf_on = (c.lanes_mask & 8) != 0;
   if (const char* e = getenv("EG_DEFER_REDUCE")) c.defer_on = atoi(e) != 0;
   Ctx* cp = &c;
   c.tape.after = [cp]() { flush_deferred(*cp); };
@@ -284,6 +288,7 @@ void use_lane(Ctx& c, int lane) {
   if (lane == c.cur_lane) return;
   c.arena.swap(c.lanes[c.cur_lane].arena);   // park the active arena in its slot
   c.arena.swap(c.lanes[lane].arena);         // bring lane's arena in (its slot keeps the empty placeholder)
+  EG_CHECK(!c.leaf_dirty, "use_lane with un-joined leaf work on lane %d", c.cur_lane);
   c.stream = c.lanes[lane].stream;
   c.scratch = c.lanes[lane].scratch;
   c.cur_lane = lane;

@@ -60,7 +60,7 @@ T wrap_tensor(Ctx& c, float* data, int n, int h, int w, int ch) {
 // Second-stage reductions (kernels.h: RedBatch) are queued and run one launch per batch.  Everything that READS a
 // gradient a queued reduction writes calls flush_deferred first: the end of a backward pass (Tape::after), the gate
 // filter's column copy, the spectral-norm backward, and a second reduction into the same buffer (summation order kept).
-void flush_deferred(Ctx& c) {
+static void run_deferred(Ctx& c, hipStream_t s) {
   if (c.deferred.empty()) return;
   RedBatch b{};
   b.count = (int)c.deferred.size();
@@ -71,17 +71,52 @@ void flush_deferred(Ctx& c) {
     at += red_desc_blocks(b.d[i]);
   }
   b.start[b.count] = at;
-  launch_reduce_batch(b, c.stream);
+  launch_reduce_batch(b, s);
   c.deferred.clear();
+}
+// Leaf stream of the active lane (engine.h: Lane::leaf): filter and bias gradients are enqueued there, behind an event
+// that marks the moment their inputs (the layer's output gradient) are final on the lane's main stream.  The queued
+// reductions follow them on the leaf stream; flush_deferred -- called exactly where a parameter gradient is read on the
+// main stream -- orders the main stream behind everything the leaf stream holds.  Same kernels, same per-buffer order
+// (all writers of one filter gradient are on the one leaf stream): bitwise the results of the one-stream schedule.
+static bool leaf_active(Ctx& c) { return c.leaf_on && c.lanes_on && c.defer_on && !c.prof_on && c.lanes[c.cur_lane].leaf; }
+struct LeafScope {
+  Ctx& c;
+  hipStream_t main;
+  bool on;
+  explicit LeafScope(Ctx& c_) : c(c_), main(c_.stream), on(leaf_active(c_)) {
+    if (!on) return;
+    Ctx::Lane& l = c.lanes[c.cur_lane];
+    EG_HIP(hipEventRecord(l.leaf_in, main));
+    EG_HIP(hipStreamWaitEvent(l.leaf, l.leaf_in, 0));
+    c.stream = l.leaf;
+    c.leaf_dirty = true;
+  }
+  ~LeafScope() {
+    if (on) c.stream = main;
+  }
+};
+void flush_deferred(Ctx& c) {
+  if (leaf_active(c) && c.stream == c.lanes[c.cur_lane].stream) {
+    Ctx::Lane& l = c.lanes[c.cur_lane];
+    run_deferred(c, l.leaf);
+    if (c.leaf_dirty) {
+      EG_HIP(hipEventRecord(l.leaf_out, l.leaf));
+      EG_HIP(hipStreamWaitEvent(c.stream, l.leaf_out, 0));
+      c.leaf_dirty = false;
+    }
+    return;
+  }
+  run_deferred(c, c.stream);
 }
 static void defer_reduction(Ctx& c, const RedDesc& d) {
   for (const RedDesc& q : c.deferred)
     if (q.dst == d.dst) {
-      flush_deferred(c);
+      run_deferred(c, c.stream);
       break;
     }
   c.deferred.push_back(d);
-  if ((int)c.deferred.size() == kRedBatch) flush_deferred(c);
+  if ((int)c.deferred.size() == kRedBatch) run_deferred(c, c.stream);
 }
 
 float* grad_acc(Ctx& c, T t, int* acc) {
@@ -564,7 +599,7 @@ static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, c
   g.defer_reduce = c.defer_on ? 1 : 0;
   for (const RedDesc& q : c.deferred)   // a queued reduction into this filter's gradient comes first (summation order)
     if (q.dst == g.dw) {
-      flush_deferred(c);
+      run_deferred(c, c.stream);
       break;
     }
   const char* nm;
@@ -667,7 +702,8 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
       Ctx& c = *cp;
       if (!y->g_set) return;
       if (fused) launch_act_bwd(y->d, y->g, y->g, 0, y->numel(), fused_act, c.stream);   // in place: g *= act'(out)
-      if (c.param_grad_enabled) {
+      if (c.param_grad_enabled && (w->want_grad || (bias && bias->want_grad))) {
+        LeafScope leaf(c);
         if (w->want_grad)
           conv_wgrad(c, x->d, x->n, x->h, x->w, Cin, y->g, OH, OW, N, w, k, stride, pt, pad == PAD_REFLECT);
         if (bias && bias->want_grad) bias_grad(c, bias, y->g, rows, N);
@@ -742,7 +778,8 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
     c.tape.push([=]() {
       Ctx& c = *cp;
       if (!y->g_set) return;
-      if (c.param_grad_enabled) {
+      if (c.param_grad_enabled && (w->want_grad || (bias && bias->want_grad))) {
+        LeafScope leaf(c);
         // dW[k][co][ci] = sum_i dy[2i+k-1][co] x[i][ci]: wgrad with the roles of x and dy swapped
         if (w->want_grad) conv_wgrad(c, y->g, x->n, OH, OW, cout, x->d, x->h, x->w, Cin, w, 5, 2, 1, 0);
         if (bias && bias->want_grad) bias_grad(c, bias, y->g, y->pixels(), cout);
@@ -1311,6 +1348,9 @@ Ctx::~Ctx() {
       if (lanes[i].scratch) (void)hipFree(lanes[i].scratch);
     }
     if (lanes[i].done) (void)hipEventDestroy(lanes[i].done);
+    if (lanes[i].leaf) (void)hipStreamDestroy(lanes[i].leaf);
+    if (lanes[i].leaf_in) (void)hipEventDestroy(lanes[i].leaf_in);
+    if (lanes[i].leaf_out) (void)hipEventDestroy(lanes[i].leaf_out);
   }
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_gen) (void)hipEventDestroy(ev_gen);
