@@ -121,8 +121,11 @@ def test_full_batch_fp32_substep_against_fp64_oracle(name):
     g64, l64, self_dev = _full_batch_oracle(name, cfg, values, b)
     net = ea.EdgeGAN(cfg, values)
     net.upload_batch(b['images'], b['z'], b['alpha'], b['eps'])
+    # scalar PReLU slopes: the margin-fixture test's rule (5 x the tensor tolerance, see there): ONE cancelling sum over up to
+    # 1.7e7 elements of dy * x behind every kink of the layer.  Measured at B=64: exact-fp32 mode <= 2.7e-3, f32x3 <= 3.5e-3
+    # (`norm_activation_merge_1` of units 2 / 3), the oracle's own fp32 run <= 1.3e-3.
     rows = _grad_rows(net, None, None, name, 1e-3, 'B=64', var_tol={vn: 3.0 * d for vn, d in self_dev.items()},
-                      precomputed=(g64, l64))
+                      scalar_tol=5e-3, precomputed=(g64, l64))
     net.close()
     if name == 'd_optim2':
         assert len(rows) >= 55 and sum('Conv_2/weights' in r[0] for r in rows) == 4 and sum('update_gate/weights' in r[0] for r in rows) == 4
