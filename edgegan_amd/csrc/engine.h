@@ -145,15 +145,14 @@ struct Ctx {
     hipStream_t leaf = nullptr;
     hipEvent_t leaf_in = nullptr, leaf_out = nullptr;
   };
-  static constexpr int kLanes = 5;   // 0-3: the four critics' lanes; 4: partner of lane 3 (second half-batch of the classifier branch)
+  static constexpr int kLanes = 4;
   Lane lanes[kLanes];
   int cur_lane = 0;
   bool lanes_on = true;
-  int lanes_mask = 31;
-  bool cls_halves = true;   // sub-steps 5 / 7: the classifier branch as two half-batch chains (EG_CLS_HALVES=0: one chain)
+  int lanes_mask = 15;
   bool leaf_on = true;      // EG_LANES bit 3
   bool leaf_dirty = false;  // the active lane's leaf stream holds work the main stream has not ordered itself behind
-  hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr, ev_branch = nullptr, ev_cls = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr, ev_branch = nullptr;
 
   // inference staging buffers (host <-> device hand-over of eg_infer), grown on demand and kept
   float *inf_in = nullptr, *inf_edge = nullptr, *inf_image = nullptr, *inf_eps = nullptr;
@@ -232,10 +231,6 @@ T gmean(Ctx& c, T x, bool pre_relu);
 T resize(Ctx& c, T x, int size);
 T concat_w(Ctx& c, T a, T b);
 T slice_w(Ctx& c, T x, int w0, int w1);   // no gradient (inputs only)
-// rows [n0, n1) of the batch as a view: shares x's data AND gradient storage (its consumers write their part of x's
-// gradient in place); the parts of one tensor must cover disjoint rows and be x's FIRST gradient writers
-T rows_view(Ctx& c, T x, int n0, int n1);
-T concat_rows(Ctx& c, T a, T b);          // [na + nb, ...] copy of two row blocks (small tensors: logits)
 T prelu(Ctx& c, T x, Param* leak, float leak_const);
 T minmax(Ctx& c, T x);
 T gate(Ctx& c, T h, T rg, T img);

@@ -9,7 +9,7 @@ namespace eg {
 
 // A/B and timing switches (EG_NO_*, EG_X3_*, EG_TRACE_GEMM, ...) exist only in builds made with -DEG_EXPERIMENTS
 // (make EXPERIMENTS=1 -> libedgegan_hip_exp.so, selected with EG_LIB_PATH by tools/gpu_ab*.py); the shipped library
-// ignores them.  Runtime options of the product proper -- EG_LANES, EG_CLS_HALVES, EG_DEFER_REDUCE, EG_RCCL_LIB -- read getenv directly.
+// ignores them.  Runtime options of the product proper -- EG_LANES, EG_DEFER_REDUCE, EG_RCCL_LIB -- read getenv directly.
 inline const char* dbg_env(const char* name) {
 #ifdef EG_EXPERIMENTS
   return getenv(name);

@@ -274,13 +274,11 @@ void build_context(Ctx& c) {
   EG_HIP(hipEventCreateWithFlags(&c.ev_gen, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_g1fwd, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_branch, hipEventDisableTiming));
-  EG_HIP(hipEventCreateWithFlags(&c.ev_cls, hipEventDisableTiming));
-  if (const char* e = getenv("EG_LANES")) {   // 0 = one stream; bit 0 = sub-steps 1-4 concurrent, bit 1 = 6/7 concurrent, bit 2 = the critics of 5 / 7 on four lanes, bit 3 = filter / bias gradients on the lanes' leaf streams, bit 4 = G2's backward of sub-steps 5 / 7 on lane 2 beside G1's
+  if (const char* e = getenv("EG_LANES")) {   // 0 = one stream; bit 0 = sub-steps 1-4 concurrent, bit 1 = 6/7 concurrent, bit 2 = the critics of 5 / 7 on four lanes, bit 3 = filter / bias gradients on the lanes' leaf streams
     c.lanes_mask = atoi(e);
     c.lanes_on = c.lanes_mask != 0;
   }
   c.leaf_on = (c.lanes_mask & 8) != 0;
-  if (const char* e = getenv("EG_CLS_HALVES")) c.cls_halves = atoi(e) != 0;
   if (const char* e = getenv("EG_DEFER_REDUCE")) c.defer_on = atoi(e) != 0;
   Ctx* cp = &c;
   c.tape.after = [cp]() { flush_deferred(*cp); };
@@ -666,11 +664,8 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       set_want_grad(c, G_G1, true);
       set_want_grad(c, G_G2, true);
       T zin = make_zin(c);
-      const size_t mgA = c.tape.ops.size();
       T edge = generator_forward(c, G_G1, zin, bn1);
-      const size_t mgB = c.tape.ops.size();
       T image = generator_forward(c, G_G2, zin, bn2);
-      const size_t mgC = c.tape.ops.size();
       T joint = concat_w(c, edge, image);
       T r_edge = resize(c, edge, cfg.dis_size), r_image = resize(c, image, cfg.dis_size);
       // The four critics are independent given the generator outputs (each writes the gradient of its OWN input tensor;
@@ -706,44 +701,10 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       seed_grad(c, di);
       launch_fill(di->g, -cfg.image_dweight / B, B, c.stream);
       const size_t m3 = c.tape.ops.size();
-      // The classifier branch is the longest of the four (54 % of the iteration's FLOPs) and runs alone once the three
-      // discriminators are through: with `halves` it is evaluated as TWO half-batch chains on lanes 3 and 4 (every
-      // classifier op is per-sample: no BatchNorm, InstanceNorm-free, min-max gates per image), so that one half's
-      // HBM-bound kernels run under the other half's matrix kernels.  The halves meet at the logits (one loss kernel
-      // over the whole batch) and write disjoint rows of d(image).  The split is a property of the sub-step, not of the
-      // schedule (EG_CLS_HALVES=0 turns it off): the one-stream schedule issues the same launches on one stream, so the
-      // results stay bitwise identical between schedules.
-      const bool halves = cfg.multiclasses() && c.cls_halves && B % 2 == 0;
-      size_t m3a = m3, m3b = m3;
       if (cfg.multiclasses()) {
         enter(3);
         await_group(G_D2);
-        T lf;
-        if (!halves) {
-          lf = classifier_forward(c, image);
-        } else {
-          if (!c.sn_prepared) {   // W / sigma of the classifier's filters: once, before the halves fork
-            sn_prepare(c);
-            c.sn_prepared = true;
-          }
-          T imA = rows_view(c, image, 0, B / 2), imB = rows_view(c, image, B / 2, B);
-          if (bl) EG_HIP(hipEventRecord(c.ev_cls, c.stream));
-          T lfA = classifier_forward(c, imA);
-          m3a = c.tape.ops.size();
-          if (bl) {
-            use_lane(c, 4);
-            c.arena.reset();   // (lane 4's previous work is fully enqueued; stream order protects its memory)
-            EG_HIP(hipStreamWaitEvent(c.stream, c.ev_cls, 0));
-          }
-          T lfB = classifier_forward(c, imB);
-          m3b = c.tape.ops.size();
-          if (bl) {
-            EG_HIP(hipEventRecord(c.lanes[4].done, c.stream));
-            use_lane(c, 3);
-            EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[4].done, 0));
-          }
-          lf = concat_rows(c, lfA, lfB);
-        }
+        T lf = classifier_forward(c, image);
         seed_grad(c, lf);
         launch_acgan_loss(lf->d, c.d_z + cfg.z_dim, cfg.z_dim + 1, c.d_losses + L_CLS_G, lf->g, B, cfg.num_classes,
                           1, c.scratch, c.stream);
@@ -757,20 +718,7 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
           c.tape.backward_range(lo, hi);
           if (lane != 0) EG_HIP(hipEventRecord(c.lanes[lane].done, c.stream));
         };
-        if (m4 > m3 && !halves) sweep(3, m3, m4);
-        if (m4 > m3 && halves) {
-          use_lane(c, 3);
-          c.tape.backward_range(m3b, m4);            // loss seed -> the two halves' logit gradients
-          EG_HIP(hipEventRecord(c.ev_cls, c.stream));
-          use_lane(c, 4);
-          EG_HIP(hipStreamWaitEvent(c.stream, c.ev_cls, 0));
-          c.tape.backward_range(m3a, m3b);           // second half on lane 4 ...
-          EG_HIP(hipEventRecord(c.lanes[4].done, c.stream));
-          use_lane(c, 3);
-          c.tape.backward_range(m3, m3a);            // ... beside the first half on lane 3
-          EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[4].done, 0));
-          EG_HIP(hipEventRecord(c.lanes[3].done, c.stream));
-        }
+        if (m4 > m3) sweep(3, m3, m4);
         // resize() is the identity when H == W/2 == dis_size: r_image IS image, so the image discriminator's input
         // gradient accumulates into the buffer the classifier's sweep (lane 3) writes first -- order lane 1 behind it
         if (m4 > m3 && r_image == image) {
@@ -782,23 +730,7 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
         sweep(0, m0, m1);
         for (int i = 1; i < 4; ++i)
           if (i != 3 || m4 > m3) EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[i].done, 0));
-        if (!(c.lanes_mask & 16)) {
-          c.tape.backward_range(0, m0);
-        } else {
-          // The two generators' backward chains (launches over 32x32 .. 4x4 maps that cannot fill the chip, each a
-          // dependent chain) are independent once the resize / concat backward has produced d(edge), d(image): G2's runs on
-          // lane 2 (idle since the edge discriminator's branch) beside G1's on lane 0
-          c.tape.backward_range(mgC, m0);
-          EG_HIP(hipEventRecord(c.ev_branch, c.stream));
-          use_lane(c, 2);
-          EG_HIP(hipStreamWaitEvent(c.stream, c.ev_branch, 0));
-          c.tape.backward_range(mgB, mgC);
-          EG_HIP(hipEventRecord(c.lanes[2].done, c.stream));
-          use_lane(c, 0);
-          c.tape.backward_range(mgA, mgB);
-          c.tape.backward_range(0, mgA);
-          EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[2].done, 0));
-        }
+        c.tape.backward_range(0, m0);
       }
       if (apply) {
         before_apply();

@@ -1168,46 +1168,6 @@ T concat_w(Ctx& c, T a, T b) {
   return out;
 }
 
-T rows_view(Ctx& c, T x, int n0, int n1) {
-  EG_CHECK(0 <= n0 && n0 < n1 && n1 <= x->n, "rows_view range");
-  const size_t per = x->numel() / x->n;
-  T v = new_tensor(c, n1 - n0, x->h, x->w, x->c, x->needs_grad, false);
-  v->d = x->d + (size_t)n0 * per;
-  if (x->needs_grad) {
-    EG_CHECK(!x->g_set, "rows_view: the views must be the first writers of the tensor's gradient");
-    if (!x->g) x->g = c.arena.allocf(x->numel());
-    v->g = x->g + (size_t)n0 * per;
-    c.tape.push([=]() {
-      if (v->g_set) x->g_set = true;
-    });
-  }
-  return v;
-}
-
-T concat_rows(Ctx& c, T a, T b) {
-  EG_CHECK(a->h == b->h && a->w == b->w && a->c == b->c, "concat_rows shapes");
-  T out = new_tensor(c, a->n + b->n, a->h, a->w, a->c, a->needs_grad || b->needs_grad);
-  launch_copy(a->d, out->d, a->numel(), c.stream);
-  launch_copy(b->d, out->d + a->numel(), b->numel(), c.stream);
-  if (out->needs_grad) {
-    Ctx* cp = &c;
-    c.tape.push([=]() {
-      Ctx& c = *cp;
-      if (!out->g_set) return;
-      size_t off = 0;
-      for (T in : {a, b}) {
-        if (in->needs_grad) {
-          int acc;
-          float* d = grad_acc(c, in, &acc);
-          launch_axpy(out->g + off, d, 1.f, acc, in->numel(), c.stream);
-        }
-        off += in->numel();
-      }
-    });
-  }
-  return out;
-}
-
 T slice_w(Ctx& c, T x, int w0, int w1) {
   T out = new_tensor(c, x->n, x->h, w1 - w0, x->c, false);
   launch_copy_cols(out->d, x->d, x->n, x->h, w1 - w0, x->w, w0, x->c, 0, 0, c.stream);
@@ -1395,8 +1355,6 @@ Ctx::~Ctx() {
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_gen) (void)hipEventDestroy(ev_gen);
   if (ev_g1fwd) (void)hipEventDestroy(ev_g1fwd);
-  if (ev_branch) (void)hipEventDestroy(ev_branch);
-  if (ev_cls) (void)hipEventDestroy(ev_cls);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
