@@ -227,6 +227,8 @@ T pool2(Ctx& c, T x);
 // pool2(a + b) in one pass (the MRU unit's `mean_pool(proj + h_new)`, conv.py:239-243); a and b must have no other
 // consumer: their gradients are then ONE shared buffer (both equal the up-sampled output gradient / 4)
 T add_pool2(Ctx& c, T a, T b);
+// pool2(a) + b, b at the pooled resolution and with no other consumer (its gradient IS the output's gradient buffer)
+T pool2_add(Ctx& c, T a, T b);
 T gmean(Ctx& c, T x, bool pre_relu);
 T resize(Ctx& c, T x, int size);
 T concat_w(Ctx& c, T a, T b);

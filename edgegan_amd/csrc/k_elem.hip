@@ -315,6 +315,33 @@ __global__ void add_pool2_fwd_v_kernel(const float* __restrict__ a, const float*
     reinterpret_cast<float4*>(y)[i] = r;
   }
 }
+// y = pool2(a) + b, b already at the pooled resolution (the MRU unit's output with the 1x1 projection evaluated on the
+// pooled hidden state: ops.cpp pool2_add)
+__global__ void pool2_add_fwd_v_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                       int H, int W, int C4, unsigned n4) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+    const unsigned c = i % C4;
+    unsigned t = i / C4;
+    const unsigned ox = t % Wo;
+    t /= Wo;
+    const unsigned oy = t % Ho, nb = t / Ho;
+    const float4* pa = reinterpret_cast<const float4*>(a) + ((size_t)(nb * H + 2 * oy) * W + 2 * ox) * C4 + c;
+    const size_t o1 = (size_t)W * C4, o2 = C4, o3 = (size_t)W * C4 + C4;
+    const float4 a0 = pa[0], a1 = pa[o1], a2 = pa[o2], a3 = pa[o3], q = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(y)[i] = make_float4((a0.x + a1.x + a2.x + a3.x) * 0.25f + q.x, (a0.y + a1.y + a2.y + a3.y) * 0.25f + q.y,
+                                                  (a0.z + a1.z + a2.z + a3.z) * 0.25f + q.z, (a0.w + a1.w + a2.w + a3.w) * 0.25f + q.w);
+  }
+}
+bool launch_pool2_add_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s) {
+  const size_t n = (size_t)NB * (H / 2) * (W / 2) * C;
+  if (!(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (size_t)NB * H * W * C < (1ull << 31) &&
+        ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0))
+    return false;
+  hipLaunchKernelGGL(pool2_add_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, a, b, y, H, W, C / 4,
+                     (unsigned)(n / 4));
+  return true;
+}
 bool launch_add_pool2_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s) {
   const size_t n = (size_t)NB * (H / 2) * (W / 2) * C;
   if (!(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (size_t)NB * H * W * C < (1ull << 31) &&

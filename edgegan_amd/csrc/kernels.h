@@ -238,6 +238,8 @@ void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hip
 void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s);
 // y = pool2(a + b), a/b [NB][H][W][C]; returns false (nothing launched) when the float4 form does not apply
 bool launch_add_pool2_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s);
+// y = pool2(a) + b with b [NB][H/2][W/2][C]; same return convention
+bool launch_pool2_add_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s);
 // global spatial mean: y[n][c] = mean_hw act(x[n][hw][c]) ; pre_relu applies relu first
 void launch_gmean_fwd(const float* x, float* y, int NB, int HW, int C, int pre_relu, hipStream_t s);
 void launch_gmean_bwd(const float* x, const float* dy, float* dx, int accumulate, int NB, int HW, int C,

@@ -447,8 +447,18 @@ T classifier_forward(Ctx& c, T x) {
     T c1 = conv2d(c, hin, wref_sn(c, P(c, b + "/Conv_1/weights")), P(c, b + "/Conv_1/biases"), 3, 1, PAD_SAME);
     c1 = prelu(c, c1, P(c, b + "/Conv_1/prelu/param"), 0.f);
     T c2 = conv2d(c, c1, wref_sn(c, P(c, b + "/Conv_2/weights")), P(c, b + "/Conv_2/biases"), 3, 1, PAD_SAME);
-    T proj = conv2d(c, h, wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
-    h = add_pool2(c, proj, c2);   // proj and c2 are conv outputs with no other consumer
+    // conv.py:229-243: ht_new = mean_pool(conv1x1(ht) + h_new).  The projection is a per-pixel linear map (+ bias) and the
+    // pool a per-channel mean over 2x2 pixels, so mean_pool(conv1x1(ht)) == conv1x1(mean_pool(ht)): the 1x1 convolution
+    // (forward, input gradient, filter gradient) runs on a quarter of the pixels and its full-resolution output -- as
+    // large as h_new -- is never written or read.  Same value up to fp32 summation order.
+    static const bool proj_full = dbg_env("EG_PROJ_FULL_RES") != nullptr;   // A/B: the reference's evaluation order
+    if (proj_full) {
+      T proj = conv2d(c, h, wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
+      h = add_pool2(c, proj, c2);   // proj and c2 are conv outputs with no other consumer
+    } else {
+      T proj = conv2d(c, pool2(c, h), wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
+      h = pool2_add(c, c2, proj);
+    }
     hidden = depth;
   }
   h = prelu(c, h, P(c, "D2/mru_conv_unit_last_norm/prelu/param"), 0.f);  // conv.py:353-355

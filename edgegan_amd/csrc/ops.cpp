@@ -696,6 +696,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   }
   if (need) {
     y->needs_grad = true;
+    y->g_inplace = fused;
     Ctx* cp = &c;
     const size_t rows = y->pixels();
     c.tape.push([=]() {
@@ -978,14 +979,23 @@ T add(Ctx& c, T a, T b, bool relu) {
     c.tape.push([=]() {
       Ctx& c = *cp;
       if (!out->g_set) return;
+      // d(a) = d(b) (= d(out) masked by the ReLU): computed once; inputs whose gradient is still unset share the buffer
+      float* shared = nullptr;
       for (T in : {a, b}) {
         if (!in->needs_grad) continue;
+        if (!in->g_set && !in->g && shared && !in->g_inplace) {
+          in->g = shared;
+          in->g_set = true;
+          continue;
+        }
+        const bool fresh = !in->g_set && !in->g;
         int acc;
         float* d = grad_acc(c, in, &acc);
         if (relu)
           launch_act_bwd(out->d, out->g, d, acc, in->numel(), ACT_RELU, c.stream);
         else
           launch_axpy(out->g, d, 1.f, acc, in->numel(), c.stream);
+        if (fresh && !shared && !in->g_inplace) shared = d;
       }
     });
   }
@@ -1040,6 +1050,39 @@ T add_pool2(Ctx& c, T a, T b) {
           float* d = grad_acc(c, in, &acc);
           launch_pool2_bwd(out->g, d, acc, in->n, in->h, in->w, in->c, c.stream);
         }
+      }
+    });
+  }
+  return out;
+}
+
+T pool2_add(Ctx& c, T a, T b) {
+  EG_CHECK(a->h % 2 == 0 && a->w % 2 == 0, "pool2_add needs even extents");
+  EG_CHECK(a->n == b->n && a->h == 2 * b->h && a->w == 2 * b->w && a->c == b->c, "pool2_add shapes");
+  T out = new_tensor(c, b->n, b->h, b->w, b->c, a->needs_grad || b->needs_grad);
+  if (!launch_pool2_add_fwd(a->d, b->d, out->d, a->n, a->h, a->w, a->c, c.stream)) {
+    launch_pool2_fwd(a->d, out->d, a->n, a->h, a->w, a->c, c.stream);
+    launch_axpy(b->d, out->d, 1.f, 1, out->numel(), c.stream);
+  }
+  if (out->needs_grad) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      if (b->needs_grad) {
+        if (!b->g_set && !b->g && !b->g_inplace) {   // d(b) = d(out): the one buffer serves both
+          b->g = out->g;
+          b->g_set = true;
+        } else {
+          int acc;
+          float* d = grad_acc(c, b, &acc);
+          launch_axpy(out->g, d, 1.f, acc, b->numel(), c.stream);
+        }
+      }
+      if (a->needs_grad) {
+        int acc;
+        float* d = grad_acc(c, a, &acc);
+        launch_pool2_bwd(out->g, d, acc, a->n, a->h, a->w, a->c, c.stream);
       }
     });
   }
