@@ -125,6 +125,7 @@ struct Tensor {
   int n = 0, h = 1, w = 1, c = 0;
   bool needs_grad = false;
   bool g_set = false;
+  bool leaf_grad = false;   // gradient chain of this tensor runs on the lane's leaf stream (classifier's image pyramid: ops.cpp)
   bool g_inplace = false;   // the producer's backward rewrites g in place (conv + fused activation): g must not be shared
   // forward-only convolution outputs left as their K-split slabs for the InstanceNorm pass that is their only reader
   // (ops.cpp: conv2d / deconv2d with Ctx::feeds_in, in_act): d is then NOT written

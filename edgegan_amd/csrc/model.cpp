@@ -399,6 +399,12 @@ T classifier_forward(Ctx& c, T x) {
   T level[4];
   level[0] = x;
   for (int i = 1; i < 4; ++i) level[i] = pool2(c, level[i - 1]);
+  // Gradients towards the 3-channel pyramid (sub-steps 5 / 7 only: d(loss)/d(G2(z))) are leaves of the hidden-state chain:
+  // every producer -- the image convolutions' and gate image rows' input gradients, the pyramid's pool backward -- runs
+  // on the lane's leaf stream, in tape order, and the chain  dgrad -> PReLU / gate backward -> dgrad  does not wait for
+  // these thin, HBM-bound launches
+  if (x->needs_grad)
+    for (int i = 0; i < 4; ++i) level[i]->leaf_grad = true;
   T h = conv2d(c, x, wref_sn(c, P(c, "D2/Conv/weights")), P(c, "D2/Conv/biases"), 7, 1, PAD_SAME);
   h = prelu(c, h, P(c, "D2/Conv/prelu/param"), 0.f);
   int hidden = 8;

@@ -709,7 +709,14 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
           conv_wgrad(c, x->d, x->n, x->h, x->w, Cin, y->g, OH, OW, N, w, k, stride, pt, pad == PAD_REFLECT);
         if (bias && bias->want_grad) bias_grad(c, bias, y->g, rows, N);
       }
-      if (x->needs_grad) conv_dgrad(c, x, y, w, k, stride, pad, pt, pl);
+      if (x->needs_grad) {
+        if (x->leaf_grad) {   // gradient towards a leaf-side tensor (the classifier's image pyramid): off the dependent chain
+          LeafScope leaf(c);
+          conv_dgrad(c, x, y, w, k, stride, pad, pt, pl);
+        } else {
+          conv_dgrad(c, x, y, w, k, stride, pad, pt, pl);
+        }
+      }
     });
   }
   if (fused_act && !fused) return act(c, y, fused_act);
@@ -1014,7 +1021,12 @@ T pool2(Ctx& c, T x) {
       if (!out->g_set) return;
       int acc;
       float* dx = grad_acc(c, x, &acc);
-      launch_pool2_bwd(out->g, dx, acc, x->n, x->h, x->w, x->c, c.stream);
+      if (x->leaf_grad) {   // (its producers ran on the leaf stream: the pyramid's whole gradient chain stays there, in order)
+        LeafScope leaf(c);
+        launch_pool2_bwd(out->g, dx, acc, x->n, x->h, x->w, x->c, c.stream);
+      } else {
+        launch_pool2_bwd(out->g, dx, acc, x->n, x->h, x->w, x->c, c.stream);
+      }
     });
   }
   return out;

@@ -286,9 +286,22 @@ def norm(x: Tensor, kind: Optional[str]) -> Tensor:
     return x
 
 
+# Test instrumentation (tests/test_tight_gpu.py): when a dict, every PReLU records sum_i |t_i| of the per-element terms
+# t_i = dL/d(leak) contributed by element i (the slope's gradient is sum_i t_i) under id(leak) -- the conditioning
+# sum|t| / |sum t| of that scalar sum, which is what a relative tolerance on it has to be scaled by.
+_SLOPE_TERMS = None
+
+
 def prelu(x: Tensor, leak: Tensor) -> Tensor:
     """activation.py:23-27: tf.maximum(leak*x, x), scalar learnable `param` (init 0.2)."""
     _kink('prelu/nchw', x)
+    if _SLOPE_TERMS is not None and leak.requires_grad:
+        le = leak * torch.ones_like(x)       # same value per element; its gradient holds the terms t_i
+
+        def _rec(g, key=id(leak)):
+            _SLOPE_TERMS[key] = _SLOPE_TERMS.get(key, 0.0) + float(g.abs().sum())
+        le.register_hook(_rec)
+        return torch.maximum(le * x, x)
     return torch.maximum(leak * x, x)
 
 
@@ -857,6 +870,8 @@ class OracleModel:
             for n, g in zip(names, gs):
                 if g is not None:                    # None => variable skipped by minimize (N4, N8)
                     grads[n] = g.detach()
+        if _SLOPE_TERMS is not None:                 # (instrumentation) slope name -> sum_i |t_i|
+            self.last_slope_l1 = {n: _SLOPE_TERMS[id(t)] for n, t in p.items() if id(t) in _SLOPE_TERMS}
         self._last_bn = bn
         return grads, {k: v.detach() for k, v in losses.items() if v.dim() == 0}
 

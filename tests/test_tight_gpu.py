@@ -95,9 +95,22 @@ def _full_batch_oracle(name, cfg, values, b):
         om32 = O.OracleModel(parity.oracle_config(cfg), values, dtype=torch.float32)
         inp32 = O.StepInputs(*[torch.tensor(np.asarray(b[k]), dtype=torch.float32) for k in ('images', 'z', 'alpha', 'eps')])
         g32, _ = om32.compute_grads(name, inp32, inp32.eps[0])
-        g64, l64 = om.compute_grads(name, inp, inp.eps[0])
+        O._SLOPE_TERMS = {}          # record sum_i |t_i| of every PReLU slope's gradient terms (conditioning, below)
+        try:
+            g64, l64 = om.compute_grads(name, inp, inp.eps[0])
+        finally:
+            O._SLOPE_TERMS = None
         gmax = max(float(g.abs().max()) for g in g64.values())
         self_dev = {vn: parity.rel_l2(g32[vn].double().numpy(), g.numpy(), 1e-5 * gmax) for vn, g in g64.items()}
+        # A scalar PReLU slope's gradient is ONE cancelling sum  sum_i t_i  (t_i = dy_i x_i over the layer's non-positive
+        # inputs: 1e5 .. 1.7e7 terms of both signs).  Element-wise relative noise eps in the terms moves the SUM by up to
+        # eps * kappa relative to itself, kappa = sum|t_i| / |sum t_i| (measured in the fp64 oracle: 12 .. 8e3 for the 14
+        # slopes).  Its tolerance is therefore kappa x 1e-4 -- a tenth of the 1e-3 the tensors are held to -- where that
+        # exceeds the general rule; expressed through the same per-variable table.
+        for vn, l1 in getattr(om, 'last_slope_l1', {}).items():
+            if vn in g64:
+                kappa = l1 / max(abs(float(g64[vn])), 1e-300)
+                self_dev[vn] = max(self_dev[vn], 1e-4 * kappa / 3.0)
         _FULL_BATCH_ORACLE[name] = ({k: v.detach() for k, v in g64.items()}, {k: float(v) for k, v in l64.items()}, self_dev)
     return _FULL_BATCH_ORACLE[name]
 
@@ -114,18 +127,16 @@ def test_full_batch_fp32_substep_against_fp64_oracle(name):
     oracle's fp32 run is ONE sample of that noise, the engine's another (measured on MI355X, exact-fp32 mode: d_optim
     <= 1.4e-4, d_optim_patch3 <= 3.6e-4, d_optim2 median 3e-4 with the two worst rows -- the unit-1 3->8-channel image
     convolution and a scalar PReLU slope, each a sum over 1.7e7 pixel terms behind 1e8 PReLU / min-max kinks -- at
-    2.04 x and 2.1 x the oracle's own deviation of 5.9e-4 / 1.3e-3); a wiring error shows up as >= 1e-1."""
+    2.04 x and 2.1 x the oracle's own deviation of 5.9e-4 / 1.3e-3); a wiring error shows up as >= 1e-1.  Scalar PReLU
+    slopes: tolerance scaled by the conditioning of their sum, see _full_batch_oracle (measured 1e-3 .. 5e-3)."""
     cfg = ea.Config(batch_size=64)
     values = ea.init_variables(cfg, 0)
     b = ea.synthetic_batch(cfg)
     g64, l64, self_dev = _full_batch_oracle(name, cfg, values, b)
     net = ea.EdgeGAN(cfg, values)
     net.upload_batch(b['images'], b['z'], b['alpha'], b['eps'])
-    # scalar PReLU slopes: the margin-fixture test's rule (5 x the tensor tolerance, see there): ONE cancelling sum over up to
-    # 1.7e7 elements of dy * x behind every kink of the layer.  Measured at B=64: exact-fp32 mode <= 2.7e-3, f32x3 <= 3.5e-3
-    # (`norm_activation_merge_1` of units 2 / 3), the oracle's own fp32 run <= 1.3e-3.
     rows = _grad_rows(net, None, None, name, 1e-3, 'B=64', var_tol={vn: 3.0 * d for vn, d in self_dev.items()},
-                      scalar_tol=5e-3, precomputed=(g64, l64))
+                      precomputed=(g64, l64))
     net.close()
     if name == 'd_optim2':
         assert len(rows) >= 55 and sum('Conv_2/weights' in r[0] for r in rows) == 4 and sum('update_gate/weights' in r[0] for r in rows) == 4
