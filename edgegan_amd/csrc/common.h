@@ -146,7 +146,7 @@ struct LimbCache {
   int planes = 0;
   hipEvent_t ready = nullptr;
   hipStream_t built_on = nullptr;
-  unsigned waited = 0;   // bit per lane that has already ordered itself behind `ready`
+  unsigned waited = 0;   // bit per stream (ops.cpp: stream_bit) that has already ordered itself behind `ready`
   // what the planes are built from (set at the first build): the batched rebuild (ops.cpp: limb_planes) refreshes every
   // stale cache of the same domain (network group / the spectral-norm weights) in one launch
   const float* src = nullptr;

@@ -72,7 +72,13 @@ struct HaloGeom {
   int pitch;               // LDS row pitch of a halo row: 20 for 16-wide tiles (conflict-free layout), 0 = dense rows
 };
 
-template <int NPROD, bool SPLITK, int BN, bool SW16>
+// S2D: a 4x4 stride-2 SAME convolution (the discriminators' forward layers) as a 2x2-tap STRIDE-1 convolution over the
+// space-to-depth view V[Y][X][(py, px, c)] = x[2Y + py - 1][2X + px - 1][c] of its input: y[oy][ox] = sum over dY, dX in
+// {0, 1}, (py, px, c) of V[oy + dY][ox + dX][(py, px, c)] w[2 dY + py][2 dX + px][c].  V is never materialised: a K chunk
+// of 32 channels lies inside ONE phase (py, px), so staging chunk (q = 2 py + px, cq) reads the halo pixels' phase-(py, px)
+// source pixels straight from x (per-row base offset + a uniform phase offset, per-row validity of the 4 phases), and
+// the chunk's filter tiles are those of taps (2 dY + py, 2 dX + px).  The halo image is shared by 4 taps (9 at 3x3).
+template <int NPROD, bool SPLITK, int BN, bool SW16, bool S2D = false>
 __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a, const HaloGeom g) {
   constexpr int NL = NPROD == 1 ? 1 : 3;
   constexpr int NSB = 3;
@@ -92,7 +98,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   const int zphase = SPLITK ? (int)blockIdx.z / a.ksplit : (int)blockIdx.z;
   const int zsplit = SPLITK ? (int)blockIdx.z - zphase * a.ksplit : 0;
   const ConvPhase ph = a.ph[zphase];
-  const int IH = a.IH, IW = a.IW, C = a.C, N = a.N, D = a.D;
+  const int IH = a.IH, IW = a.IW, C = a.C, N = a.N, D = S2D ? 1 : a.D;
+  const int nTy = S2D ? 2 : ph.Ty, nTx = S2D ? 2 : ph.Tx;   // taps the K loop walks
   const int TW = 1 << g.lTW, TH = 1 << g.lTH;
   // tile position
   const int tpi = g.tiles_x * g.tiles_y;
@@ -101,8 +108,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   const int img0 = tn * g.TI, oy0 = tyy * TH, ox0 = txx * TW;
   const int n0 = blockIdx.y * BN;
   // halo geometry of this phase (stride 1): input pixel of output (oy, ox), tap (ty, tx) = (oy + ty D + offy, ox + tx D + offx)
-  const int dminy = min(ph.offy, (ph.Ty - 1) * D + ph.offy), dminx = min(ph.offx, (ph.Tx - 1) * D + ph.offx);
-  const int HH = TH + ph.Ty - 1, HW = TW + ph.Tx - 1, HU = g.TI * HH * HW;   // HU staged halo pixels
+  const int offy = S2D ? 0 : ph.offy, offx = S2D ? 0 : ph.offx;   // (S2D: ph.off* is the source offset of phase 0, below)
+  const int dminy = min(offy, (nTy - 1) * D + offy), dminx = min(offx, (nTx - 1) * D + offx);
+  const int HH = TH + nTy - 1, HW = TW + nTx - 1, HU = g.TI * HH * HW;   // HU staged halo pixels
   // LDS image: pixel (ti, hy, hx) lives in row ti HPI + hy HWP + hx.  16-wide tiles: pitch 20 (a multiple of 4, so a row's
   // bank quarter is hx mod 4) with the 16-byte chunk swizzled by (hx >> 2) & 3 -- the four rows of a ds_read_b128 lane
   // group that share a bank quarter are hx = h, h + 12 (one tile row) and h + 4, h + 8 (the next one): four different
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   // ---- staging: thread -> (halo row, channel quad) units u = tid + 512 j; global byte offsets are per block constants ---
   const int c4 = tid & 7;
   unsigned goff[NA];
-  int srow[NA];    // LDS row of the unit (-1: none), bits 16..17: its chunk swizzle
+  int srow[NA];    // LDS row of the unit (-1: none), bits 16..17: its chunk swizzle; S2D: bits 20..23 = source row / column of phase py = 0, 1 / px = 0, 1 inside the image
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int u = (tid + 512 * j) >> 3;
@@ -123,14 +131,23 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
       const int ti = u / (HH * HW), rem = u - ti * (HH * HW);
       const int hy = rem / HW, hx = rem - hy * HW;
       int iy = oy0 + dminy + hy, ix = ox0 + dminx + hx;
-      if (a.reflect) {
-        iy = reflect_h(iy, IH);
-        ix = reflect_h(ix, IW);
-      }
-      if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW)
+      int vbits = 0;
+      if constexpr (S2D) {   // source pixel of phase (0, 0); the offset may be "negative" (wraps; only used where valid)
+        iy = 2 * iy + ph.offy;
+        ix = 2 * ix + ph.offx;
         off = (unsigned)(((((img0 + ti) * IH + iy) * IW + ix) * a.x_ps + c4 * 4) * 4);
+        vbits = ((unsigned)iy < (unsigned)IH ? 1 : 0) | ((unsigned)(iy + 1) < (unsigned)IH ? 2 : 0) |
+                ((unsigned)ix < (unsigned)IW ? 4 : 0) | ((unsigned)(ix + 1) < (unsigned)IW ? 8 : 0);
+      } else {
+        if (a.reflect) {
+          iy = reflect_h(iy, IH);
+          ix = reflect_h(ix, IW);
+        }
+        if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW)
+          off = (unsigned)(((((img0 + ti) * IH + iy) * IW + ix) * a.x_ps + c4 * 4) * 4);
+      }
       const int row = ti * HPI + hy * HWP + hx;
-      srow[j] = row | ((sw16 ? (hx >> 2) & 3 : swz_h(row)) << 16);
+      srow[j] = row | ((sw16 ? (hx >> 2) & 3 : swz_h(row)) << 16) | (vbits << 20);
     }
     goff[j] = off;
   }
@@ -138,17 +155,28 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   const __amdgpu_buffer_rsrc_t wres =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wgt_bf), 0, a.wbf_bytes, 0x00020000);
   f32x4 ra[NA];
+  const int cpt = C / 32;
   auto load_halo = [&](int cc) __attribute__((always_inline)) {
+    if constexpr (S2D) {
+      const int q = cc / cpt, cq = cc - q * cpt, py = q >> 1, px = q & 1;   // (uniform: once per chunk = per 4 K steps)
+      const unsigned soff = (unsigned)((((py * IW + px) * a.x_ps) + cq * 32) * 4);
 #pragma unroll
-    for (int j = 0; j < NA; ++j)
-      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, goff[j], cc * 128, 0));
+      for (int j = 0; j < NA; ++j) {
+        const bool ok = ((srow[j] >> (20 + py)) & (srow[j] >> (22 + px)) & 1) != 0 && srow[j] >= 0;
+        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? goff[j] + soff : 0x80000000u, 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NA; ++j)
+        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, goff[j], cc * 128, 0));
+    }
   };
   auto store_halo = [&]() __attribute__((always_inline)) {
     if constexpr ((EG_X3H_DBG & 2) != 0) return;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       if (srow[j] >= 0) {
-        const int o = (srow[j] & 0xffff) * 32 + (((c4 >> 1) ^ (srow[j] >> 16)) * 8) + (c4 & 1) * 4;
+        const int o = (srow[j] & 0xffff) * 32 + (((c4 >> 1) ^ ((srow[j] >> 16) & 3)) * 8) + (c4 & 1) * 4;
         if constexpr (NL == 1) {
           *reinterpret_cast<u32x2*>(&Ah[0][o]) = (u32x2){pack2h(ra[j][0], ra[j][1]), pack2h(ra[j][2], ra[j][3])};
         } else {
@@ -167,18 +195,22 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   const int lsw = (((-((lane >> 4) & 3)) & 3) ^ (wave & 1));   // swz(wave*16 + lane/4)
   const unsigned woff = (unsigned)(((size_t)min(n0 + wave * 16 + (lane >> 2), N - 1) * 32 + ((lane & 3) ^ lsw) * 8) * 2);
   const int plane_bytes = (int)(a.wbf_plane * 2);
-  const int cpt = C / 32, ntaps = ph.Ty * ph.Tx;
+  const int ntaps = nTy * nTx;
+  const int vcpt = S2D ? 4 * cpt : cpt;   // K chunks the loop walks (S2D: 4 phases x C / 32)
   const int wtile = N * 32 * 2;
-  int cc_lo = 0, cc_hi = cpt;
+  int cc_lo = 0, cc_hi = vcpt;
   if constexpr (SPLITK) {
-    const int per = (cpt + a.ksplit - 1) / a.ksplit;
-    cc_lo = min(cpt, zsplit * per);
-    cc_hi = min(cpt, cc_lo + per);
+    const int per = (vcpt + a.ksplit - 1) / a.ksplit;
+    cc_lo = min(vcpt, zsplit * per);
+    cc_hi = min(vcpt, cc_lo + per);
   }
   const int ncc = cc_hi - cc_lo, nt = ncc * ntaps;
   int rq_cc = cc_lo, rq_ty = 0, rq_tx = 0, rq_slot = 0;   // next filter tile to request
+  [[maybe_unused]] int rq_q = S2D ? cc_lo / cpt : 0;      // S2D: phase and channel chunk of K chunk rq_cc
+  [[maybe_unused]] int rq_cq = S2D ? cc_lo - rq_q * cpt : 0;
   auto request_b = [&]() __attribute__((always_inline)) {
-    const int wsoff = (((ph.kh0 + rq_ty * a.kst) * a.KW + (ph.kw0 + rq_tx * a.kst)) * cpt + rq_cc) * wtile;
+    const int wsoff = S2D ? (((2 * rq_ty + (rq_q >> 1)) * a.KW + (2 * rq_tx + (rq_q & 1))) * cpt + rq_cq) * wtile
+                          : (((ph.kh0 + rq_ty * a.kst) * a.KW + (ph.kw0 + rq_tx * a.kst)) * cpt + rq_cc) * wtile;
     if (issuer && (EG_X3H_DBG & 4) == 0) {
 #pragma unroll
       for (int p = 0; p < NL; ++p)
@@ -187,12 +219,18 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
     }
     rq_slot = rq_slot == NSB - 1 ? 0 : rq_slot + 1;
     rq_tx += 1;
-    const bool wx = rq_tx == ph.Tx;
+    const bool wx = rq_tx == nTx;
     rq_tx = wx ? 0 : rq_tx;
     rq_ty += wx ? 1 : 0;
-    const bool wy = rq_ty == ph.Ty;
+    const bool wy = rq_ty == nTy;
     rq_ty = wy ? 0 : rq_ty;
     rq_cc += wy ? 1 : 0;
+    if constexpr (S2D) {
+      rq_cq += wy ? 1 : 0;
+      const bool wc = rq_cq == cpt;
+      rq_cq = wc ? 0 : rq_cq;
+      rq_q += wc ? 1 : 0;
+    }
   };
 
   // ---- fragments --------------------------------------------------------------------------------------------------------
@@ -258,8 +296,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   [[maybe_unused]] constexpr std::integral_constant<int, 2> P2{};
   // fragment addresses of a tap: halo row of the lane's output pixel + the tap's row offset, chunk swizzled by that row
   auto tap_addr = [&](int ty, int tx, unsigned (&aa)[MI]) __attribute__((always_inline)) {
-    const int dxx = tx * D + ph.offx - dminx;
-    const int toff = (ty * D + ph.offy - dminy) * HWP + dxx;
+    const int dxx = tx * D + offx - dminx;
+    const int toff = (ty * D + offy - dminy) * HWP + dxx;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int row = (EG_X3H_DBG & 16) ? (lane & 31) : base_row[i] + toff;
@@ -319,7 +357,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
       }
       // next tap's position
       tx += 1;
-      const bool wx = tx == ph.Tx;
+      const bool wx = tx == nTx;
       tx = wx ? 0 : tx;
       ty += wx ? 1 : 0;
       if constexpr (NPROD == 1) {
@@ -433,7 +471,16 @@ static int ilog2h(int v) {
   return l;
 }
 
-static bool x3h_geometry(const ConvArgs& a, HaloGeom* g) {
+static bool x3h_s2d_shape(const ConvArgs& a) {   // 4x4 stride-2 SAME forward convolution (one phase, taps as stored)
+  const ConvPhase& p = a.ph[0];
+  return a.S == 2 && a.nphase == 1 && a.KW == 4 && p.Ty == 4 && p.Tx == 4 && a.kst == 1 && a.D == 1 && a.os == 1 && p.kh0 == 0 &&
+         p.kw0 == 0 && p.offy == -1 && p.offx == -1 && p.ophy == 0 && p.ophx == 0 && !a.reflect && a.IH == 2 * p.OHp &&
+         a.IW == 2 * p.OWp;
+}
+
+static bool x3h_geometry(const ConvArgs& a_in, HaloGeom* g) {
+  ConvArgs a = a_in;
+  if (x3h_s2d_shape(a)) a.ph[0].Ty = a.ph[0].Tx = 2;   // the halo is that of the 2x2-tap space-to-depth form
   const int OH = a.ph[0].OHp, OW = a.ph[0].OWp;
   for (int p = 0; p < a.nphase; ++p)
     if (a.ph[p].OHp != OH || a.ph[p].OWp != OW) return false;
@@ -464,36 +511,44 @@ static bool x3h_geometry(const ConvArgs& a, HaloGeom* g) {
 bool conv_x3h_eligible(const ConvArgs& a) {
   static const bool off = dbg_env("EG_NO_HALO") != nullptr;
   if (off || !a.wgt_bf || !(a.limbs == 3 || a.limbs == 1) || a.shuf) return false;
-  if (a.S != 1 || !(a.D == 1 || a.D == -1) || a.C % 32 != 0 || a.N < 64 || a.N % 4 != 0) return false;
+  static const bool no_s2d = dbg_env("EG_NO_S2D") != nullptr;
+  const bool s2d = x3h_s2d_shape(a) && !no_s2d;
+  if (!(a.S == 1 || s2d) || !(a.D == 1 || a.D == -1) || a.C % 32 != 0 || a.N < 64 || a.N % 4 != 0) return false;
   if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || !a.x_bytes || !a.wbf_bytes || a.wbf_plane % 8 != 0) return false;
   if ((((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.wgt_bf) & 15) != 0 || (a.bias && (((uintptr_t)a.bias) & 15) != 0)) return false;
-  if (a.ksplit > 1 && a.ksplit > a.C / 32) return false;
+  if (a.ksplit > 1 && a.ksplit > (s2d ? 4 : 1) * (a.C / 32)) return false;
   HaloGeom g;
   return x3h_geometry(a, &g);
+}
+
+template <int NPROD, int BN, bool S2D>
+static void x3h_launch_variant(const ConvArgs& a, const HaloGeom& g, dim3 grid, hipStream_t s) {
+  if (g.pitch) {
+    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<NPROD, true, BN, true, S2D>), grid, dim3(512), 0, s, a, g);
+    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<NPROD, false, BN, true, S2D>), grid, dim3(512), 0, s, a, g);
+  } else {
+    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<NPROD, true, BN, false, S2D>), grid, dim3(512), 0, s, a, g);
+    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<NPROD, false, BN, false, S2D>), grid, dim3(512), 0, s, a, g);
+  }
 }
 
 template <int BN>
 static const char* x3h_launch(const ConvArgs& a, const HaloGeom& g, hipStream_t s) {
   const int zs = a.ksplit > 1 ? a.ksplit : 1;
   dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, (a.N + BN - 1) / BN, a.nphase * zs);
+  const bool s2d = x3h_s2d_shape(a);
   if (a.limbs == 1) {
-    if (g.pitch) {
-      if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, true, BN, true>), grid, dim3(512), 0, s, a, g);
-      else hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, false, BN, true>), grid, dim3(512), 0, s, a, g);
-    } else {
-      if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, true, BN, false>), grid, dim3(512), 0, s, a, g);
-      else hipLaunchKernelGGL((conv_gemm_x3h_kernel<1, false, BN, false>), grid, dim3(512), 0, s, a, g);
-    }
+    if (s2d) x3h_launch_variant<1, BN, true>(a, g, grid, s);
+    else x3h_launch_variant<1, BN, false>(a, g, grid, s);
+    if (s2d) return BN == 128 ? (a.ksplit > 1 ? "conv_gemm_bf16h<256,128,s2d,splitk>" : "conv_gemm_bf16h<256,128,s2d>")
+                              : (a.ksplit > 1 ? "conv_gemm_bf16h<256,64,s2d,splitk>" : "conv_gemm_bf16h<256,64,s2d>");
     return BN == 128 ? (a.ksplit > 1 ? "conv_gemm_bf16h<256,128,splitk>" : "conv_gemm_bf16h<256,128>")
                      : (a.ksplit > 1 ? "conv_gemm_bf16h<256,64,splitk>" : "conv_gemm_bf16h<256,64>");
   }
-  if (g.pitch) {
-    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, true, BN, true>), grid, dim3(512), 0, s, a, g);
-    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, false, BN, true>), grid, dim3(512), 0, s, a, g);
-  } else {
-    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, true, BN, false>), grid, dim3(512), 0, s, a, g);
-    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<6, false, BN, false>), grid, dim3(512), 0, s, a, g);
-  }
+  if (s2d) x3h_launch_variant<6, BN, true>(a, g, grid, s);
+  else x3h_launch_variant<6, BN, false>(a, g, grid, s);
+  if (s2d) return BN == 128 ? (a.ksplit > 1 ? "conv_gemm_x3h<256,128,s2d,splitk>" : "conv_gemm_x3h<256,128,s2d>")
+                            : (a.ksplit > 1 ? "conv_gemm_x3h<256,64,s2d,splitk>" : "conv_gemm_x3h<256,64,s2d>");
   return BN == 128 ? (a.ksplit > 1 ? "conv_gemm_x3h<256,128,splitk>" : "conv_gemm_x3h<256,128>")
                    : (a.ksplit > 1 ? "conv_gemm_x3h<256,64,splitk>" : "conv_gemm_x3h<256,64>");
 }

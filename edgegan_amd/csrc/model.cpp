@@ -274,6 +274,7 @@ void build_context(Ctx& c) {
   EG_HIP(hipEventCreateWithFlags(&c.ev_gen, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_g1fwd, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_branch, hipEventDisableTiming));
+  EG_HIP(hipEventCreateWithFlags(&c.ev_cls, hipEventDisableTiming));
   if (const char* e = getenv("EG_LANES")) {   // 0 = one stream; bit 0 = sub-steps 1-4 concurrent, bit 1 = 6/7 concurrent, bit 2 = the critics of 5 / 7 on four lanes, bit 3 = filter / bias gradients on the lanes' leaf streams
     c.lanes_mask = atoi(e);
     c.lanes_on = c.lanes_mask != 0;
@@ -459,9 +460,12 @@ T classifier_forward(Ctx& c, T x) {
     // large as h_new -- is never written or read.  Same value up to fp32 summation order.
     static const bool proj_full = dbg_env("EG_PROJ_FULL_RES") != nullptr;   // A/B: the reference's evaluation order
     if (proj_full) {
-      T proj = conv2d(c, h, wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
-      h = add_pool2(c, proj, c2);   // proj and c2 are conv outputs with no other consumer
+      T pf = conv2d(c, h, wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
+      h = add_pool2(c, pf, c2);   // pf and c2 are conv outputs with no other consumer
     } else {
+      // (measured and not kept: this projection and the image convolution above on the leaf stream beside the gate chain
+      //  -- 1,530 -> 1,476 images/s, profiles/r03f_ab_forward_leaves_negative.txt: thin persistent kernels beside the
+      //  one-block-per-CU matrix kernels of the same chain take CUs from them)
       T proj = conv2d(c, pool2(c, h), wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
       h = pool2_add(c, c2, proj);
     }
@@ -680,22 +684,32 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       set_want_grad(c, G_G1, true);
       set_want_grad(c, G_G2, true);
       T zin = make_zin(c);
-      T edge = generator_forward(c, G_G1, zin, bn1);
+      // G2 first: the classifier branch -- the longest of the four critics, and with sub-step 4 in front of it the
+      // iteration's critical chain -- reads G2(z) only, so with branch lanes it forks off right behind G2's forward
+      // (ev_cls) while G1's forward, the concat and the resizes are still being computed on lane 0
+      const bool bl = opts && opts->branch_lanes && c.cur_lane == 0;
+      const size_t mg2 = c.tape.ops.size();
       T image = generator_forward(c, G_G2, zin, bn2);
+      if (bl) EG_HIP(hipEventRecord(c.ev_cls, c.stream));
+      const size_t mg1 = c.tape.ops.size();
+      T edge = generator_forward(c, G_G1, zin, bn1);
+      const size_t mcat = c.tape.ops.size();   // concat: entries mcat (edge's part), mcat + 1 (image's part)
       T joint = concat_w(c, edge, image);
-      T r_edge = resize(c, edge, cfg.dis_size), r_image = resize(c, image, cfg.dis_size);
+      const size_t mre = c.tape.ops.size();
+      T r_edge = resize(c, edge, cfg.dis_size);
+      const size_t mri = c.tape.ops.size();
+      T r_image = resize(c, image, cfg.dis_size);
       // The four critics are independent given the generator outputs (each writes the gradient of its OWN input tensor;
       // `image`'s gradient gets the classifier's contributions first, then -- after the join -- the resize's and the
       // concat's, the order of the single-stream sweep).  With branch lanes each runs forward and backward on the lane that
-      // trained it, directly behind that sub-step; the generators' backward waits for all four.
-      const bool bl = opts && opts->branch_lanes && c.cur_lane == 0;
+      // trained it, directly behind that sub-step.
       const size_t m0 = c.tape.ops.size();
       if (bl) EG_HIP(hipEventRecord(c.ev_branch, c.stream));
-      auto enter = [&](int lane) {
+      auto enter = [&](int lane, hipEvent_t after) {
         if (!bl || lane == 0) return;
         use_lane(c, lane);
         c.arena.reset();   // (this lane's previous sub-step is fully enqueued; stream order protects its memory)
-        EG_HIP(hipStreamWaitEvent(c.stream, c.ev_branch, 0));
+        EG_HIP(hipStreamWaitEvent(c.stream, after, 0));
       };
       await_group(G_D);
       T dj = disc_forward(c, G_D, joint, nullptr, nullptr);
@@ -703,14 +717,14 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       seed_grad(c, dj);
       launch_fill(dj->g, -cfg.joint_dweight / B, B, c.stream);
       const size_t m1 = c.tape.ops.size();
-      enter(2);
+      enter(2, c.ev_branch);
       await_group(G_DP3);
       T de = disc_forward(c, G_DP3, r_edge, nullptr, nullptr);
       launch_mean_neg(de->d, c.d_losses + L_EDGE_G, B, c.stream);
       seed_grad(c, de);
       launch_fill(de->g, -cfg.edge_dweight / B, B, c.stream);
       const size_t m2 = c.tape.ops.size();
-      enter(1);
+      enter(1, c.ev_branch);
       await_group(G_DP2);
       T di = disc_forward(c, G_DP2, r_image, nullptr, nullptr);
       launch_mean_neg(di->d, c.d_losses + L_IMAGE_G, B, c.stream);
@@ -718,7 +732,7 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       launch_fill(di->g, -cfg.image_dweight / B, B, c.stream);
       const size_t m3 = c.tape.ops.size();
       if (cfg.multiclasses()) {
-        enter(3);
+        enter(3, c.ev_cls);
         await_group(G_D2);
         T lf = classifier_forward(c, image);
         seed_grad(c, lf);
@@ -744,9 +758,19 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
         sweep(1, m2, m3);
         sweep(2, m1, m2);
         sweep(0, m0, m1);
-        for (int i = 1; i < 4; ++i)
-          if (i != 3 || m4 > m3) EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[i].done, 0));
-        c.tape.backward_range(0, m0);
+        // G1's side needs the joint (lane 0) and the edge (lane 2) discriminators only: d(edge) = resize backward, then the
+        // concat's edge columns -- the per-buffer order of the single-stream sweep -- and G1's backward chain run while
+        // the classifier branch is still busy.  G2's side follows once the image discriminator and the classifier are in.
+        EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[2].done, 0));
+        c.tape.backward_range(mre, mri);          // resize(edge)
+        c.tape.backward_range(mcat, mcat + 1);    // concat: edge columns
+        c.tape.backward_range(mg1, mcat);         // G1
+        EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[1].done, 0));
+        if (m4 > m3) EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[3].done, 0));
+        c.tape.backward_range(mri, m0);           // resize(image)
+        c.tape.backward_range(mcat + 1, mre);     // concat: image columns
+        c.tape.backward_range(mg2, mg1);          // G2
+        c.tape.backward_range(0, mg2);
       }
       if (apply) {
         before_apply();

@@ -79,6 +79,8 @@ static void run_deferred(Ctx& c, hipStream_t s) {
 // reductions follow them on the leaf stream; flush_deferred -- called exactly where a parameter gradient is read on the
 // main stream -- orders the main stream behind everything the leaf stream holds.  Same kernels, same per-buffer order
 // (all writers of one filter gradient are on the one leaf stream): bitwise the results of the one-stream schedule.
+// one bit per stream the context enqueues on: lanes' main streams 0 .., their leaf streams 16 ..
+static unsigned stream_bit(Ctx& c) { return 1u << (c.stream == c.lanes[c.cur_lane].stream ? c.cur_lane : 16 + c.cur_lane); }
 static bool leaf_active(Ctx& c) { return c.leaf_on && c.lanes_on && c.defer_on && !c.prof_on && c.lanes[c.cur_lane].leaf; }
 struct LeafScope {
   Ctx& c;
@@ -356,11 +358,10 @@ static unsigned short* limb_planes(Ctx& c, WRef* w, bool transposed, int nplanes
       }
       flush();
       for (LimbCache* q : built) EG_HIP(hipEventRecord(q->ready, c.stream));
-    } else if (lc->built_on != c.stream && !(lc->waited & (1u << c.cur_lane))) {
-      // built on another lane's stream: this lane's reads go behind the build (later reads on this lane follow in
-      // stream order)
+    } else if (lc->built_on != c.stream && !(lc->waited & stream_bit(c))) {
+      // built on another stream: this stream's reads go behind the build (later reads on it follow in stream order)
       EG_HIP(hipStreamWaitEvent(c.stream, lc->ready, 0));
-      lc->waited |= 1u << c.cur_lane;
+      lc->waited |= stream_bit(c);
     }
     return lc->buf;
   }
@@ -1205,20 +1206,20 @@ T concat_w(Ctx& c, T a, T b) {
   launch_copy_cols(a->d, out->d, a->n, a->h, a->w, out->w, 0, a->c, 1, 0, c.stream);
   launch_copy_cols(b->d, out->d, b->n, b->h, b->w, out->w, a->w, b->c, 1, 0, c.stream);
   if (out->needs_grad) {
+    // one tape entry per input (a's, then b's: two consecutive indices), so that a caller which schedules the two
+    // producers' backward chains separately (model.cpp, sub-steps 5 / 7) can run each input's part on its own
     Ctx* cp = &c;
-    c.tape.push([=]() {
-      Ctx& c = *cp;
-      if (!out->g_set) return;
-      int wo = 0;
-      for (T in : {a, b}) {
-        if (in->needs_grad) {
-          int acc;
-          float* d = grad_acc(c, in, &acc);
-          launch_copy_cols(d, out->g, in->n, in->h, in->w, out->w, wo, in->c, 0, acc, c.stream);
-        }
-        wo += in->w;
-      }
-    });
+    int wo = 0;
+    for (T in : {a, b}) {
+      c.tape.push([=]() {
+        Ctx& c = *cp;
+        if (!out->g_set || !in->needs_grad) return;
+        int acc;
+        float* d = grad_acc(c, in, &acc);
+        launch_copy_cols(d, out->g, in->n, in->h, in->w, out->w, wo, in->c, 0, acc, c.stream);
+      });
+      wo += in->w;
+    }
   }
   return out;
 }
@@ -1410,6 +1411,8 @@ Ctx::~Ctx() {
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_gen) (void)hipEventDestroy(ev_gen);
   if (ev_g1fwd) (void)hipEventDestroy(ev_g1fwd);
+  if (ev_branch) (void)hipEventDestroy(ev_branch);
+  if (ev_cls) (void)hipEventDestroy(ev_cls);
   if (stream) (void)hipStreamDestroy(stream);
 }
 

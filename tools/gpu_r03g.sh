@@ -1,0 +1,10 @@
+#!/bin/bash
+OUT=gpurun_out/r03g
+mkdir -p $OUT
+export TMPDIR=/tmp
+python -m pytest tests/test_step_gpu.py -x -q -k "lanes or train_step_equals or substeps_14 or single_class" > $OUT/pytest_step.txt 2>&1; echo "step rc=$?" >> $OUT/rc.txt
+python -m pytest tests/test_dp_gpu.py -x -q > $OUT/pytest_dp.txt 2>&1; echo "dp rc=$?" >> $OUT/rc.txt
+python tools/gpu_ab.py edgegan_amd/libedgegan_hip_prev.so edgegan_amd/libedgegan_hip.so 4 > $OUT/ab_g1_off_chain.txt 2>&1
+EG_TIGHT_REPORT=1 python -m pytest tests/test_tight_gpu.py tests/test_x3_gpu.py -q -s -k "full_batch and g_optim_u" > $OUT/pytest_fullbatch.txt 2>&1; echo "fullbatch rc=$?" >> $OUT/rc.txt
+cat $OUT/rc.txt $OUT/ab_g1_off_chain.txt
+for f in $OUT/pytest_*.txt; do tail -n 3 $f; done
