@@ -206,11 +206,14 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   }
   const int ncc = cc_hi - cc_lo, nt = ncc * ntaps;
   int rq_cc = cc_lo, rq_ty = 0, rq_tx = 0, rq_slot = 0;   // next filter tile to request
-  [[maybe_unused]] int rq_q = S2D ? cc_lo / cpt : 0;      // S2D: phase and channel chunk of K chunk rq_cc
-  [[maybe_unused]] int rq_cq = S2D ? cc_lo - rq_q * cpt : 0;
   auto request_b = [&]() __attribute__((always_inline)) {
-    const int wsoff = S2D ? (((2 * rq_ty + (rq_q >> 1)) * a.KW + (2 * rq_tx + (rq_q & 1))) * cpt + rq_cq) * wtile
-                          : (((ph.kh0 + rq_ty * a.kst) * a.KW + (ph.kw0 + rq_tx * a.kst)) * cpt + rq_cc) * wtile;
+    int wsoff;
+    if constexpr (S2D) {   // K chunk rq_cc = phase q, channel chunk cq (uniform arithmetic, once per K step)
+      const int q = rq_cc / cpt, cq = rq_cc - q * cpt;
+      wsoff = (((2 * rq_ty + (q >> 1)) * a.KW + (2 * rq_tx + (q & 1))) * cpt + cq) * wtile;
+    } else {
+      wsoff = (((ph.kh0 + rq_ty * a.kst) * a.KW + (ph.kw0 + rq_tx * a.kst)) * cpt + rq_cc) * wtile;
+    }
     if (issuer && (EG_X3H_DBG & 4) == 0) {
 #pragma unroll
       for (int p = 0; p < NL; ++p)
@@ -225,12 +228,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
     const bool wy = rq_ty == nTy;
     rq_ty = wy ? 0 : rq_ty;
     rq_cc += wy ? 1 : 0;
-    if constexpr (S2D) {
-      rq_cq += wy ? 1 : 0;
-      const bool wc = rq_cq == cpt;
-      rq_cq = wc ? 0 : rq_cq;
-      rq_q += wc ? 1 : 0;
-    }
   };
 
   // ---- fragments --------------------------------------------------------------------------------------------------------
@@ -317,8 +314,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every issue arbitration otherwise (+0.5 %)
   if (nt > 0) {
     load_halo(cc_lo);
+    // (S2D: the vmcnt waits below count on the issue ORDER halo loads, tile 0, tile 1; the phase arithmetic in front of
+    //  the S2D loads gives the scheduler room to hoist the address-free DMA requests above them -- pin the order)
+    if constexpr (S2D) __builtin_amdgcn_sched_barrier(0);
     request_b();
     if (nt > 1) request_b();
+    if constexpr (S2D) __builtin_amdgcn_sched_barrier(0);
     // filter tile 0 (outstanding, oldest first: halo, tile 0, tile 1)
     if (!issuer) {
     } else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");
@@ -335,7 +336,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
     if (!issuer || k + 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");
     store_halo();
+    if constexpr (S2D) __builtin_amdgcn_sched_barrier(0);
     if (has_next) load_halo(cc_lo + c + 1);
+    if constexpr (S2D) __builtin_amdgcn_sched_barrier(0);
     unsigned aa[MI];
     tap_addr(0, 0, aa);
     int ty = 0, tx = 0;
@@ -512,7 +515,9 @@ bool conv_x3h_eligible(const ConvArgs& a) {
   static const bool off = dbg_env("EG_NO_HALO") != nullptr;
   if (off || !a.wgt_bf || !(a.limbs == 3 || a.limbs == 1) || a.shuf) return false;
   static const bool no_s2d = dbg_env("EG_NO_S2D") != nullptr;
-  const bool s2d = x3h_s2d_shape(a) && !no_s2d;
+  // (limb mode only: the one-plane bf16 form of the S2D variant is correct un-split but WRONG with split K for C >= 128 --
+  //  tools/gpu_s2d_check.py reproduces it, cause not found -- so the bf16 mode keeps the tap-gather kernel for these layers)
+  const bool s2d = x3h_s2d_shape(a) && a.limbs == 3 && !no_s2d;
   if (!(a.S == 1 || s2d) || !(a.D == 1 || a.D == -1) || a.C % 32 != 0 || a.N < 64 || a.N % 4 != 0) return false;
   if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || !a.x_bytes || !a.wbf_bytes || a.wbf_plane % 8 != 0) return false;
   if ((((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.wgt_bf) & 15) != 0 || (a.bias && (((uintptr_t)a.bias) & 15) != 0)) return false;
@@ -536,7 +541,7 @@ template <int BN>
 static const char* x3h_launch(const ConvArgs& a, const HaloGeom& g, hipStream_t s) {
   const int zs = a.ksplit > 1 ? a.ksplit : 1;
   dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, (a.N + BN - 1) / BN, a.nphase * zs);
-  const bool s2d = x3h_s2d_shape(a);
+  const bool s2d = x3h_s2d_shape(a) && a.limbs == 3;
   if (a.limbs == 1) {
     if (s2d) x3h_launch_variant<1, BN, true>(a, g, grid, s);
     else x3h_launch_variant<1, BN, false>(a, g, grid, s);

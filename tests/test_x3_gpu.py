@@ -55,6 +55,13 @@ def test_x3_ops_at_fp32_tolerances():
                      (f'u1 Conv_2 128->128 @64 nb{nb}', nb, 64, 64, 128, 128, 3, 1, 0, True),
                      (f'Dp conv_3 4x4s2 128->256 @32 nb{nb}', nb, 32, 32, 128, 256, 4, 2, 0, False)]:
             rows += parity.check_conv(net, case, seed=5)
+    # the discriminators' 4x4 stride-2 forward layers in the space-to-depth halo form (k_gemm_x3h.hip, S2D): shapes large
+    # enough for the cost model to pick the 256-pixel tiles -- un-split, split K with K chunks crossing the 4 phases,
+    # 8 images of 4x8 outputs per tile
+    for case in [('Dp conv_1 4x4s2 64->128 @64 nb64 (s2d halo)', 64, 64, 64, 64, 128, 4, 2, 0, False),
+                 ('Dp conv_3 4x4s2 128->256 @32 nb64 (s2d halo, split K)', 64, 32, 32, 128, 256, 4, 2, 0, False),
+                 ('D conv_4 4x4s2 256->512 8x16 nb64 (s2d halo, 8 images per tile)', 64, 8, 16, 256, 512, 4, 2, 0, False)]:
+        rows += parity.check_conv(net, case, seed=7)
     net.close()
     assert len(rows) > 150
     _assert(rows)
