@@ -234,8 +234,9 @@ T resize(Ctx& c, T x, int size);
 T concat_w(Ctx& c, T a, T b);
 T slice_w(Ctx& c, T x, int w0, int w1);   // no gradient (inputs only)
 T prelu(Ctx& c, T x, Param* leak, float leak_const);
-T minmax(Ctx& c, T x);
+T minmax(Ctx& c, T x, float pre_leak = 0.f);   // pre_leak != 0: minmax(lrelu(x)) in one pass each way
 T gate(Ctx& c, T h, T rg, T img);
+T gate_prelu(Ctx& c, T h, T rg, T img, Param* leak);   // prelu(h + rg * img, leak) in one pass each way
 T reparam(Ctx& c, T mu, T ls, const float* eps_dev);
 void sn_prepare(Ctx& c);                  // W/sigma for every live SN weight + tape entry for its backward
 void seed_grad(Ctx& c, T t);              // marks t->g as holding a value (after a loss kernel wrote it)

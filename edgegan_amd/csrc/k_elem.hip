@@ -586,8 +586,16 @@ void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, floa
 }
 
 // ---- per-(n,c) spatial min-max normalisation of the MRU update gate (conv.py:197-198) ----------
+// lk != 0: the fixed-leak lrelu in front of it (conv.py:190-196, activation.py:30-32: maximum(lk x, x)) is applied while
+// loading, u = lrelu(x), and its derivative (slope lk where lk x >= x, i.e. also at 0: Appendix B.8) while storing the
+// gradient -- lrelu's output is never materialised, its backward is not a pass of its own
+__device__ __forceinline__ float mm_pre(float v, float lk) { return lk != 0.f ? fmaxf(lk * v, v) : v; }
+__device__ __forceinline__ float mm_slope(float v, float lk) { return (lk != 0.f && lk * v >= v) ? lk : 1.f; }
+__device__ __forceinline__ float4 mm_pre4(float4 v, float lk) {
+  return make_float4(mm_pre(v.x, lk), mm_pre(v.y, lk), mm_pre(v.z, lk), mm_pre(v.w, lk));
+}
 __global__ __launch_bounds__(256) void minmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                         float* __restrict__ mm, int HW, int C) {
+                                                         float* __restrict__ mm, int HW, int C, float lk) {
   __shared__ float red[2 * 4 * 64];
   const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
   const int n = blockIdx.x, c = blockIdx.y * 64 + cx;
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(256) void minmax_fwd_kernel(const float* __restrict
   float mn = INFINITY, mx = -INFINITY;
   if (cv)
     for (int p = py; p < HW; p += 4) {
-      const float v = x[base + (size_t)p * C];
+      const float v = mm_pre(x[base + (size_t)p * C], lk);
       mn = fminf(mn, v);
       mx = fmaxf(mx, v);
     }
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(256) void minmax_fwd_kernel(const float* __restrict
   mx = fmaxf(fmaxf(red[256 + cx], red[320 + cx]), fmaxf(red[384 + cx], red[448 + cx]));
   if (cv) {
     const float inv = 1.f / (mx - mn);
-    for (int p = py; p < HW; p += 4) y[base + (size_t)p * C] = (x[base + (size_t)p * C] - mn) * inv;
+    for (int p = py; p < HW; p += 4) y[base + (size_t)p * C] = (mm_pre(x[base + (size_t)p * C], lk) - mn) * inv;
     if (py == 0) {
       mm[((size_t)n * C + c) * 2 + 0] = mn;
       mm[((size_t)n * C + c) * 2 + 1] = mx;
@@ -616,7 +624,7 @@ __global__ __launch_bounds__(256) void minmax_fwd_kernel(const float* __restrict
 }
 __global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mm,
                                                          const float* __restrict__ dy, float* __restrict__ dx, int acc,
-                                                         int HW, int C) {
+                                                         int HW, int C, float lk) {
   __shared__ float red[4 * 4 * 64];
   const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
   const int n = blockIdx.x, c = blockIdx.y * 64 + cx;
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* __restrict
   float s1 = 0.f, s2 = 0.f, cmn = 0.f, cmx = 0.f;
   if (cv)
     for (int p = py; p < HW; p += 4) {
-      const float v = x[base + (size_t)p * C], g = dy[base + (size_t)p * C];
+      const float v = mm_pre(x[base + (size_t)p * C], lk), g = dy[base + (size_t)p * C];
       s1 += g;
       s2 += g * (v - mn);
       cmn += (v == mn) ? 1.f : 0.f;
@@ -648,17 +656,18 @@ __global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* __restrict
     const float dmx = (-v4[1] / (d * d)) / v4[3];
     for (int p = py; p < HW; p += 4) {
       const size_t i = base + (size_t)p * C;
-      const float v = x[i];
+      const float xv = x[i], v = mm_pre(xv, lk);
       float g = dy[i] / d;
       if (v == mn) g += dmn;
       if (v == mx) g += dmx;
+      g *= mm_slope(xv, lk);
       dx[i] = acc ? dx[i] + g : g;
     }
   }
 }
 template <int CQ>
 __global__ __launch_bounds__(256) void minmax_fwd_v(const float* __restrict__ x, float* __restrict__ y,
-                                                    float* __restrict__ mm, int HW, int C) {
+                                                    float* __restrict__ mm, int HW, int C, float lk) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[2 * 4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(256) void minmax_fwd_v(const float* __restrict__ x,
   const size_t base = (size_t)n * HW * C + c;
   float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
   for (int p = pl; p < HW; p += PL) {
-    const float4 v = ld4(x + base + (size_t)p * C);
+    const float4 v = mm_pre4(ld4(x + base + (size_t)p * C), lk);
     mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
     mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
   }
@@ -674,7 +683,7 @@ __global__ __launch_bounds__(256) void minmax_fwd_v(const float* __restrict__ x,
   const float4 inv = make_float4(1.f / (mx.x - mn.x), 1.f / (mx.y - mn.y), 1.f / (mx.z - mn.z), 1.f / (mx.w - mn.w));
   for (int p = pl; p < HW; p += PL) {
     const size_t i = base + (size_t)p * C;
-    const float4 v = ld4(x + i);
+    const float4 v = mm_pre4(ld4(x + i), lk);
     st4(y + i, make_float4((v.x - mn.x) * inv.x, (v.y - mn.y) * inv.y, (v.z - mn.z) * inv.z, (v.w - mn.w) * inv.w));
   }
   if (pl == 0) {
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(256) void minmax_fwd_v(const float* __restrict__ x,
 template <int CQ>
 __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x, const float* __restrict__ mm,
                                                     const float* __restrict__ dy, float* __restrict__ dx, int acc,
-                                                    int HW, int C) {
+                                                    int HW, int C, float lk) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[4 * 4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x,
   float4 s[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};  // sum g, sum g*(x-mn), count==mn, count==mx
   for (int p = pl; p < HW; p += PL) {
     const size_t i = base + (size_t)p * C;
-    const float4 v = ld4(x + i), g = ld4(dy + i);
+    const float4 v = mm_pre4(ld4(x + i), lk), g = ld4(dy + i);
     s[0].x += g.x; s[0].y += g.y; s[0].z += g.z; s[0].w += g.w;
     s[1].x += g.x * (v.x - mn[0]); s[1].y += g.y * (v.y - mn[1]); s[1].z += g.z * (v.z - mn[2]); s[1].w += g.w * (v.w - mn[3]);
     s[2].x += v.x == mn[0] ? 1.f : 0.f; s[2].y += v.y == mn[1] ? 1.f : 0.f; s[2].z += v.z == mn[2] ? 1.f : 0.f; s[2].w += v.w == mn[3] ? 1.f : 0.f;
@@ -715,14 +724,15 @@ __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x,
   }
   for (int p = pl; p < HW; p += PL) {
     const size_t i = base + (size_t)p * C;
-    const float4 v = ld4(x + i), g = ld4(dy + i);
-    const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+    const float4 xv = ld4(x + i), v = mm_pre4(xv, lk), g = ld4(dy + i);
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
     float r[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       r[j] = gg[j] / d[j];
       if (vv[j] == mn[j]) r[j] += dmn[j];
       if (vv[j] == mx[j]) r[j] += dmx[j];
+      r[j] *= mm_slope(xx[j], lk);
     }
     float4 o = make_float4(r[0], r[1], r[2], r[3]);
     if (acc) { const float4 t = ld4(dx + i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
@@ -730,28 +740,28 @@ __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x,
   }
 }
 
-void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s) {
+void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s, float pre_leak) {
   if (C % 32 == 0) {
-    hipLaunchKernelGGL(minmax_fwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, y, mm, HW, C);
+    hipLaunchKernelGGL(minmax_fwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, y, mm, HW, C, pre_leak);
     return;
   }
   if (C % 8 == 0) {
-    hipLaunchKernelGGL(minmax_fwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, y, mm, HW, C);
+    hipLaunchKernelGGL(minmax_fwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, y, mm, HW, C, pre_leak);
     return;
   }
-  hipLaunchKernelGGL(minmax_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, y, mm, HW, C);
+  hipLaunchKernelGGL(minmax_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, y, mm, HW, C, pre_leak);
 }
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
-                       int HW, int C, hipStream_t s) {
+                       int HW, int C, hipStream_t s, float pre_leak) {
   if (C % 32 == 0) {
-    hipLaunchKernelGGL(minmax_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C);
+    hipLaunchKernelGGL(minmax_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak);
     return;
   }
   if (C % 8 == 0) {
-    hipLaunchKernelGGL(minmax_bwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C);
+    hipLaunchKernelGGL(minmax_bwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak);
     return;
   }
-  hipLaunchKernelGGL(minmax_bwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C);
+  hipLaunchKernelGGL(minmax_bwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak);
 }
 
 __global__ void gate_fwd_kernel(const float* __restrict__ h, const float* __restrict__ rg,
@@ -774,6 +784,114 @@ void launch_gate_fwd(const float* h, const float* rg, const float* img, float* o
 void launch_gate_bwd(const float* rg, const float* img, const float* dout, float* dh, int acc_h, float* drg,
                      float* dimg, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, rg, img, dout, dh, acc_h, drg, dimg, n);
+}
+
+// gate merge + PReLU in one pass (ops.cpp gate_prelu): same expressions, in the same order, as gate_* followed by prelu_*
+__global__ void gate_prelu_fwd_kernel(const float* __restrict__ h, const float* __restrict__ rg, const float* __restrict__ img,
+                                      const float* __restrict__ leak_p, float* __restrict__ o, size_t n) {
+  const float lk = *leak_p;
+  GRID_STRIDE(i, n) {
+    const float v = h[i] + rg[i] * img[i];
+    o[i] = fmaxf(lk * v, v);
+  }
+}
+__global__ __launch_bounds__(256) void gate_prelu_bwd_kernel(const float* __restrict__ h, const float* __restrict__ rg,
+                                                             const float* __restrict__ img, const float* __restrict__ leak_p,
+                                                             const float* __restrict__ d, float* __restrict__ dh, int acc_h,
+                                                             float* __restrict__ drg, float* __restrict__ dimg,
+                                                             float* __restrict__ part, size_t n) {
+  __shared__ float sm[4];
+  const float lk = *leak_p;
+  float s = 0.f;
+  GRID_STRIDE(i, n) {
+    const float r = rg[i], m = img[i];
+    const float v = h[i] + r * m, gy = d[i];
+    const bool first = (lk * v >= v);   // tf.maximum sends the gradient to the first argument on ties
+    const float g = first ? lk * gy : gy;
+    if (first) s += gy * v;
+    if (dh) dh[i] = acc_h ? dh[i] + g : g;
+    drg[i] = g * m;
+    dimg[i] = g * r;
+  }
+  if (part) {
+    const float tot = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  }
+}
+// float4 forms (n % 4 == 0, 16-byte aligned buffers)
+__global__ void gate_prelu_fwd_v_kernel(const float* __restrict__ h, const float* __restrict__ rg, const float* __restrict__ img,
+                                        const float* __restrict__ leak_p, float* __restrict__ o, size_t n4) {
+  const float lk = *leak_p;
+  GRID_STRIDE(i, n4) {
+    const float4 a = reinterpret_cast<const float4*>(h)[i], r = reinterpret_cast<const float4*>(rg)[i],
+                 m = reinterpret_cast<const float4*>(img)[i];
+    const float v0 = a.x + r.x * m.x, v1 = a.y + r.y * m.y, v2 = a.z + r.z * m.z, v3 = a.w + r.w * m.w;
+    reinterpret_cast<float4*>(o)[i] = make_float4(fmaxf(lk * v0, v0), fmaxf(lk * v1, v1), fmaxf(lk * v2, v2), fmaxf(lk * v3, v3));
+  }
+}
+__global__ __launch_bounds__(256) void gate_prelu_bwd_v_kernel(const float* __restrict__ h, const float* __restrict__ rg,
+                                                               const float* __restrict__ img, const float* __restrict__ leak_p,
+                                                               const float* __restrict__ d, float* __restrict__ dh, int acc_h,
+                                                               float* __restrict__ drg, float* __restrict__ dimg,
+                                                               float* __restrict__ part, size_t n4) {
+  __shared__ float sm[4];
+  const float lk = *leak_p;
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(h)[i], r = reinterpret_cast<const float4*>(rg)[i],
+                 m = reinterpret_cast<const float4*>(img)[i], gy = reinterpret_cast<const float4*>(d)[i];
+    const float v[4] = {a.x + r.x * m.x, a.y + r.y * m.y, a.z + r.z * m.z, a.w + r.w * m.w};
+    const float gg[4] = {gy.x, gy.y, gy.z, gy.w};
+    float g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool first = (lk * v[j] >= v[j]);
+      g[j] = first ? lk * gg[j] : gg[j];
+      s += first ? gg[j] * v[j] : 0.f;
+    }
+    if (dh) {
+      float4 o = make_float4(g[0], g[1], g[2], g[3]);
+      if (acc_h) {
+        const float4 q = reinterpret_cast<const float4*>(dh)[i];
+        o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+      }
+      reinterpret_cast<float4*>(dh)[i] = o;
+    }
+    reinterpret_cast<float4*>(drg)[i] = make_float4(g[0] * m.x, g[1] * m.y, g[2] * m.z, g[3] * m.w);
+    reinterpret_cast<float4*>(dimg)[i] = make_float4(g[0] * r.x, g[1] * r.y, g[2] * r.z, g[3] * r.w);
+  }
+  if (part) {
+    const float tot = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  }
+}
+static bool gp_vec_ok(size_t n, const void* a, const void* b, const void* c, const void* d, const void* e = nullptr,
+                      const void* f = nullptr, const void* g = nullptr) {
+  return (n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d) | ((uintptr_t)e) | ((uintptr_t)f) |
+                           ((uintptr_t)g)) & 15) == 0;
+}
+void launch_gate_prelu_fwd(const float* h, const float* rg, const float* img, const float* leak, float* out, size_t n,
+                           hipStream_t s) {
+  if (gp_vec_ok(n, h, rg, img, out)) {
+    hipLaunchKernelGGL(gate_prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, h, rg, img, leak, out, n / 4);
+    return;
+  }
+  hipLaunchKernelGGL(gate_prelu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, h, rg, img, leak, out, n);
+}
+void launch_gate_prelu_bwd(const float* h, const float* rg, const float* img, const float* leak, const float* dout, float* dh,
+                           int acc_h, float* drg, float* dimg, float* dleak, int acc_dleak, size_t n, float* scratch,
+                           hipStream_t s) {
+  int nb;
+  if (gp_vec_ok(n, h, rg, img, dout, dh, drg, dimg)) {
+    nb = ew_blocks(n / 4, 2048);
+    hipLaunchKernelGGL(gate_prelu_bwd_v_kernel, dim3(nb), dim3(256), 0, s, h, rg, img, leak, dout, dh, acc_h, drg, dimg,
+                       dleak ? scratch : nullptr, n / 4);
+  } else {
+    nb = ew_blocks(n, 2048);
+    hipLaunchKernelGGL(gate_prelu_bwd_kernel, dim3(nb), dim3(256), 0, s, h, rg, img, leak, dout, dh, acc_h, drg, dimg,
+                       dleak ? scratch : nullptr, n);
+  }
+  if (dleak) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, nb, dleak, acc_dleak, 1.0f);
 }
 
 // ---- N == 1 linear head (d_linear_5, discriminator.py:74) --------------------------------------

@@ -256,13 +256,20 @@ size_t prelu_scratch_floats();
 void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, float leak_c, float* dx, int acc_dx,
                       float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s);
 // per-(n,c) spatial min-max normalisation (conv.py:197-198) fwd/bwd; mm[n][c] = {min,max}
-void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s);
+// pre_leak != 0: y = minmax(lrelu_{pre_leak}(x)) with the lrelu applied on load / its slope on the gradient store
+void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s, float pre_leak = 0.f);
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
-                       int HW, int C, hipStream_t s);
+                       int HW, int C, hipStream_t s, float pre_leak = 0.f);
 // gate merge: out = h + rg*img ; backward
 void launch_gate_fwd(const float* h, const float* rg, const float* img, float* out, size_t n, hipStream_t s);
 void launch_gate_bwd(const float* rg, const float* img, const float* dout, float* dh, int acc_h, float* drg,
                      float* dimg, size_t n, hipStream_t s);
+// out = prelu(h + rg*img, *leak) ; backward with the pre-activation recomputed; dleak (+)= sum(dout * pre [leak*pre >= pre])
+void launch_gate_prelu_fwd(const float* h, const float* rg, const float* img, const float* leak, float* out, size_t n,
+                           hipStream_t s);
+void launch_gate_prelu_bwd(const float* h, const float* rg, const float* img, const float* leak, const float* dout, float* dh,
+                           int acc_h, float* drg, float* dimg, float* dleak, int acc_dleak, size_t n, float* scratch,
+                           hipStream_t s);
 // add bias over last dim in place (y[r][c] += b[c]), optional prelu/lrelu fused variants are separate ops
 void launch_bias_add(float* y, const float* b, size_t R, int C, hipStream_t s);
 

@@ -446,11 +446,9 @@ T classifier_forward(Ctx& c, T x) {
     WRef* wr_x = wref_raw(c, w_x, g_x, f_x, full->want_grad, 9, 3, hidden, wg->name + "[image rows]");
     T rg = conv2d(c, hp, wr_h, P(c, b + "/update_gate/biases"), 3, 1, PAD_SAME);
     conv2d(c, xin, wr_x, nullptr, 3, 1, PAD_SAME, rg);
-    rg = prelu(c, rg, nullptr, 0.2f);  // lrelu (activation.py:30-32)
-    rg = minmax(c, rg);
+    rg = minmax(c, rg, 0.2f);   // lrelu (activation.py:30-32) + the min-max gate of conv.py:197-198, one pass each way
     T img = conv2d(c, xin, wref_sn(c, P(c, b + "/Conv/weights")), P(c, b + "/Conv/biases"), 3, 1, PAD_SAME);
-    T hplus = gate(c, h, rg, img);
-    T hin = prelu(c, hplus, P(c, b + "/norm_activation_merge_1/prelu/param"), 0.f);
+    T hin = gate_prelu(c, h, rg, img, P(c, b + "/norm_activation_merge_1/prelu/param"));   // conv.py:207-209
     T c1 = conv2d(c, hin, wref_sn(c, P(c, b + "/Conv_1/weights")), P(c, b + "/Conv_1/biases"), 3, 1, PAD_SAME);
     c1 = prelu(c, c1, P(c, b + "/Conv_1/prelu/param"), 0.f);
     T c2 = conv2d(c, c1, wref_sn(c, P(c, b + "/Conv_2/weights")), P(c, b + "/Conv_2/biases"), 3, 1, PAD_SAME);

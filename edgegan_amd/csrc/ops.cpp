@@ -1255,11 +1255,11 @@ T prelu(Ctx& c, T x, Param* leak, float leak_const) {
 }
 
 // conv.py:197-198
-T minmax(Ctx& c, T x) {
+T minmax(Ctx& c, T x, float pre_leak) {
   T out = new_tensor(c, x->n, x->h, x->w, x->c, x->needs_grad);
   T mm = new_tensor(c, x->n, 1, 1, 2 * x->c, false);
   const int HW = x->h * x->w;
-  launch_minmax_fwd(x->d, out->d, mm->d, x->n, HW, x->c, c.stream);
+  launch_minmax_fwd(x->d, out->d, mm->d, x->n, HW, x->c, c.stream, pre_leak);
   if (x->needs_grad) {
     Ctx* cp = &c;
     c.tape.push([=]() {
@@ -1267,7 +1267,7 @@ T minmax(Ctx& c, T x) {
       if (!out->g_set) return;
       int acc;
       float* dx = grad_acc(c, x, &acc);
-      launch_minmax_bwd(x->d, mm->d, out->g, dx, acc, x->n, HW, x->c, c.stream);
+      launch_minmax_bwd(x->d, mm->d, out->g, dx, acc, x->n, HW, x->c, c.stream, pre_leak);
     });
   }
   return out;
@@ -1291,6 +1291,29 @@ T gate(Ctx& c, T h, T rg, T img) {
       launch_gate_bwd(rg->d, img->d, out->g, dh, acc_h, drg, dimg, h->numel(), c.stream);
     });
   }
+  return out;
+}
+
+// conv.py:207-209 in one pass: prelu(ht + rg * img_new, leak).  ht_plus is not materialised: the backward recomputes it
+// from its three inputs for the PReLU mask and the slope's gradient (exactly the values the two-pass form reads back)
+T gate_prelu(Ctx& c, T h, T rg, T img, Param* leak) {
+  T out = new_tensor(c, h->n, h->h, h->w, h->c, true);
+  launch_gate_prelu_fwd(h->d, rg->d, img->d, leak->w, out->d, h->numel(), c.stream);
+  Ctx* cp = &c;
+  c.tape.push([=]() {
+    Ctx& c = *cp;
+    if (!out->g_set) return;
+    float* dh = nullptr;
+    int acc_h = 0, a1, a2;
+    if (h->needs_grad) dh = grad_acc(c, h, &acc_h);
+    float* drg = grad_acc(c, rg, &a1);
+    float* dimg = grad_acc(c, img, &a2);
+    EG_CHECK(!a1 && !a2, "gate operands are single-use");
+    const bool pg = leak->want_grad && c.param_grad_enabled;
+    launch_gate_prelu_bwd(h->d, rg->d, img->d, leak->w, out->g, dh, acc_h, drg, dimg, pg ? leak->g : nullptr,
+                          pg && leak->g_set ? 1 : 0, h->numel(), c.scratch, c.stream);
+    if (pg) leak->g_set = true;
+  });
   return out;
 }
 
