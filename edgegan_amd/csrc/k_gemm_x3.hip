@@ -991,6 +991,313 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
   }
 }
 
+template <int NPROD>
+__global__ __launch_bounds__(512, 1) void wgrad_x3t_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
+  constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64;
+  constexpr int NL = NPROD == 1 ? 1 : 3;
+  static_assert(NPROD == 6, "the transpose-read form exists for the three-limb mode");
+  __shared__ __attribute__((aligned(16))) unsigned short AsG[2][NL][BKX * BM];   // per group: [pixel][c] (pixel-major, 256-byte rows)
+  __shared__ __attribute__((aligned(16))) unsigned short BsG[2][NL][BKX * BN];   // per K-step parity: [pixel][n]
+  // per group, per 256-pixel block parity (8 K steps), per row half of the unit: gathered-pixel byte offsets.  The two
+  // halves (rows 0-63 / 64-127 of the A tile) belong to the same tap when C >= 128 and to two consecutive taps when
+  // C == 64 (a unit is then taps 2u, 2u+1 x all 64 channels: no half-empty tiles for the 64-channel layers)
+  __shared__ unsigned poffG[2][2][2][256];
+
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  const int wm = wave >> 1, wn = wave & 1;
+  unsigned short (&As)[NL][BKX * BM] = AsG[grp];
+  unsigned (&poff)[2][2][256] = poffG[grp];
+  const int C = a.C, N = a.N, IH = a.IH, IW = a.IW;
+  const int T = a.KH * a.KW;
+  const bool two_taps = C == 64;
+  const int ctiles = (C + BM - 1) / BM, ntn = (N + BN - 1) / BN, units = two_taps ? (T + 1) / 2 : T * ctiles;
+  const int unit = ((int)blockIdx.x / ntn) * 2 + grp;
+  const bool uvalid = unit < units;                      // an idle group still splits its half of dY and keeps the barriers
+  const int tap = uvalid ? (two_taps ? 2 * unit : unit / ctiles) : 0;
+  const int tap1 = two_taps ? tap + 1 : tap;             // tap of the tile's upper row half (may be == T: an empty half)
+  const int c0 = (uvalid && !two_taps ? unit % ctiles : 0) * BM, n0 = ((int)blockIdx.x % ntn) * BN;
+  const int khh[2] = {tap / a.KW, tap1 / a.KW};
+  const int kwh[2] = {tap - khh[0] * a.KW, tap1 - khh[1] * a.KW};
+  const int M = a.NB * a.OH * a.OW;
+  int chunk = (M + a.nsplit - 1) / a.nsplit;
+  chunk = (chunk + BKX - 1) / BKX * BKX;
+  const int p_lo = (int)blockIdx.y * chunk;
+  const int p_hi = min(M, p_lo + chunk);
+  const int nt = p_hi > p_lo ? (p_hi - p_lo + BKX - 1) / BKX : 0;
+
+  // unit = (pixel pair mp of the K step, channel quad cq): a half wave is 8 consecutive quads (one 128-byte line of
+  // a pixel) x 4 pixel pairs of ONE 8-pixel chunk
+  const int cq8 = tid & 7, mpl = (tid >> 3) & 3, rest = tid >> 5;
+  const int kch = rest & 3;
+  const int mp = kch * 4 + mpl;
+  const int cqb = (rest >> 2) * 8 + cq8;          // A: quads cqb, cqb + 16; B: quad cqb + 16 * grp
+  // pixel-major image: row p = 128 channels = 32 chunks of 4 channels (8 bytes); chunk k4 = c / 4 of pixel p sits at
+  // chunk position ((k4 >> 2) ^ fsw(p)) * 4 + (k4 & 3) -- the XOR moves 16-channel blocks only, so the four chunks a
+  // transpose read needs stay one 32-byte run -- with fsw(p) bits {p2, p0 ^ p1, p1}: the (pixel 0..3) x (two 16-channel
+  // blocks) x (4 chunks) addresses of a half wave's ds_read_b64_tr_b16 cover all 64 banks once, and the (8 quads) x (4 pixel
+  // pairs) ds_write_b64 of a half wave hit every bank pair exactly twice (the 2-cycle minimum of a 256-byte store)
+  auto fsw = [](int p) __attribute__((always_inline)) { return ((p >> 2) & 1) | (((p ^ (p >> 1)) & 1) << 1) | (((p >> 1) & 1) << 2); };
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  unsigned a_coff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = two_taps ? cqb * 4 : c0 + (cqb + 16 * i) * 4;
+    const bool ok = two_taps ? (i == 0 ? tap : tap1) < T : c < C;
+    a_coff[i] = (uvalid && ok) ? (unsigned)(c * 4) : 0x40000000u;   // (extents are < 1 GB: launch_wgrad)
+  }
+  const int bn = n0 + (cqb + 16 * grp) * 4;
+  const unsigned b_noff = bn < N ? (unsigned)(bn * 4) : 0x40000000u;
+
+  auto decode_block = [&](int blk) __attribute__((always_inline)) {
+    const int m = p_lo + blk * 256 + tid;
+    unsigned off[2] = {0x80000000u, 0x80000000u};
+    if (m < p_hi) {
+      const int ox = m % a.OW;
+      const int t2 = m / a.OW;
+      const int oy = t2 % a.OH;
+      const int nb = t2 / a.OH;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int iy = oy * a.S + khh[h] - a.pad, ix = ox * a.S + kwh[h] - a.pad;
+        if (a.reflect) {
+          iy = reflect_x(iy, IH);
+          ix = reflect_x(ix, IW);
+        }
+        if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) off[h] = (unsigned)(((nb * IH + iy) * IW + ix) * a.x_ps * 4);
+      }
+    }
+    poff[blk & 1][0][tid] = off[0];
+    poff[blk & 1][1][tid] = off[1];
+  };
+  f32x4 ra0[2][2], ra1[2][2], rb0[2], rb1[2];
+  auto load_a = [&](int t, f32x4 (&ra)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned* po = &poff[(t >> 3) & 1][i][(t & 7) * 32 + 2 * mp];
+      const unsigned o0 = po[0], o1 = po[1];
+      ra[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, o0 + a_coff[i], 0, 0));
+      ra[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, o1 + a_coff[i], 0, 0));
+    }
+  };
+  auto load_b = [&](int t, f32x4 (&rb)[2]) __attribute__((always_inline)) {
+    const int m = p_lo + t * BKX + 2 * mp;
+    const unsigned r0 = m < p_hi ? (unsigned)(m * a.dy_ps * 4) : 0x80000000u;
+    const unsigned r1 = m + 1 < p_hi ? (unsigned)((m + 1) * a.dy_ps * 4) : 0x80000000u;
+    rb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r0 + b_noff, 0, 0));
+    rb[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r1 + b_noff, 0, 0));
+  };
+  // 4 channels x 2 pixels -> per plane and pixel ONE 8-byte store of the pixel's 4 channels (pairs split along channels)
+  auto store_unit = [&](unsigned short (&P)[NL][BKX * BM], int cq, const f32x4& lo, const f32x4& hi) __attribute__((always_inline)) {
+    const int p0 = 2 * mp, p1 = 2 * mp + 1;
+    const int o0 = p0 * BM + ((((cq >> 2) ^ fsw(p0)) << 2) | (cq & 3)) * 4;
+    const int o1 = p1 * BM + ((((cq >> 2) ^ fsw(p1)) << 2) | (cq & 3)) * 4;
+    unsigned a0, a1, a2, b0, b1, b2;
+    split_pair(lo[0], lo[1], a0, a1, a2);
+    split_pair(lo[2], lo[3], b0, b1, b2);
+    *reinterpret_cast<u32x2*>(&P[0][o0]) = (u32x2){a0, b0};
+    *reinterpret_cast<u32x2*>(&P[1][o0]) = (u32x2){a1, b1};
+    *reinterpret_cast<u32x2*>(&P[2][o0]) = (u32x2){a2, b2};
+    split_pair(hi[0], hi[1], a0, a1, a2);
+    split_pair(hi[2], hi[3], b0, b1, b2);
+    *reinterpret_cast<u32x2*>(&P[0][o1]) = (u32x2){a0, b0};
+    *reinterpret_cast<u32x2*>(&P[1][o1]) = (u32x2){a1, b1};
+    *reinterpret_cast<u32x2*>(&P[2][o1]) = (u32x2){a2, b2};
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // ds_read_b64_tr_b16 (gfx950): in a 16-lane group, lane 4r + q supplies the address of 4 consecutive channels (chunk q)
+  // of pixel row r and RECEIVES, for channel column (its index in the group), the values of the four rows -- i.e. the
+  // k-contiguous MFMA operand out of a pixel-major image (semantics probed on the hardware: profiles/r03c_ds_read_b64_tr_b16_probe.txt).
+  // A fragment (32 rows x 16 k, lane = row l & 31, k = 8 (l >> 5) .. + 7) = two reads: pixels +0..3 and +4..7.
+  const int tg = lane >> 4, ti = lane & 15, tr = ti >> 2, tq = ti & 3;
+  unsigned ea[2][2], eb[2][2];   // byte addresses: [32-row block][first / second 4 pixels] of K half 0, plane 0
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pix = 8 * (tg >> 1) + 4 * h + tr;
+      const int cba = 2 * (wm * 2 + i) + (tg & 1), cbb = 2 * (wn * 2 + i) + (tg & 1);
+      ea[i][h] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&As[0][0] +
+                 (unsigned)((pix * BM + (((cba ^ fsw(pix)) << 2) | tq) * 4) * 2);
+      eb[i][h] = (unsigned)((pix * BN + (((cbb ^ fsw(pix)) << 2) | tq) * 4) * 2);
+    }
+  unsigned bcur = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&BsG[0][0][0];
+  constexpr int PLB = BKX * BM * 2;      // bytes of one plane
+  constexpr int KHB = 16 * BM * 2;       // bytes between the two K halves (16 pixel rows)
+#define EG_TRR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  struct Frag { u32x2 h[2][2][2]; };    // [block][K half][first / second 4 pixels]
+  // (macros, not lambdas: the plane offset must reach the instruction as an immediate)
+#define EG_RDA(f, pl)                                                                                     \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
+      EG_TRR(f.h[i_][0][0], ea[i_][0], (pl) * PLB); EG_TRR(f.h[i_][0][1], ea[i_][1], (pl) * PLB);           \
+      EG_TRR(f.h[i_][1][0], ea[i_][0], (pl) * PLB + KHB); EG_TRR(f.h[i_][1][1], ea[i_][1], (pl) * PLB + KHB); \
+    }                                                                                                     \
+  } while (0)
+#define EG_RDB(f, pl)                                                                                     \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                    \
+      const unsigned b0_ = bcur + eb[j_][0], b1_ = bcur + eb[j_][1];                                      \
+      EG_TRR(f.h[j_][0][0], b0_, (pl) * PLB); EG_TRR(f.h[j_][0][1], b1_, (pl) * PLB);                       \
+      EG_TRR(f.h[j_][1][0], b0_, (pl) * PLB + KHB); EG_TRR(f.h[j_][1][1], b1_, (pl) * PLB + KHB);           \
+    }                                                                                                     \
+  } while (0)
+  auto op8 = [](const Frag& f, int i, int kk) __attribute__((always_inline)) {
+    const u32x4_ v = {f.h[i][kk][0][0], f.h[i][kk][0][1], f.h[i][kk][1][0], f.h[i][kk][1][1]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto mm = [&](const Frag& af, const Frag& bf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op8(bf, j, kk), op8(af, i, kk), acc[i][j], 0, 0, 0);
+  };
+  // lgkmcnt waits with the fragments they release as operands (the compiler cannot see the asm reads' latency)
+#define EG_TRW(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f.h[0][0][0]), "+v"(f.h[0][0][1]), "+v"(f.h[0][1][0]), "+v"(f.h[0][1][1]), \
+                                  "+v"(f.h[1][0][0]), "+v"(f.h[1][0][1]), "+v"(f.h[1][1][0]), "+v"(f.h[1][1][1]))
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  const int nblk = (nt + 7) / 8;
+
+  auto run = [&](auto GRP) __attribute__((always_inline)) {
+    constexpr int LEAD = decltype(GRP)::value;   // X stages its dY half of step k in VALU phase k, Y that of step k + 1
+    // one VALU phase: requests for the next tiles first, then split + store; RT = run-time guards (tail only)
+    auto valu_phase = [&](auto RT, int k, const f32x4 (&ra)[2][2], f32x4 (&ran)[2][2], const f32x4 (&rb)[2], f32x4 (&rbn)[2])
+                          __attribute__((always_inline)) {
+      constexpr bool rt = decltype(RT)::value;
+      if (!rt || k + 1 < nt) load_a(k + 1, ran);
+      if (!rt || k + 1 + LEAD < nt) load_b(k + 1 + LEAD, rbn);
+      if constexpr (!rt) __builtin_amdgcn_sched_barrier(0);
+      if ((k & 7) == 2 && (k >> 3) + 1 < nblk) decode_block((k >> 3) + 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) store_unit(As, cqb + 16 * i, ra[i][0], ra[i][1]);
+      if (!rt || k + LEAD < nt) store_unit(BsG[(k + LEAD) & 1], cqb + 16 * LEAD, rb[0], rb[1]);
+    };
+    auto mfma_phase = [&](int k) __attribute__((always_inline)) {
+      lds_barrier();
+      bcur = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&BsG[k & 1][0][0];
+      // six limb products a0b0 a0b1 a0b2 a1b0 a1b1 a2b0; every fragment set is 8 reads, issued one set ahead of its use
+      // (LDS reads return in order; at most 15 are tracked, the hardware holds back the rest)
+      Frag a0, b0, b1, b2, a1, a2;
+      EG_RDA(a0, 0);
+      EG_RDB(b0, 0);
+      EG_RDB(b1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      EG_TRW(8, a0); EG_TRW(8, b0);
+      mm(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      EG_RDB(b2, 2);
+      EG_TRW(8, b1);
+      mm(a0, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      EG_RDA(a1, 1);
+      EG_TRW(8, b2);
+      mm(a0, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      EG_RDA(a2, 2);
+      EG_TRW(8, a1);
+      mm(a1, b0);
+      mm(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      EG_TRW(0, a2);
+      mm(a2, b0);
+      lds_barrier();
+    };
+    constexpr std::true_type guarded{};
+    constexpr std::false_type steady{};
+    // prologue: X holds A(0), B(0); Y holds A(0), B(1) and has already stored its half of B(0) (in its idle slot 0)
+    if (nt > 0) {
+      decode_block(0);
+      lds_barrier();           // both groups: the offset tables are per group, but the barrier is block-wide
+      load_a(0, ra0);
+      if constexpr (LEAD == 0) {
+        load_b(0, rb0);
+      } else {
+        load_b(0, rb0);
+        if (nt > 1) load_b(1, rb1);
+        store_unit(BsG[0], cqb + 16, rb0[0], rb0[1]);
+        lds_barrier();         // Y's idle slot 0
+      }
+    }
+    // staging sets: A(k) in ra[k & 1]; X: B(k) in rb[k & 1]; Y: B(k + 1) in rb[(k + 1) & 1]
+    int k = 0;
+    for (; k + 3 < nt; k += 2) {
+      if constexpr (LEAD == 0) {
+        valu_phase(steady, k, ra0, ra1, rb0, rb1);
+        mfma_phase(k);
+        valu_phase(steady, k + 1, ra1, ra0, rb1, rb0);
+        mfma_phase(k + 1);
+      } else {
+        valu_phase(steady, k, ra0, ra1, rb1, rb0);
+        mfma_phase(k);
+        valu_phase(steady, k + 1, ra1, ra0, rb0, rb1);
+        mfma_phase(k + 1);
+      }
+    }
+    if (k < nt) {   // up to 3 steps left (k even), straight-line with run-time guards
+      if constexpr (LEAD == 0) valu_phase(guarded, k, ra0, ra1, rb0, rb1);
+      else valu_phase(guarded, k, ra0, ra1, rb1, rb0);
+      mfma_phase(k);
+      if (k + 1 < nt) {
+        if constexpr (LEAD == 0) valu_phase(guarded, k + 1, ra1, ra0, rb1, rb0);
+        else valu_phase(guarded, k + 1, ra1, ra0, rb0, rb1);
+        mfma_phase(k + 1);
+        if (k + 2 < nt) {
+          if constexpr (LEAD == 0) valu_phase(guarded, k + 2, ra0, ra1, rb0, rb1);
+          else valu_phase(guarded, k + 2, ra0, ra1, rb1, rb0);
+          mfma_phase(k + 2);
+        }
+      }
+    }
+    if constexpr (LEAD == 0)
+      if (nt > 0) lds_barrier();   // X's idle last slot
+  };
+  if (grp == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+
+  // lane l holds filter row c = .. + (l & 31) and, in registers 4g .. 4g+3, output channels 8g + 4 (l >> 5) .. +3
+  if (!uvalid) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    // the wave's 64 rows are one half of the tile: in the two-tap form that half is a tap of its own
+    const int c = two_taps ? i * 32 + l31 : c0 + wm * WTM + i * 32 + l31;
+    const int otap = two_taps ? tap + wm : tap;
+    if (c >= C || otap >= T) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * WTN + j * 32 + g * 8 + lh * 4;
+        if (n >= N) continue;
+        float* q = dense_out ? out + (((size_t)blockIdx.y * T + otap) * C + c) * N + n
+                             : out + (size_t)otap * a.w_ts + (size_t)c * a.ldw + n;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (!dense_out && a.accumulate) {
+          const float4 o = *reinterpret_cast<const float4*>(q);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(q) = v;
+      }
+  }
+}
+#undef EG_TRR
+#undef EG_TRW
+#undef EG_RDA
+#undef EG_RDB
+
 const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s) {
   (void)big_tile;
   const int units = a.C == 64 ? (a.KH * a.KW + 1) / 2 : a.KH * a.KW * ((a.C + 127) / 128), ntn = (a.N + 127) / 128;
@@ -998,6 +1305,11 @@ const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_
   if (a.limbs == 1) {
     hipLaunchKernelGGL((wgrad_x3pp_kernel<1>), grid, dim3(512), 0, s, a, out, dense);
     return "wgrad_bf16pp<2x128,128>";
+  }
+  static const bool no_tr = dbg_env("EG_NO_WGRAD_TR") != nullptr;   // A/B: the channel-major image with plain 16-byte fragment reads
+  if (!no_tr) {
+    hipLaunchKernelGGL((wgrad_x3t_kernel<6>), grid, dim3(512), 0, s, a, out, dense);
+    return "wgrad_x3t<2x128,128>";
   }
   hipLaunchKernelGGL((wgrad_x3pp_kernel<6>), grid, dim3(512), 0, s, a, out, dense);
   return "wgrad_x3pp<2x128,128>";
