@@ -387,6 +387,39 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
   const int C = a.C, N = a.N, IH = a.IH, IW = a.IW, OWp = ph.OWp, npix = ph.OHp * ph.OWp;
   const int n0 = (int)blockIdx.y * BN;
 
+  const int dy_lo = min(ph.offy, (ph.Ty - 1) * a.D + ph.offy), dy_hi = max(ph.offy, (ph.Ty - 1) * a.D + ph.offy);
+  const float* bl_lane = Bl + ((size_t)kq * BN + p15) * 4;
+  const int total_tiles = a.NB * tiles_per_img;
+
+  // The rows of the NEXT tile are fetched into registers before the current tile is multiplied and stored, and written to
+  // LDS after it: the fetch latency runs under the MFMAs, and (vmcnt is one in-order counter for loads and stores on
+  // gfx9) waiting for those loads does not wait for the output stores issued after them.  Round barriers are LDS-only.
+  constexpr int PF = 6;   // 16-byte registers per thread: tiles stage <= 24 KB of rows (smallc_geometry)
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  f32x4 pf[PF];
+  int pf_n4 = 0;
+  auto tile_rows = [&](int tile, int* nb_, int* q_lo_, int* q_hi_, int* ylo_) __attribute__((always_inline)) {
+    const int nb = tile / tiles_per_img, q_lo = (tile - nb * tiles_per_img) * subs * (64 * PT);
+    const int q_hi = min(q_lo + subs * (64 * PT), npix) - 1;
+    const int ylo = max(0, (q_lo / OWp) * a.S + dy_lo), yhi = min(IH - 1, (q_hi / OWp) * a.S + dy_hi);
+    *nb_ = nb; *q_lo_ = q_lo; *q_hi_ = q_hi; *ylo_ = ylo;
+    return max(0, yhi - ylo + 1) * IW * C >> 2;   // 16-byte units
+  };
+  auto prefetch = [&](int tile) __attribute__((always_inline)) {
+    pf_n4 = 0;
+    if (tile >= total_tiles) return;
+    int nb, q_lo, q_hi, ylo;
+    pf_n4 = tile_rows(tile, &nb, &q_lo, &q_hi, &ylo);
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.x + ((size_t)nb * IH + ylo) * IW * C);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i = u * 256 + tid;
+      if (i < pf_n4) pf[u] = src[i];
+    }
+  };
+  // the first tile's input rows are requested before anything else: their round trip runs under the table / filter staging
+  prefetch(blockIdx.x);
+
   // ---- tap table ---------------------------------------------------------------------------------------------------
   for (int k = tid; k < K16; k += 256) {
     int2 e = {-1, 0};
@@ -448,37 +481,6 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
       }
     }
   }
-  const int dy_lo = min(ph.offy, (ph.Ty - 1) * a.D + ph.offy), dy_hi = max(ph.offy, (ph.Ty - 1) * a.D + ph.offy);
-  const float* bl_lane = Bl + ((size_t)kq * BN + p15) * 4;
-  const int total_tiles = a.NB * tiles_per_img;
-
-  // The rows of the NEXT tile are fetched into registers before the current tile is multiplied and stored, and written to
-  // LDS after it: the fetch latency runs under the MFMAs, and (vmcnt is one in-order counter for loads and stores on
-  // gfx9) waiting for those loads does not wait for the output stores issued after them.  Round barriers are LDS-only.
-  constexpr int PF = 6;   // 16-byte registers per thread: tiles stage <= 24 KB of rows (smallc_geometry)
-  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  f32x4 pf[PF];
-  int pf_n4 = 0;
-  auto tile_rows = [&](int tile, int* nb_, int* q_lo_, int* q_hi_, int* ylo_) __attribute__((always_inline)) {
-    const int nb = tile / tiles_per_img, q_lo = (tile - nb * tiles_per_img) * subs * (64 * PT);
-    const int q_hi = min(q_lo + subs * (64 * PT), npix) - 1;
-    const int ylo = max(0, (q_lo / OWp) * a.S + dy_lo), yhi = min(IH - 1, (q_hi / OWp) * a.S + dy_hi);
-    *nb_ = nb; *q_lo_ = q_lo; *q_hi_ = q_hi; *ylo_ = ylo;
-    return max(0, yhi - ylo + 1) * IW * C >> 2;   // 16-byte units
-  };
-  auto prefetch = [&](int tile) __attribute__((always_inline)) {
-    pf_n4 = 0;
-    if (tile >= total_tiles) return;
-    int nb, q_lo, q_hi, ylo;
-    pf_n4 = tile_rows(tile, &nb, &q_lo, &q_hi, &ylo);
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.x + ((size_t)nb * IH + ylo) * IW * C);
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int i = u * 256 + tid;
-      if (i < pf_n4) pf[u] = src[i];
-    }
-  };
-  prefetch(blockIdx.x);
   __syncthreads();   // filter image complete
 
   for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
