@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = 93.551 - 2 * 0.3263
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (never the 2:1-sparse figure)
-PMC_SET = 'r02g'                # the profile set profiles/pmc_utilisation_latest.csv was derived from (tools/gpu_round_profile.sh)
+PMC_SET = 'r03l'                # the profile set profiles/pmc_utilisation_latest.csv was derived from (tools/gpu_round_profile.sh)
 X3_LIMB_PRODUCTS = 6            # limb products issued per fp32 product in f32x3 mode (edgegan_amd/csrc/k_gemm_x3.hip)
 
 
@@ -337,7 +337,10 @@ def loop_bench(args, ea, np, local):
 
 
 def main():
-    ap = argparse.ArgumentParser()
+    ap = argparse.ArgumentParser(epilog='N > 1: launch under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` '
+                                        '(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  The RCCL id travels through a '
+                                        'file keyed on the launcher process; a launcher whose ranks do not share a parent process must '
+                                        'export the same EG_RDZV_KEY to every rank.  EG_RCCL_LIB=<path> binds a specific librccl.')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)

@@ -127,6 +127,8 @@ struct Tensor {
   bool g_set = false;
   bool leaf_grad = false;   // gradient chain of this tensor runs on the lane's leaf stream (classifier's image pyramid: ops.cpp)
   bool g_inplace = false;   // the producer's backward rewrites g in place (conv + fused activation): g must not be shared
+  int fused_act = 0;        // ... that activation (Act enum); g_act_done: its derivative was already applied to g by the
+  bool g_act_done = false;  //     input-gradient kernel that wrote it (ConvArgs::epi_act)
   // forward-only convolution outputs left as their K-split slabs for the InstanceNorm pass that is their only reader
   // (ops.cpp: conv2d / deconv2d with Ctx::feeds_in, in_act): d is then NOT written
   const float* slabs = nullptr;

@@ -63,6 +63,13 @@ struct ConvArgs {
   int nphase;
   ConvPhase ph[4];
   int keep_slabs;   // K-split launches: leave the slabs in ws (no conv_split_reduce); the caller's consumer sums them
+  // Activation backward in the epilogue (input-gradient launches): y holds dL/d(act output); with epi_act = ACT_RELU /
+  // ACT_LRELU and epi_ref = that activation's OUTPUT (same layout as y) the kernel stores y * act'(out) instead -- the
+  // in-place pass of the producing conv + activation is then skipped.  Honoured by the un-split halo kernel only; the
+  // launcher reports it in epi_applied.
+  const float* epi_ref;
+  int epi_act;
+  int epi_applied;
 };
 
 // flops (2*M*N*K summed over phases) are returned for the profiler.

@@ -2,6 +2,7 @@
 // for its forward and records a closure that launches the kernels of its backward.
 // Reference semantics are cited per op; TF-1.14 op conventions follow SURVEY.md Appendix B.
 #include <cmath>
+#include <cstring>
 
 #include "engine.h"
 
@@ -132,7 +133,7 @@ void seed_grad(Ctx& c, T t) {
   t->g_set = true;
 }
 void reset_grads(Ctx& c) {
-  for (auto& t : c.tensors) t.g_set = false;
+  for (auto& t : c.tensors) t.g_set = t.g_act_done = false;
   for (auto& p : c.params) p->g_set = false;
   for (auto& s : c.sn) s.dWbar_set = false;
 }
@@ -445,6 +446,8 @@ static void run_conv(Ctx& c, ConvArgs& a) {
   }
   ProfScope ps(c);
   const double fl = launch_conv_gemm(a, c.stream, &nm);
+  a.epi_applied = a.epi_act && (strncmp(nm, "conv_gemm_x3h<", 14) == 0 || strncmp(nm, "conv_gemm_bf16h<", 16) == 0) &&
+                          !strstr(nm, "splitk") ? 1 : 0;   // (the kernels that honour ConvArgs::epi_act)
   if (x3_timing && a.limbs == 3 && a.ksplit <= 1 && a.ws) {
     long long h[128];
     EG_HIP(hipStreamSynchronize(c.stream));
@@ -540,6 +543,13 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
     int acc;
     a.y = grad_acc(c, x, &acc);
     a.accumulate = acc;
+    static const bool epi_on = dbg_env("EG_NO_EPI_ACT") == nullptr;
+    if (epi_on && x->g_inplace && !acc && (x->fused_act == ACT_RELU || x->fused_act == ACT_LRELU)) {
+      // x = act(conv(..)) with the activation fused in its producer (d_conv_0): this launch is the only writer of its
+      // gradient, so the activation's backward rides in the epilogue (if the un-split halo kernel runs the layer)
+      a.epi_ref = x->d;
+      a.epi_act = x->fused_act;
+    }
     a.OHf = x->h;
     a.OWf = x->w;
     a.kst = 2;
@@ -562,6 +572,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
       }
   }
   run_conv(c, a);
+  if (!a.accumulate) x->g_act_done = a.epi_applied != 0;   // (first writer: decides anew in every backward sweep)
 }
 
 static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, const float* dy, int OH, int OW,
@@ -698,12 +709,13 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   if (need) {
     y->needs_grad = true;
     y->g_inplace = fused;
+    y->fused_act = fused ? fused_act : 0;
     Ctx* cp = &c;
     const size_t rows = y->pixels();
     c.tape.push([=]() {
       Ctx& c = *cp;
       if (!y->g_set) return;
-      if (fused) launch_act_bwd(y->d, y->g, y->g, 0, y->numel(), fused_act, c.stream);   // in place: g *= act'(out)
+      if (fused && !y->g_act_done) launch_act_bwd(y->d, y->g, y->g, 0, y->numel(), fused_act, c.stream);   // in place: g *= act'(out)
       if (c.param_grad_enabled && (w->want_grad || (bias && bias->want_grad))) {
         LeafScope leaf(c);
         if (w->want_grad)

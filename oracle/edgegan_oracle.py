@@ -33,7 +33,7 @@ Tensor = torch.Tensor
 # bf16-operand emulation (for the engine's compute_dtype='bf16' mode; the reference itself is fp32)
 # --------------------------------------------------------------------------------------
 # Inside `with bf16_operands():` every dense contraction y = f(x, w) (conv, transposed conv, linear) is evaluated
-# the way the engine's bf16 mode evaluates it (DESIGN.md 4.6): each of its three bilinear maps -- forward,
+# the way the engine's bf16 mode evaluates it (DESIGN.md 3.2): each of its three bilinear maps -- forward,
 # input gradient, filter gradient -- rounds BOTH of its operands to bf16 (round-to-nearest-even) when that map
 # qualifies for the bf16 MFMA, and multiplies / accumulates exactly (in the oracle's own precision):
 #     y  = f(r(x), r(w))                      if conv rule(K = contracted channels, n_out)

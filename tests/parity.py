@@ -3,7 +3,7 @@
 Each check returns rows (name, error, tolerance).  Error metric: max|a-b| / (max|b| + 1e-30) with b the
 fp64 oracle value -- a scale-relative max-norm error.  Tolerances (fp32 arithmetic, different
 summation order than the oracle): forward 2e-5, backward 5e-5 unless a row says otherwise; the
-full-step tolerances are documented in tests/test_substeps_gpu.py.
+full-step tolerances are documented at substep_checks below and in tests/test_step_gpu.py / tests/test_tight_gpu.py.
 """
 from __future__ import annotations
 
@@ -92,13 +92,13 @@ def bf16r(t):
 
 
 def bf16_conv_rule(K, n_out):
-    """DESIGN.md 4.6: a conv / dgrad / transposed-conv contraction takes bf16 operands iff its contracted channel
+    """DESIGN.md 3.2: a conv / dgrad / transposed-conv contraction takes bf16 operands iff its contracted channel
     count K is a multiple of 32 and it produces more than 16 channels, a multiple of 4."""
     return K % 32 == 0 and n_out > 16 and n_out % 4 == 0
 
 
 def bf16_wgrad_rule(C, N):
-    """DESIGN.md 4.6: a weight gradient takes bf16 operands iff both channel counts are multiples of 4 and the
+    """DESIGN.md 3.2: a weight gradient takes bf16 operands iff both channel counts are multiples of 4 and the
     gathered operand has more than 16 channels (the flattened-(tap,c) kernel for C <= 16 stays fp32)."""
     return C % 4 == 0 and N % 4 == 0 and C > 16
 
