@@ -1,5 +1,6 @@
 // C ABI of libedgegan_hip.so (see include/edgegan_hip.h).  Translates exceptions to error codes.
 #include <algorithm>
+#include <cstdlib>
 #include <sstream>
 
 #include "../../include/edgegan_hip.h"

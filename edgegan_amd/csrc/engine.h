@@ -152,6 +152,7 @@ struct Ctx {
   int lanes_mask = 15;
   bool leaf_on = true;      // EG_LANES bit 3
   bool leaf_dirty = false;  // the active lane's leaf stream holds work the main stream has not ordered itself behind
+  std::vector<hipStream_t> placeholder_streams;   // model.cpp: stream -> hardware queue placement
   hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr, ev_branch = nullptr, ev_cls = nullptr;
 
   // inference staging buffers (host <-> device hand-over of eg_infer), grown on demand and kept

@@ -260,13 +260,33 @@ void build_context(Ctx& c) {
   // lane 0 is the context's own stream / scratch; lanes 1.. get their own
   c.lanes[0].stream = c.stream;
   c.lanes[0].scratch = c.scratch;
-  for (int i = 0; i < Ctx::kLanes; ++i) {
-    if (i > 0) {
-      EG_HIP(hipStreamCreateWithFlags(&c.lanes[i].stream, hipStreamNonBlocking));
-      EG_HIP(hipMalloc(&c.lanes[i].scratch, c.scratch_floats * 4));
+  // Stream -> hardware queue placement.  The HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES (4) hardware
+  // queues in CREATION order, round-robin, and two streams on one queue serialise; more queues are not an option (8 / 16
+  // queues measured -19 % / -25 %: the big one-block-per-CU matrix kernels of different streams then really share the
+  // chip; profiles/r03q_hw_queues.txt).  Which streams share a queue is worth up to 13 % (profiles/r03r_stream_plan_sweep*.txt,
+  // 14 placements x 4 workloads): best everywhere is  lane 0 | lane 1 + ALL leaf streams | lane 2 | lane 3  -- the four
+  // dependent chains never wait for one another, and the filter gradients (leaves) queue up behind one another and behind the
+  // image-discriminator lane.  The plan string is the creation order: a-d = the lanes' main streams (a = the context's own
+  // stream, created first in build_context), A-D their leaf streams, x = a placeholder stream that only advances the
+  // round-robin.  EG_STREAM_PLAN (experiments build) overrides it for A/B runs.  (The placement assumes the engine is the
+  // first creator of streams in the process, as it is under bench.py / train.py / test.py.)
+  {
+    const char* plan = dbg_env("EG_STREAM_PLAN") ? dbg_env("EG_STREAM_PLAN") : "bcdxAxxxBxxxCxxxD";
+    for (const char* q = plan; *q; ++q) {
+      hipStream_t* slot = nullptr;
+      hipStream_t dummy = nullptr;
+      if (*q >= 'b' && *q <= 'd') slot = &c.lanes[*q - 'a'].stream;
+      else if (*q >= 'A' && *q <= 'D') slot = &c.lanes[*q - 'A'].leaf;
+      else if (*q == 'x') slot = &dummy;
+      EG_CHECK(slot && !*slot, "EG_STREAM_PLAN: bad or repeated token '%c'", *q);
+      EG_HIP(hipStreamCreateWithFlags(slot, hipStreamNonBlocking));
+      if (slot == &dummy) c.placeholder_streams.push_back(dummy);
     }
+    for (int i = 0; i < Ctx::kLanes; ++i) EG_CHECK(c.lanes[i].stream && c.lanes[i].leaf, "EG_STREAM_PLAN misses a stream");
+  }
+  for (int i = 0; i < Ctx::kLanes; ++i) {
+    if (i > 0) EG_HIP(hipMalloc(&c.lanes[i].scratch, c.scratch_floats * 4));
     EG_HIP(hipEventCreateWithFlags(&c.lanes[i].done, hipEventDisableTiming));
-    EG_HIP(hipStreamCreateWithFlags(&c.lanes[i].leaf, hipStreamNonBlocking));
     EG_HIP(hipEventCreateWithFlags(&c.lanes[i].leaf_in, hipEventDisableTiming));
     EG_HIP(hipEventCreateWithFlags(&c.lanes[i].leaf_out, hipEventDisableTiming));
   }

@@ -1443,6 +1443,7 @@ Ctx::~Ctx() {
     if (lanes[i].leaf_in) (void)hipEventDestroy(lanes[i].leaf_in);
     if (lanes[i].leaf_out) (void)hipEventDestroy(lanes[i].leaf_out);
   }
+  for (auto st : placeholder_streams) (void)hipStreamDestroy(st);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_gen) (void)hipEventDestroy(ev_gen);
   if (ev_g1fwd) (void)hipEventDestroy(ev_g1fwd);

@@ -1,6 +1,6 @@
 """Two BUILDS of the library (e.g. the previous round's HEAD and this one) timed alternately in one process group on one
 box, through the core entry points only (create / upload / train_step / sync), so that an older library without the newer
-exports still loads:   python tools/gpu_ab_rounds.py libA.so libB.so [rounds] [--height H --width W --batch B --dtype D]"""
+exports still loads:   python tools/gpu_ab_rounds.py libA.so libB.so [libC.so ...] [--rounds R] [--height H --width W --batch B --dtype D]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
@@ -40,8 +40,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.exit(0)
 import argparse
 ap = argparse.ArgumentParser()
-ap.add_argument('libs', nargs=2)
-ap.add_argument('rounds', nargs='?', type=int, default=3)
+ap.add_argument('libs', nargs='+')
+ap.add_argument('--rounds', type=int, default=3)
 ap.add_argument('--height', type=int, default=64)
 ap.add_argument('--width', type=int, default=128)
 ap.add_argument('--batch', type=int, default=64)
