@@ -417,6 +417,13 @@ T classifier_forward(Ctx& c, T x) {
     c.sn_prepared = true;
   }
   // input pyramid by 2x2 mean pooling (classifier.py:27-35); levels 64,32,16,8 are used
+  if (x->needs_grad) {
+    // (pushed first = runs LAST in this forward's backward range: the image pyramid's gradient chain lives on the leaf
+    //  stream, see below; whatever follows on the main stream -- the resize / concat backward, the generator's -- reads and
+    //  accumulates into d(x) only behind it)
+    Ctx* cp = &c;
+    c.tape.push([cp]() { leaf_join(*cp); });
+  }
   T level[4];
   level[0] = x;
   for (int i = 1; i < 4; ++i) level[i] = pool2(c, level[i - 1]);

@@ -99,15 +99,21 @@ struct LeafScope {
     if (on) c.stream = main;
   }
 };
+// The main stream orders itself behind everything its lane's leaf stream holds (no-op when there is nothing).
+void leaf_join(Ctx& c) {
+  if (!c.leaf_dirty || !leaf_active(c) || c.stream != c.lanes[c.cur_lane].stream) return;
+  Ctx::Lane& l = c.lanes[c.cur_lane];
+  EG_HIP(hipEventRecord(l.leaf_out, l.leaf));
+  EG_HIP(hipStreamWaitEvent(c.stream, l.leaf_out, 0));
+  c.leaf_dirty = false;
+}
 void flush_deferred(Ctx& c) {
   if (leaf_active(c) && c.stream == c.lanes[c.cur_lane].stream) {
-    Ctx::Lane& l = c.lanes[c.cur_lane];
-    run_deferred(c, l.leaf);
-    if (c.leaf_dirty) {
-      EG_HIP(hipEventRecord(l.leaf_out, l.leaf));
-      EG_HIP(hipStreamWaitEvent(c.stream, l.leaf_out, 0));
-      c.leaf_dirty = false;
+    if (!c.deferred.empty()) {
+      run_deferred(c, c.lanes[c.cur_lane].leaf);
+      c.leaf_dirty = true;
     }
+    leaf_join(c);
     return;
   }
   run_deferred(c, c.stream);

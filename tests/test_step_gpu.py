@@ -182,6 +182,39 @@ def test_branch_lanes_when_the_resize_is_the_identity(dtype, monkeypatch):
     assert digests[0] == digests[1] == digests[2], digests
 
 
+@pytest.mark.parametrize('dtype', ['f32x3', 'bf16'])
+def test_gradient_probes_reproduce_themselves_and_the_one_stream_schedule(dtype, monkeypatch):
+    """eg_substep(k, apply=0) -- the path every parity test reads gradients through -- runs ONE backward sweep on the
+    lane's main stream with the filter gradients and the classifier's image-pyramid gradient chain on its leaf stream
+    (ops.cpp: LeafScope).  Everything the main stream reads or accumulates behind a leaf-stream writer must be ordered
+    behind it (round 3 found d(G2(z)) read by the resize / concat / generator backward before the pyramid chain had
+    finished): each sub-step's gradients must come out bit-identical when the probe is repeated, and identical to the
+    one-stream schedule (EG_LANES=0)."""
+    cfg = ea.Config(batch_size=16, compute_dtype=dtype)
+    values = ea.init_variables(cfg, 2)
+    b = ea.synthetic_batch(cfg, seed=17)
+    names = {1: ['D/d_conv_1/conv2d/w'], 4: ['D2/mru_conv_unit_t_2_layer_0/Conv_2/weights', 'D2/Conv/weights'],
+             5: ['G2/g_dconv_3/deconv2d/w', 'G2/g_lin_0/Matrix', 'G1/g_dconv_1/deconv2d/w'], 6: ['E/e_resnet_128_1/res1/conv2d/w'],
+             7: ['G2/g_dconv_4/deconv2d/w', 'G1/g_dconv_3/deconv2d/w']}
+    got = {}
+    for lanes in ('15', '0'):
+        monkeypatch.setenv('EG_LANES', lanes)
+        net = ea.EdgeGAN(cfg, values)
+        net.upload_batch(**b)
+        for rep in range(3):
+            for k, vns in names.items():
+                net.substep(k, apply=False)
+                for vn in vns:
+                    g = net.get_variable(vn + '/grad')
+                    assert np.all(np.isfinite(g)), (lanes, rep, k, vn)
+                    key = (k, vn)
+                    if key in got:
+                        assert np.array_equal(g, got[key]), f'EG_LANES={lanes} repetition {rep}: sub-step {k} {vn} differs'
+                    else:
+                        got[key] = g
+        net.close()
+
+
 def test_rccl_single_rank_allreduce_and_overlap_path():
     """nranks=1 communicator: exercises the RCCL binding, the all-reduce on the real library and the side-stream
     overlap of (all-reduce + RMSProp) with the next sub-step's compute.  With one rank the exchange is the
