@@ -9,6 +9,8 @@ export TMPDIR=/tmp
 EG_LANES=0 bash tools/gpu_pmc.sh $OUT/pmc "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" -- python bench.py --steps 2 --warmup 1 --profile-steps 0 --no-cpu-baseline --no-alt > $OUT/pmc.log 2>&1
 python tools/pmc_derive.py $OUT/pmc/summary.csv $OUT/pmc_utilisation.csv && cp $OUT/pmc_utilisation.csv profiles/pmc_utilisation_latest.csv
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
+python bench.py --mode loop --steps 30 --no-cpu-baseline > $OUT/bench_loop.json 2>> $OUT/bench.err
 python bench.py --dtype bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2>> $OUT/bench.err
 python bench.py --mode infer --no-cpu-baseline > $OUT/bench_infer.json 2>> $OUT/bench.err
 python bench.py --height 256 --width 512 --batch 16 --no-cpu-baseline --steps 5 --warmup 2 > $OUT/bench_256x512_b16.json 2>> $OUT/bench.err
