@@ -924,12 +924,14 @@ void train_step(Ctx& c) {
   }
   comm_wait_groups(c, 1u << G_G1);   // G1's pending update (data parallel) must be in before its filters are read
   warm_transposes(c, G_G1);
-  fork(2);
+  static const int l6 = dbg_env("EG_SS6_LANE") ? atoi(dbg_env("EG_SS6_LANE")) : 1;   // A/B: the lane that hosts sub-step 6
+  EG_HIP(hipEventRecord(c.ev_fork, c.lanes[0].stream));
+  EG_HIP(hipStreamWaitEvent(c.lanes[l6].stream, c.ev_fork, 0));
   {
     SubOpts o6;
     o6.bn_times_g1 = 0;              // sub-step 7 evaluates the same G1 forward: it applies both updates
     o6.record_after_g1_fwd = c.ev_g1fwd;
-    use_lane(c, 1);
+    use_lane(c, l6);
     run_substep(c, 6, true, &o6);
     SubOpts o7;
     o7.bn_times_g1 = 2;
@@ -939,7 +941,9 @@ void train_step(Ctx& c) {
     use_lane(c, 0);
     run_substep(c, 7, true, &o7);
   }
-  join(2);
+  use_lane(c, 0);
+  EG_HIP(hipEventRecord(c.lanes[l6].done, c.lanes[l6].stream));
+  EG_HIP(hipStreamWaitEvent(c.lanes[0].stream, c.lanes[l6].done, 0));
   ++c.step_count;
 }
 
