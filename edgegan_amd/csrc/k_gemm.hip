@@ -989,7 +989,8 @@ static bool wgrad_x3(const WgradArgs& a) {   // (limbs == 1: the same kernel wit
 int wgrad_pick_splits(const WgradArgs& a) {
   const long long M = (long long)a.NB * a.OH * a.OW;
   if (wgrad_x3(a)) {   // ping-pong blocks: two (tap, 128-channel) units x 128 output channels, one block per CU
-    const long long units = a.C == 64 ? (a.KH * a.KW + 1) / 2 : (long long)a.KH * a.KW * ((a.C + 127) / 128);
+    const long long units = wgrad_x3_rowhalo_units(a) ? wgrad_x3_rowhalo_units(a)     // (filter row, column phase, 64-channel block)
+                            : a.C == 64 ? (a.KH * a.KW + 1) / 2 : (long long)a.KH * a.KW * ((a.C + 127) / 128);
     const long long tiles = ((units + 1) / 2) * ((a.N + 127) / 128);
     // one block per CU (512 threads, 100 KB LDS): 256 blocks = one full wave of blocks.  Measured against 512 (two
     // waves): filter-gradient kernels 7.05 -> 6.70 ms per iteration and half the partial slabs to write and reduce

@@ -767,17 +767,22 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
   const int T = a.KH * a.KW;
   const bool two_taps = C == 64;
   const int ctiles = (C + BM - 1) / BM, ntn = (N + BN - 1) / BN, units = two_taps ? (T + 1) / 2 : T * ctiles;
-  const int unit = ((int)blockIdx.x / ntn) * 2 + grp;
+  // XCD-aware block map: the blocks of one pixel slab (same split index, all units and output tiles) read the same x
+  // and dY; the dispatcher places block b on XCD b % 8, so without a remap a slab is fetched into several XCDs' L2s
+  // (measured 4.5x the algorithmic HBM reads).  xcd_remap gives every XCD a contiguous range of virtual ids.
+  const unsigned vblk = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, a.dbg & 16);
+  const int bx = __builtin_amdgcn_readfirstlane(vblk % gridDim.x), by = __builtin_amdgcn_readfirstlane(vblk / gridDim.x);
+  const int unit = (bx / ntn) * 2 + grp;
   const bool uvalid = unit < units;                      // an idle group still splits its half of dY and keeps the barriers
   const int tap = uvalid ? (two_taps ? 2 * unit : unit / ctiles) : 0;
   const int tap1 = two_taps ? tap + 1 : tap;             // tap of the tile's upper row half (may be == T: an empty half)
-  const int c0 = (uvalid && !two_taps ? unit % ctiles : 0) * BM, n0 = ((int)blockIdx.x % ntn) * BN;
+  const int c0 = (uvalid && !two_taps ? unit % ctiles : 0) * BM, n0 = (bx % ntn) * BN;
   const int khh[2] = {tap / a.KW, tap1 / a.KW};
   const int kwh[2] = {tap - khh[0] * a.KW, tap1 - khh[1] * a.KW};
   const int M = a.NB * a.OH * a.OW;
   int chunk = (M + a.nsplit - 1) / a.nsplit;
   chunk = (chunk + BKX - 1) / BKX * BKX;
-  const int p_lo = (int)blockIdx.y * chunk;
+  const int p_lo = by * chunk;
   const int p_hi = min(M, p_lo + chunk);
   const int nt = p_hi > p_lo ? (p_hi - p_lo + BKX - 1) / BKX : 0;
 
@@ -979,7 +984,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3pp_kernel(const WgradArgs a, f
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * WTN + j * 32 + g * 8 + lh * 4;
         if (n >= N) continue;
-        float* q = dense_out ? out + (((size_t)blockIdx.y * T + otap) * C + c) * N + n
+        float* q = dense_out ? out + (((size_t)by * T + otap) * C + c) * N + n
                              : out + (size_t)otap * a.w_ts + (size_t)c * a.ldw + n;
         float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         if (!dense_out && a.accumulate) {
@@ -1006,23 +1011,33 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3t_kernel(const WgradArgs a, fl
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
   const int wm = wave >> 1, wn = wave & 1;
+#ifdef EG_EXPERIMENTS
+  const int dbg = a.dbg;     // limiter probes: 1 no limb split, 2 no fragment reads, 4 no LDS stores, 8 no global loads
+#else
+  constexpr int dbg = 0;
+#endif
   unsigned short (&As)[NL][BKX * BM] = AsG[grp];
   unsigned (&poff)[2][2][256] = poffG[grp];
   const int C = a.C, N = a.N, IH = a.IH, IW = a.IW;
   const int T = a.KH * a.KW;
   const bool two_taps = C == 64;
   const int ctiles = (C + BM - 1) / BM, ntn = (N + BN - 1) / BN, units = two_taps ? (T + 1) / 2 : T * ctiles;
-  const int unit = ((int)blockIdx.x / ntn) * 2 + grp;
+  // XCD-aware block map: the blocks of one pixel slab (same split index, all units and output tiles) read the same x
+  // and dY; the dispatcher places block b on XCD b % 8, so without a remap a slab is fetched into several XCDs' L2s
+  // (measured 4.5x the algorithmic HBM reads).  xcd_remap gives every XCD a contiguous range of virtual ids.
+  const unsigned vblk = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, a.dbg & 16);
+  const int bx = __builtin_amdgcn_readfirstlane(vblk % gridDim.x), by = __builtin_amdgcn_readfirstlane(vblk / gridDim.x);
+  const int unit = (bx / ntn) * 2 + grp;
   const bool uvalid = unit < units;                      // an idle group still splits its half of dY and keeps the barriers
   const int tap = uvalid ? (two_taps ? 2 * unit : unit / ctiles) : 0;
   const int tap1 = two_taps ? tap + 1 : tap;             // tap of the tile's upper row half (may be == T: an empty half)
-  const int c0 = (uvalid && !two_taps ? unit % ctiles : 0) * BM, n0 = ((int)blockIdx.x % ntn) * BN;
+  const int c0 = (uvalid && !two_taps ? unit % ctiles : 0) * BM, n0 = (bx % ntn) * BN;
   const int khh[2] = {tap / a.KW, tap1 / a.KW};
   const int kwh[2] = {tap - khh[0] * a.KW, tap1 - khh[1] * a.KW};
   const int M = a.NB * a.OH * a.OW;
   int chunk = (M + a.nsplit - 1) / a.nsplit;
   chunk = (chunk + BKX - 1) / BKX * BKX;
-  const int p_lo = (int)blockIdx.y * chunk;
+  const int p_lo = by * chunk;
   const int p_hi = min(M, p_lo + chunk);
   const int nt = p_hi > p_lo ? (p_hi - p_lo + BKX - 1) / BKX : 0;
 
@@ -1074,18 +1089,22 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3t_kernel(const WgradArgs a, fl
   };
   f32x4 ra0[2][2], ra1[2][2], rb0[2], rb1[2];
   auto load_a = [&](int t, f32x4 (&ra)[2][2]) __attribute__((always_inline)) {
+    if (dbg & 8) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const unsigned* po = &poff[(t >> 3) & 1][i][(t & 7) * 32 + 2 * mp];
-      const unsigned o0 = po[0], o1 = po[1];
+      unsigned o0 = po[0], o1 = po[1];
+      if (dbg & 32) { o0 &= 0x80000fffu; o1 &= 0x80000fffu; }   // probe: every gather inside one 4 KB window (cache-resident)
       ra[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, o0 + a_coff[i], 0, 0));
       ra[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, o1 + a_coff[i], 0, 0));
     }
   };
   auto load_b = [&](int t, f32x4 (&rb)[2]) __attribute__((always_inline)) {
+    if (dbg & 8) return;
     const int m = p_lo + t * BKX + 2 * mp;
-    const unsigned r0 = m < p_hi ? (unsigned)(m * a.dy_ps * 4) : 0x80000000u;
-    const unsigned r1 = m + 1 < p_hi ? (unsigned)((m + 1) * a.dy_ps * 4) : 0x80000000u;
+    unsigned r0 = m < p_hi ? (unsigned)(m * a.dy_ps * 4) : 0x80000000u;
+    unsigned r1 = m + 1 < p_hi ? (unsigned)((m + 1) * a.dy_ps * 4) : 0x80000000u;
+    if (dbg & 32) { r0 &= 0x80000fffu; r1 &= 0x80000fffu; }
     rb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r0 + b_noff, 0, 0));
     rb[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r1 + b_noff, 0, 0));
   };
@@ -1095,6 +1114,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3t_kernel(const WgradArgs a, fl
     const int o0 = p0 * BM + ((((cq >> 2) ^ fsw(p0)) << 2) | (cq & 3)) * 4;
     const int o1 = p1 * BM + ((((cq >> 2) ^ fsw(p1)) << 2) | (cq & 3)) * 4;
     unsigned a0, a1, a2, b0, b1, b2;
+    if (dbg & 4) return;
+    if (dbg & 1) {
+      const u32x4 l = __builtin_bit_cast(u32x4, lo), h = __builtin_bit_cast(u32x4, hi);
+      *reinterpret_cast<u32x2*>(&P[0][o0]) = (u32x2){l[0], l[1]};
+      *reinterpret_cast<u32x2*>(&P[1][o0]) = (u32x2){l[2], l[3]};
+      *reinterpret_cast<u32x2*>(&P[2][o0]) = (u32x2){l[0], l[2]};
+      *reinterpret_cast<u32x2*>(&P[0][o1]) = (u32x2){h[0], h[1]};
+      *reinterpret_cast<u32x2*>(&P[1][o1]) = (u32x2){h[2], h[3]};
+      *reinterpret_cast<u32x2*>(&P[2][o1]) = (u32x2){h[0], h[2]};
+      return;
+    }
     split_pair(lo[0], lo[1], a0, a1, a2);
     split_pair(lo[2], lo[3], b0, b1, b2);
     *reinterpret_cast<u32x2*>(&P[0][o0]) = (u32x2){a0, b0};
@@ -1140,6 +1170,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3t_kernel(const WgradArgs a, fl
   // (macros, not lambdas: the plane offset must reach the instruction as an immediate)
 #define EG_RDA(f, pl)                                                                                     \
   do {                                                                                                    \
+    if (dbg & 2) break;                                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
       EG_TRR(f.h[i_][0][0], ea[i_][0], (pl) * PLB); EG_TRR(f.h[i_][0][1], ea[i_][1], (pl) * PLB);           \
       EG_TRR(f.h[i_][1][0], ea[i_][0], (pl) * PLB + KHB); EG_TRR(f.h[i_][1][1], ea[i_][1], (pl) * PLB + KHB); \
@@ -1147,6 +1178,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3t_kernel(const WgradArgs a, fl
   } while (0)
 #define EG_RDB(f, pl)                                                                                     \
   do {                                                                                                    \
+    if (dbg & 2) break;                                                                                   \
     _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                    \
       const unsigned b0_ = bcur + eb[j_][0], b1_ = bcur + eb[j_][1];                                      \
       EG_TRR(f.h[j_][0][0], b0_, (pl) * PLB); EG_TRR(f.h[j_][0][1], b1_, (pl) * PLB);                       \
@@ -1282,7 +1314,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3t_kernel(const WgradArgs a, fl
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * WTN + j * 32 + g * 8 + lh * 4;
         if (n >= N) continue;
-        float* q = dense_out ? out + (((size_t)blockIdx.y * T + otap) * C + c) * N + n
+        float* q = dense_out ? out + (((size_t)by * T + otap) * C + c) * N + n
                              : out + (size_t)otap * a.w_ts + (size_t)c * a.ldw + n;
         float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         if (!dense_out && a.accumulate) {
@@ -1298,9 +1330,383 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3t_kernel(const WgradArgs a, fl
 #undef EG_RDA
 #undef EG_RDB
 
+
+// =============================================================================================
+// filter gradient, ROW-HALO form (three-limb mode): 3x3 stride 1, 4x4 stride 2, 5x5 stride 2 (KW <= 3 S).
+// wgrad_x3t above stages, per (tap, 128-channel) unit and K step, the 32 gathered pixels of ONE tap: every staged element
+// feeds one tap's products and the staging (gather latency, limb split, LDS stores) is what bounds it (limiter probes:
+// profiles/r03w_wgrad_limiter.txt).  Here a unit is (filter ROW ky, column phase par < S, 64-channel block): a K step's 32
+// output pixels are R = 32 / W image-row segments of W = min(OW, 32) pixels, and the unit's taps kx = par + S d (d < 3)
+// read the same R x (W + ntaps - 1) input pixels -- those of columns S (ox + hx) + par - pad -- shifted by one halo column
+// per tap: staged ONCE, pixel-major, and read ntaps times with ds_read_b64_tr_b16 (each lane addresses its own pixel row,
+// so a column shift is free).  Staged elements per MFMA at 3x3: 14.7 against 32.
+// Block = two groups (units 2b, 2b+1) x four waves; wave w owns output channels 32w..32w+31 of the 128-wide dY tile
+// (shared by the groups as in wgrad_x3t) and all 64 filter rows of its unit for the three taps: 6 accumulators.
+// =============================================================================================
+template <int S, int KW>
+__global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
+  constexpr int BC = 64, BN = 128, NL = 3, HPMAX = 48, NU = 3;
+  __shared__ __attribute__((aligned(16))) unsigned short AsG[2][NL][HPMAX * BC];   // per group: [halo pixel][c], 128-byte rows
+  __shared__ __attribute__((aligned(16))) unsigned short BsG[2][NL][BKX * BN];     // per K-step parity: [pixel][n]
+
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  const int C = a.C, N = a.N, OH = a.OH, OW = a.OW;
+  constexpr int nph = S < KW ? S : KW, NT = (KW + S - 1) / S;   // NT: most taps a unit has (compile time: register budget)
+  static_assert(NT <= 3, "at most three taps per (filter row, column phase)");
+  const int cblocks = C / BC, ntn = (N + BN - 1) / BN, upr = nph * cblocks, units = a.KH * upr;   // upr: units per filter row
+  const unsigned vblk = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, a.dbg & 16);
+  const int bx = __builtin_amdgcn_readfirstlane(vblk % gridDim.x), by = __builtin_amdgcn_readfirstlane(vblk / gridDim.x);
+  const int unit = (bx / ntn) * 2 + grp;
+  const bool uvalid = unit < units;                      // an idle group still splits its half of dY and keeps the barriers
+  const int ky = uvalid ? unit / upr : 0, urem = uvalid ? unit - ky * upr : 0;
+  const int par = urem / cblocks;                         // column phase: the unit's taps are kx = par + S d
+  constexpr int ntaps = NT;    // (5x5 stride 2: the odd phase has two taps; its third is computed and dropped -- no run-time tap count in the loop)
+  const int c0 = (urem - par * cblocks) * BC, n0 = (bx % ntn) * BN;
+  const int IH = a.IH, IW = a.IW;
+  const int M = a.NB * OH * OW;
+  int chunk = (M + a.nsplit - 1) / a.nsplit;
+  chunk = (chunk + BKX - 1) / BKX * BKX;
+  const int p_lo = by * chunk;
+  const int p_hi = min(M, p_lo + chunk);
+  const int nt = p_hi > p_lo ? (p_hi - p_lo + BKX - 1) / BKX : 0;
+  // OW, OH are powers of two (launch_wgrad_x3): a K step = R rows x W columns, halo = R x (W + 2) pixels
+  const int lOW = __builtin_ctz(OW), lOH = __builtin_ctz(OH);
+  const int lW = min(lOW, 5), W = 1 << lW, HWP = W + ntaps - 1, HP = (32 >> lW) * HWP;
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
+
+  // ---- A staging: unit u = tid + 256 j = (halo pixel h = u >> 4, channel quad u & 15); the 16 lanes of a halo pixel store
+  // its 128-byte row.  Row q's 16-channel blocks are XORed with fa(q) = 2 ((q >> 1) & 1): the (4 consecutive rows) x (two
+  // 16-channel blocks) x (4 chunks) addresses of a half wave's transpose read cover all 64 banks once for any row
+  // alignment (so for every tap shift), and the two rows a half wave stores are one 256-byte run.
+  auto fa = [](int q) __attribute__((always_inline)) { return q & 2; };
+  const unsigned as_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&AsG[grp][0][0];
+  int hrow[NU], hcol[NU];
+  unsigned sa[NU], a_coff[NU];
+  bool hv[NU];
+#pragma unroll
+  for (int j = 0; j < NU; ++j) {
+    const int u = tid + 256 * j, h = u >> 4, cq = u & 15;
+    hv[j] = uvalid && h < HP;
+    hrow[j] = h / HWP;
+    hcol[j] = h - hrow[j] * HWP;          // halo column: input column S (ox0 + hcol) + par - pad
+    sa[j] = as_base + (unsigned)(h * (BC * 2) + ((((cq >> 2) ^ fa(h)) << 2) | (cq & 3)) * 8);
+    a_coff[j] = (unsigned)((c0 + cq * 4) * 4);
+  }
+  // (wave-uniform) does unit j of this wave hold any halo pixel?
+  bool wact[NU];
+#pragma unroll
+  for (int j = 0; j < NU; ++j) wact[j] = ((wave * 64 + 256 * j) >> 4) < HP;
+  auto a_off = [&](int j, int t) __attribute__((always_inline)) {
+    const int m = p_lo + t * BKX;
+    const int grow = (m >> lOW) + hrow[j];
+    const int nb = grow >> lOH, oy = grow & (OH - 1);
+    int iy = oy * S + ky - a.pad, ix = ((m & (OW - 1)) + hcol[j]) * S + par - a.pad;
+    if (a.reflect) {
+      iy = reflect_x(iy, IH);
+      ix = reflect_x(ix, IW);
+    }
+    const bool ok = hv[j] && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+    return ok ? (unsigned)(((nb * IH + iy) * IW + ix) * a.x_ps * 4) + a_coff[j] : 0x80000000u;
+  };
+  // ---- B staging (as wgrad_x3t): unit = (pixel pair mp, channel quad), this group stages quads cqb + 16 grp
+  const int cq8 = tid & 7, mpl = (tid >> 3) & 3, rest = tid >> 5;
+  const int mp = (rest & 3) * 4 + mpl;
+  const int cqb = (rest >> 2) * 8 + cq8;
+  auto fsw = [](int p) __attribute__((always_inline)) { return ((p >> 2) & 1) | (((p ^ (p >> 1)) & 1) << 1) | (((p >> 1) & 1) << 2); };
+  const int bn = n0 + (cqb + 16 * grp) * 4;
+  const unsigned b_noff = bn < N ? (unsigned)(bn * 4) : 0x40000000u;
+
+  f32x4 ra0[NU], ra1[NU], rb0[2], rb1[2];
+  auto load_a = [&](int t, f32x4 (&ra)[NU]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+      if (wact[j]) ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, a_off(j, t), 0, 0));
+  };
+  auto load_b = [&](int t, f32x4 (&rb)[2]) __attribute__((always_inline)) {
+    const int m = p_lo + t * BKX + 2 * mp;
+    const unsigned r0 = m < p_hi ? (unsigned)(m * a.dy_ps * 4) : 0x80000000u;
+    const unsigned r1 = m + 1 < p_hi ? (unsigned)((m + 1) * a.dy_ps * 4) : 0x80000000u;
+    rb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r0 + b_noff, 0, 0));
+    rb[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r1 + b_noff, 0, 0));
+  };
+  constexpr int PLA = HPMAX * BC * 2;    // bytes of one A plane
+  auto store_a = [&](int j, const f32x4& v) __attribute__((always_inline)) {
+    unsigned x0, x1, x2, y0, y1, y2;
+    split_pair(v[0], v[1], x0, x1, x2);
+    split_pair(v[2], v[3], y0, y1, y2);
+    __attribute__((address_space(3))) char* q = (__attribute__((address_space(3))) char*)(uintptr_t)sa[j];
+    *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q) = (u32x2){x0, y0};
+    *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q + PLA) = (u32x2){x1, y1};
+    *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q + 2 * PLA) = (u32x2){x2, y2};
+  };
+  auto store_b = [&](unsigned short (&P)[NL][BKX * BN], int cq, const f32x4& lo, const f32x4& hi) __attribute__((always_inline)) {
+    const int p0 = 2 * mp, p1 = 2 * mp + 1;
+    const int o0 = p0 * BN + ((((cq >> 2) ^ fsw(p0)) << 2) | (cq & 3)) * 4;
+    const int o1 = p1 * BN + ((((cq >> 2) ^ fsw(p1)) << 2) | (cq & 3)) * 4;
+    unsigned x0, x1, x2, y0, y1, y2;
+    split_pair(lo[0], lo[1], x0, x1, x2);
+    split_pair(lo[2], lo[3], y0, y1, y2);
+    *reinterpret_cast<u32x2*>(&P[0][o0]) = (u32x2){x0, y0};
+    *reinterpret_cast<u32x2*>(&P[1][o0]) = (u32x2){x1, y1};
+    *reinterpret_cast<u32x2*>(&P[2][o0]) = (u32x2){x2, y2};
+    split_pair(hi[0], hi[1], x0, x1, x2);
+    split_pair(hi[2], hi[3], y0, y1, y2);
+    *reinterpret_cast<u32x2*>(&P[0][o1]) = (u32x2){x0, y0};
+    *reinterpret_cast<u32x2*>(&P[1][o1]) = (u32x2){x1, y1};
+    *reinterpret_cast<u32x2*>(&P[2][o1]) = (u32x2){x2, y2};
+  };
+
+  f32x16 acc[NT][2];    // [tap d][32-row block of the unit's 64 filter rows]
+#pragma unroll
+  for (int d = 0; d < NT; ++d)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[d][i][r] = 0.f;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // transpose reads (see wgrad_x3t): lane 4r + q of a 16-lane group addresses chunk q of pixel row r
+  const int tg = lane >> 4, ti = lane & 15, tr = ti >> 2, tq = ti & 3;
+  unsigned ea[2][2][NT];   // A: [K half][first / second 4 pixels][tap column], 32-row block 0 (block 1 = ^ 64), plane 0
+  unsigned eb[2];         // B: [first / second 4 pixels] of K half 0, plane 0, relative to the parity's base
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p = 16 * kk + 8 * (tg >> 1) + 4 * h + tr;
+      const int q0 = (p >> lW) * HWP + (p & (W - 1));
+#pragma unroll
+      for (int d = 0; d < NT; ++d) {
+        const int q = q0 + d;
+        ea[kk][h][d] = as_base + (unsigned)(q * (BC * 2) + (((((tg & 1)) ^ fa(q)) << 2) | tq) * 8);
+      }
+    }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int pix = 8 * (tg >> 1) + 4 * h + tr;
+    const int cbb = 2 * wave + (tg & 1);
+    eb[h] = (unsigned)((pix * BN + (((cbb ^ fsw(pix)) << 2) | tq) * 4) * 2);
+  }
+  unsigned bcur = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&BsG[0][0][0];
+  constexpr int PLB = BKX * BN * 2;      // bytes of one B plane
+  constexpr int KHB = 16 * BN * 2;       // bytes between the two K halves of the B tile (16 pixel rows)
+#define EG_TRR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  struct FragA { u32x2 h[2][2][2]; };    // [32-row block][K half][first / second 4 pixels]
+  struct FragB { u32x2 h[2][2]; };       // [K half][first / second 4 pixels]
+#define EG_RDA(f, pl, d)                                                                                  \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) {                                                    \
+      EG_TRR(f.h[0][k_][0], ea[k_][0][d], (pl) * PLA); EG_TRR(f.h[0][k_][1], ea[k_][1][d], (pl) * PLA);     \
+      const unsigned x0_ = ea[k_][0][d] ^ 64u, x1_ = ea[k_][1][d] ^ 64u;                                  \
+      EG_TRR(f.h[1][k_][0], x0_, (pl) * PLA); EG_TRR(f.h[1][k_][1], x1_, (pl) * PLA);                       \
+    }                                                                                                     \
+  } while (0)
+#define EG_RDB(f, pl)                                                                                     \
+  do {                                                                                                    \
+    const unsigned b0_ = bcur + eb[0], b1_ = bcur + eb[1];                                                \
+    EG_TRR(f.h[0][0], b0_, (pl) * PLB); EG_TRR(f.h[0][1], b1_, (pl) * PLB);                                 \
+    EG_TRR(f.h[1][0], b0_, (pl) * PLB + KHB); EG_TRR(f.h[1][1], b1_, (pl) * PLB + KHB);                     \
+  } while (0)
+#define EG_TWA(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f.h[0][0][0]), "+v"(f.h[0][0][1]), "+v"(f.h[0][1][0]), "+v"(f.h[0][1][1]), \
+                                  "+v"(f.h[1][0][0]), "+v"(f.h[1][0][1]), "+v"(f.h[1][1][0]), "+v"(f.h[1][1][1]))
+#define EG_TWB(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f.h[0][0]), "+v"(f.h[0][1]), "+v"(f.h[1][0]), "+v"(f.h[1][1]))
+  auto opa = [](const FragA& f, int i, int kk) __attribute__((always_inline)) {
+    const u32x4 v = {f.h[i][kk][0][0], f.h[i][kk][0][1], f.h[i][kk][1][0], f.h[i][kk][1][1]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto opb = [](const FragB& f, int kk) __attribute__((always_inline)) {
+    const u32x4 v = {f.h[kk][0][0], f.h[kk][0][1], f.h[kk][1][0], f.h[kk][1][1]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  auto run = [&](auto GRP) __attribute__((always_inline)) {
+    constexpr int LEAD = decltype(GRP)::value;   // X stages its dY half of step k in VALU phase k, Y that of step k + 1
+    auto valu_phase = [&](auto RT, int k, const f32x4 (&ra)[NU], f32x4 (&ran)[NU], const f32x4 (&rb)[2], f32x4 (&rbn)[2])
+                          __attribute__((always_inline)) {
+      constexpr bool rt = decltype(RT)::value;
+      if (!rt || k + 1 < nt) load_a(k + 1, ran);
+      if (!rt || k + 1 + LEAD < nt) load_b(k + 1 + LEAD, rbn);
+      if constexpr (!rt) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+        if (wact[j]) store_a(j, ra[j]);
+      if (!rt || k + LEAD < nt) store_b(BsG[(k + LEAD) & 1], cqb + 16 * LEAD, rb[0], rb[1]);
+    };
+    auto mfma_phase = [&](int k) __attribute__((always_inline)) {
+      lds_barrier();
+      bcur = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&BsG[k & 1][0][0];
+      // per tap column the six limb products a0b0 a0b1 a0b2 a1b0 a1b1 a2b0 (4 MFMAs each); the dY fragments are read once
+      // and serve the three taps; every fragment set is requested at least one product ahead of its use
+      FragB b0, b1, b2;
+      FragA a0, a1, a2;
+      auto mm = [&](int d, const FragA& af, const FragB& bf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[d][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opb(bf, kk), opa(af, i, kk), acc[d][i], 0, 0, 0);
+      };
+      EG_RDB(b0, 0);
+      EG_RDA(a0, 0, 0);
+      EG_RDB(b1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      EG_TWB(4, b0); EG_TWA(4, a0);
+      mm(0, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      EG_RDB(b2, 2);
+      EG_TWB(4, b1);
+      mm(0, a0, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      EG_RDA(a1, 1, 0);
+      EG_TWB(8, b2);
+      mm(0, a0, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      EG_RDA(a2, 2, 0);
+      EG_TWA(8, a1);
+      mm(0, a1, b0);
+      mm(0, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (NT > 1 && ntaps > 1) {      // (wave-uniform)
+        EG_RDA(a0, 0, NT > 1 ? 1 : 0);
+        EG_TWA(8, a2);
+      } else {
+        EG_TWA(0, a2);
+      }
+      mm(0, a2, b0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int d = 1; d < NT; ++d) {
+        if (d >= ntaps) break;
+        EG_RDA(a1, 1, d);
+        EG_TWA(8, a0);
+        mm(d, a0, b0);
+        mm(d, a0, b1);
+        mm(d, a0, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        EG_RDA(a2, 2, d);
+        EG_TWA(8, a1);
+        mm(d, a1, b0);
+        mm(d, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d == 1 && NT > 2 && ntaps > 2) {
+          EG_RDA(a0, 0, NT > 2 ? 2 : 0);
+          EG_TWA(8, a2);
+        } else {
+          EG_TWA(0, a2);
+        }
+        mm(d, a2, b0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      lds_barrier();
+    };
+    constexpr std::true_type guarded{};
+    constexpr std::false_type steady{};
+    // prologue: X holds A(0), B(0); Y holds A(0), B(1) and has already stored its half of B(0) (in its idle slot 0)
+    if (nt > 0) {
+      load_a(0, ra0);
+      if constexpr (LEAD == 0) {
+        load_b(0, rb0);
+      } else {
+        load_b(0, rb0);
+        if (nt > 1) load_b(1, rb1);
+        store_b(BsG[0], cqb + 16, rb0[0], rb0[1]);
+        lds_barrier();         // Y's idle slot 0
+      }
+    }
+    // staging sets: A(k) in ra[k & 1]; X: B(k) in rb[k & 1]; Y: B(k + 1) in rb[(k + 1) & 1]
+    int k = 0;
+    for (; k + 3 < nt; k += 2) {
+      if constexpr (LEAD == 0) {
+        valu_phase(steady, k, ra0, ra1, rb0, rb1);
+        mfma_phase(k);
+        valu_phase(steady, k + 1, ra1, ra0, rb1, rb0);
+        mfma_phase(k + 1);
+      } else {
+        valu_phase(steady, k, ra0, ra1, rb1, rb0);
+        mfma_phase(k);
+        valu_phase(steady, k + 1, ra1, ra0, rb0, rb1);
+        mfma_phase(k + 1);
+      }
+    }
+    if (k < nt) {   // up to 3 steps left (k even), straight-line with run-time guards
+      if constexpr (LEAD == 0) valu_phase(guarded, k, ra0, ra1, rb0, rb1);
+      else valu_phase(guarded, k, ra0, ra1, rb1, rb0);
+      mfma_phase(k);
+      if (k + 1 < nt) {
+        if constexpr (LEAD == 0) valu_phase(guarded, k + 1, ra1, ra0, rb1, rb0);
+        else valu_phase(guarded, k + 1, ra1, ra0, rb0, rb1);
+        mfma_phase(k + 1);
+        if (k + 2 < nt) {
+          if constexpr (LEAD == 0) valu_phase(guarded, k + 2, ra0, ra1, rb0, rb1);
+          else valu_phase(guarded, k + 2, ra0, ra1, rb1, rb0);
+          mfma_phase(k + 2);
+        }
+      }
+    }
+    if constexpr (LEAD == 0)
+      if (nt > 0) lds_barrier();   // X's idle last slot
+  };
+  if (grp == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+
+  // lane l holds filter row c = .. + (l & 31) and, in registers 4g .. 4g+3, output channels 8g + 4 (l >> 5) .. +3
+  if (!uvalid) return;
+  const int T = a.KH * KW;
+#pragma unroll
+  for (int d = 0; d < NT; ++d)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (par + S * d >= KW) continue;
+      const int c = c0 + i * 32 + l31, otap = ky * KW + par + S * d;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wave * 32 + g * 8 + lh * 4;
+        if (n >= N) continue;
+        float* q = dense_out ? out + (((size_t)by * T + otap) * C + c) * N + n
+                             : out + (size_t)otap * a.w_ts + (size_t)c * a.ldw + n;
+        float4 v = make_float4(acc[d][i][4 * g], acc[d][i][4 * g + 1], acc[d][i][4 * g + 2], acc[d][i][4 * g + 3]);
+        if (!dense_out && a.accumulate) {
+          const float4 o = *reinterpret_cast<const float4*>(q);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(q) = v;
+      }
+    }
+}
+#undef EG_TRR
+#undef EG_RDA
+#undef EG_RDB
+#undef EG_TWA
+#undef EG_TWB
+
+// the row-halo form applies to: at most three taps per (filter row, column phase) -- 3x3 stride 1, 4x4 and 5x5 stride 2 --
+// 64-channel blocks, power-of-two output maps at least 4 wide; returns its unit count (0: does not apply)
+int wgrad_x3_rowhalo_units(const WgradArgs& a) {
+  static const int mode = dbg_env("EG_WGRAD_ROWHALO") ? atoi(dbg_env("EG_WGRAD_ROWHALO")) : 3;   // A/B: bit 0 stride 1, bit 1 stride 2
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  const bool shape = (a.S == 1 && a.KW == 3) || (a.S == 2 && (a.KW == 4 || a.KW == 5));
+  const bool ok = a.limbs == 3 && shape && a.KH == a.KW && ((mode >> (a.S - 1)) & 1) && a.C % 64 == 0 &&
+                  pow2(a.OW) && pow2(a.OH) && a.OW >= 4;
+  return ok ? a.KH * std::min(a.S, a.KW) * (a.C / 64) : 0;
+}
+
 const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s) {
   (void)big_tile;
-  const int units = a.C == 64 ? (a.KH * a.KW + 1) / 2 : a.KH * a.KW * ((a.C + 127) / 128), ntn = (a.N + 127) / 128;
+#ifdef EG_EXPERIMENTS
+  const_cast<WgradArgs&>(a).dbg = dbg_env("EG_WG_DBG") ? atoi(dbg_env("EG_WG_DBG")) : 0;
+#endif
+  const int ntn = (a.N + 127) / 128;
+  if (const int ru = wgrad_x3_rowhalo_units(a)) {
+    dim3 grid(((ru + 1) / 2) * ntn, a.nsplit);
+    if (a.S == 1) hipLaunchKernelGGL((wgrad_x3r_kernel<1, 3>), grid, dim3(512), 0, s, a, out, dense);
+    else if (a.KW == 4) hipLaunchKernelGGL((wgrad_x3r_kernel<2, 4>), grid, dim3(512), 0, s, a, out, dense);
+    else hipLaunchKernelGGL((wgrad_x3r_kernel<2, 5>), grid, dim3(512), 0, s, a, out, dense);
+    return a.S == 1 ? "wgrad_x3r<3x3,2x64,128>" : a.KW == 4 ? "wgrad_x3r<4x4s2,2x64,128>" : "wgrad_x3r<5x5s2,2x64,128>";
+  }
+  const int units = a.C == 64 ? (a.KH * a.KW + 1) / 2 : a.KH * a.KW * ((a.C + 127) / 128);
   dim3 grid(((units + 1) / 2) * ntn, a.nsplit);
   if (a.limbs == 1) {
     hipLaunchKernelGGL((wgrad_x3pp_kernel<1>), grid, dim3(512), 0, s, a, out, dense);

@@ -70,6 +70,7 @@ struct HaloGeom {
   int lTW, lTH, TI;        // tile = TI images x 2^lTH rows x 2^lTW columns = 256 output pixels
   int tiles_x, tiles_y;    // tiles per image
   int pitch;               // LDS row pitch of a halo row: 20 for 16-wide tiles (conflict-free layout), 0 = dense rows
+  int dispatch_order;      // experiments: 1 = blockIdx as dispatched (no XCD-aware block map)
 };
 
 // S2D: a 4x4 stride-2 SAME convolution (the discriminators' forward layers) as a 2x2-tap STRIDE-1 convolution over the
@@ -95,18 +96,24 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7: two waves per SIMD
   const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
   const bool issuer = wave < BN / 16;         // waves that carry a share of the filter DMA (16 rows per instruction)
-  const int zphase = SPLITK ? (int)blockIdx.z / a.ksplit : (int)blockIdx.z;
-  const int zsplit = SPLITK ? (int)blockIdx.z - zphase * a.ksplit : 0;
+  // XCD-aware block map: the output tiles (blockIdx.y) of one pixel tile stage the same halo; the dispatcher places block b
+  // on XCD b % 8, so the remap makes them neighbours in ONE XCD's contiguous range (halo fetched into one L2, not gridDim.y)
+  const unsigned gxy = gridDim.x * gridDim.y;
+  const unsigned vblk = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gxy * gridDim.z, g.dispatch_order);
+  const int bz = __builtin_amdgcn_readfirstlane(vblk / gxy), bxy = __builtin_amdgcn_readfirstlane(vblk % gxy);
+  const int bx = bxy / (int)gridDim.y, by = bxy - bx * (int)gridDim.y;
+  const int zphase = SPLITK ? bz / a.ksplit : bz;
+  const int zsplit = SPLITK ? bz - zphase * a.ksplit : 0;
   const ConvPhase ph = a.ph[zphase];
   const int IH = a.IH, IW = a.IW, C = a.C, N = a.N, D = S2D ? 1 : a.D;
   const int nTy = S2D ? 2 : ph.Ty, nTx = S2D ? 2 : ph.Tx;   // taps the K loop walks
   const int TW = 1 << g.lTW, TH = 1 << g.lTH;
   // tile position
   const int tpi = g.tiles_x * g.tiles_y;
-  const int tn = (int)blockIdx.x / tpi, trem = (int)blockIdx.x - tn * tpi;
+  const int tn = bx / tpi, trem = bx - tn * tpi;
   const int tyy = trem / g.tiles_x, txx = trem - tyy * g.tiles_x;
   const int img0 = tn * g.TI, oy0 = tyy * TH, ox0 = txx * TW;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = by * BN;
   // halo geometry of this phase (stride 1): input pixel of output (oy, ox), tap (ty, tx) = (oy + ty D + offy, ox + tx D + offx)
   const int offy = S2D ? 0 : ph.offy, offx = S2D ? 0 : ph.offx;   // (S2D: ph.off* is the source offset of phase 0, below)
   const int dminy = min(offy, (nTy - 1) * D + offy), dminx = min(offx, (nTx - 1) * D + offx);
@@ -570,6 +577,8 @@ static const char* x3h_launch(const ConvArgs& a, const HaloGeom& g, hipStream_t 
 const char* launch_conv_gemm_x3h(const ConvArgs& a, hipStream_t s) {
   HaloGeom g;
   x3h_geometry(a, &g);
+  static const bool dispatch_order = dbg_env("EG_NO_XCD_MAP") != nullptr;
+  g.dispatch_order = dispatch_order;
   return a.N >= 128 ? x3h_launch<128>(a, g, s) : x3h_launch<64>(a, g, s);
 }
 

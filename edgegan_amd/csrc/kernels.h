@@ -100,7 +100,18 @@ struct WgradArgs {
   int defer_reduce;  // 1: the caller runs the second-stage reduction of the split partials itself (launch_wgrad sets
                      //    reduce_deferred when it left the reduction out: the float4 form applies)
   int reduce_deferred;
+  int dbg;           // experiments build only: limiter probes of the filter-gradient kernel (k_gemm_x3.hip)
 };
+#ifdef __HIPCC__
+// XCD-aware block map (MI355X: 8 XCDs with private L2s; block b of a launch is observed on XCD b % 8): dispatch index ->
+// virtual index such that every XCD owns one contiguous range of virtual indices (bijective for any block count)
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned total, int off = 0) {
+  if (off) return b;
+  const unsigned q = total >> 3, r = total & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+#endif
+int wgrad_x3_rowhalo_units(const WgradArgs& a);   // k_gemm_x3.hip: units of the row-halo filter-gradient kernel (0: it does not apply)
 int wgrad_pick_splits(const WgradArgs& a);
 size_t wgrad_workspace_floats(const WgradArgs& a);
 double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name);

@@ -924,7 +924,9 @@ void train_step(Ctx& c) {
   }
   comm_wait_groups(c, 1u << G_G1);   // G1's pending update (data parallel) must be in before its filters are read
   warm_transposes(c, G_G1);
-  static const int l6 = dbg_env("EG_SS6_LANE") ? atoi(dbg_env("EG_SS6_LANE")) : 1;   // A/B: the lane that hosts sub-step 6
+  // (lane 1 -- the lane whose hardware queue also hosts the leaf streams -- measured best: lanes 2 / 3 -1.9 % / -1.5 %,
+  //  profiles/r03v_ab_substep6_lane*.txt)
+  static const int l6 = dbg_env("EG_SS6_LANE") ? atoi(dbg_env("EG_SS6_LANE")) : 1;
   EG_HIP(hipEventRecord(c.ev_fork, c.lanes[0].stream));
   EG_HIP(hipStreamWaitEvent(c.lanes[l6].stream, c.ev_fork, 0));
   {
