@@ -1343,9 +1343,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3t_kernel(const WgradArgs a, fl
 // Block = two groups (units 2b, 2b+1) x four waves; wave w owns output channels 32w..32w+31 of the 128-wide dY tile
 // (shared by the groups as in wgrad_x3t) and all 64 filter rows of its unit for the three taps: 6 accumulators.
 // =============================================================================================
-template <int S, int KW>
+template <int S, int KW, int NL>   // NL: limb planes -- 3 (six limb products, fp32 result) or 1 (bf16-rounded operands)
 __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
-  constexpr int BC = 64, BN = 128, NL = 3, HPMAX = 48, NU = 3;
+  constexpr int BC = 64, BN = 128, HPMAX = 48, NU = 3;
   __shared__ __attribute__((aligned(16))) unsigned short AsG[2][NL][HPMAX * BC];   // per group: [halo pixel][c], 128-byte rows
   __shared__ __attribute__((aligned(16))) unsigned short BsG[2][NL][BKX * BN];     // per K-step parity: [pixel][n]
 
@@ -1434,29 +1434,38 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
   };
   constexpr int PLA = HPMAX * BC * 2;    // bytes of one A plane
   auto store_a = [&](int j, const f32x4& v) __attribute__((always_inline)) {
+    __attribute__((address_space(3))) char* q = (__attribute__((address_space(3))) char*)(uintptr_t)sa[j];
+    if constexpr (NL == 1) {
+      *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q) = (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
+      return;
+    }
     unsigned x0, x1, x2, y0, y1, y2;
     split_pair(v[0], v[1], x0, x1, x2);
     split_pair(v[2], v[3], y0, y1, y2);
-    __attribute__((address_space(3))) char* q = (__attribute__((address_space(3))) char*)(uintptr_t)sa[j];
     *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q) = (u32x2){x0, y0};
-    *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q + PLA) = (u32x2){x1, y1};
-    *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q + 2 * PLA) = (u32x2){x2, y2};
+    *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q + (NL > 1 ? PLA : 0)) = (u32x2){x1, y1};
+    *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q + (NL > 1 ? 2 * PLA : 0)) = (u32x2){x2, y2};
   };
   auto store_b = [&](unsigned short (&P)[NL][BKX * BN], int cq, const f32x4& lo, const f32x4& hi) __attribute__((always_inline)) {
     const int p0 = 2 * mp, p1 = 2 * mp + 1;
     const int o0 = p0 * BN + ((((cq >> 2) ^ fsw(p0)) << 2) | (cq & 3)) * 4;
     const int o1 = p1 * BN + ((((cq >> 2) ^ fsw(p1)) << 2) | (cq & 3)) * 4;
+    if constexpr (NL == 1) {
+      *reinterpret_cast<u32x2*>(&P[0][o0]) = (u32x2){pack2(lo[0], lo[1]), pack2(lo[2], lo[3])};
+      *reinterpret_cast<u32x2*>(&P[0][o1]) = (u32x2){pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
+      return;
+    }
     unsigned x0, x1, x2, y0, y1, y2;
     split_pair(lo[0], lo[1], x0, x1, x2);
     split_pair(lo[2], lo[3], y0, y1, y2);
     *reinterpret_cast<u32x2*>(&P[0][o0]) = (u32x2){x0, y0};
-    *reinterpret_cast<u32x2*>(&P[1][o0]) = (u32x2){x1, y1};
-    *reinterpret_cast<u32x2*>(&P[2][o0]) = (u32x2){x2, y2};
+    *reinterpret_cast<u32x2*>(&P[NL > 1 ? 1 : 0][o0]) = (u32x2){x1, y1};
+    *reinterpret_cast<u32x2*>(&P[NL > 1 ? 2 : 0][o0]) = (u32x2){x2, y2};
     split_pair(hi[0], hi[1], x0, x1, x2);
     split_pair(hi[2], hi[3], y0, y1, y2);
     *reinterpret_cast<u32x2*>(&P[0][o1]) = (u32x2){x0, y0};
-    *reinterpret_cast<u32x2*>(&P[1][o1]) = (u32x2){x1, y1};
-    *reinterpret_cast<u32x2*>(&P[2][o1]) = (u32x2){x2, y2};
+    *reinterpret_cast<u32x2*>(&P[NL > 1 ? 1 : 0][o1]) = (u32x2){x1, y1};
+    *reinterpret_cast<u32x2*>(&P[NL > 1 ? 2 : 0][o1]) = (u32x2){x2, y2};
   };
 
   f32x16 acc[NT][2];    // [tap d][32-row block of the unit's 64 filter rows]
@@ -1549,6 +1558,26 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
           for (int i = 0; i < 2; ++i)
             acc[d][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opb(bf, kk), opa(af, i, kk), acc[d][i], 0, 0, 0);
       };
+      if constexpr (NL == 1) {   // one product per tap: the three taps' fragments are a0, a1, a2
+        EG_RDB(b0, 0);
+        EG_RDA(a0, 0, 0);
+        if constexpr (NT > 1) EG_RDA(a1, 0, NT > 1 ? 1 : 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NT > 1) { EG_TWB(8, b0); EG_TWA(8, a0); } else { EG_TWB(0, b0); EG_TWA(0, a0); }
+        mm(0, a0, b0);
+        if constexpr (NT > 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (NT > 2) { EG_RDA(a2, 0, NT > 2 ? 2 : 0); EG_TWA(8, a1); } else { EG_TWA(0, a1); }
+          mm(1, a1, b0);
+          if constexpr (NT > 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            EG_TWA(0, a2);
+            mm(2, a2, b0);
+          }
+        }
+        lds_barrier();
+        return;
+      }
       EG_RDB(b0, 0);
       EG_RDA(a0, 0, 0);
       EG_RDB(b1, 1);
@@ -1685,10 +1714,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
 // the row-halo form applies to: at most three taps per (filter row, column phase) -- 3x3 stride 1, 4x4 and 5x5 stride 2 --
 // 64-channel blocks, power-of-two output maps at least 4 wide; returns its unit count (0: does not apply)
 int wgrad_x3_rowhalo_units(const WgradArgs& a) {
-  static const int mode = dbg_env("EG_WGRAD_ROWHALO") ? atoi(dbg_env("EG_WGRAD_ROWHALO")) : 3;   // A/B: bit 0 stride 1, bit 1 stride 2
+  static const int mode = dbg_env("EG_WGRAD_ROWHALO") ? atoi(dbg_env("EG_WGRAD_ROWHALO")) : 3;   // A/B: bit 0 stride 1, bit 1 stride 2, bit 2 the bf16 mode
+  // (bf16 mode stays on the per-tap kernel: with one product per tap the row-halo form's per-step address arithmetic and
+  //  three short MFMA bursts lose to it, 350-385 against 446-495 TFLOP/s, iteration -3.7 %: profiles/r03w_wgrad_rowhalo_check_bf16.txt)
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   const bool shape = (a.S == 1 && a.KW == 3) || (a.S == 2 && (a.KW == 4 || a.KW == 5));
-  const bool ok = a.limbs == 3 && shape && a.KH == a.KW && ((mode >> (a.S - 1)) & 1) && a.C % 64 == 0 &&
+  const bool ok = (a.limbs == 3 || (a.limbs == 1 && (mode & 4))) && shape && a.KH == a.KW && ((mode >> (a.S - 1)) & 1) && a.C % 64 == 0 &&
                   pow2(a.OW) && pow2(a.OH) && a.OW >= 4;
   return ok ? a.KH * std::min(a.S, a.KW) * (a.C / 64) : 0;
 }
@@ -1701,9 +1732,15 @@ const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_
   const int ntn = (a.N + 127) / 128;
   if (const int ru = wgrad_x3_rowhalo_units(a)) {
     dim3 grid(((ru + 1) / 2) * ntn, a.nsplit);
-    if (a.S == 1) hipLaunchKernelGGL((wgrad_x3r_kernel<1, 3>), grid, dim3(512), 0, s, a, out, dense);
-    else if (a.KW == 4) hipLaunchKernelGGL((wgrad_x3r_kernel<2, 4>), grid, dim3(512), 0, s, a, out, dense);
-    else hipLaunchKernelGGL((wgrad_x3r_kernel<2, 5>), grid, dim3(512), 0, s, a, out, dense);
+    if (a.limbs == 1) {
+      if (a.S == 1) hipLaunchKernelGGL((wgrad_x3r_kernel<1, 3, 1>), grid, dim3(512), 0, s, a, out, dense);
+      else if (a.KW == 4) hipLaunchKernelGGL((wgrad_x3r_kernel<2, 4, 1>), grid, dim3(512), 0, s, a, out, dense);
+      else hipLaunchKernelGGL((wgrad_x3r_kernel<2, 5, 1>), grid, dim3(512), 0, s, a, out, dense);
+      return a.S == 1 ? "wgrad_bf16r<3x3,2x64,128>" : a.KW == 4 ? "wgrad_bf16r<4x4s2,2x64,128>" : "wgrad_bf16r<5x5s2,2x64,128>";
+    }
+    if (a.S == 1) hipLaunchKernelGGL((wgrad_x3r_kernel<1, 3, 3>), grid, dim3(512), 0, s, a, out, dense);
+    else if (a.KW == 4) hipLaunchKernelGGL((wgrad_x3r_kernel<2, 4, 3>), grid, dim3(512), 0, s, a, out, dense);
+    else hipLaunchKernelGGL((wgrad_x3r_kernel<2, 5, 3>), grid, dim3(512), 0, s, a, out, dense);
     return a.S == 1 ? "wgrad_x3r<3x3,2x64,128>" : a.KW == 4 ? "wgrad_x3r<4x4s2,2x64,128>" : "wgrad_x3r<5x5s2,2x64,128>";
   }
   const int units = a.C == 64 ? (a.KH * a.KW + 1) / 2 : a.KH * a.KW * ((a.C + 127) / 128);
