@@ -62,8 +62,19 @@ def test_x3_ops_at_fp32_tolerances():
                  ('Dp conv_3 4x4s2 128->256 @32 nb64 (s2d halo, split K)', 64, 32, 32, 128, 256, 4, 2, 0, False),
                  ('D conv_4 4x4s2 256->512 8x16 nb64 (s2d halo, 8 images per tile)', 64, 8, 16, 256, 512, 4, 2, 0, False)]:
         rows += parity.check_conv(net, case, seed=7)
+    # the row-halo filter-gradient kernel (k_gemm_x3.hip: wgrad_x3r -- 3x3 stride 1, 4x4 / 5x5 stride 2, 64-channel units)
+    # at its edges: 8 image rows per K step across 3 images, ragged output-channel tile, 192 channels (3 blocks), the
+    # 32-pixel segments of a 128-wide row, reflect and zero padding, odd image counts
+    for case in [('rowhalo 3x3 REFLECT C128->128 4x4 nb3', 3, 4, 4, 128, 128, 3, 1, 1, True),
+                 ('rowhalo 3x3 C64->132 16x8 nb5', 5, 16, 8, 64, 132, 3, 1, 0, False),
+                 ('rowhalo 3x3 REFLECT C192->128 8x16', 2, 8, 16, 192, 128, 3, 1, 1, True),
+                 ('rowhalo 3x3 C64->256 128x128', 1, 128, 128, 64, 256, 3, 1, 0, False),
+                 ('rowhalo 4x4s2 C64->128 8x8 nb3', 3, 8, 8, 64, 128, 4, 2, 0, False),
+                 ('rowhalo 4x4s2 C128->132 16x8 nb5', 5, 16, 8, 128, 132, 4, 2, 0, False)]:
+        rows += parity.check_conv(net, case, seed=11)
+    rows += parity.check_deconv(net, ('rowhalo 5x5s2 256->128 4x8 nb3', 3, 4, 8, 256, 128), seed=11)
     net.close()
-    assert len(rows) > 150
+    assert len(rows) > 170
     _assert(rows)
     assert max(r[1] / r[2] for r in rows) < 0.2, 'f32x3 op errors are expected an order of magnitude inside the fp32 bounds'
 
