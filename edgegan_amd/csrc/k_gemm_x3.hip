@@ -1340,8 +1340,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3t_kernel(const WgradArgs a, fl
 // read the same R x (W + ntaps - 1) input pixels -- those of columns S (ox + hx) + par - pad -- shifted by one halo column
 // per tap: staged ONCE, pixel-major, and read ntaps times with ds_read_b64_tr_b16 (each lane addresses its own pixel row,
 // so a column shift is free).  Staged elements per MFMA at 3x3: 14.7 against 32.
-// Block = two groups (units 2b, 2b+1) x four waves; wave w owns output channels 32w..32w+31 of the 128-wide dY tile
-// (shared by the groups as in wgrad_x3t) and all 64 filter rows of its unit for the three taps: 6 accumulators.
+// Block = two groups (units 2b, 2b+1) x four waves, the 128-wide dY tile shared by the groups as in wgrad_x3t; a wave owns
+// 32 filter rows x 64 output channels for the unit's taps (6 accumulators at three taps).
 // =============================================================================================
 template <int S, int KW, int NL>   // NL: limb planes -- 3 (six limb products, fp32 result) or 1 (bf16-rounded operands)
 __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, float* __restrict__ out, int dense_out) {
@@ -1468,7 +1468,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
     *reinterpret_cast<u32x2*>(&P[NL > 1 ? 2 : 0][o1]) = (u32x2){x2, y2};
   };
 
-  f32x16 acc[NT][2];    // [tap d][32-row block of the unit's 64 filter rows]
+  // wave (wc, wn2) owns filter rows 32 wc .. +31 of the unit and output channels 64 wn2 .. +63 of the dY tile: the dY
+  // fragments (two 32-channel blocks) are read once per K step and serve every tap, the per-tap x fragment is one block --
+  // 60 transpose reads per 72 MFMAs (the 64 x 32 split needs 84)
+  const int wc = wave >> 1, wn2 = wave & 1;
+  f32x16 acc[NT][2];    // [tap d][32-channel block j of the wave's 64 output channels]
 #pragma unroll
   for (int d = 0; d < NT; ++d)
 #pragma unroll
@@ -1478,8 +1482,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
   const int l31 = lane & 31, lh = lane >> 5;
   // transpose reads (see wgrad_x3t): lane 4r + q of a 16-lane group addresses chunk q of pixel row r
   const int tg = lane >> 4, ti = lane & 15, tr = ti >> 2, tq = ti & 3;
-  unsigned ea[2][2][NT];   // A: [K half][first / second 4 pixels][tap column], 32-row block 0 (block 1 = ^ 64), plane 0
-  unsigned eb[2];         // B: [first / second 4 pixels] of K half 0, plane 0, relative to the parity's base
+  unsigned ea[2][2][NT];   // A: [K half][first / second 4 pixels][tap column], plane 0
+  unsigned eb[2][2];      // B: [32-channel block][first / second 4 pixels] of K half 0, plane 0, relative to the parity's base
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1489,44 +1493,45 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
 #pragma unroll
       for (int d = 0; d < NT; ++d) {
         const int q = q0 + d;
-        ea[kk][h][d] = as_base + (unsigned)(q * (BC * 2) + (((((tg & 1)) ^ fa(q)) << 2) | tq) * 8);
+        ea[kk][h][d] = as_base + (unsigned)(q * (BC * 2) + ((((2 * wc + (tg & 1)) ^ fa(q)) << 2) | tq) * 8);
       }
     }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int pix = 8 * (tg >> 1) + 4 * h + tr;
-    const int cbb = 2 * wave + (tg & 1);
-    eb[h] = (unsigned)((pix * BN + (((cbb ^ fsw(pix)) << 2) | tq) * 4) * 2);
-  }
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pix = 8 * (tg >> 1) + 4 * h + tr;
+      const int cbb = 2 * (2 * wn2 + jb) + (tg & 1);
+      eb[jb][h] = (unsigned)((pix * BN + (((cbb ^ fsw(pix)) << 2) | tq) * 4) * 2);
+    }
   unsigned bcur = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&BsG[0][0][0];
   constexpr int PLB = BKX * BN * 2;      // bytes of one B plane
   constexpr int KHB = 16 * BN * 2;       // bytes between the two K halves of the B tile (16 pixel rows)
 #define EG_TRR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-  struct FragA { u32x2 h[2][2][2]; };    // [32-row block][K half][first / second 4 pixels]
-  struct FragB { u32x2 h[2][2]; };       // [K half][first / second 4 pixels]
+  struct FragA { u32x2 h[2][2]; };       // [K half][first / second 4 pixels]                      (4 reads)
+  struct FragB { u32x2 h[2][2][2]; };    // [32-channel block][K half][first / second 4 pixels]  (8 reads)
 #define EG_RDA(f, pl, d)                                                                                  \
   do {                                                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) {                                                    \
-      EG_TRR(f.h[0][k_][0], ea[k_][0][d], (pl) * PLA); EG_TRR(f.h[0][k_][1], ea[k_][1][d], (pl) * PLA);     \
-      const unsigned x0_ = ea[k_][0][d] ^ 64u, x1_ = ea[k_][1][d] ^ 64u;                                  \
-      EG_TRR(f.h[1][k_][0], x0_, (pl) * PLA); EG_TRR(f.h[1][k_][1], x1_, (pl) * PLA);                       \
-    }                                                                                                     \
+    EG_TRR(f.h[0][0], ea[0][0][d], (pl) * PLA); EG_TRR(f.h[0][1], ea[0][1][d], (pl) * PLA);                 \
+    EG_TRR(f.h[1][0], ea[1][0][d], (pl) * PLA); EG_TRR(f.h[1][1], ea[1][1][d], (pl) * PLA);                 \
   } while (0)
 #define EG_RDB(f, pl)                                                                                     \
   do {                                                                                                    \
-    const unsigned b0_ = bcur + eb[0], b1_ = bcur + eb[1];                                                \
-    EG_TRR(f.h[0][0], b0_, (pl) * PLB); EG_TRR(f.h[0][1], b1_, (pl) * PLB);                                 \
-    EG_TRR(f.h[1][0], b0_, (pl) * PLB + KHB); EG_TRR(f.h[1][1], b1_, (pl) * PLB + KHB);                     \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                    \
+      const unsigned b0_ = bcur + eb[j_][0], b1_ = bcur + eb[j_][1];                                      \
+      EG_TRR(f.h[j_][0][0], b0_, (pl) * PLB); EG_TRR(f.h[j_][0][1], b1_, (pl) * PLB);                       \
+      EG_TRR(f.h[j_][1][0], b0_, (pl) * PLB + KHB); EG_TRR(f.h[j_][1][1], b1_, (pl) * PLB + KHB);           \
+    }                                                                                                     \
   } while (0)
-#define EG_TWA(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f.h[0][0][0]), "+v"(f.h[0][0][1]), "+v"(f.h[0][1][0]), "+v"(f.h[0][1][1]), \
+#define EG_TWB(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f.h[0][0][0]), "+v"(f.h[0][0][1]), "+v"(f.h[0][1][0]), "+v"(f.h[0][1][1]), \
                                   "+v"(f.h[1][0][0]), "+v"(f.h[1][0][1]), "+v"(f.h[1][1][0]), "+v"(f.h[1][1][1]))
-#define EG_TWB(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f.h[0][0]), "+v"(f.h[0][1]), "+v"(f.h[1][0]), "+v"(f.h[1][1]))
-  auto opa = [](const FragA& f, int i, int kk) __attribute__((always_inline)) {
-    const u32x4 v = {f.h[i][kk][0][0], f.h[i][kk][0][1], f.h[i][kk][1][0], f.h[i][kk][1][1]};
+#define EG_TWA(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f.h[0][0]), "+v"(f.h[0][1]), "+v"(f.h[1][0]), "+v"(f.h[1][1]))
+  auto opa = [](const FragA& f, int kk) __attribute__((always_inline)) {
+    const u32x4 v = {f.h[kk][0][0], f.h[kk][0][1], f.h[kk][1][0], f.h[kk][1][1]};
     return __builtin_bit_cast(bf16x8, v);
   };
-  auto opb = [](const FragB& f, int kk) __attribute__((always_inline)) {
-    const u32x4 v = {f.h[kk][0][0], f.h[kk][0][1], f.h[kk][1][0], f.h[kk][1][1]};
+  auto opb = [](const FragB& f, int jb, int kk) __attribute__((always_inline)) {
+    const u32x4 v = {f.h[jb][kk][0][0], f.h[jb][kk][0][1], f.h[jb][kk][1][0], f.h[jb][kk][1][1]};
     return __builtin_bit_cast(bf16x8, v);
   };
   auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -1555,19 +1560,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-            acc[d][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opb(bf, kk), opa(af, i, kk), acc[d][i], 0, 0, 0);
+          for (int jb = 0; jb < 2; ++jb)
+            acc[d][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opb(bf, jb, kk), opa(af, kk), acc[d][jb], 0, 0, 0);
       };
       if constexpr (NL == 1) {   // one product per tap: the three taps' fragments are a0, a1, a2
         EG_RDB(b0, 0);
         EG_RDA(a0, 0, 0);
         if constexpr (NT > 1) EG_RDA(a1, 0, NT > 1 ? 1 : 0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NT > 1) { EG_TWB(8, b0); EG_TWA(8, a0); } else { EG_TWB(0, b0); EG_TWA(0, a0); }
+        if constexpr (NT > 1) { EG_TWB(4, b0); EG_TWA(4, a0); } else { EG_TWB(0, b0); EG_TWA(0, a0); }
         mm(0, a0, b0);
         if constexpr (NT > 1) {
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (NT > 2) { EG_RDA(a2, 0, NT > 2 ? 2 : 0); EG_TWA(8, a1); } else { EG_TWA(0, a1); }
+          if constexpr (NT > 2) { EG_RDA(a2, 0, NT > 2 ? 2 : 0); EG_TWA(4, a1); } else { EG_TWA(0, a1); }
           mm(1, a1, b0);
           if constexpr (NT > 2) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1578,29 +1583,30 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
         lds_barrier();
         return;
       }
+      // (outstanding reads in brackets; LDS reads return in order)
       EG_RDB(b0, 0);
       EG_RDA(a0, 0, 0);
-      EG_RDB(b1, 1);
+      EG_RDB(b1, 1);                  // [b0 8, a0 4, b1 8]
       __builtin_amdgcn_sched_barrier(0);
-      EG_TWB(4, b0); EG_TWA(4, a0);
+      EG_TWB(8, b0); EG_TWA(8, a0);
       mm(0, a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      EG_RDB(b2, 2);
-      EG_TWB(4, b1);
+      EG_RDB(b2, 2);                  // [b1 8, b2 8]
+      EG_TWB(8, b1);
       mm(0, a0, b1);
       __builtin_amdgcn_sched_barrier(0);
-      EG_RDA(a1, 1, 0);
-      EG_TWB(8, b2);
+      EG_RDA(a1, 1, 0);               // [b2 8, a1 4]
+      EG_TWB(4, b2);
       mm(0, a0, b2);
       __builtin_amdgcn_sched_barrier(0);
-      EG_RDA(a2, 2, 0);
-      EG_TWA(8, a1);
+      EG_RDA(a2, 2, 0);               // [a1 4, a2 4]
+      EG_TWA(4, a1);
       mm(0, a1, b0);
       mm(0, a1, b1);
       __builtin_amdgcn_sched_barrier(0);
-      if (NT > 1 && ntaps > 1) {      // (wave-uniform)
-        EG_RDA(a0, 0, NT > 1 ? 1 : 0);
-        EG_TWA(8, a2);
+      if (NT > 1 && ntaps > 1) {      // (compile time)
+        EG_RDA(a0, 0, NT > 1 ? 1 : 0);   // [a2 4, a0 4]
+        EG_TWA(4, a2);
       } else {
         EG_TWA(0, a2);
       }
@@ -1610,19 +1616,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
       for (int d = 1; d < NT; ++d) {
         if (d >= ntaps) break;
         EG_RDA(a1, 1, d);
-        EG_TWA(8, a0);
+        EG_TWA(4, a0);
         mm(d, a0, b0);
         mm(d, a0, b1);
         mm(d, a0, b2);
         __builtin_amdgcn_sched_barrier(0);
         EG_RDA(a2, 2, d);
-        EG_TWA(8, a1);
+        EG_TWA(4, a1);
         mm(d, a1, b0);
         mm(d, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         if (d == 1 && NT > 2 && ntaps > 2) {
           EG_RDA(a0, 0, NT > 2 ? 2 : 0);
-          EG_TWA(8, a2);
+          EG_TWA(4, a2);
         } else {
           EG_TWA(0, a2);
         }
@@ -1687,12 +1693,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
 #pragma unroll
   for (int d = 0; d < NT; ++d)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {     // (i: the wave's 32-channel block of output channels)
       if (par + S * d >= KW) continue;
-      const int c = c0 + i * 32 + l31, otap = ky * KW + par + S * d;
+      const int c = c0 + wc * 32 + l31, otap = ky * KW + par + S * d;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wave * 32 + g * 8 + lh * 4;
+        const int n = n0 + wn2 * 64 + i * 32 + g * 8 + lh * 4;
         if (n >= N) continue;
         float* q = dense_out ? out + (((size_t)by * T + otap) * C + c) * N + n
                              : out + (size_t)otap * a.w_ts + (size_t)c * a.ldw + n;
