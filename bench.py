@@ -464,6 +464,13 @@ def main():
                                          'executed_gflop_per_image': round(tot_fl / args.profile_steps / args.batch / 1e9, 2)},
                     'per_kernel': {k['name']: {'ms_per_step': round(k['ms'] / args.profile_steps, 3),
                                                'tflops': round(k['flops'] / (k['ms'] * 1e-3) / 1e12, 2)} for k in ks}}
+            if peak == PEAK_BF16_MFMA_TFLOPS:
+                # what the matrix pipe of THIS device sustains on a memory-free bf16 MFMA loop, measured now: `peak` stays
+                # the guide's nominal figure; with random operands the power management clocks the pipe lower
+                sus_c, sus_r = net.mfma_probe(20000, False), net.mfma_probe(20000, True)
+                roof['sustained_mfma_loop'] = {'constant_operands_tflops': round(sus_c, 1), 'random_operands_tflops': round(sus_r, 1),
+                                               'frac_of_random_operand_rate': round(ach / sus_r, 4),
+                                               'what': 'eg_mfma_probe: one 8-wave block per CU, 4 independent 32x32x16 bf16 MFMA chains per wave, no memory traffic'}
     net.comm_barrier()
     ci = net.comm_info()
     iters_run = args.warmup + args.steps + (args.profile_steps if args.profile_steps > 0 else 0)

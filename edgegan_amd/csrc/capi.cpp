@@ -468,6 +468,39 @@ int eg_profile_layers(eg_ctx* ctx, char* buf, long long cap) {
   EG_API_END(ctx)
 }
 
+int eg_mfma_probe(eg_ctx* ctx, int iters, int random_operands, double* tflops) {
+  EG_API_BEGIN
+  EG_CHECK(tflops && iters > 0, "bad argument");
+  int dev = 0, cus = 0;
+  EG_HIP(hipGetDevice(&dev));
+  EG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  EG_HIP(hipStreamSynchronize(ctx->c.stream));
+  float* scratch = nullptr;
+  EG_HIP(hipMalloc(&scratch, (size_t)cus * 512 * sizeof(float)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms = 0.f;
+  try {
+    EG_HIP(hipEventCreate(&e0));
+    EG_HIP(hipEventCreate(&e1));
+    launch_mfma_probe(scratch, cus, 64, random_operands, ctx->c.stream);   // warm-up
+    EG_HIP(hipEventRecord(e0, ctx->c.stream));
+    launch_mfma_probe(scratch, cus, iters, random_operands, ctx->c.stream);
+    EG_HIP(hipEventRecord(e1, ctx->c.stream));
+    EG_HIP(hipEventSynchronize(e1));
+    EG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  } catch (...) {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(scratch);
+    throw;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  EG_HIP(hipFree(scratch));
+  *tflops = 2.0 * 32 * 32 * 16 * 16.0 * iters * 8 * cus / (ms * 1e9);
+  EG_API_END(ctx)
+}
+
 int eg_memory_stats(eg_ctx* ctx, long long* peak, long long* reserved) {
   EG_API_BEGIN
   size_t pk = ctx->c.arena.peak(), rs = ctx->c.arena.reserved();   // active lane + the parked ones

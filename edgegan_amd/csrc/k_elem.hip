@@ -1320,4 +1320,40 @@ void launch_rmsprop(float* w, const float* g, float* ms, float* mom, size_t n, f
   hipLaunchKernelGGL(rmsprop_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, w, g, ms, mom, n, lr, gscale);
 }
 
+
+// =============================================================================================
+// What the matrix pipe sustains on v_mfma_f32_32x32x16_bf16 with nothing else in the way (bench.py's roofline context):
+// one block of 8 waves per CU, each wave `iters` x 16 MFMAs on 4 independent accumulators, no memory traffic.  With
+// constant operands the pipe runs at the nominal clock; with random mantissas / signs the power management lowers it
+// (MI355X here: 2,482 vs 1,985 TFLOP/s, profiles/r03x_mfma_peak.txt) -- the second figure is what a kernel on real data
+// can approach, the guide's 2.5 PFLOP/s what `roofline.peak` is priced against.
+// =============================================================================================
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(512, 1) void mfma_probe_kernel(float* out, int iters, int random_operands) {
+  probe_f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  probe_bf16x8 a, b;
+  unsigned h = (blockIdx.x * 1024u + threadIdx.x) * 2654435761u + 12345u;
+  for (int i = 0; i < 8; ++i) {
+    h = h * 1664525u + 1013904223u;
+    const unsigned short ra = (unsigned short)(0x3f00u | ((h >> 9) & 0x80ffu)), rb = (unsigned short)(0x3f00u | ((h >> 17) & 0x80ffu));
+    a[i] = random_operands ? __builtin_bit_cast(__bf16, ra) : (__bf16)(float)(threadIdx.x & 3);
+    b[i] = random_operands ? __builtin_bit_cast(__bf16, rb) : (__bf16)1.0f;
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) s += acc[i][threadIdx.x & 15];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+void launch_mfma_probe(float* scratch, int blocks, int iters, int random_operands, hipStream_t s) {
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(512), 0, s, scratch, iters, random_operands);
+}
+
 }  // namespace eg

@@ -111,6 +111,8 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned total, int of
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 #endif
+// k_elem.hip: a memory-free v_mfma_f32_32x32x16_bf16 loop, blocks x 8 waves x iters x 16 MFMAs (scratch >= blocks * 512 floats)
+void launch_mfma_probe(float* scratch, int blocks, int iters, int random_operands, hipStream_t s);
 int wgrad_x3_rowhalo_units(const WgradArgs& a);   // k_gemm_x3.hip: units of the row-halo filter-gradient kernel (0: it does not apply)
 int wgrad_pick_splits(const WgradArgs& a);
 size_t wgrad_workspace_floats(const WgradArgs& a);

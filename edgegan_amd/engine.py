@@ -293,6 +293,12 @@ class EdgeGAN:
         self._check(self._lib.eg_memory_stats(self._ctx, C.byref(a), C.byref(b)))
         return {'arena_peak_bytes': a.value, 'arena_reserved_bytes': b.value}
 
+    def mfma_probe(self, iters: int = 20000, random_operands: bool = True) -> float:
+        """TFLOP/s of a memory-free bf16 MFMA loop on this device (include/edgegan_hip.h: eg_mfma_probe)."""
+        t = C.c_double()
+        self._check(self._lib.eg_mfma_probe(self._ctx, int(iters), int(bool(random_operands)), C.byref(t)))
+        return t.value
+
     # -- test entry points ------------------------------------------------------------------------
     def test_op(self, op: str, inputs, iparams, out_shapes):
         fp = C.POINTER(C.c_float)

@@ -157,6 +157,10 @@ int eg_profile_end(eg_ctx* ctx, char* buf, int cap);
  * the per-layer roofline table of profiles/ (tools/layer_table.py) */
 int eg_profile_layers(eg_ctx* ctx, char* buf, long long cap);
 int eg_memory_stats(eg_ctx* ctx, long long* arena_peak_bytes, long long* arena_reserved_bytes);
+/* TFLOP/s the matrix pipe of this device sustains on a memory-free v_mfma_f32_32x32x16_bf16 loop (one 8-wave block per
+ * CU, iters x 16 MFMAs per wave), with constant (random_operands = 0) or pseudo-random bf16 operands: the data toggling
+ * sets the pipe's power and with it its clock.  bench.py prints both next to roofline.peak (no reference counterpart). */
+int eg_mfma_probe(eg_ctx* ctx, int iters, int random_operands, double* tflops);
 
 /* ---- per-op / per-network test entry points (parity tests against oracle/) ----------------------
  * eg_test_op runs ONE tape op forward and, if a cotangent is supplied, backward, through exactly

@@ -435,3 +435,12 @@ def test_post_update_evaluation_matches_oracle_forward_graph():
         if 'moving_' not in k:
             assert np.array_equal(v, after[k]), k
     net.close()
+
+
+def test_mfma_probe_reports_the_matrix_pipes_sustained_rate():
+    """eg_mfma_probe (bench.py's roofline context): a memory-free bf16 MFMA loop cannot beat the nominal dense peak, and
+    random operands cannot be faster than constant ones (they only cost clock)."""
+    net = ea.EdgeGAN(ea.Config(batch_size=2))
+    const, rnd = net.mfma_probe(4000, False), net.mfma_probe(4000, True)
+    net.close()
+    assert 500.0 < rnd <= const * 1.03 and const < 2600.0, (const, rnd)
