@@ -373,8 +373,13 @@ const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s) {
 // gradient of g_dconv_4 (conv.py:49-53).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT, int PT>
-__global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, int K, int K16, int tiles_per_img, int subs) {
+__global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, int K, int K16, int tiles_per_img, int subs, int dbg_) {
   constexpr int BN = NT * 16;
+#ifdef EG_EXPERIMENTS
+  const int dbg = dbg_;    // limiter probes: 1 no output stores, 2 no MFMAs, 4 no A-operand LDS reads, 8 no input staging
+#else
+  constexpr int dbg = 0;
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Bl = smem;                                          // [K16 / 4][BN][4]
   int2* kt = reinterpret_cast<int2*>(Bl + (size_t)K16 * BN); // [K16] {packed (dy, dx) or -1, LDS offset (dy IW + dx) C + c}
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
   };
   auto prefetch = [&](int tile) __attribute__((always_inline)) {
     pf_n4 = 0;
-    if (tile >= total_tiles) return;
+    if (tile >= total_tiles || (dbg & 8)) return;
     int nb, q_lo, q_hi, ylo;
     pf_n4 = tile_rows(tile, &nb, &q_lo, &q_hi, &ylo);
     const f32x4* src = reinterpret_cast<const f32x4*>(a.x + ((size_t)nb * IH + ylo) * IW * C);
@@ -417,6 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
       if (i < pf_n4) pf[u] = src[i];
     }
   };
+  if (dbg & 16) return;    // probe: launch + LDS allocation only
   // the first tile's input rows are requested before anything else: their round trip runs under the table / filter staging
   prefetch(blockIdx.x);
 
@@ -482,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
     }
   }
   __syncthreads();   // filter image complete
+  if (dbg & 32) return;    // probe: ... + table and filter staging
 
   for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     int nb, q_lo, q_hi, ylo;
@@ -497,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
 
     for (int sub = 0; sub < subs; ++sub) {
       const int qb = q_lo + sub * (64 * PT) + wave * (16 * PT);
-      if (qb > q_hi) break;
+      if (qb > q_hi || (dbg & 64)) break;
       int oyS[PT], oxS[PT], base[PT];
       bool pv[PT];
 #pragma unroll
@@ -517,6 +524,13 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
       // A operands of K group kg: table entry -> predicate + staged-row address -> LDS read.  They are requested one group
       // ahead (av0 / av1 alternate), so the two dependent LDS round trips run under the previous group's MFMAs.
       auto load_av = [&](int kg, float (&av)[PT][4]) __attribute__((always_inline)) {
+        if (dbg & 128) {   // probe: no table reads, predicates or operand reads at all
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) av[pt][j] = 1.f;
+          return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int2 e = kt[kg * 16 + kq * 4 + j];
@@ -524,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) {
             const bool ok = pv[pt] && e.x >= 0 && (unsigned)(oyS[pt] + dy) < (unsigned)IH && (unsigned)(oxS[pt] + dx) < (unsigned)IW;
+            if (dbg & 4) { av[pt][j] = ok ? 1.f : 0.f; continue; }
             const float v = Xs[ok ? base[pt] + e.y : 0];
             av[pt][j] = ok ? v : 0.f;
           }
@@ -533,11 +548,14 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
         const float* bk = bl_lane + (size_t)kg * 4 * BN * 4;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(bk + t * 16 * 4);
+          const f32x4 b = (dbg & 256) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(bk + t * 16 * 4);   // probe 256: no filter reads
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) acc[pt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], av[pt][j], acc[pt][t], 0, 0, 0);
+            for (int pt = 0; pt < PT; ++pt) {
+              if (dbg & 2) asm volatile("" : "+v"(acc[pt][t]) : "v"(b[j]), "v"(av[pt][j]));
+              else acc[pt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], av[pt][j], acc[pt][t], 0, 0, 0);
+            }
         }
       };
       const int nkg = K16 / 16;
@@ -585,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void conv_smallc_kernel(const ConvArgs a, i
       }
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
-        if (!pv[pt]) continue;
+        if (!pv[pt] || ((dbg & 1) && acc[pt][0][0] != 12345.678f)) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int n = n0 + t * 16 + kq * 4;
@@ -655,7 +673,8 @@ static void smallc_launch(const ConvArgs& a, int K, int K16, int tiles, int subs
   // persistent blocks: the filter is staged once per block, which then walks over (image, 512-pixel tile) pairs
   const int ny = (a.N + NT * 16 - 1) / (NT * 16);
   dim3 grid(std::min(a.NB * tiles, std::max(1, 512 / ny)), ny);
-  hipLaunchKernelGGL((conv_smallc_kernel<NT, 4>), grid, dim3(256), lds, s, a, K, K16, tiles, subs);
+  static const int dbg = dbg_env("EG_SMALLC_DBG") ? atoi(dbg_env("EG_SMALLC_DBG")) : 0;
+  hipLaunchKernelGGL((conv_smallc_kernel<NT, 4>), grid, dim3(256), lds, s, a, K, K16, tiles, subs, dbg);
 }
 
 const char* launch_conv_smallc(const ConvArgs& a, hipStream_t s) {
