@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void in_fwd_v(const float* __restrict__ x, flo
 template <int NP, int CQ>
 __global__ __launch_bounds__(256) void in_fwd_vr(const float* __restrict__ x, float* __restrict__ out,
                                                  float* __restrict__ stats, int HW, int C, int act, int nslab,
-                                                 size_t slab_stride, const float* __restrict__ slab_bias) {
+                                                 size_t slab_stride, const float* __restrict__ slab_bias,
+                                                 float* __restrict__ xsum) {
   constexpr int PL = 256 / CQ;   // CQ = 4 for the 32x32 layers: 16 channels per block -> twice the blocks, half the registers
   __shared__ float4 red[4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -253,6 +254,8 @@ __global__ __launch_bounds__(256) void in_fwd_vr(const float* __restrict__ x, fl
           const float4 q = ld4(xp + (size_t)k * slab_stride + (size_t)p * C);
           v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
+        // training: the summed pre-norm tensor is what the backward (and the gradient penalty's tangent pass) reads
+        if (xsum) st4(xsum + (size_t)n * HW * C + c + (size_t)p * C, v);
       }
       xv[i] = v;
     } else {
@@ -400,10 +403,10 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
 }
 
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s, int nslab,
-                   size_t slab_stride, const float* slab_bias) {
+                   size_t slab_stride, const float* slab_bias, float* xsum) {
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
-#define EG_IN_FWD(NP, CQ, G) hipLaunchKernelGGL((in_fwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, HW, C, act, nslab, slab_stride, slab_bias)
+#define EG_IN_FWD(NP, CQ, G) hipLaunchKernelGGL((in_fwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, HW, C, act, nslab, slab_stride, slab_bias, xsum)
     if (HW <= 64) EG_IN_FWD(2, 8, grid);
     else if (HW <= 128) EG_IN_FWD(4, 8, grid);
     else if (HW <= 256) EG_IN_FWD(8, 8, grid);

@@ -203,8 +203,9 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
 // InstanceNorm (x-mean)/(sqrt(var)+1e-5) + act, per (n,c) over H*W. stats[n][c] = {mean, sigma}.
 // nslab > 1: x is the first of nslab K-split slabs (slab_stride floats apart) of a convolution output that was never
 // summed; the load pass forms bias + slab 0 + slab 1 + ... in conv_split_reduce's order (C % 32 == 0, HW <= 1024 only)
+// and, with xsum, also stores that sum (training: the pre-norm tensor the backward reads)
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s,
-                   int nslab = 0, size_t slab_stride = 0, const float* slab_bias = nullptr);
+                   int nslab = 0, size_t slab_stride = 0, const float* slab_bias = nullptr, float* xsum = nullptr);
 // dx (+)= J * (dout * act'(out))   (J = IN Jacobian, symmetric)
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
                    int accumulate, int NB, int HW, int C, int act, hipStream_t s);

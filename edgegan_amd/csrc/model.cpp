@@ -351,6 +351,7 @@ T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_o
     WRef* w = wref_param(c, P(c, p + "/" + kDiscNames[i] + "/conv2d/w"), 16, ch[i], ch[i + 1]);
     // (first block: conv + LeakyReLU, fused where the small-C kernel runs the conv; `pre` is then the activated output,
     //  which is all the tangent pass and the backward need of it)
+    c.feeds_in = i > 0 && !tangent_of;   // conv_block: the InstanceNorm is the convolution's only forward reader
     T pre = conv2d(c, x, w, nullptr, 4, 2, PAD_SAME, nullptr, (i == 0 && !tangent_of) ? ACT_LRELU : 0);
     T out, st = nullptr;
     if (!tangent_of) {

@@ -700,10 +700,12 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   }
   if (c.prof_on) c.cur_label = w->name + " fwd";
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
-  // forward-only convolution read by an InstanceNorm alone (Ctx::feeds_in): a K-split launch keeps its slabs, the
-  // norm's load pass sums them (bias + slabs in conv_split_reduce's order: same bits, one launch and one round trip less)
+  // convolution read by an InstanceNorm alone (Ctx::feeds_in): a K-split launch keeps its slabs, the norm's load pass sums
+  // them (bias + slabs in conv_split_reduce's order: same bits, one launch and one round trip less) and, in training,
+  // stores the sum as this tensor's value for the backward passes (in_act)
   static const bool slab_fusion = dbg_env("EG_NO_SLAB_IN") == nullptr;
-  const bool slabs_ok = c.feeds_in && slab_fusion && !need && !accumulate_into && !fused_act && N % 32 == 0 && OH * OW <= 1024;
+  static const bool slab_train = dbg_env("EG_NO_SLAB_IN_TRAIN") == nullptr;   // A/B: the fusion in training graphs
+  const bool slabs_ok = c.feeds_in && slab_fusion && (!need || slab_train) && !accumulate_into && !fused_act && N % 32 == 0 && OH * OW <= 1024;
   c.feeds_in = false;
   a.keep_slabs = slabs_ok ? 1 : 0;
   run_conv(c, a);
@@ -790,7 +792,8 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
   if (c.prof_on) c.cur_label = w->name + " fwd";
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
   static const bool slab_fusion = dbg_env("EG_NO_SLAB_IN") == nullptr;
-  const bool slabs_ok = c.feeds_in && slab_fusion && !need && !merged && cout % 32 == 0 && OH * OW <= 1024;   // see conv2d
+  static const bool slab_train = dbg_env("EG_NO_SLAB_IN_TRAIN") == nullptr;
+  const bool slabs_ok = c.feeds_in && slab_fusion && (!need || slab_train) && !merged && cout % 32 == 0 && OH * OW <= 1024;   // see conv2d
   c.feeds_in = false;
   a.keep_slabs = slabs_ok ? 1 : 0;
   if (!merged) run_conv(c, a);
@@ -903,9 +906,12 @@ T in_act(Ctx& c, T x, int a, T* stats_out) {
   T st = new_tensor(c, x->n, 1, 1, 2 * x->c, false);
   const int HW = x->h * x->w;
   EG_CHECK(x->nslab <= 1 || (x->c % 32 == 0 && HW <= 1024), "in_act: slab input needs C %% 32 == 0 and HW <= 1024");
-  if (x->nslab > 1)   // a forward-only K-split convolution output that was left as slabs for this pass (conv2d)
-    launch_in_fwd(x->slabs, out->d, st->d, x->n, HW, x->c, a, c.stream, x->nslab, x->numel(), x->slab_bias);
-  else
+  if (x->nslab > 1) {   // a K-split convolution output that was left as slabs for this pass (conv2d); in a training graph
+                        // the pass also stores the sum into x->d: from here on x is an ordinary tensor
+    launch_in_fwd(x->slabs, out->d, st->d, x->n, HW, x->c, a, c.stream, x->nslab, x->numel(), x->slab_bias,
+                  x->needs_grad ? x->d : nullptr);
+    if (x->needs_grad) x->nslab = 0;
+  } else
     launch_in_fwd(x->d, out->d, st->d, x->n, HW, x->c, a, c.stream);
   if (stats_out) *stats_out = st;
   if (x->needs_grad) {
