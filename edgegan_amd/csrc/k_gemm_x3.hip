@@ -380,7 +380,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const ConvArgs a) 
 template <bool SPLITK, int NPROD, bool REFLECT, bool TIMING = false>
 __global__ __launch_bounds__(512, 1) void conv_gemm_x3pp_kernel(const ConvArgs a) {
   constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64;
-  constexpr int MI = WTM / 16, NJ = WTN / 16;
   constexpr int NL = NPROD == 1 ? 1 : 3;   // limb planes (1: operands rounded to bf16, the compute_dtype bf16 arithmetic)
   __shared__ __attribute__((aligned(16))) unsigned short AsG[2][NL][BM * ROWX];   // per group
   __shared__ __attribute__((aligned(16))) unsigned short BsG[3][NL][BN * ROWX];   // per K step mod 3
@@ -584,7 +583,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3pp_kernel(const ConvArgs a
       if (tim && k >= 8 && k < 12) tbuf[(k - 8) * 8 + 4] = __builtin_amdgcn_s_memtime();
     };
     constexpr std::true_type yes{};
-    constexpr std::false_type no{};
     if (nt > 0) {
       if constexpr (X) {
         dma_b_tile(0);

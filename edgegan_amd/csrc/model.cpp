@@ -855,13 +855,6 @@ void train_step(Ctx& c) {
     EG_HIP(hipEventRecord(c.ev_fork, c.lanes[0].stream));
     for (int i = 1; i < nl; ++i) EG_HIP(hipStreamWaitEvent(c.lanes[i].stream, c.ev_fork, 0));
   };
-  auto join = [&](int nl) {   // lane 0 continues after lanes 1..nl-1
-    use_lane(c, 0);
-    for (int i = 1; i < nl; ++i) {
-      EG_HIP(hipEventRecord(c.lanes[i].done, c.lanes[i].stream));
-      EG_HIP(hipStreamWaitEvent(c.lanes[0].stream, c.lanes[i].done, 0));
-    }
-  };
   use_lane(c, 0);
   const bool conc_a = c.lanes_mask & 1, conc_c = c.lanes_mask & 2;
   // ---- phase A: the four discriminator-side sub-steps ------------------------------------------------------
