@@ -1407,6 +1407,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
       ix = reflect_x(ix, IW);
     }
     const bool ok = hv[j] && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+#ifdef EG_EXPERIMENTS
+    if (a.dbg & 32) return ok ? ((unsigned)(((nb * IH + iy) * IW + ix) * a.x_ps * 4) & 0xfffu) + a_coff[j] : 0x80000000u;   // probe: cache-resident gathers
+#endif
     return ok ? (unsigned)(((nb * IH + iy) * IW + ix) * a.x_ps * 4) + a_coff[j] : 0x80000000u;
   };
   // ---- B staging (as wgrad_x3t): unit = (pixel pair mp, channel quad), this group stages quads cqb + 16 grp
@@ -1425,14 +1428,26 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
   };
   auto load_b = [&](int t, f32x4 (&rb)[2]) __attribute__((always_inline)) {
     const int m = p_lo + t * BKX + 2 * mp;
-    const unsigned r0 = m < p_hi ? (unsigned)(m * a.dy_ps * 4) : 0x80000000u;
-    const unsigned r1 = m + 1 < p_hi ? (unsigned)((m + 1) * a.dy_ps * 4) : 0x80000000u;
+    unsigned r0 = m < p_hi ? (unsigned)(m * a.dy_ps * 4) : 0x80000000u;
+    unsigned r1 = m + 1 < p_hi ? (unsigned)((m + 1) * a.dy_ps * 4) : 0x80000000u;
+#ifdef EG_EXPERIMENTS
+    if (a.dbg & 32) { r0 &= 0x80000fffu; r1 &= 0x80000fffu; }
+#endif
     rb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r0 + b_noff, 0, 0));
     rb[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, r1 + b_noff, 0, 0));
   };
   constexpr int PLA = HPMAX * BC * 2;    // bytes of one A plane
   auto store_a = [&](int j, const f32x4& v) __attribute__((always_inline)) {
     __attribute__((address_space(3))) char* q = (__attribute__((address_space(3))) char*)(uintptr_t)sa[j];
+#ifdef EG_EXPERIMENTS
+    if (a.dbg & 1) {   // probe: no limb split
+      const u32x4 l = __builtin_bit_cast(u32x4, v);
+      *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q) = (u32x2){l[0], l[1]};
+      *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q + (NL > 1 ? PLA : 0)) = (u32x2){l[2], l[3]};
+      *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q + (NL > 1 ? 2 * PLA : 0)) = (u32x2){l[0], l[2]};
+      return;
+    }
+#endif
     if constexpr (NL == 1) {
       *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(q) = (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
       return;

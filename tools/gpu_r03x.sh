@@ -1,6 +1,8 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out/r03x
 export EG_LIB_PATH=/root/repo/edgegan_amd/libedgegan_hip_exp.so
-DTYPE=f32x3 SHAPES='cls Conv_1 u1,D.conv0,cls h0' timeout 300 python tools/gpu_microbench.py 2>&1 | grep -i "smallc\|scatter\|flatm" | tee gpurun_out/r03x/smallc_batched_gather.txt
-unset EG_LIB_PATH
-timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -3 | tee -a gpurun_out/r03x/smallc_batched_gather.txt
+for d in 0 32 1 33 0; do
+  echo "== EG_WG_DBG=$d" >> gpurun_out/r03x/wgrad_x3r_limiter.txt
+  DTYPE=f32x3 SHAPES='cls Conv_2 u1,cls Conv_2 u3,D.conv3,D.conv4 patch' EG_WG_DBG=$d timeout 300 python tools/gpu_microbench.py 2>&1 | grep -i "wgrad" >> gpurun_out/r03x/wgrad_x3r_limiter.txt
+done
+cat gpurun_out/r03x/wgrad_x3r_limiter.txt
