@@ -331,11 +331,14 @@ __global__ void conv_split_reduce_kernel(const float* __restrict__ ws, float* __
 // (two 128x128 tiles, one block per CU) advances 2 tiles per 2 units; two 64x64 blocks share a CU at ~0.66 of that
 // kernel's per-flop rate; a K split adds the slab reduction (HBM-bound) and needs >= 4 K steps per slab.
 static int pick_x3(ConvArgs& a) {
-  int maxM = 0, nk = 1 << 30;
+  int maxM = 0, nk = 1 << 30, nk_max = 0;   // nk: K steps of the shortest phase (split bound); nk_max: of the longest (time)
   for (int p = 0; p < a.nphase; ++p) {
     maxM = std::max(maxM, a.NB * a.ph[p].OHp * a.ph[p].OWp);
     nk = std::min(nk, a.ph[p].Ty * a.ph[p].Tx * (a.C / 32));
+    nk_max = std::max(nk_max, a.ph[p].Ty * a.ph[p].Tx * (a.C / 32));
   }
+  static const bool by_longest = dbg_env("EG_X3_COST_MIN_PHASE") == nullptr;   // A/B: the model's former step count
+  const int nk_t = by_longest ? nk_max : nk;
   const long long tpp = (long long)((maxM + 255) / 256) * ((a.N + 127) / 128) * a.nphase;
   const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase;
   const bool pp_ok = a.N >= 128 && a.x_bytes != 0 && a.wbf_bytes != 0;
@@ -347,7 +350,7 @@ static int pick_x3(ConvArgs& a) {
       if (ks > 1 && nk / ks < 4) break;
       const long long blocks = (tile == 1 ? tpp : t64) * ks;
       const long long slots = tile == 1 ? 256 : 512;
-      const double steps = (double)((nk + ks - 1) / ks);
+      const double steps = (double)((nk_t + ks - 1) / ks);   // the launch lasts as long as its longest phase
       double t = (double)((blocks + slots - 1) / slots) * steps * (tile == 1 ? 2.0 : 0.76) + (tile == 1 ? 3.0 : 1.0);
       if (ks > 1) t += (ks + 1) * out_bytes / 3.0e12 / 1.3e-6 + 4.0;   // slab reduction + its launch
       if (t < best) {
