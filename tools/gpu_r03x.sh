@@ -1,4 +1,5 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out/r03x
-timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -4 | tee gpurun_out/r03x/pytest_gpu.txt
-python tools/layer_table.py gpurun_out/r03x/layers.csv 2> /dev/null
+export EG_LIB_PATH=/root/repo/edgegan_amd/libedgegan_hip_exp.so
+timeout 900 python tools/gpu_ab_env.py EG_NO_X3H_PAIR=1 EG_LANES=15 4 2>&1 | tee gpurun_out/r03x/ab_x3h_pair.txt
+timeout 600 python tools/gpu_ab_env.py EG_NO_X3H_PAIR=1 EG_LANES=15 2 --height 256 --width 512 --batch 16 2>&1 | tee gpurun_out/r03x/ab_x3h_pair_256.txt
