@@ -564,7 +564,10 @@ static bool ew_vec_ok(size_t n, const void* a, const void* b, const void* c = nu
 }
 void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s) {
   if (ew_vec_ok(n, x, y)) {
-    hipLaunchKernelGGL(prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, leak_p, leak_c, y, n / 4);
+    // (experiments: EG_DUP_PRELU_FWD = N extra, idempotent launches -- what does an HBM-bound pass on a lane cost the iteration?)
+    static const int dup = dbg_env("EG_DUP_PRELU_FWD") ? atoi(dbg_env("EG_DUP_PRELU_FWD")) : 0;
+    for (int r = 0; r <= dup; ++r)
+      hipLaunchKernelGGL(prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, leak_p, leak_c, y, n / 4);
     return;
   }
   hipLaunchKernelGGL(prelu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, leak_p, leak_c, y, n);

@@ -1,6 +1,5 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out/r03x
 export EG_LIB_PATH=/root/repo/edgegan_amd/libedgegan_hip_exp.so
-timeout 900 python tools/gpu_ab_env.py EG_NO_EPI_PRELU=1 EG_LANES=15 4 2>&1 | tee gpurun_out/r03x/ab_epi_prelu.txt
-unset EG_LIB_PATH
-timeout 1500 python -m pytest tests/test_x3_gpu.py tests/test_tight_gpu.py -x -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -8 | tee gpurun_out/r03x/pytest_x3_tight.txt
+timeout 900 python tools/gpu_ab_env.py EG_DUP_PRELU_FWD=0 EG_DUP_PRELU_FWD=2 4 2>&1 | tee gpurun_out/r03x/ab_dup_prelu_fwd.txt
+timeout 900 python tools/gpu_ab_env.py EG_DUP_PRELU_FWD=0 EG_DUP_PRELU_FWD=6 3 2>&1 | tee -a gpurun_out/r03x/ab_dup_prelu_fwd.txt
