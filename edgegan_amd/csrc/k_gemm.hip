@@ -339,6 +339,9 @@ static int pick_x3(ConvArgs& a) {
   }
   static const bool by_longest = dbg_env("EG_X3_COST_MIN_PHASE") == nullptr;   // A/B: the model's former step count
   const int nk_t = by_longest ? nk_max : nk;
+  static const bool chunk_split_on = dbg_env("EG_X3_COST_STEP_SPLIT") == nullptr;   // A/B: the model's former step-granular split
+  const int chunks = (a.S == 2 ? 4 : 1) * (a.C / 32);
+  const bool chunk_split = chunk_split_on && chunks > 0 && nk_t % chunks == 0;
   const long long tpp = (long long)((maxM + 255) / 256) * ((a.N + 127) / 128) * a.nphase;
   const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase;
   const bool pp_ok = a.N >= 128 && a.x_bytes != 0 && a.wbf_bytes != 0;
@@ -350,7 +353,14 @@ static int pick_x3(ConvArgs& a) {
       if (ks > 1 && nk / ks < 4) break;
       const long long blocks = (tile == 1 ? tpp : t64) * ks;
       const long long slots = tile == 1 ? 256 : 512;
-      const double steps = (double)((nk_t + ks - 1) / ks);   // the launch lasts as long as its longest phase
+      double steps = (double)((nk_t + ks - 1) / ks);   // the launch lasts as long as its longest phase
+      if (tile == 1 && chunk_split) {
+        // the halo kernel splits K by whole 32-channel chunks (S2D: by the 4 C / 32 phase chunks): 16 chunks over 5 slabs
+        // are 4 + 4 + 4 + 4 + 0 -- price what will run, and never an empty slab
+        const int per = (chunks + ks - 1) / ks;
+        if (per * (ks - 1) >= chunks && ks > 1) continue;
+        steps = (double)per * (nk_t / chunks);
+      }
       double t = (double)((blocks + slots - 1) / slots) * steps * (tile == 1 ? 2.0 : 0.76) + (tile == 1 ? 3.0 : 1.0);
       if (ks > 1) t += (ks + 1) * out_bytes / 3.0e12 / 1.3e-6 + 4.0;   // slab reduction + its launch
       if (t < best) {
