@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Throughput bench of the EdgeGAN training hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -336,8 +336,45 @@ def loop_bench(args, ea, np, local):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same command line (one process per GPU, as
+    the reference is one process per device, edgegan/train.py:77), with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and a
+    launch-unique EG_RDZV_KEY in their environment (the ranks' RCCL id travels through edgegan_amd/rendezvous.py).  Rank
+    0's stdout -- the ONE JSON line -- is passed through; a rank that fails takes the others down with it."""
+    import secrets
+    import socket
+    import subprocess
+    with socket.socket() as sk:          # a free port: part of the rendezvous key and what torch-style tools expect
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    key = os.environ.get('EG_RDZV_KEY') or f'bench{os.getpid()}_{secrets.token_hex(4)}'
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), EG_RDZV_KEY=key)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f'bench.py: rank {r} exited with {code}; stopping the other ranks', file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
-    ap = argparse.ArgumentParser(epilog='N > 1: launch under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` '
+    ap = argparse.ArgumentParser(epilog='N > 1: either plain `python bench.py --gpus N` (this process then starts the N ranks itself) or '
+                                        '`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` '
                                         '(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  The RCCL id travels through a '
                                         'file keyed on the launcher process; a launcher whose ranks do not share a parent process must '
                                         'export the same EG_RDZV_KEY to every rank.  EG_RCCL_LIB=<path> binds a specific librccl.')
@@ -370,10 +407,9 @@ def main():
     if 'EG_FORCE_DEVICE' in os.environ:      # test hook: several ranks on one GPU (1-GPU dev boxes)
         local = int(os.environ['EG_FORCE_DEVICE'])
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f'bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}',
-                  file=sys.stderr)
-            sys.exit(2)
+        if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N` (no launcher): this process becomes the launcher of N ranks
+            sys.exit(self_launch(args.gpus))
         args.gpus = world
 
     import numpy as np

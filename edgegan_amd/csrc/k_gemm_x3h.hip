@@ -315,9 +315,23 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   // step k+1, and -- the halo image being constant within a chunk -- the first halo plane of the next tap: a step
   // opens with its first product's operands already in registers, and the other five products' planes return under it.
   // Product order a0b0, a1b0, a2b0 | (b0 free: next b0) | a0b1, a0b2 | (a0 free: next a0) | a1b1.
-#define EG_TOP(a, b) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) :: "memory")
-#define EG_TOP_NB(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) :: "memory")
-  bf16x8 a0[MI][2], b0[2][2];
+  // Every fragment register an inline-assembly read targets is an in/out operand of the wait that retires the read: the
+  // compiler believes an asm read's result exists when the statement ends, so a destination that is DEAD in the program
+  // (the look-ahead a0 read after a chunk's last tap, whose value the re-read at t == 0 replaces) is free for its register
+  // allocator at once -- round 3's one-plane S2D split-K instantiations kept the NEXT b0 fragment address in such a
+  // register and the stale data landed on it (tools/isa_async_lint.py finds the pattern in the ISA).
+  // Listing the registers here keeps them allocated until the data has landed.
+#define EG_TOP_ASM(text, a, b)                                                                                                  \
+  do {                                                                                                                          \
+    if constexpr (MI == 2)                                                                                                      \
+      asm volatile(text : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[MI - 1][0]), "+v"(a[MI - 1][1]), "+v"(b[0][0]), "+v"(b[0][1]),   \
+                   "+v"(b[1][0]), "+v"(b[1][1])::"memory");                                                                     \
+    else                                                                                                                        \
+      asm volatile(text : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1])::"memory");  \
+  } while (0)
+#define EG_TOP(a, b) EG_TOP_ASM("s_waitcnt lgkmcnt(0)\n\ts_barrier", a, b)
+#define EG_TOP_NB(a, b) EG_TOP_ASM("s_waitcnt lgkmcnt(0)", a, b)
+  bf16x8 a0[MI][2] = {}, b0[2][2] = {};   // (defined values: both are in/out operands of the first wait)
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every issue arbitration otherwise (+0.5 %)
   if (nt > 0) {
     load_halo(cc_lo);
@@ -338,7 +352,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   for (int c = 0; c < ncc; ++c) {
     const bool has_next = c + 1 < ncc;
     // ---- chunk start: the previous chunk's fragment reads are done (barrier), its successor's halo is in registers --------
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (a0 holds the stale look-ahead read of the previous chunk's last tap: in flight until this wait, see EG_TOP_ASM)
+    EG_TOP(a0, b0);
     // the halo loads are older than the newest filter request (tile k+1, issued in the previous chunk's last step)
     if (!issuer || k + 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBI) : "memory");
@@ -433,10 +448,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
     }
   }
   // the last step's look-ahead reads still target a0 / b0: they land before anything else may use those registers
-  if (nt > 0) {
-    EG_TOP_NB(a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  EG_TOP_NB(a0, b0);
+  __builtin_amdgcn_sched_barrier(0);
+#undef EG_TOP_ASM
 #undef EG_TOP
 #undef EG_TOP_NB
 #undef EG_DSR
@@ -531,9 +545,7 @@ bool conv_x3h_eligible(const ConvArgs& a) {
   static const bool off = dbg_env("EG_NO_HALO") != nullptr;
   if (off || !a.wgt_bf || !(a.limbs == 3 || a.limbs == 1) || a.shuf) return false;
   static const bool no_s2d = dbg_env("EG_NO_S2D") != nullptr;
-  // (limb mode only: the one-plane bf16 form of the S2D variant is correct un-split but WRONG with split K for C >= 128 --
-  //  tools/gpu_s2d_check.py reproduces it, cause not found -- so the bf16 mode keeps the tap-gather kernel for these layers)
-  const bool s2d = x3h_s2d_shape(a) && a.limbs == 3 && !no_s2d;
+  const bool s2d = x3h_s2d_shape(a) && !no_s2d;
   if (!(a.S == 1 || s2d) || !(a.D == 1 || a.D == -1) || a.C % 32 != 0 || a.N < 64 || a.N % 4 != 0) return false;
   if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || !a.x_bytes || !a.wbf_bytes || a.wbf_plane % 8 != 0) return false;
   if ((((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.wgt_bf) & 15) != 0 || (a.bias && (((uintptr_t)a.bias) & 15) != 0)) return false;
@@ -557,7 +569,7 @@ template <int BN>
 static const char* x3h_launch(const ConvArgs& a, const HaloGeom& g, hipStream_t s) {
   const int zs = a.ksplit > 1 ? a.ksplit : 1;
   dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, (a.N + BN - 1) / BN, a.nphase * zs);
-  const bool s2d = x3h_s2d_shape(a) && a.limbs == 3;
+  const bool s2d = x3h_s2d_shape(a);
   if (a.limbs == 1) {
     if (s2d) x3h_launch_variant<1, BN, true>(a, g, grid, s);
     else x3h_launch_variant<1, BN, false>(a, g, grid, s);
