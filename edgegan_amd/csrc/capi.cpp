@@ -41,7 +41,7 @@ static Config to_config(const eg_config* k) {
 #define EG_API_BEGIN try {
 // entry points that enqueue work: always start on lane 0 (the context's own stream; train_step ends there too, and
 // an error in the middle of a concurrent iteration may have left another lane active)
-#define EG_API_BEGIN_CTX(ctxp) try { use_lane((ctxp)->c, 0); (ctxp)->c.infer_lanes = false; (ctxp)->c.feeds_in = false;
+#define EG_API_BEGIN_CTX(ctxp) try { api_enter((ctxp)->c);
 #define EG_API_END(ctxp)                                  \
   }                                                       \
   catch (const eg::Error& e) {                            \
@@ -225,10 +225,25 @@ int eg_train_batch(eg_ctx* ctx, const float* images, const float* z, const float
   const size_t n_img = (size_t)cfg.B * cfg.H * cfg.W * cfg.c_dim, n_z = (size_t)cfg.B * zc, n_a = (size_t)3 * cfg.B;
   const int slot = (int)(c.feed_count & 1);
   if (!c.feed_host[slot]) {
-    EG_HIP(hipHostMalloc((void**)&c.feed_host[slot], (n_img + n_z + n_a + 4) * sizeof(float), hipHostMallocDefault));
-    EG_HIP(hipHostMalloc((void**)&c.loss_host[slot], 64 * sizeof(float), hipHostMallocDefault));
-    EG_HIP(hipEventCreateWithFlags(&c.feed_copied[slot], hipEventDisableTiming));
-    EG_HIP(hipEventCreateWithFlags(&c.loss_ready[slot], hipEventDisableTiming));
+    // all four per-slot resources or none: a failure half way must not leave a slot that looks initialised
+    float *fh = nullptr, *lh = nullptr;
+    hipEvent_t e1 = nullptr, e2 = nullptr;
+    try {
+      EG_HIP(hipHostMalloc((void**)&fh, (n_img + n_z + n_a + 4) * sizeof(float), hipHostMallocDefault));
+      EG_HIP(hipHostMalloc((void**)&lh, 64 * sizeof(float), hipHostMallocDefault));
+      EG_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+      EG_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    } catch (...) {
+      if (fh) (void)hipHostFree(fh);
+      if (lh) (void)hipHostFree(lh);
+      if (e1) (void)hipEventDestroy(e1);
+      if (e2) (void)hipEventDestroy(e2);
+      throw;
+    }
+    c.loss_host[slot] = lh;
+    c.feed_copied[slot] = e1;
+    c.loss_ready[slot] = e2;
+    c.feed_host[slot] = fh;
   } else {
     EG_HIP(hipEventSynchronize(c.feed_copied[slot]));   // the copies out of this slot (two feeds ago): long done
   }
@@ -759,6 +774,15 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
     io.down(0, w, ip[0]);
     io.down(1, ms, ip[0]);
     io.down(2, mom, ip[0]);
+  } else if (op == "fault_mid_backward") {
+    // test hook (tests/test_step_gpu.py): leave the context the way an exception in the middle of a concurrent
+    // iteration's backward sweep does -- another lane active, its stream pointing at the lane's leaf stream with
+    // un-joined work, a queued second-stage reduction of the abandoned sweep -- and fail.  The NEXT call has to recover
+    // (model.cpp: api_enter).
+    use_lane(c, 2);
+    if (c.lanes[2].leaf) c.stream = c.lanes[2].leaf;
+    c.leaf_dirty = true;
+    fail(7, "injected fault: lane %d active, leaf work un-joined", c.cur_lane);
   } else {
     fail(1, "unknown test op '%s'", op_);
   }

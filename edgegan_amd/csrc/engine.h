@@ -201,6 +201,7 @@ T wrap_tensor(Ctx& c, float* data, int n, int h, int w, int ch);
 float* grad_acc(Ctx& c, T t, int* acc);   // returns t->g; *acc = 1 if it already holds a value
 void reset_step(Ctx& c);                  // arena + tape + tensor list (start of a sub-step)
 void flush_deferred(Ctx& c);              // runs the queued second-stage reductions on the current stream
+void api_enter(Ctx& c);                   // model.cpp: entry state of every enqueueing C-ABI call (recovers from a failed one)
 void leaf_join(Ctx& c);                   // the lane's main stream waits for its leaf stream (ops.cpp: LeafScope)
 void reset_grads(Ctx& c);                 // forget every activation / weight gradient (keeps buffers)
 void set_want_grad(Ctx& c, int group, bool on);

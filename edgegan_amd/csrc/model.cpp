@@ -307,12 +307,32 @@ void build_context(Ctx& c) {
 
 void use_lane(Ctx& c, int lane) {
   if (lane == c.cur_lane) return;
+  // (checked BEFORE anything is swapped: a throw from here must leave the context exactly as it was)
+  EG_CHECK(!c.leaf_dirty, "use_lane with un-joined leaf work on lane %d", c.cur_lane);
   c.arena.swap(c.lanes[c.cur_lane].arena);   // park the active arena in its slot
   c.arena.swap(c.lanes[lane].arena);         // bring lane's arena in (its slot keeps the empty placeholder)
-  EG_CHECK(!c.leaf_dirty, "use_lane with un-joined leaf work on lane %d", c.cur_lane);
   c.stream = c.lanes[lane].stream;
   c.scratch = c.lanes[lane].scratch;
   c.cur_lane = lane;
+}
+
+// Every C-ABI entry point that enqueues work starts here (capi.cpp: EG_API_BEGIN_CTX).  An exception in the middle of a
+// backward sweep (a HIP error, "variable received no gradient", ...) unwinds past leaf_join, i.e. it can leave leaf_dirty
+// set, the context's stream pointing at a lane's LEAF stream (LeafScope restores it, an error inside run_deferred does
+// not) and another lane active.  The next call must not inherit that: drain the device (whatever the failed call
+// enqueued is finished or failed), put the active lane back on its main stream, drop the queued reductions of the
+// abandoned sweep, then return to lane 0.
+void api_enter(Ctx& c) {
+  if (c.leaf_dirty || c.stream != c.lanes[c.cur_lane].stream) {
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    c.stream = c.lanes[c.cur_lane].stream;
+    c.deferred.clear();
+    c.leaf_dirty = false;
+  }
+  use_lane(c, 0);
+  c.infer_lanes = false;
+  c.feeds_in = false;
 }
 
 // ---------------------------------------------------------------------------------------------

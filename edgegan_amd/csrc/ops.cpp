@@ -130,6 +130,10 @@ static void defer_reduction(Ctx& c, const RedDesc& d) {
 
 float* grad_acc(Ctx& c, T t, int* acc) {
   if (!t->g) t->g = c.arena.allocf(t->numel());
+  // ConvArgs::epi_act: the FIRST writer applied the fused activation's derivative in its epilogue and the producer will
+  // skip its in-place pass -- exact only if that writer stays the ONLY one.  A second consumer accumulating a raw
+  // dL/d(out) into the same buffer would go unmasked: refuse loudly (no graph of this engine does it today).
+  EG_CHECK(!(t->g_set && t->g_act_done), "a second gradient contribution reached a tensor whose activation backward was fused into the first writer's epilogue");
   *acc = t->g_set ? 1 : 0;
   t->g_set = true;
   return t->g;

@@ -99,10 +99,20 @@ def test_shard_means_equal_global_batch_gradient():
         assert torch.allclose((ga + gb) / 2, gg, rtol=1e-9, atol=1e-12), n
 
 
-def test_bench_refuses_multi_gpu_without_launcher():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True,
+def test_bench_launches_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment starts the two ranks itself
+    (bench.py:self_launch; the GPU leg is tests/test_dp_gpu.py::test_bench_launches_its_own_ranks).  Without a GPU both
+    ranks must fail LOUDLY in eg_create -- the product has no CPU fallback -- and the launcher must pass that on as a
+    non-zero status with no JSON line, instead of hanging in a rendezvous."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU box: covered by tests/test_dp_gpu.py')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300,
                        env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
-    assert r.returncode == 2 and 'torch.distributed.run' in r.stderr
+    assert r.returncode != 0
+    assert 'no CPU fallback' in r.stderr and 'stopping the other ranks' in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
 
 
 def _shard_worker(rank, world, key, root, out):

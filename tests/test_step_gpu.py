@@ -132,6 +132,65 @@ def test_train_step_equals_sequential_substeps_and_is_deterministic():
     assert np.all(outs[0]['D2/Conv_1/weights/RMSProp'] == 1)
 
 
+def test_context_recovers_from_an_error_in_the_middle_of_a_backward_sweep():
+    """an exception that unwinds out of a concurrent iteration's backward sweep leaves another lane active, the
+    context's stream on that lane's LEAF stream and leaf_dirty set.  The next C-ABI call must start from a sane state
+    (csrc/model.cpp: api_enter) -- after the injected fault two iterations must reproduce a fresh engine bit for bit."""
+    cfg = ea.Config(batch_size=2)
+    values = ea.init_variables(cfg, 0)
+    batch = ea.synthetic_batch(cfg)
+    outs = []
+    for inject in (False, True):
+        net = ea.EdgeGAN(cfg, values)
+        net.upload_batch(**batch)
+        net.train_step()
+        if inject:
+            with pytest.raises(ea.EdgeGANLibError, match='injected fault'):
+                net.test_op('fault_mid_backward', [], [], [])
+            with pytest.raises(ea.EdgeGANLibError, match='injected fault'):      # twice in a row: recovery is idempotent
+                net.test_op('fault_mid_backward', [], [], [])
+        net.train_step()
+        outs.append((net.losses(), net.get_variables(slots=True)))
+        net.close()
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_pipelined_feed_and_loss_readback_equal_the_synchronous_calls():
+    """train.py's default loop is eg_train_batch + eg_losses_wait (update_model_async / losses_async: feed through
+    two pinned host slots, losses one iteration late).  It must be the same computation as upload_batch + train_step +
+    read_losses: per-iteration losses (both back = 1 and back = 0 slot selection) and the final state, bit for bit."""
+    cfg = ea.Config(batch_size=2)
+    values = ea.init_variables(cfg, 2)
+    batches = [ea.synthetic_batch(cfg, seed=300 + i) for i in range(5)]
+    sync = ea.EdgeGAN(cfg, values)
+    want = []
+    for b in batches:
+        sync.update_model(b['images'], b['z'], alpha=b['alpha'], eps=b['eps'])
+        want.append(sync.losses())
+    want_state = sync.get_variables(slots=True)
+    sync.close()
+    net = ea.EdgeGAN(cfg, values)
+    got = []
+    for i, b in enumerate(batches):
+        net.update_model_async(b['images'], b['z'], alpha=b['alpha'], eps=b['eps'])
+        if i == 2:
+            got.append(net.losses_async(back=1))     # iteration 1, asked for AFTER iteration 2 was enqueued ...
+            got.append(net.losses_async(back=0))     # ... then iteration 2 at once (the checkpoint-iteration flush of train.py)
+        elif i > 0 and i != 3:
+            got.append(net.losses_async(back=1))
+    got.append(net.losses_async(back=1))             # iteration 3 (skipped above: both slots of the ring were in use)
+    got.append(net.losses_async(back=0))             # iteration 4
+    state = net.get_variables(slots=True)
+    net.close()
+    assert len(got) == len(want) == 5
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (i, a, b)
+    for k in want_state:
+        assert np.array_equal(want_state[k], state[k]), k
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_concurrent_lanes_equal_one_stream_over_many_iterations(dtype, monkeypatch):
     """The concurrent sub-step schedule against the one-stream schedule: 25 iterations with a fresh

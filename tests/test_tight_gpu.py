@@ -138,6 +138,13 @@ def test_full_batch_fp32_substep_against_fp64_oracle(name):
     rows = _grad_rows(net, None, None, name, 1e-3, 'B=64', var_tol={vn: 3.0 * d for vn, d in self_dev.items()},
                       precomputed=(g64, l64))
     net.close()
+    if os.environ.get('EG_TIGHT_RATIOS'):     # tools: every variable's error over the oracle's own fp32-vs-fp64 deviation
+        with open(os.environ['EG_TIGHT_RATIOS'], 'a') as f:
+            for r in rows:
+                vn = r[0].split(' grad ')[-1].split(' [')[0] if ' grad ' in r[0] else None
+                if vn in self_dev:
+                    f.write(json.dumps({'mode': os.environ.get('EG_F32_MODE', 'f32'), 'substep': name, 'variable': vn, 'err': r[1],
+                                        'self_dev': self_dev[vn], 'ratio': r[1] / max(self_dev[vn], 1e-30), 'tol': r[2]}) + '\n')
     if name == 'd_optim2':
         assert len(rows) >= 55 and sum('Conv_2/weights' in r[0] for r in rows) == 4 and sum('update_gate/weights' in r[0] for r in rows) == 4
     if os.environ.get('EG_TIGHT_REPORT'):
