@@ -134,6 +134,12 @@ struct Tensor {
   const float* slabs = nullptr;
   const float* slab_bias = nullptr;
   int nslab = 0;
+  // bf16 planes ([pixel][c] bf16) of d / g for the plane-fed kernels of the bf16 mode (k_conv_bf16p.hip).  Written by the
+  // tensor's own producer kernel as a second store (then *_bf_stream == nullptr: the plane is visible wherever d / g is),
+  // or on demand by launch_cvt_bf16 on the stream recorded here (ops.cpp: tensor_plane decides who else may read it)
+  unsigned short* d_bf = nullptr;
+  unsigned short* g_bf = nullptr;
+  hipStream_t d_bf_stream = nullptr, g_bf_stream = nullptr;
   size_t numel() const { return (size_t)n * h * w * c; }
   size_t pixels() const { return (size_t)n * h * w; }
 };

@@ -1,0 +1,488 @@
+// bf16-mode convolution fed from a bf16 PLANE of its gathered operand -- no VALU staging at all.
+//
+//   conv_bf16p_kernel : Y[pix_out][n] (+)= b[n] + sum_taps sum_c Xbf[pix_out + d(tap)][c] * Wbf[tap][c][n]
+//                       stride-1 layers with 2 .. 9 taps per phase (3x3 convolutions and their input gradients, the
+//                       sub-pixel phases of the stride-2 transposed convolutions / stride-2 input gradients) -- the
+//                       layers of edgegan/nn/modules/conv.py:13-36,39-58,133-243 that k_gemm_x3h.hip serves in limb mode.
+//
+// Round 3's bf16 mode kept fp32 activations in HBM and rounded them on their way into LDS (k_gemm_x3h.hip, NPROD = 1): per
+// 32-channel chunk 7 x 16-byte fp32 loads per thread into registers, a v_cvt_pk_bf16_f32 pass, ds_write_b64 stores, one block
+// per CU (8 waves, 150 KB of LDS in the shared template) -- its K loop is 6x shorter than the limb kernel's, so the un-overlapped
+// prologue / VALU phase / epilogue dominated: 520-650 TFLOP/s = 0.21-0.26 of the dense bf16 peak (profiles/r04b_layers_bf16.csv).
+// Here the PRODUCER of the operand (InstanceNorm / PReLU / gate / pool kernels, or launch_cvt_bf16 for tensors whose producer
+// has no plane store yet) leaves a bf16 copy [pixel][C] next to the fp32 tensor, and this kernel's halo image arrives by
+// `buffer_load ... lds` (LDS-DMA): 16 halo rows x 64 bytes per wave-instruction, the XOR chunk swizzle applied on the
+// GLOBAL side (the LDS destination of a DMA is lane-linear), zero padding = out-of-range buffer offsets, REFLECT = mirrored
+// source pixels.  No staging registers, no conversion, no LDS stores.
+//
+// Shape: 256 threads = 4 waves, (WM x WN) wave grid, wave tile (32 MI) pixels x 64 channels of v_mfma_f32_32x32x16_bf16;
+// block tile PX = 32 MI WM pixels x BN = 64 WN channels.  LDS = two halo buffers (chunk c + 1 lands while chunk c is
+// multiplied) + a 2-slot filter ring = 43 KB at PX = 128, BN = 128: THREE blocks per CU, so one block's prologue, epilogue
+// store burst and barrier bubbles are covered by its neighbours' MFMAs.  Per K step (one tap x 32 channels):
+//   top:  s_waitcnt vmcnt(0)  (this wave's DMA pieces of step k-1: filter tile k+1, possibly the next halo)
+//         s_waitcnt lgkmcnt(0) + s_barrier     (tile k+1 / the halo visible to every wave; every read of tile k done)
+//         DMA: filter tile k+2 -> ring slot k & 1;  at a chunk's first tap: the NEXT chunk's halo -> the other buffer
+//         look-ahead fragment reads of step k+1 (second register set)
+//         MFMAs of step k
+// The first version of this loop walked (chunk, tap) with run-time state: ~70 SALU + ~20 VALU instructions per step of 8
+// MFMAs, and a CU has ONE scalar unit for its 12 resident waves -- with the DMA, the reads and the MFMAs all removed the
+// launch still took 0.030 of its 0.096 ms (profiles/r04d_bf16p_limiter.txt).  Now the taps of a chunk AND pairs of chunks are
+// unrolled at compile time (the phase's tap grid is a template argument of the loop): halo buffer, ring slot, register
+// set, the tap's row / column shift and its filter offset are all immediates or loop-invariant registers -- a step of the
+// 16-wide-tile form is 8 ds_read_b128 with immediate offsets, 8 MFMAs, 2 DMA requests, one wait + barrier, ~8 SALU, 0 VALU.
+// Fragment reads are inline assembly (the compiler would guard ordinary LDS reads against the DMA in flight with
+// vmcnt(0)); every fragment register is an in/out operand of the wait that retires its read.
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace eg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef EG_BF16P_DBG
+#define EG_BF16P_DBG 0   // timing experiments (wrong results): 1 no per-step barrier, 2 no halo DMA, 4 no filter DMA, 8 no MFMA, 16 no fragment reads, 32 no output stores, 64 no vmcnt wait at the step top
+#endif
+namespace {
+__device__ __forceinline__ int swz_p(int row) { return ((-((row >> 2) & 3)) & 3) ^ ((row >> 4) & 1); }
+__device__ __forceinline__ int reflect_p(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+}  // namespace
+
+struct PlaneGeom {
+  int lTW, lTH, TI;        // tile = TI images x 2^lTH rows x 2^lTW columns = PX output pixels
+  int tiles_x, tiles_y;    // tiles per image
+  int pitch;               // LDS row pitch of a halo row: 20 for 16-wide tiles (conflict-free layout), 0 = dense rows
+};
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// PH: the tap grids of the launch's phases -- 0: 3x3 (stride-1 convolutions and their input gradients), 1: 2x2 (the four
+// phases of a 4x4 stride-2 input gradient), 2: any of 3x3 / 3x2 / 2x3 / 2x2 per phase (5x5 stride-2 transposed convolutions)
+template <int MI, int WN, bool SPLITK, bool SW16, int HR, int PH>
+__global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p_kernel(const ConvArgs a, const PlaneGeom g) {
+  constexpr int BN = 64 * WN;                // block tile: (4 / WN) waves x 32 MI pixels by WN waves x 64 channels
+  constexpr int WROWS = 32 * MI;
+  constexpr int NSB = 2;                     // ring slots: tile k + 1 is being read while tile k + 2 lands in tile k's slot
+  constexpr int APL = HR * 64;             // bytes of one halo buffer
+  constexpr int BPL = BN * 64;             // bytes of one ring slot
+  constexpr int NPC = HR / 16;             // DMA pieces (16 rows x 64 B) of one halo image
+  constexpr int NAJ = (NPC + 3) / 4;       // ... per wave
+  constexpr int NBJ = BN / 64;             // filter DMA pieces per wave and K step (16 rows each; 4 waves)
+  static_assert(HR % 16 == 0, "halo rows come in 16-row DMA pieces");
+  __shared__ __attribute__((aligned(16))) unsigned short Ah[2][HR * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[NSB][BN * 32];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+  // XCD-aware block map (as k_gemm_x3h.hip): the output-channel tiles of one pixel tile are neighbours inside one XCD
+  const unsigned gxy = gridDim.x * gridDim.y;
+  const unsigned vblk = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gxy * gridDim.z, 0);
+  const int bz = __builtin_amdgcn_readfirstlane(vblk / gxy), bxy = __builtin_amdgcn_readfirstlane(vblk % gxy);
+  const int bx = bxy / (int)gridDim.y, by = bxy - bx * (int)gridDim.y;
+  const int zphase = SPLITK ? bz / a.ksplit : bz;
+  const int zsplit = SPLITK ? bz - zphase * a.ksplit : 0;
+  const ConvPhase ph = a.ph[zphase];
+  const int IH = a.IH, IW = a.IW, C = a.C, N = a.N, D = a.D;
+  const int nTy = ph.Ty, nTx = ph.Tx;
+  const int TW = 1 << g.lTW, TH = 1 << g.lTH;
+  const int tpi = g.tiles_x * g.tiles_y;
+  const int tn = bx / tpi, trem = bx - tn * tpi;
+  const int tyy = trem / g.tiles_x, txx = trem - tyy * g.tiles_x;
+  const int img0 = tn * g.TI, oy0 = tyy * TH, ox0 = txx * TW;
+  const int n0 = by * BN;
+  const int offy = ph.offy, offx = ph.offx;
+  const int dminy = min(offy, (nTy - 1) * D + offy), dminx = min(offx, (nTx - 1) * D + offx);
+  const int HH = TH + nTy - 1, HW = TW + nTx - 1;
+  constexpr bool sw16 = SW16;
+  const int HWP = sw16 ? 20 : HW, HPI = HH * HWP;
+
+  // ---- halo DMA: piece p = wave + 4 j covers LDS rows 16 p .. 16 p + 15; lane (r, q) = (lane >> 2, lane & 3) brings the
+  //      16-byte channel group (q ^ swizzle(row)) of the row's source pixel; rows without a pixel / padding read zeros -----
+  unsigned goffA[NAJ];
+#pragma unroll
+  for (int j = 0; j < NAJ; ++j) {
+    const int row = (wave + 4 * j) * 16 + (lane >> 2);
+    unsigned off = 0x80000000u;
+    if (wave + 4 * j < NPC) {
+      const int ti = row / HPI, rem = row - ti * HPI;
+      const int hy = rem / HWP, hx = rem - hy * HWP;
+      if (ti < g.TI && hx < HW) {
+        int iy = oy0 + dminy + hy, ix = ox0 + dminx + hx;
+        if (a.reflect) {
+          iy = reflect_p(iy, IH);
+          ix = reflect_p(ix, IW);
+        }
+        if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) {
+          const int sw = sw16 ? (hx >> 2) & 3 : swz_p(row);
+          off = (unsigned)(((((img0 + ti) * IH + iy) * IW + ix) * a.xbf_ps + (((lane & 3) ^ sw) * 8)) * 2);
+        }
+      }
+    }
+    goffA[j] = off;
+  }
+  const __amdgpu_buffer_rsrc_t xres =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x_bf), 0, a.xbf_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wgt_bf), 0, a.wbf_bytes, 0x00020000);
+  // (hipcc 7.2 quirk: with the DMA builtin's voffset argument written as an element of a template-sized local array the HOST
+  //  pass silently drops the kernel's launch stub -- "undefined symbol __device_stub__..." at load time; a scalar copy is fine)
+  auto request_halo = [&](int cc, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NAJ; ++j)
+      if (wave + 4 * j < NPC && (EG_BF16P_DBG & 2) == 0)
+      {
+        const unsigned voff = goffA[j];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (__attribute__((address_space(3))) void*)&Ah[buf][(wave + 4 * j) * 16 * 32], 16,
+                                                 voff, cc * 64, 0, 0);
+      }
+  };
+
+  // ---- filter ring: piece (wave, j) fills rows (wave NBJ + j) 16 + lane / 4 of the slot -----------------------------------
+  unsigned woff[NBJ];
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) {
+    const int row = (wave * NBJ + j) * 16 + (lane >> 2);
+    woff[j] = (unsigned)(((size_t)min(n0 + row, N - 1) * 32 + ((lane & 3) ^ swz_p(row)) * 8) * 2);
+  }
+  const int cpt = C / 32;
+  const int wtile = N * 32 * 2;
+  int cc_lo = 0, cc_hi = cpt;
+  if constexpr (SPLITK) {
+    const int per = (cpt + a.ksplit - 1) / a.ksplit;
+    cc_lo = min(cpt, zsplit * per);
+    cc_hi = min(cpt, cc_lo + per);
+  }
+  const int ncc = cc_hi - cc_lo;
+
+  // ---- fragments --------------------------------------------------------------------------------------------------------
+  const int l31 = lane & 31, lh = lane >> 5;
+  const unsigned ah_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&Ah[0][0];
+  const unsigned bs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&Bs[0][0];
+  int base_row[MI], base_px[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int r = wm * WROWS + i * 32 + l31;
+    const int ti = r >> (g.lTW + g.lTH), py = (r >> g.lTW) & (TH - 1), px = r & (TW - 1);
+    base_row[i] = ti * HPI + py * HWP + px;
+    base_px[i] = px;
+  }
+  // 16-wide tiles: the fragment address of (32-row block i, column shift e, K half kk) is a per-lane constant -- the row
+  // shift of a tap and the halo buffer are immediate offsets (pitch 20 rows of 64 bytes)
+  unsigned abase[MI][3][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        abase[i][e][kk] = ah_base + (base_row[i] + e) * 64 + ((((kk << 1) | lh) ^ (((base_px[i] + e) >> 2) & 3)) * 16);
+  const unsigned bb0 = bs_base + ((wn * 64 + l31) * 32 + ((lh ^ swz_p(l31)) * 8)) * 2, bb1 = bb0 ^ 32u;
+
+  f32x16 acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#if (EG_BF16P_DBG & 16)
+#define EG_DSR(dst, addr, off) asm volatile("" : "+v"(dst) : "v"(addr), "n"(off))
+#else
+#define EG_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#endif
+  struct Frags {
+    bf16x8 a[MI][2], b[2][2];
+  };
+  // s_waitcnt lgkmcnt(0) (+ barrier) with every register of the fragment set as in/out operand
+  auto land = [&](Frags& f, auto BAR) __attribute__((always_inline)) {
+    if constexpr (MI == 2) {
+      if constexpr (decltype(BAR)::value)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1])::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1])::"memory");
+    } else if constexpr (MI == 1) {
+      if constexpr (decltype(BAR)::value)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1])::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1])::"memory");
+    } else {
+      static_assert(MI == 4, "wave tiles of 32, 64 or 128 pixels");
+      if constexpr (decltype(BAR)::value)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[2][0]), "+v"(f.a[2][1]), "+v"(f.a[3][0]), "+v"(f.a[3][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1])::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.a[2][0]), "+v"(f.a[2][1]), "+v"(f.a[3][0]), "+v"(f.a[3][1]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1])::"memory");
+    }
+  };
+  constexpr std::true_type WITH_BARRIER{};
+  constexpr std::false_type NO_BARRIER{};
+  auto mm = [&](const Frags& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr ((EG_BF16P_DBG & 8) != 0) asm volatile("" : "+v"(acc[i][j]) : "v"(f.b[j][kk]), "v"(f.a[i][kk]));
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[j][kk], f.a[i][kk], acc[i][j], 0, 0, 0);
+        }
+  };
+
+  // ---- the K loop of one phase: TY x TX taps (row shift f, column shift e of the halo; the filter tap they pair with
+  //      depends on the sign of D), walked chunk by chunk; everything about a tap is a compile-time constant ----------------
+  auto kloop = [&](auto TYc, auto TXc) __attribute__((always_inline)) {
+    constexpr int TY = decltype(TYc)::value, TX = decltype(TXc)::value, NT = TY * TX;
+    // byte offset of tap t's filter tile inside a chunk row of the K-step-major plane ([tap][C/32][N][32] bf16)
+    int tapoff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int f = t / TX, e = t - f * TX;
+      const int ty = D > 0 ? f : TY - 1 - f, tx = D > 0 ? e : TX - 1 - e;
+      tapoff[t] = ((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * cpt * wtile;
+    }
+    Frags fs[2] = {};
+    // fragment reads of step (halo buffer BUF, tap T, ring slot SLOT) -- all three compile-time
+    auto read_step = [&](Frags& fr, auto BUFc, auto Tc, auto SLOTc) __attribute__((always_inline)) {
+      constexpr int BUF = decltype(BUFc)::value, T = decltype(Tc)::value, SLOT = decltype(SLOTc)::value;
+      constexpr int f = T / TX, e = T - f * TX;
+      if constexpr (SW16) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          // (named copies: a variable that a generic lambda uses ONLY as an asm operand is not captured by hipcc 7.2)
+          const unsigned p0 = abase[i][e][0], p1 = abase[i][e][1];
+          EG_DSR(fr.a[i][0], p0, BUF * APL + f * 20 * 64);
+          EG_DSR(fr.a[i][1], p1, BUF * APL + f * 20 * 64);
+        }
+      } else {
+        const int toff = f * HWP + e;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int row = base_row[i] + toff;
+          const unsigned aa = ah_base + row * 64 + ((lh ^ swz_p(row)) * 16);
+          EG_DSR(fr.a[i][0], aa, BUF * APL);
+          EG_DSR(fr.a[i][1], aa ^ 32u, BUF * APL);
+        }
+      }
+      const unsigned q0 = bb0, q1 = bb1;
+      EG_DSR(fr.b[0][0], q0, SLOT * BPL);
+      EG_DSR(fr.b[0][1], q1, SLOT * BPL);
+      EG_DSR(fr.b[1][0], q0, SLOT * BPL + 2048);
+      EG_DSR(fr.b[1][1], q1, SLOT * BPL + 2048);
+    };
+    auto request_b = [&](auto SLOTc, int wsoff) __attribute__((always_inline)) {
+      constexpr int SLOT = decltype(SLOTc)::value;
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j)
+        if constexpr ((EG_BF16P_DBG & 4) == 0) {
+          const unsigned voff = woff[j];
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (__attribute__((address_space(3))) void*)&Bs[SLOT][(wave * NBJ + j) * 16 * 32], 16,
+                                                   voff, wsoff, 0, 0);
+        }
+    };
+    constexpr std::integral_constant<int, 0> I0{};
+    constexpr std::integral_constant<int, 1> I1{};
+    if (ncc > 0) {
+      request_halo(cc_lo, 0);
+      request_b(I0, tapoff[0] + cc_lo * wtile);
+      request_b(I1, tapoff[1] + cc_lo * wtile);     // (NT >= 2)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      read_step(fs[0], I0, I0, I0);
+    }
+    // one chunk, the H-th of a pair (H = 0: halo buffer 0, H = 1: buffer 1); global step k = (2 p + H) NT + T, so the
+    // register set and ring slot of a step are (H NT + T) & 1
+    auto chunk = [&](auto Hc, int cc, bool has_next) __attribute__((always_inline)) {
+      constexpr int H = decltype(Hc)::value;
+      const int wrow = cc * wtile;
+      static_for<NT>([&](auto Tc) __attribute__((always_inline)) {
+        constexpr int T = decltype(Tc)::value;
+        constexpr int SET = (H * NT + T) & 1;
+        constexpr std::integral_constant<int, SET> SETc{};
+        constexpr std::integral_constant<int, SET ^ 1> NXTc{};
+        if constexpr ((EG_BF16P_DBG & 64) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr ((EG_BF16P_DBG & 1) != 0) land(fs[SET], NO_BARRIER);
+        else land(fs[SET], WITH_BARRIER);
+        // filter tile k + 2 -> the slot tile k was read from
+        if constexpr (T + 2 < NT) request_b(SETc, tapoff[T + 2] + wrow);
+        else if (has_next) request_b(SETc, tapoff[T + 2 - NT] + wrow + wtile);
+        if constexpr (T == 0)
+          if (has_next) request_halo(cc + 1, H ^ 1);
+        // look-ahead: the fragments of step k + 1
+        if constexpr (T + 1 < NT) read_step(fs[SET ^ 1], Hc, std::integral_constant<int, T + 1>{}, NXTc);
+        else if (has_next) read_step(fs[SET ^ 1], std::integral_constant<int, H ^ 1>{}, I0, NXTc);
+        mm(fs[SET]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    int c = 0;
+    for (; c + 1 < ncc; c += 2) {
+      chunk(I0, cc_lo + c, true);
+      chunk(I1, cc_lo + c + 1, c + 2 < ncc);
+    }
+    if (c < ncc) chunk(I0, cc_lo + c, false);
+    // nothing is in flight here (the last step issued no reads); sets whose reads were never issued hold zeros
+    land(fs[0], NO_BARRIER);
+    land(fs[1], NO_BARRIER);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  constexpr std::integral_constant<int, 2> K2{};
+  constexpr std::integral_constant<int, 3> K3{};
+  if constexpr (PH == 0) {
+    kloop(K3, K3);
+  } else if constexpr (PH == 1) {
+    kloop(K2, K2);
+  } else {
+    if (nTy == 3 && nTx == 3) kloop(K3, K3);
+    else if (nTy == 3) kloop(K3, K2);
+    else if (nTx == 3) kloop(K2, K3);
+    else kloop(K2, K2);
+  }
+#undef EG_DSR
+
+  // D^T layout of the 32x32 accumulator: lane l holds pixel row l & 31 and, in registers 4q .. 4q+3, the four consecutive
+  // output channels 8q + 4 (l >> 5) .. +3 of its 32-channel block: one 16-byte store per register quad
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int r = wm * WROWS + i * 32 + l31;
+    const int ti = r >> (g.lTW + g.lTH), py = (r >> g.lTW) & (TH - 1), px = r & (TW - 1);
+    const int nb = img0 + ti, oy = oy0 + py, ox = ox0 + px;
+    float* yrow = (SPLITK ? a.ws + (size_t)zsplit * a.y_total : a.y) +
+                  ((size_t)(nb * a.OHf + oy * a.os + ph.ophy) * a.OWf + ox * a.os + ph.ophx) * a.y_ps;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + j * 32 + q * 8 + lh * 4;
+        if (n < N) {
+          float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          if constexpr (!SPLITK) {
+            if (a.bias) {
+              const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);
+              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            }
+            if (a.accumulate) {
+              const float4 o = *reinterpret_cast<const float4*>(yrow + n);
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            if (a.epi_act) {   // dL/d(pre-activation) = dL/d(out) * act'(out), slopes as act_grad_from_out (k_norm.hip)
+              const float4 o = *reinterpret_cast<const float4*>(a.epi_ref + (yrow - a.y) + n);
+              const float neg = a.epi_act == ACT_LRELU ? 0.2f : 0.f;
+              if (a.epi_act == ACT_LRELU) {
+                v.x *= o.x >= 0.f ? 1.f : neg; v.y *= o.y >= 0.f ? 1.f : neg; v.z *= o.z >= 0.f ? 1.f : neg; v.w *= o.w >= 0.f ? 1.f : neg;
+              } else {
+                v.x *= o.x > 0.f ? 1.f : neg; v.y *= o.y > 0.f ? 1.f : neg; v.z *= o.z > 0.f ? 1.f : neg; v.w *= o.w > 0.f ? 1.f : neg;
+              }
+            }
+          }
+          if ((EG_BF16P_DBG & 32) == 0 || v.x == 123.456f) *reinterpret_cast<float4*>(yrow + n) = v;
+        }
+      }
+  }
+}
+
+static int ilog2p(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// tile geometry for PX output pixels per block and at most HR halo rows; false when the kernel does not take the shape
+static bool bf16p_geometry(const ConvArgs& a, int PX, int HR, PlaneGeom* g) {
+  const int OH = a.ph[0].OHp, OW = a.ph[0].OWp;
+  for (int p = 0; p < a.nphase; ++p)
+    if (a.ph[p].OHp != OH || a.ph[p].OWp != OW) return false;
+  if (OW < 4 || OH < 4 || (OW & (OW - 1)) != 0) return false;
+  const int TW = std::min(16, OW);
+  int TH = std::min(PX / TW, OH);
+  if ((TH & (TH - 1)) != 0 || OH % TH != 0 || OW % TW != 0) return false;
+  const int TI = PX / (TW * TH);
+  if (TI * TW * TH != PX || a.NB % TI != 0) return false;
+  g->pitch = TW == 16 ? 20 : 0;
+  for (int p = 0; p < a.nphase; ++p)
+    if (TI * (TH + a.ph[p].Ty - 1) * 20 > HR) g->pitch = 0;
+  for (int p = 0; p < a.nphase; ++p) {
+    const ConvPhase& ph = a.ph[p];
+    if (ph.Ty < 2 || ph.Ty > 3 || ph.Tx < 2 || ph.Tx > 3) return false;   // (the K loop's tap grids)
+    if (TI * (TH + ph.Ty - 1) * (TW + ph.Tx - 1) > HR) return false;
+  }
+  g->lTW = ilog2p(TW);
+  g->lTH = ilog2p(TH);
+  g->TI = TI;
+  g->tiles_x = OW / TW;
+  g->tiles_y = OH / TH;
+  return true;
+}
+
+constexpr int kHR128 = 208, kHR256 = 400;
+
+bool conv_bf16p_eligible(const ConvArgs& a) {
+  static const bool off = dbg_env("EG_NO_BF16P") != nullptr;
+  if (off || !a.x_bf || !a.wgt_bf || a.limbs != 1 || a.shuf) return false;
+  if (a.S != 1 || !(a.D == 1 || a.D == -1) || a.C % 32 != 0 || a.N < 64 || a.N % 4 != 0) return false;
+  if (a.xbf_ps % 8 != 0 || a.y_ps % 4 != 0 || !a.xbf_bytes || !a.wbf_bytes) return false;
+  if ((((uintptr_t)a.x_bf | (uintptr_t)a.y | (uintptr_t)a.wgt_bf) & 15) != 0 || (a.bias && (((uintptr_t)a.bias) & 15) != 0)) return false;
+  if (a.ksplit > 1 && a.ksplit > a.C / 32) return false;
+  PlaneGeom g;
+  return bf16p_geometry(a, a.N >= 128 ? 128 : 256, a.N >= 128 ? kHR128 : kHR256, &g);
+}
+
+// tap-grid class of a launch (the kernel's PH): 0 all phases 3x3, 1 all 2x2, 2 mixed (each of Ty, Tx in {2, 3}); -1: none
+static int bf16p_phase_class(const ConvArgs& a) {
+  bool all33 = true, all22 = true;
+  for (int p = 0; p < a.nphase; ++p) {
+    const int ty = a.ph[p].Ty, tx = a.ph[p].Tx;
+    if (ty < 2 || ty > 3 || tx < 2 || tx > 3) return -1;
+    all33 = all33 && ty == 3 && tx == 3;
+    all22 = all22 && ty == 2 && tx == 2;
+  }
+  return all33 ? 0 : all22 ? 1 : 2;
+}
+
+template <int MI, int WN, int HR, int PH>
+static void bf16p_launch_ph(const ConvArgs& a, const PlaneGeom& g, dim3 grid, hipStream_t s) {
+  if (g.pitch) {
+    if (a.ksplit > 1) hipLaunchKernelGGL((conv_bf16p_kernel<MI, WN, true, true, HR, PH>), grid, dim3(256), 0, s, a, g);
+    else hipLaunchKernelGGL((conv_bf16p_kernel<MI, WN, false, true, HR, PH>), grid, dim3(256), 0, s, a, g);
+  } else {
+    if (a.ksplit > 1) hipLaunchKernelGGL((conv_bf16p_kernel<MI, WN, true, false, HR, PH>), grid, dim3(256), 0, s, a, g);
+    else hipLaunchKernelGGL((conv_bf16p_kernel<MI, WN, false, false, HR, PH>), grid, dim3(256), 0, s, a, g);
+  }
+}
+
+template <int MI, int WN, int HR>
+static void bf16p_launch_variant(const ConvArgs& a, const PlaneGeom& g, dim3 grid, hipStream_t s) {
+  const int pc = bf16p_phase_class(a);
+  if (pc == 0) bf16p_launch_ph<MI, WN, HR, 0>(a, g, grid, s);
+  else if (pc == 1) bf16p_launch_ph<MI, WN, HR, 1>(a, g, grid, s);
+  else bf16p_launch_ph<MI, WN, HR, 2>(a, g, grid, s);
+}
+
+const char* launch_conv_bf16p(const ConvArgs& a, hipStream_t s) {
+  PlaneGeom g;
+  const int zs = a.ksplit > 1 ? a.ksplit : 1;
+  if (a.N >= 128) {   // 128 pixels x 128 channels, waves 2 x 2
+    bf16p_geometry(a, 128, kHR128, &g);
+    dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, (a.N + 127) / 128, a.nphase * zs);
+    bf16p_launch_variant<2, 2, kHR128>(a, g, grid, s);
+    return a.ksplit > 1 ? "conv_bf16p<128,128,splitk>" : "conv_bf16p<128,128>";
+  }
+  // 64 .. 127 output channels: 256 pixels x 64 channels, waves 4 x 1
+  bf16p_geometry(a, 256, kHR256, &g);
+  dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, (a.N + 63) / 64, a.nphase * zs);
+  bf16p_launch_variant<2, 1, kHR256>(a, g, grid, s);
+  return a.ksplit > 1 ? "conv_bf16p<256,64,splitk>" : "conv_bf16p<256,64>";
+}
+
+}  // namespace eg

@@ -459,7 +459,9 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     };
     const double e128 = a.N >= 128 ? 0.95 * balance(t128) : 0.0;
     const double e64 = 0.80 * balance(t64);
-    if (conv_x3_eligible(a))
+    if (conv_bf16p_eligible(a))   // bf16 mode, the operand's bf16 plane is there: staged by LDS-DMA (k_conv_bf16p.hip)
+      nm = launch_conv_bf16p(a, s);
+    else if (conv_x3_eligible(a))
       nm = launch_conv_gemm_x3(a, maxM, a.x3_tile ? a.x3_tile == 1 : e128 >= e64, s);
     else if (conv_bf16_eligible(a))
       nm = launch_conv_gemm_bf16(a, maxM, e128 >= e64, s);

@@ -35,7 +35,9 @@ struct ConvPhase {
 
 struct ConvArgs {
   const float* x;    // [NB][IH][IW] pixels, x_ps floats per pixel, C channels used
-  const unsigned short* x_bf;   // optional bf16 copy of x (same pixel pitch, in elements): read by the bf16 kernels
+  const unsigned short* x_bf;   // optional bf16 PLANE of x ([pixel][xbf_ps] bf16, written by x's producer or by launch_cvt_bf16):
+  int xbf_ps;                   //   pixel pitch of the plane in elements, xbf_bytes its extent (buffer-load bound; 0 = >= 2 GB).
+  unsigned xbf_bytes;           //   The plane-fed kernel (k_conv_bf16p.hip) stages it by LDS-DMA; x itself is then not read
   int x_is_activation;          // x is a forward activation (written once per sub-step): its bf16 copy may be kept and reused
   const float* wgt;  // element (tap wt, c, n) at wgt[wt*w_ts + c*ldw + n]
   const float* bias; // [N] or null
@@ -156,6 +158,10 @@ const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hi
 const char* launch_wgrad_bf16(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s);
 void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);
 void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int R, int Cc, hipStream_t s);
+
+// plane-fed bf16 kernel for stride-1 layers (k_conv_bf16p.hip): the gathered operand arrives from a bf16 plane by LDS-DMA
+bool conv_bf16p_eligible(const ConvArgs& a);
+const char* launch_conv_bf16p(const ConvArgs& a, hipStream_t s);
 
 // halo-staged limb / bf16 kernel for stride-1 layers (k_gemm_x3h.hip)
 bool conv_x3h_eligible(const ConvArgs& a);

@@ -143,7 +143,10 @@ void seed_grad(Ctx& c, T t) {
   t->g_set = true;
 }
 void reset_grads(Ctx& c) {
-  for (auto& t : c.tensors) t.g_set = t.g_act_done = false;
+  for (auto& t : c.tensors) {
+    t.g_set = t.g_act_done = false;
+    t.g_bf = nullptr;   // (the plane of a gradient is as short-lived as the gradient)
+  }
   for (auto& p : c.params) p->g_set = false;
   for (auto& s : c.sn) s.dWbar_set = false;
 }
@@ -242,7 +245,7 @@ const float* wref_transposed(Ctx& c, WRef* w) {
   return buf;
 }
 
-static void run_conv(Ctx& c, ConvArgs& a);
+static void run_conv(Ctx& c, ConvArgs& a, T xsrc = nullptr, bool xgrad = false);
 
 // Phase-merged 3x3 filter [9][C][12] of a stride-2 filter [k*k][3][C] with 3 image channels (kernels.h:
 // launch_merge_phase_filter); kept per variable until the variable changes, like the per-tap transposes.
@@ -424,8 +427,28 @@ static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
   a.ldwbf = a.C;
 }
 
-// launch one implicit-GEMM conv; layers too small to fill the chip with output tiles split K over blocks
-static void run_conv(Ctx& c, ConvArgs& a) {
+// bf16 plane of a tensor's data / gradient (bf16 mode; common.h: Tensor::d_bf).  A plane its producer wrote is visible
+// wherever the tensor is.  One made on demand lives on the stream that made it: the same stream may reuse it, and so may
+// the lane's LEAF stream for a plane made on the lane's main stream (a LeafScope orders the leaf stream behind everything
+// the main stream held when the scope was entered, and nothing is enqueued on the main stream inside a scope); anybody
+// else -- another lane reading a shared tensor -- converts for itself.
+static const unsigned short* tensor_plane(Ctx& c, T t, bool grad) {
+  unsigned short*& p = grad ? t->g_bf : t->d_bf;
+  hipStream_t& ps = grad ? t->g_bf_stream : t->d_bf_stream;
+  const Ctx::Lane& l = c.lanes[c.cur_lane];
+  if (p && (ps == nullptr || ps == c.stream || (c.stream == l.leaf && ps == l.stream))) return p;
+  unsigned short* q = reinterpret_cast<unsigned short*>(c.arena.allocf((t->numel() + 1) / 2));
+  launch_cvt_bf16(grad ? t->g : t->d, q, t->numel(), c.stream);
+  if (!p) {
+    p = q;
+    ps = c.stream;
+  }
+  return q;
+}
+
+// launch one implicit-GEMM conv; layers too small to fill the chip with output tiles split K over blocks.
+// xsrc / xgrad: the tensor whose data (gradient) a.x is -- the bf16 mode's plane-fed kernel reads its bf16 plane instead
+static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
   a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
   {
     const size_t xb = (size_t)a.NB * a.IH * a.IW * a.x_ps * sizeof(float);
@@ -448,6 +471,13 @@ static void run_conv(Ctx& c, ConvArgs& a) {
     if (blocks * ks < 128 || !conv_x3h_eligible(a)) a = keep;
   }
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
+  if (c.cfg.bf16 && a.limbs == 1 && xsrc && a.x == (xgrad ? xsrc->g : xsrc->d) && a.x_ps == xsrc->c) {
+    const size_t pb = xsrc->numel() * sizeof(unsigned short);
+    a.x_bf = reinterpret_cast<const unsigned short*>(uintptr_t(16));   // (placeholder: eligibility looks at alignment only)
+    a.xbf_ps = xsrc->c;
+    a.xbf_bytes = pb < (1ull << 31) ? (unsigned)pb : 0u;
+    a.x_bf = conv_bf16p_eligible(a) ? tensor_plane(c, xsrc, xgrad) : nullptr;
+  }
   const char* nm;
   static const bool x3_timing = dbg_env("EG_X3_TIMING") != nullptr;   // experiment: per-phase s_memtime stamps of block 0
   if (x3_timing && a.limbs == 3 && a.ksplit <= 1) {
@@ -456,7 +486,7 @@ static void run_conv(Ctx& c, ConvArgs& a) {
   }
   ProfScope ps(c);
   const double fl = launch_conv_gemm(a, c.stream, &nm);
-  a.epi_applied = a.epi_act && (strncmp(nm, "conv_gemm_x3h<", 14) == 0 || strncmp(nm, "conv_gemm_bf16h<", 16) == 0) &&
+  a.epi_applied = a.epi_act && (strncmp(nm, "conv_gemm_x3h<", 14) == 0 || strncmp(nm, "conv_gemm_bf16h<", 16) == 0 || strncmp(nm, "conv_bf16p<", 11) == 0) &&
                           !strstr(nm, "splitk") ? 1 : 0;   // (the kernels that honour ConvArgs::epi_act)
   if (x3_timing && a.limbs == 3 && a.ksplit <= 1 && a.ws) {
     long long h[128];
@@ -530,7 +560,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
       a.OWf = Wp;
       a.accumulate = 0;
       a.ph[0] = ConvPhase{Hp, Wp, 0, 0, k, k, 0, 0, 0, 0};
-      run_conv(c, a);
+      run_conv(c, a, y, true);
       int acc;
       float* dx = grad_acc(c, x, &acc);
       launch_reflect_fold(dpad, dx, acc, x->n, x->h, x->w, Cin, pt, c.stream);
@@ -581,7 +611,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
         p.offx = (px + pl - kw0) / 2;
       }
   }
-  run_conv(c, a);
+  run_conv(c, a, y, true);
   if (!a.accumulate) x->g_act_done = a.epi_applied != 0;   // (first writer: decides anew in every backward sweep)
 }
 
@@ -712,7 +742,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   const bool slabs_ok = c.feeds_in && slab_fusion && (!need || slab_train) && !accumulate_into && !fused_act && N % 32 == 0 && OH * OW <= 1024;
   c.feeds_in = false;
   a.keep_slabs = slabs_ok ? 1 : 0;
-  run_conv(c, a);
+  run_conv(c, a, x, false);
   if (slabs_ok && a.ksplit > 1) {
     y->slabs = a.ws;
     y->nslab = a.ksplit;
@@ -800,7 +830,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
   const bool slabs_ok = c.feeds_in && slab_fusion && (!need || slab_train) && !merged && cout % 32 == 0 && OH * OW <= 1024;   // see conv2d
   c.feeds_in = false;
   a.keep_slabs = slabs_ok ? 1 : 0;
-  if (!merged) run_conv(c, a);
+  if (!merged) run_conv(c, a, x, false);
   if (slabs_ok && a.ksplit > 1) {
     y->slabs = a.ws;
     y->nslab = a.ksplit;
@@ -846,7 +876,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
         b.ph[0] = ConvPhase{x->h, x->w, 0, 0, 5, 5, 0, 0, -1, -1};
         attach_bf16(c, b, w, true);    // rows = Cin, contracted = Cout
         if (c.prof_on) c.cur_label = w->name + " dgrad";
-        run_conv(c, b);
+        run_conv(c, b, y, true);
       }
     });
   }

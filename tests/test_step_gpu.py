@@ -178,10 +178,9 @@ def test_pipelined_feed_and_loss_readback_equal_the_synchronous_calls():
         if i == 2:
             got.append(net.losses_async(back=1))     # iteration 1, asked for AFTER iteration 2 was enqueued ...
             got.append(net.losses_async(back=0))     # ... then iteration 2 at once (the checkpoint-iteration flush of train.py)
-        elif i > 0 and i != 3:
-            got.append(net.losses_async(back=1))
-    got.append(net.losses_async(back=1))             # iteration 3 (skipped above: both slots of the ring were in use)
-    got.append(net.losses_async(back=0))             # iteration 4
+        elif i in (1, 4):                            # (i == 3: iteration 2 was already reported at once)
+            got.append(net.losses_async(back=1))     # iterations 0 and 3, each one enqueue late
+    got.append(net.losses_async(back=0))             # iteration 4: the loop's last read-back
     state = net.get_variables(slots=True)
     net.close()
     assert len(got) == len(want) == 5
