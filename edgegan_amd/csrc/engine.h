@@ -151,6 +151,8 @@ struct Ctx {
   bool lanes_on = true;
   int lanes_mask = 15;
   bool leaf_on = true;      // EG_LANES bit 3
+  WRef* alt_w = nullptr;    // ops.cpp attach_bf16 -> run_conv: the filter of the launch being prepared (64 .. 127 output channels,
+  bool alt_transposed = false;   //   bf16 mode), should run_conv decide for the plane-fed kernel and need its K-step-major plane
   bool leaf_dirty = false;  // the active lane's leaf stream holds work the main stream has not ordered itself behind
   std::vector<hipStream_t> placeholder_streams;   // model.cpp: stream -> hardware queue placement
   hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr, ev_branch = nullptr, ev_cls = nullptr;

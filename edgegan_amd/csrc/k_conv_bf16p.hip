@@ -180,14 +180,13 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
   }
   // 16-wide tiles: the fragment address of (32-row block i, column shift e, K half kk) is a per-lane constant -- the row
   // shift of a tap and the halo buffer are immediate offsets (pitch 20 rows of 64 bytes)
-  unsigned abase[MI][3][2];
+  // (the wave's 32-row blocks i are 2 tile rows = 40 halo rows apart and share the pixel column: another immediate)
+  unsigned abase[3][2];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int e = 0; e < 3; ++e)
 #pragma unroll
-    for (int e = 0; e < 3; ++e)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        abase[i][e][kk] = ah_base + (base_row[i] + e) * 64 + ((((kk << 1) | lh) ^ (((base_px[i] + e) >> 2) & 3)) * 16);
+    for (int kk = 0; kk < 2; ++kk)
+      abase[e][kk] = ah_base + (base_row[0] + e) * 64 + ((((kk << 1) | lh) ^ (((base_px[0] + e) >> 2) & 3)) * 16);
   const unsigned bb0 = bs_base + ((wn * 64 + l31) * 32 + ((lh ^ swz_p(l31)) * 8)) * 2, bb1 = bb0 ^ 32u;
 
   f32x16 acc[MI][2];
@@ -252,7 +251,10 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
       const int ty = D > 0 ? f : TY - 1 - f, tx = D > 0 ? e : TX - 1 - e;
       tapoff[t] = ((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * cpt * wtile;
     }
-    Frags fs[2] = {};
+    // two fragment sets (the look-ahead reads of step k + 1 are issued before the MFMAs of step k) where the registers
+    // allow it; the 128 x 64 wave tile (128 accumulator registers) keeps ONE set: reads after the MFMAs that consumed it
+    constexpr int NSETS = MI == 4 ? 1 : 2;
+    Frags fs[NSETS] = {};
     // fragment reads of step (halo buffer BUF, tap T, ring slot SLOT) -- all three compile-time
     auto read_step = [&](Frags& fr, auto BUFc, auto Tc, auto SLOTc) __attribute__((always_inline)) {
       constexpr int BUF = decltype(BUFc)::value, T = decltype(Tc)::value, SLOT = decltype(SLOTc)::value;
@@ -261,9 +263,9 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           // (named copies: a variable that a generic lambda uses ONLY as an asm operand is not captured by hipcc 7.2)
-          const unsigned p0 = abase[i][e][0], p1 = abase[i][e][1];
-          EG_DSR(fr.a[i][0], p0, BUF * APL + f * 20 * 64);
-          EG_DSR(fr.a[i][1], p1, BUF * APL + f * 20 * 64);
+          const unsigned p0 = abase[e][0], p1 = abase[e][1];
+          EG_DSR(fr.a[i][0], p0, BUF * APL + (f + 2 * i) * 20 * 64);
+          EG_DSR(fr.a[i][1], p1, BUF * APL + (f + 2 * i) * 20 * 64);
         }
       } else {
         const int toff = f * HWP + e;
@@ -308,21 +310,26 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
       const int wrow = cc * wtile;
       static_for<NT>([&](auto Tc) __attribute__((always_inline)) {
         constexpr int T = decltype(Tc)::value;
-        constexpr int SET = (H * NT + T) & 1;
-        constexpr std::integral_constant<int, SET> SETc{};
-        constexpr std::integral_constant<int, SET ^ 1> NXTc{};
+        constexpr int SLOT = (H * NT + T) & 1;                   // ring slot of tile k (and of tile k + 2)
+        constexpr int SET = NSETS == 2 ? SLOT : 0, NXT = NSETS == 2 ? SLOT ^ 1 : 0;
+        constexpr std::integral_constant<int, SLOT> SLOTc{};
+        constexpr std::integral_constant<int, SLOT ^ 1> NSLOTc{};
         if constexpr ((EG_BF16P_DBG & 64) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr ((EG_BF16P_DBG & 1) != 0) land(fs[SET], NO_BARRIER);
         else land(fs[SET], WITH_BARRIER);
         // filter tile k + 2 -> the slot tile k was read from
-        if constexpr (T + 2 < NT) request_b(SETc, tapoff[T + 2] + wrow);
-        else if (has_next) request_b(SETc, tapoff[T + 2 - NT] + wrow + wtile);
+        if constexpr (T + 2 < NT) request_b(SLOTc, tapoff[T + 2] + wrow);
+        else if (has_next) request_b(SLOTc, tapoff[T + 2 - NT] + wrow + wtile);
         if constexpr (T == 0)
           if (has_next) request_halo(cc + 1, H ^ 1);
-        // look-ahead: the fragments of step k + 1
-        if constexpr (T + 1 < NT) read_step(fs[SET ^ 1], Hc, std::integral_constant<int, T + 1>{}, NXTc);
-        else if (has_next) read_step(fs[SET ^ 1], std::integral_constant<int, H ^ 1>{}, I0, NXTc);
-        mm(fs[SET]);
+        if constexpr (NSETS == 1) {
+          mm(fs[0]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the fragments of step k + 1
+        if constexpr (T + 1 < NT) read_step(fs[NXT], Hc, std::integral_constant<int, T + 1>{}, NSLOTc);
+        else if (has_next) read_step(fs[NXT], std::integral_constant<int, H ^ 1>{}, I0, NSLOTc);
+        if constexpr (NSETS == 2) mm(fs[SET]);
         __builtin_amdgcn_sched_barrier(0);
       });
     };
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
     if (c < ncc) chunk(I0, cc_lo + c, false);
     // nothing is in flight here (the last step issued no reads); sets whose reads were never issued hold zeros
     land(fs[0], NO_BARRIER);
-    land(fs[1], NO_BARRIER);
+    if constexpr (NSETS == 2) land(fs[1], NO_BARRIER);
     __builtin_amdgcn_sched_barrier(0);
   };
   constexpr std::integral_constant<int, 2> K2{};
@@ -472,6 +479,17 @@ static void bf16p_launch_variant(const ConvArgs& a, const PlaneGeom& g, dim3 gri
 const char* launch_conv_bf16p(const ConvArgs& a, hipStream_t s) {
   PlaneGeom g;
   const int zs = a.ksplit > 1 ? a.ksplit : 1;
+  // 256 pixels x 128 channels, waves 2 x 2 with 128 x 64 wave tiles (16 MFMAs per 12 fragment reads, half the filter DMA
+  // per MFMA of the 128-pixel form; 2 blocks per CU): when there are at least two such blocks for every CU
+  static const bool big_on = dbg_env("EG_BF16P_NO_BIG") == nullptr;
+  if (big_on && a.N >= 128 && bf16p_geometry(a, 256, kHR256, &g) && g.pitch) {
+    const long long blocks = (long long)(a.NB / g.TI) * g.tiles_x * g.tiles_y * ((a.N + 127) / 128) * a.nphase * zs;
+    if (blocks >= 512) {
+      dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, (a.N + 127) / 128, a.nphase * zs);
+      bf16p_launch_variant<4, 2, kHR256>(a, g, grid, s);
+      return a.ksplit > 1 ? "conv_bf16p<256,128,splitk>" : "conv_bf16p<256,128>";
+    }
+  }
   if (a.N >= 128) {   // 128 pixels x 128 channels, waves 2 x 2
     bf16p_geometry(a, 128, kHR128, &g);
     dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, (a.N + 127) / 128, a.nphase * zs);

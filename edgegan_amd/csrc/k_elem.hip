@@ -28,6 +28,19 @@ __device__ __forceinline__ float block_sum(float v, float* sm /*[4]*/) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16 plane of a tensor, written by its producer as a second store (bf16 mode: kernels.h, k_conv_bf16p.hip): element quad i4
+// of the plane = the quad just stored to the fp32 tensor, rounded to nearest even -- the rounding the staging pass of the
+// round-3 kernels applied on the operand's way into LDS (v_cvt_pk_bf16_f32), so the products are the same numbers
+__device__ __forceinline__ void st_bf4(unsigned short* __restrict__ bf, size_t i4, const float4& v) {
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ lo = {v.x, v.y}, hi = {v.z, v.w};
+  uint2 o;
+  o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_));
+  o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_));
+  reinterpret_cast<uint2*>(bf)[i4] = o;
+}
+
 __global__ void fill_kernel(float* p, float v, size_t n) { GRID_STRIDE(i, n) p[i] = v; }
 __global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) { GRID_STRIDE(i, n) b[i] = a[i]; }
 __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, float a, int acc, size_t n) {
@@ -268,7 +281,7 @@ __global__ void pool2_fwd_v_kernel(const float* __restrict__ x, float* __restric
   }
 }
 __global__ void pool2_bwd_v_kernel(const float* __restrict__ dy, float* __restrict__ dx, int acc, int H, int W, int C4,
-                                   unsigned n4) {
+                                   unsigned n4, unsigned short* __restrict__ dx_bf) {
   const int Ho = H / 2, Wo = W / 2;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
     const unsigned c = i % C4;
@@ -288,6 +301,7 @@ __global__ void pool2_bwd_v_kernel(const float* __restrict__ dy, float* __restri
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
       }
       p[offs[k]] = v;
+      if (dx_bf) st_bf4(dx_bf, (size_t)(p - reinterpret_cast<float4*>(dx)) + offs[k], v);
     }
   }
 }
@@ -359,13 +373,18 @@ void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hip
   }
   hipLaunchKernelGGL(pool2_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, H, W, C, n);
 }
-void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s) {
+void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s,
+                      unsigned short* dx_bf) {
   const size_t n = (size_t)NB * H * W * C;
   if (C % 4 == 0 && n < (1ull << 31) && H % 2 == 0 && W % 2 == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0) {
     const size_t no4 = n / 16;   // output quads
     hipLaunchKernelGGL(pool2_bwd_v_kernel, dim3(ew_blocks(no4)), dim3(256), 0, s, dy, dx, accumulate, H, W, C / 4,
-                       (unsigned)no4);
+                       (unsigned)no4, dx_bf);
     return;
+  }
+  if (dx_bf) {
+    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from the scalar form of pool2_bwd\n");
+    abort();
   }
   hipLaunchKernelGGL(pool2_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, dx, accumulate, H, W, C, n);
 }
@@ -520,7 +539,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ leak_p, float leak_c,
                                                           float* __restrict__ dx, int acc_dx, float* __restrict__ part,
-                                                          size_t n4) {
+                                                          size_t n4, unsigned short* __restrict__ dx_bf) {
   __shared__ float sm[4];
   const float lk = leak_p ? *leak_p : leak_c;
   float s = 0.f;
@@ -534,6 +553,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restric
         o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
       }
       reinterpret_cast<float4*>(dx)[i] = o;
+      if (dx_bf) st_bf4(dx_bf, i, o);
     }
     s += (f0 ? g.x * v.x : 0.f) + (f1 ? g.y * v.y : 0.f) + (f2 ? g.z * v.z : 0.f) + (f3 ? g.w * v.w : 0.f);
   }
@@ -543,12 +563,13 @@ __global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restric
   }
 }
 __global__ void prelu_fwd_v_kernel(const float* __restrict__ x, const float* __restrict__ leak_p, float leak_c,
-                                   float* __restrict__ y, size_t n4) {
+                                   float* __restrict__ y, size_t n4, unsigned short* __restrict__ y_bf) {
   const float lk = leak_p ? *leak_p : leak_c;
   GRID_STRIDE(i, n4) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
-    reinterpret_cast<float4*>(y)[i] = make_float4(fmaxf(lk * v.x, v.x), fmaxf(lk * v.y, v.y), fmaxf(lk * v.z, v.z),
-                                                  fmaxf(lk * v.w, v.w));
+    const float4 o = make_float4(fmaxf(lk * v.x, v.x), fmaxf(lk * v.y, v.y), fmaxf(lk * v.z, v.z), fmaxf(lk * v.w, v.w));
+    reinterpret_cast<float4*>(y)[i] = o;
+    if (y_bf) st_bf4(y_bf, i, o);
   }
 }
 __global__ void sum_partials_kernel(const float* __restrict__ part, int np, float* __restrict__ out, int acc,
@@ -562,25 +583,33 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, int np, floa
 static bool ew_vec_ok(size_t n, const void* a, const void* b, const void* c = nullptr) {
   return (n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
 }
-void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s) {
+void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s, unsigned short* y_bf) {
+  if (y_bf && !ew_vec_ok(n, x, y)) {
+    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from the scalar form of prelu_fwd\n");
+    abort();
+  }
   if (ew_vec_ok(n, x, y)) {
     // (experiments: EG_DUP_PRELU_FWD = N extra, idempotent launches -- what does an HBM-bound pass on a lane cost the iteration?)
     static const int dup = dbg_env("EG_DUP_PRELU_FWD") ? atoi(dbg_env("EG_DUP_PRELU_FWD")) : 0;
     for (int r = 0; r <= dup; ++r)
-      hipLaunchKernelGGL(prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, leak_p, leak_c, y, n / 4);
+      hipLaunchKernelGGL(prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, leak_p, leak_c, y, n / 4, y_bf);
     return;
   }
   hipLaunchKernelGGL(prelu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, leak_p, leak_c, y, n);
 }
 size_t prelu_scratch_floats() { return 2048; }
 void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, float leak_c, float* dx, int acc_dx,
-                      float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s) {
+                      float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s, unsigned short* dx_bf) {
   int nb;
   if (ew_vec_ok(n, x, dy, dx)) {
     nb = ew_blocks(n / 4, 2048);
     hipLaunchKernelGGL(prelu_bwd_v_kernel, dim3(nb), dim3(256), 0, s, x, dy, leak_p, leak_c, dx, acc_dx,
-                       dleak ? scratch : nullptr, n / 4);
+                       dleak ? scratch : nullptr, n / 4, dx_bf);
   } else {
+    if (dx_bf) {
+      fprintf(stderr, "edgegan_hip: a bf16 plane was requested from the scalar form of prelu_bwd\n");
+      abort();
+    }
     nb = ew_blocks(n, 1024);
     hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, s, x, dy, leak_p, leak_c, dx, acc_dx,
                        dleak ? scratch : nullptr, n);
@@ -698,7 +727,7 @@ __global__ __launch_bounds__(256) void minmax_fwd_v(const float* __restrict__ x,
 template <int CQ>
 __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x, const float* __restrict__ mm,
                                                     const float* __restrict__ dy, float* __restrict__ dx, int acc,
-                                                    int HW, int C, float lk) {
+                                                    int HW, int C, float lk, unsigned short* __restrict__ dx_bf) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[4 * 4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -740,6 +769,7 @@ __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x,
     float4 o = make_float4(r[0], r[1], r[2], r[3]);
     if (acc) { const float4 t = ld4(dx + i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
     st4(dx + i, o);
+    if (dx_bf) st_bf4(dx_bf, i >> 2, o);
   }
 }
 
@@ -755,13 +785,17 @@ void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int 
   hipLaunchKernelGGL(minmax_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, y, mm, HW, C, pre_leak);
 }
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
-                       int HW, int C, hipStream_t s, float pre_leak) {
+                       int HW, int C, hipStream_t s, float pre_leak, unsigned short* dx_bf) {
   if (C % 32 == 0) {
-    hipLaunchKernelGGL(minmax_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak);
+    hipLaunchKernelGGL(minmax_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, dx_bf);
     return;
   }
+  if (dx_bf) {
+    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from minmax_bwd with C %% 32 != 0\n");
+    abort();
+  }
   if (C % 8 == 0) {
-    hipLaunchKernelGGL(minmax_bwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak);
+    hipLaunchKernelGGL(minmax_bwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, nullptr);
     return;
   }
   hipLaunchKernelGGL(minmax_bwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak);
@@ -823,13 +857,16 @@ __global__ __launch_bounds__(256) void gate_prelu_bwd_kernel(const float* __rest
 }
 // float4 forms (n % 4 == 0, 16-byte aligned buffers)
 __global__ void gate_prelu_fwd_v_kernel(const float* __restrict__ h, const float* __restrict__ rg, const float* __restrict__ img,
-                                        const float* __restrict__ leak_p, float* __restrict__ o, size_t n4) {
+                                        const float* __restrict__ leak_p, float* __restrict__ o, size_t n4,
+                                        unsigned short* __restrict__ o_bf) {
   const float lk = *leak_p;
   GRID_STRIDE(i, n4) {
     const float4 a = reinterpret_cast<const float4*>(h)[i], r = reinterpret_cast<const float4*>(rg)[i],
                  m = reinterpret_cast<const float4*>(img)[i];
     const float v0 = a.x + r.x * m.x, v1 = a.y + r.y * m.y, v2 = a.z + r.z * m.z, v3 = a.w + r.w * m.w;
-    reinterpret_cast<float4*>(o)[i] = make_float4(fmaxf(lk * v0, v0), fmaxf(lk * v1, v1), fmaxf(lk * v2, v2), fmaxf(lk * v3, v3));
+    const float4 y = make_float4(fmaxf(lk * v0, v0), fmaxf(lk * v1, v1), fmaxf(lk * v2, v2), fmaxf(lk * v3, v3));
+    reinterpret_cast<float4*>(o)[i] = y;
+    if (o_bf) st_bf4(o_bf, i, y);
   }
 }
 __global__ __launch_bounds__(256) void gate_prelu_bwd_v_kernel(const float* __restrict__ h, const float* __restrict__ rg,
@@ -874,10 +911,14 @@ static bool gp_vec_ok(size_t n, const void* a, const void* b, const void* c, con
                            ((uintptr_t)g)) & 15) == 0;
 }
 void launch_gate_prelu_fwd(const float* h, const float* rg, const float* img, const float* leak, float* out, size_t n,
-                           hipStream_t s) {
+                           hipStream_t s, unsigned short* out_bf) {
   if (gp_vec_ok(n, h, rg, img, out)) {
-    hipLaunchKernelGGL(gate_prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, h, rg, img, leak, out, n / 4);
+    hipLaunchKernelGGL(gate_prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, h, rg, img, leak, out, n / 4, out_bf);
     return;
+  }
+  if (out_bf) {
+    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from the scalar form of gate_prelu_fwd\n");
+    abort();
   }
   hipLaunchKernelGGL(gate_prelu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, h, rg, img, leak, out, n);
 }

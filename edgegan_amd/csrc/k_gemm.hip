@@ -431,7 +431,7 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     a.ksplit = 1;   // only the fully vectorised kernels have a split-K form
   const long long blocks128 = (long long)((maxM + 127) / 128) * ((a.N + 127) / 128) * a.nphase;
   const char* nm;
-  if (!a.wgt && !(a.N > 16 && (conv_x3_eligible(a) || conv_bf16_eligible(a)))) {
+  if (!a.wgt && !(a.N > 16 && (conv_bf16p_eligible(a) || conv_x3_eligible(a) || conv_bf16_eligible(a)))) {
     fprintf(stderr, "edgegan_hip: conv launch without an fp32 filter that no limb / bf16 kernel accepts (N=%d C=%d)\n", a.N, a.C);
     abort();
   }

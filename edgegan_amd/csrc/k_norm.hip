@@ -190,9 +190,21 @@ __device__ __forceinline__ float4 actg4(float4 o, int act) {
                      act_grad_from_out(o.w, act));
 }
 
+// bf16 plane of the tensor just stored (bf16 mode's second store; k_elem.hip: st_bf4 -- same rounding): element i of the plane
+__device__ __forceinline__ void st_bf4n(unsigned short* __restrict__ bf, size_t i, const float4& v) {
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ lo = {v.x, v.y}, hi = {v.z, v.w};
+  uint2 o;
+  o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_));
+  o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_));
+  *reinterpret_cast<uint2*>(bf + i) = o;
+}
+
 template <int CQ>
 __global__ __launch_bounds__(256) void in_fwd_v(const float* __restrict__ x, float* __restrict__ out,
-                                                float* __restrict__ stats, int HW, int C, int act) {
+                                                float* __restrict__ stats, int HW, int C, int act,
+                                                unsigned short* __restrict__ out_bf) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -219,8 +231,9 @@ __global__ __launch_bounds__(256) void in_fwd_v(const float* __restrict__ x, flo
   float* op = out + (size_t)n * HW * C + c;
   for (int p = pl; p < HW; p += PL) {
     const float4 v = ld4(xp + (size_t)p * C);
-    st4(op + (size_t)p * C, act4(make_float4((v.x - mean.x) * r.x, (v.y - mean.y) * r.y, (v.z - mean.z) * r.z,
-                                             (v.w - mean.w) * r.w), act));
+    const float4 y = act4(make_float4((v.x - mean.x) * r.x, (v.y - mean.y) * r.y, (v.z - mean.z) * r.z, (v.w - mean.w) * r.w), act);
+    st4(op + (size_t)p * C, y);
+    if (out_bf) st_bf4n(out_bf, (size_t)n * HW * C + c + (size_t)p * C, y);
   }
   if (pl == 0) {
     float* sp = stats + ((size_t)n * C + c) * 2;
@@ -235,7 +248,7 @@ template <int NP, int CQ>
 __global__ __launch_bounds__(256) void in_fwd_vr(const float* __restrict__ x, float* __restrict__ out,
                                                  float* __restrict__ stats, int HW, int C, int act, int nslab,
                                                  size_t slab_stride, const float* __restrict__ slab_bias,
-                                                 float* __restrict__ xsum) {
+                                                 float* __restrict__ xsum, unsigned short* __restrict__ out_bf) {
   constexpr int PL = 256 / CQ;   // CQ = 4 for the 32x32 layers: 16 channels per block -> twice the blocks, half the registers
   __shared__ float4 red[4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -282,9 +295,12 @@ __global__ __launch_bounds__(256) void in_fwd_vr(const float* __restrict__ x, fl
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int p = pl + i * PL;
-    if (p < HW)
-      st4(op + (size_t)p * C, act4(make_float4((xv[i].x - mean.x) * r.x, (xv[i].y - mean.y) * r.y,
-                                               (xv[i].z - mean.z) * r.z, (xv[i].w - mean.w) * r.w), act));
+    if (p < HW) {
+      const float4 y = act4(make_float4((xv[i].x - mean.x) * r.x, (xv[i].y - mean.y) * r.y, (xv[i].z - mean.z) * r.z,
+                                        (xv[i].w - mean.w) * r.w), act);
+      st4(op + (size_t)p * C, y);
+      if (out_bf) st_bf4n(out_bf, (size_t)n * HW * C + c + (size_t)p * C, y);
+    }
   }
   if (pl == 0) {
     float* sp = stats + ((size_t)n * C + c) * 2;
@@ -307,7 +323,8 @@ __device__ __forceinline__ Stat4 load_stats4(const float* stats, size_t nc) {
 template <int MODE, int CQ>
 __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, const float* __restrict__ out,
                                                    const float* __restrict__ v, const float* __restrict__ stats,
-                                                   float* __restrict__ dst, int accumulate, int HW, int C, int act) {
+                                                   float* __restrict__ dst, int accumulate, int HW, int C, int act,
+                                                   unsigned short* __restrict__ dst_bf) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[2 * 4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -347,6 +364,7 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
       res.x += d.x; res.y += d.y; res.z += d.z; res.w += d.w;
     }
     st4(dst + i, res);
+    if (dst_bf) st_bf4n(dst_bf, i, res);
   }
 }
 
@@ -355,7 +373,8 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
 template <int NP, int CQ>
 __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, const float* __restrict__ out,
                                                  const float* __restrict__ v, const float* __restrict__ stats,
-                                                 float* __restrict__ dst, int accumulate, int HW, int C, int act) {
+                                                 float* __restrict__ dst, int accumulate, int HW, int C, int act,
+                                                 unsigned short* __restrict__ dst_bf) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[2 * 4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -398,21 +417,26 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
         res.x += d.x; res.y += d.y; res.z += d.z; res.w += d.w;
       }
       st4(dst + i, res);
+      if (dst_bf) st_bf4n(dst_bf, i, res);
     }
   }
 }
 
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s, int nslab,
-                   size_t slab_stride, const float* slab_bias, float* xsum) {
+                   size_t slab_stride, const float* slab_bias, float* xsum, unsigned short* out_bf) {
+  if (out_bf && C % 32 != 0) {
+    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from in_fwd with C %% 32 != 0\n");
+    abort();
+  }
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
-#define EG_IN_FWD(NP, CQ, G) hipLaunchKernelGGL((in_fwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, HW, C, act, nslab, slab_stride, slab_bias, xsum)
+#define EG_IN_FWD(NP, CQ, G) hipLaunchKernelGGL((in_fwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, HW, C, act, nslab, slab_stride, slab_bias, xsum, out_bf)
     if (HW <= 64) EG_IN_FWD(2, 8, grid);
     else if (HW <= 128) EG_IN_FWD(4, 8, grid);
     else if (HW <= 256) EG_IN_FWD(8, 8, grid);
     else if (HW <= 512) EG_IN_FWD(16, 8, grid);
     else if (HW <= 1024) EG_IN_FWD(16, 4, dim3(NB, C / 16));
-    else hipLaunchKernelGGL(in_fwd_v<8>, grid, dim3(256), 0, s, x, out, stats, HW, C, act);
+    else hipLaunchKernelGGL(in_fwd_v<8>, grid, dim3(256), 0, s, x, out, stats, HW, C, act, out_bf);
 #undef EG_IN_FWD
     return;
   }
@@ -420,19 +444,23 @@ void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int
   hipLaunchKernelGGL(in_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, stats, HW, C, act);
 }
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
-                   int accumulate, int NB, int HW, int C, int act, hipStream_t s) {
+                   int accumulate, int NB, int HW, int C, int act, hipStream_t s, unsigned short* dx_bf) {
+  if (dx_bf && C % 32 != 0) {
+    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from in_bwd with C %% 32 != 0\n");
+    abort();
+  }
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
-#define EG_IN_BWD(NP) hipLaunchKernelGGL((in_bwd_vr<NP, 8>), grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act)
+#define EG_IN_BWD(NP) hipLaunchKernelGGL((in_bwd_vr<NP, 8>), grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act, dx_bf)
     if (HW <= 64) EG_IN_BWD(2);
     else if (HW <= 128) EG_IN_BWD(4);
     else if (HW <= 256) EG_IN_BWD(8);
     else if (HW <= 512) EG_IN_BWD(16);
     else if (HW <= 1024)
       hipLaunchKernelGGL((in_bwd_vr<16, 4>), dim3(NB, C / 16), dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW,
-                         C, act);
+                         C, act, dx_bf);
     else
-      hipLaunchKernelGGL((in_japply_v<0, 8>), grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act);
+      hipLaunchKernelGGL((in_japply_v<0, 8>), grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act, dx_bf);
 #undef EG_IN_BWD
     return;
   }
@@ -440,9 +468,9 @@ void launch_in_bwd(const float* x, const float* out, const float* dout, const fl
                      accumulate, HW, C, act);
 }
 void launch_in_tangent_fwd(const float* x, const float* out, const float* stats, const float* tx, float* tout,
-                           int NB, int HW, int C, int act, hipStream_t s) {
+                           int NB, int HW, int C, int act, hipStream_t s, unsigned short* tout_bf) {
   if (C % 32 == 0) {
-    hipLaunchKernelGGL((in_japply_v<1, 8>), dim3(NB, C / 32), dim3(256), 0, s, x, out, tx, stats, tout, 0, HW, C, act);
+    hipLaunchKernelGGL((in_japply_v<1, 8>), dim3(NB, C / 32), dim3(256), 0, s, x, out, tx, stats, tout, 0, HW, C, act, tout_bf);
     return;
   }
   hipLaunchKernelGGL(in_japply_kernel<1>, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, tx, stats, tout, 0, HW,

@@ -211,13 +211,14 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
 // summed; the load pass forms bias + slab 0 + slab 1 + ... in conv_split_reduce's order (C % 32 == 0, HW <= 1024 only)
 // and, with xsum, also stores that sum (training: the pre-norm tensor the backward reads)
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s,
-                   int nslab = 0, size_t slab_stride = 0, const float* slab_bias = nullptr, float* xsum = nullptr);
+                   int nslab = 0, size_t slab_stride = 0, const float* slab_bias = nullptr, float* xsum = nullptr,
+                   unsigned short* out_bf = nullptr);   // *_bf: also store the bf16 plane of the output (bf16 mode, C % 32 == 0)
 // dx (+)= J * (dout * act'(out))   (J = IN Jacobian, symmetric)
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
-                   int accumulate, int NB, int HW, int C, int act, hipStream_t s);
+                   int accumulate, int NB, int HW, int C, int act, hipStream_t s, unsigned short* dx_bf = nullptr);
 // tangent forward: tout = act'(out_primal) * (J * tx)
 void launch_in_tangent_fwd(const float* x, const float* out, const float* stats, const float* tx, float* tout,
-                           int NB, int HW, int C, int act, hipStream_t s);
+                           int NB, int HW, int C, int act, hipStream_t s, unsigned short* tout_bf = nullptr);
 // tangent backward: given dtout, produce dtx (+)= ..., dx_primal (+)= ...
 void launch_in_tangent_bwd(const float* x, const float* out, const float* stats, const float* tx,
                            const float* dtout, float* dtx, int acc_dtx, float* dx, int acc_dx, int NB, int HW,
@@ -262,7 +263,8 @@ size_t col_sum_scratch_floats(size_t R, int C);
 void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C, float* scratch, hipStream_t s);
 // 2x2 mean pool NHWC fwd / bwd
 void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hipStream_t s);
-void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s);
+void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s,
+                      unsigned short* dx_bf = nullptr);   // dx_bf: also store the bf16 plane of dx (k_elem.hip: st_bf4)
 // y = pool2(a + b), a/b [NB][H][W][C]; returns false (nothing launched) when the float4 form does not apply
 bool launch_add_pool2_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s);
 // y = pool2(a) + b with b [NB][H/2][W/2][C]; same return convention
@@ -277,23 +279,24 @@ void launch_resize(const float* x, float* y, int accumulate, int NB, int IH, int
                    const int* ty_i, const float* ty_w, int tyn, const int* tx_i, const float* tx_w, int txn,
                    hipStream_t s);
 // prelu / fixed leak: y = max(leak*x, x); leak read from device scalar (leak_p) or constant
-void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s);
+void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s,
+                      unsigned short* y_bf = nullptr);
 // dx (+)= ..., dleak (+)= sum(dy*x [x<0 or tie]) (when dleak != null)
 size_t prelu_scratch_floats();
 void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, float leak_c, float* dx, int acc_dx,
-                      float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s);
+                      float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s, unsigned short* dx_bf = nullptr);
 // per-(n,c) spatial min-max normalisation (conv.py:197-198) fwd/bwd; mm[n][c] = {min,max}
 // pre_leak != 0: y = minmax(lrelu_{pre_leak}(x)) with the lrelu applied on load / its slope on the gradient store
 void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s, float pre_leak = 0.f);
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
-                       int HW, int C, hipStream_t s, float pre_leak = 0.f);
+                       int HW, int C, hipStream_t s, float pre_leak = 0.f, unsigned short* dx_bf = nullptr);
 // gate merge: out = h + rg*img ; backward
 void launch_gate_fwd(const float* h, const float* rg, const float* img, float* out, size_t n, hipStream_t s);
 void launch_gate_bwd(const float* rg, const float* img, const float* dout, float* dh, int acc_h, float* drg,
                      float* dimg, size_t n, hipStream_t s);
 // out = prelu(h + rg*img, *leak) ; backward with the pre-activation recomputed; dleak (+)= sum(dout * pre [leak*pre >= pre])
 void launch_gate_prelu_fwd(const float* h, const float* rg, const float* img, const float* leak, float* out, size_t n,
-                           hipStream_t s);
+                           hipStream_t s, unsigned short* out_bf = nullptr);
 void launch_gate_prelu_bwd(const float* h, const float* rg, const float* img, const float* leak, const float* dout, float* dh,
                            int acc_h, float* drg, float* dimg, float* dleak, int acc_dleak, size_t n, float* scratch,
                            hipStream_t s);

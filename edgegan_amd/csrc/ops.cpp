@@ -136,6 +136,7 @@ float* grad_acc(Ctx& c, T t, int* acc) {
   EG_CHECK(!(t->g_set && t->g_act_done), "a second gradient contribution reached a tensor whose activation backward was fused into the first writer's epilogue");
   *acc = t->g_set ? 1 : 0;
   t->g_set = true;
+  t->g_bf = nullptr;   // whoever asks is about to write g: a plane of its previous value is stale (the writer may set a new one)
   return t->g;
 }
 void seed_grad(Ctx& c, T t) {
@@ -415,6 +416,12 @@ static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
     if (a.wbf_bytes) return;
     a.limbs = 0;
   }
+  // 64 .. 127 output channels: the plane-fed kernel (k_conv_bf16p.hip) has a 64-channel form; whether it takes the launch is
+  // only known in run_conv (K split, tile geometry) -- remember the filter so that run_conv can ask for its K-step-major plane
+  if (a.N >= 64) {
+    c.alt_w = w;
+    c.alt_transposed = transposed;
+  }
   unsigned short*& slot = transposed ? w->wbT : w->wb;
   if (!slot) {
     const size_t n = (size_t)w->T * w->R * w->Cc;
@@ -446,6 +453,18 @@ static const unsigned short* tensor_plane(Ctx& c, T t, bool grad) {
   return q;
 }
 
+// Producer-side planes: in bf16 mode an element-wise kernel whose output (or output gradient) is shaped like a dense
+// contraction's operand (channels a multiple of 32) stores the bf16 plane next to the fp32 tensor -- 2 extra bytes per
+// element once instead of a conversion pass (4 B read + 2 B written) per consumer.  Returns the plane to write, or null.
+static unsigned short* producer_plane(Ctx& c, T t, bool grad) {
+  static const bool on = dbg_env("EG_NO_PRODUCER_PLANES") == nullptr;
+  if (!on || !c.cfg.bf16 || t->c % 32 != 0 || t->numel() * sizeof(unsigned short) >= (1ull << 31)) return nullptr;
+  unsigned short* q = reinterpret_cast<unsigned short*>(c.arena.allocf((t->numel() + 1) / 2));
+  (grad ? t->g_bf : t->d_bf) = q;
+  (grad ? t->g_bf_stream : t->d_bf_stream) = nullptr;   // visible wherever the tensor's data / gradient is
+  return q;
+}
+
 // launch one implicit-GEMM conv; layers too small to fill the chip with output tiles split K over blocks.
 // xsrc / xgrad: the tensor whose data (gradient) a.x is -- the bf16 mode's plane-fed kernel reads its bf16 plane instead
 static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
@@ -471,6 +490,28 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
     if (blocks * ks < 128 || !conv_x3h_eligible(a)) a = keep;
   }
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
+  WRef* alt_w = c.alt_w;
+  c.alt_w = nullptr;
+  if (c.cfg.bf16 && a.limbs == 0 && alt_w && xsrc && a.x == (xgrad ? xsrc->g : xsrc->d) && a.x_ps == xsrc->c) {
+    // a 64 .. 127-channel layer on the rounded-copy path: would the plane-fed kernel take it with a K-step-major filter plane?
+    ConvArgs b = a;
+    const size_t n = (size_t)alt_w->T * alt_w->R * alt_w->Cc, pb = xsrc->numel() * sizeof(unsigned short);
+    b.limbs = 1;
+    b.wbf_plane = (long long)n;
+    b.wbf_bytes = 2 * n < (1ull << 31) ? (unsigned)(2 * n) : 0u;
+    b.wgt_bf = reinterpret_cast<const unsigned short*>(uintptr_t(16));
+    b.x_bf = reinterpret_cast<const unsigned short*>(uintptr_t(16));
+    b.xbf_ps = xsrc->c;
+    b.xbf_bytes = pb < (1ull << 31) ? (unsigned)pb : 0u;
+    b.ksplit = 1;   // (the cost model above priced the 64x64 rounded-copy kernel; the 256-pixel x 64-channel tiles run un-split)
+    if (conv_bf16p_eligible(b)) {
+      a.limbs = 1;
+      a.wbf_plane = b.wbf_plane;
+      a.wbf_bytes = b.wbf_bytes;
+      a.wgt_bf = limb_planes(c, alt_w, c.alt_transposed, 1);
+      a.ksplit = 1;
+    }
+  }
   if (c.cfg.bf16 && a.limbs == 1 && xsrc && a.x == (xgrad ? xsrc->g : xsrc->d) && a.x_ps == xsrc->c) {
     const size_t pb = xsrc->numel() * sizeof(unsigned short);
     a.x_bf = reinterpret_cast<const unsigned short*>(uintptr_t(16));   // (placeholder: eligibility looks at alignment only)
@@ -943,10 +984,10 @@ T in_act(Ctx& c, T x, int a, T* stats_out) {
   if (x->nslab > 1) {   // a K-split convolution output that was left as slabs for this pass (conv2d); in a training graph
                         // the pass also stores the sum into x->d: from here on x is an ordinary tensor
     launch_in_fwd(x->slabs, out->d, st->d, x->n, HW, x->c, a, c.stream, x->nslab, x->numel(), x->slab_bias,
-                  x->needs_grad ? x->d : nullptr);
+                  x->needs_grad ? x->d : nullptr, producer_plane(c, out, false));
     if (x->needs_grad) x->nslab = 0;
   } else
-    launch_in_fwd(x->d, out->d, st->d, x->n, HW, x->c, a, c.stream);
+    launch_in_fwd(x->d, out->d, st->d, x->n, HW, x->c, a, c.stream, 0, 0, nullptr, nullptr, producer_plane(c, out, false));
   if (stats_out) *stats_out = st;
   if (x->needs_grad) {
     Ctx* cp = &c;
@@ -955,7 +996,7 @@ T in_act(Ctx& c, T x, int a, T* stats_out) {
       if (!out->g_set) return;
       int acc;
       float* dx = grad_acc(c, x, &acc);
-      launch_in_bwd(x->d, out->d, out->g, st->d, dx, acc, x->n, HW, x->c, a, c.stream);
+      launch_in_bwd(x->d, out->d, out->g, st->d, dx, acc, x->n, HW, x->c, a, c.stream, producer_plane(c, x, true));
     });
   }
   return out;
@@ -965,7 +1006,8 @@ T in_act(Ctx& c, T x, int a, T* stats_out) {
 T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int a) {
   T tout = new_tensor(c, tx->n, tx->h, tx->w, tx->c, true);
   const int HW = tx->h * tx->w;
-  launch_in_tangent_fwd(x_prim->d, out_prim->d, stats_prim->d, tx->d, tout->d, tx->n, HW, tx->c, a, c.stream);
+  launch_in_tangent_fwd(x_prim->d, out_prim->d, stats_prim->d, tx->d, tout->d, tx->n, HW, tx->c, a, c.stream,
+                        producer_plane(c, tout, false));
   Ctx* cp = &c;
   c.tape.push([=]() {
     Ctx& c = *cp;
@@ -1084,7 +1126,7 @@ T pool2(Ctx& c, T x) {
         LeafScope leaf(c);
         launch_pool2_bwd(out->g, dx, acc, x->n, x->h, x->w, x->c, c.stream);
       } else {
-        launch_pool2_bwd(out->g, dx, acc, x->n, x->h, x->w, x->c, c.stream);
+        launch_pool2_bwd(out->g, dx, acc, x->n, x->h, x->w, x->c, c.stream, producer_plane(c, x, true));
       }
     });
   }
@@ -1153,7 +1195,7 @@ T pool2_add(Ctx& c, T a, T b) {
       if (a->needs_grad) {
         int acc;
         float* d = grad_acc(c, a, &acc);
-        launch_pool2_bwd(out->g, d, acc, a->n, a->h, a->w, a->c, c.stream);
+        launch_pool2_bwd(out->g, d, acc, a->n, a->h, a->w, a->c, c.stream, producer_plane(c, a, true));
       }
     });
   }
@@ -1291,7 +1333,7 @@ T slice_w(Ctx& c, T x, int w0, int w1) {
 // activation.py:23-32
 T prelu(Ctx& c, T x, Param* leak, float leak_const) {
   T out = new_tensor(c, x->n, x->h, x->w, x->c, false);
-  launch_prelu_fwd(x->d, leak ? leak->w : nullptr, leak_const, out->d, x->numel(), c.stream);
+  launch_prelu_fwd(x->d, leak ? leak->w : nullptr, leak_const, out->d, x->numel(), c.stream, producer_plane(c, out, false));
   const bool need = x->needs_grad || (leak && leak->want_grad);
   if (need) {
     out->needs_grad = true;
@@ -1305,7 +1347,7 @@ T prelu(Ctx& c, T x, Param* leak, float leak_const) {
       const bool pg = leak && leak->want_grad && c.param_grad_enabled;
       if (!dx && !pg) return;
       launch_prelu_bwd(x->d, out->g, leak ? leak->w : nullptr, leak_const, dx, acc, pg ? leak->g : nullptr,
-                       pg && leak->g_set ? 1 : 0, x->numel(), c.scratch, c.stream);
+                       pg && leak->g_set ? 1 : 0, x->numel(), c.scratch, c.stream, dx ? producer_plane(c, x, true) : nullptr);
       if (pg) leak->g_set = true;
     });
   }
@@ -1325,7 +1367,7 @@ T minmax(Ctx& c, T x, float pre_leak) {
       if (!out->g_set) return;
       int acc;
       float* dx = grad_acc(c, x, &acc);
-      launch_minmax_bwd(x->d, mm->d, out->g, dx, acc, x->n, HW, x->c, c.stream, pre_leak);
+      launch_minmax_bwd(x->d, mm->d, out->g, dx, acc, x->n, HW, x->c, c.stream, pre_leak, producer_plane(c, x, true));
     });
   }
   return out;
@@ -1356,7 +1398,7 @@ T gate(Ctx& c, T h, T rg, T img) {
 // from its three inputs for the PReLU mask and the slope's gradient (exactly the values the two-pass form reads back)
 T gate_prelu(Ctx& c, T h, T rg, T img, Param* leak) {
   T out = new_tensor(c, h->n, h->h, h->w, h->c, true);
-  launch_gate_prelu_fwd(h->d, rg->d, img->d, leak->w, out->d, h->numel(), c.stream);
+  launch_gate_prelu_fwd(h->d, rg->d, img->d, leak->w, out->d, h->numel(), c.stream, producer_plane(c, out, false));
   Ctx* cp = &c;
   c.tape.push([=]() {
     Ctx& c = *cp;
