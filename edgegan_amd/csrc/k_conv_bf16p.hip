@@ -68,7 +68,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // PH: the tap grids of the launch's phases -- 0: 3x3 (stride-1 convolutions and their input gradients), 1: 2x2 (the four
-// phases of a 4x4 stride-2 input gradient), 2: any of 3x3 / 3x2 / 2x3 / 2x2 per phase (5x5 stride-2 transposed convolutions)
+// phases of a 4x4 stride-2 input gradient), 2: any of 3x3 / 3x2 / 2x3 / 2x2 per phase (5x5 stride-2 transposed convolutions),
+// 3: a 4x4 stride-2 SAME forward convolution (the discriminators' layers, edgegan/models/discriminator.py:61-72) in
+//    space-to-depth form (k_gemm_x3h.hip, S2D): a 2x2-tap stride-1 convolution over the view V[Y][X][(py, px, c)] =
+//    x[2Y + py - 1][2X + px - 1][c]; K chunk (q = 2 py + px, cq) stages phase (py, px) of the halo pixels' source pixels
+//    straight from x's plane (a uniform phase offset + per-row validity of the 4 phases) and pairs with the filter taps
+//    (2 dY + py, 2 dX + px)
 template <int MI, int WN, bool SPLITK, bool SW16, int HR, int PH>
 __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p_kernel(const ConvArgs a, const PlaneGeom g) {
   constexpr int BN = 64 * WN;                // block tile: (4 / WN) waves x 32 MI pixels by WN waves x 64 channels
@@ -94,15 +99,16 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
   const int zphase = SPLITK ? bz / a.ksplit : bz;
   const int zsplit = SPLITK ? bz - zphase * a.ksplit : 0;
   const ConvPhase ph = a.ph[zphase];
-  const int IH = a.IH, IW = a.IW, C = a.C, N = a.N, D = a.D;
-  const int nTy = ph.Ty, nTx = ph.Tx;
+  constexpr bool S2D = PH == 3;
+  const int IH = a.IH, IW = a.IW, C = a.C, N = a.N, D = S2D ? 1 : a.D;
+  const int nTy = S2D ? 2 : ph.Ty, nTx = S2D ? 2 : ph.Tx;
   const int TW = 1 << g.lTW, TH = 1 << g.lTH;
   const int tpi = g.tiles_x * g.tiles_y;
   const int tn = bx / tpi, trem = bx - tn * tpi;
   const int tyy = trem / g.tiles_x, txx = trem - tyy * g.tiles_x;
   const int img0 = tn * g.TI, oy0 = tyy * TH, ox0 = txx * TW;
   const int n0 = by * BN;
-  const int offy = ph.offy, offx = ph.offx;
+  const int offy = S2D ? 0 : ph.offy, offx = S2D ? 0 : ph.offx;   // (S2D: ph.off* is the source offset of phase (0, 0), below)
   const int dminy = min(offy, (nTy - 1) * D + offy), dminx = min(offx, (nTx - 1) * D + offx);
   const int HH = TH + nTy - 1, HW = TW + nTx - 1;
   constexpr bool sw16 = SW16;
@@ -111,15 +117,26 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
   // ---- halo DMA: piece p = wave + 4 j covers LDS rows 16 p .. 16 p + 15; lane (r, q) = (lane >> 2, lane & 3) brings the
   //      16-byte channel group (q ^ swizzle(row)) of the row's source pixel; rows without a pixel / padding read zeros -----
   unsigned goffA[NAJ];
+  [[maybe_unused]] int vbA[NAJ];   // S2D: bits 0 / 1 = source row of phase py = 0 / 1 inside the image, bits 2 / 3 = column of px = 0 / 1
 #pragma unroll
   for (int j = 0; j < NAJ; ++j) {
     const int row = (wave + 4 * j) * 16 + (lane >> 2);
     unsigned off = 0x80000000u;
+    vbA[j] = 0;
     if (wave + 4 * j < NPC) {
       const int ti = row / HPI, rem = row - ti * HPI;
       const int hy = rem / HWP, hx = rem - hy * HWP;
       if (ti < g.TI && hx < HW) {
         int iy = oy0 + dminy + hy, ix = ox0 + dminx + hx;
+        if constexpr (S2D) {   // source pixel of phase (0, 0); the offset may be "negative" (wraps; only used where valid)
+          iy = 2 * iy + ph.offy;
+          ix = 2 * ix + ph.offx;
+          const int sw = sw16 ? (hx >> 2) & 3 : swz_p(row);
+          off = (unsigned)(((((img0 + ti) * IH + iy) * IW + ix) * a.xbf_ps + (((lane & 3) ^ sw) * 8)) * 2);
+          vbA[j] = ((unsigned)iy < (unsigned)IH ? 1 : 0) | ((unsigned)(iy + 1) < (unsigned)IH ? 2 : 0) |
+                   ((unsigned)ix < (unsigned)IW ? 4 : 0) | ((unsigned)(ix + 1) < (unsigned)IW ? 8 : 0);
+          iy = ix = -1;        // (the generic path below does not apply)
+        }
         if (a.reflect) {
           iy = reflect_p(iy, IH);
           ix = reflect_p(ix, IW);
@@ -138,14 +155,30 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wgt_bf), 0, a.wbf_bytes, 0x00020000);
   // (hipcc 7.2 quirk: with the DMA builtin's voffset argument written as an element of a template-sized local array the HOST
   //  pass silently drops the kernel's launch stub -- "undefined symbol __device_stub__..." at load time; a scalar copy is fine)
+  const int cpt = C / 32;
   auto request_halo = [&](int cc, int buf) __attribute__((always_inline)) {
+    [[maybe_unused]] int py = 0, px = 0;
+    [[maybe_unused]] unsigned soff = 0;
+    if constexpr (S2D) {   // K chunk cc = phase q, channel chunk cq (uniform arithmetic, once per chunk)
+      const int q = cc / cpt, cq = cc - q * cpt;
+      py = q >> 1;
+      px = q & 1;
+      soff = (unsigned)((((py * IW + px) * a.xbf_ps) + cq * 32) * 2);
+    }
 #pragma unroll
     for (int j = 0; j < NAJ; ++j)
       if (wave + 4 * j < NPC && (EG_BF16P_DBG & 2) == 0)
       {
-        const unsigned voff = goffA[j];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (__attribute__((address_space(3))) void*)&Ah[buf][(wave + 4 * j) * 16 * 32], 16,
-                                                 voff, cc * 64, 0, 0);
+        if constexpr (S2D) {   // (the sum is formed here, mod 2^32: a "negative" phase-(0,0) offset plus the phase offset is in range again)
+          const bool ok = ((vbA[j] >> py) & (vbA[j] >> (2 + px)) & 1) != 0;
+          const unsigned voff = ok ? goffA[j] + soff : 0x80000000u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (__attribute__((address_space(3))) void*)&Ah[buf][(wave + 4 * j) * 16 * 32], 16,
+                                                   voff, 0, 0, 0);
+        } else {
+          const unsigned voff = goffA[j];
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (__attribute__((address_space(3))) void*)&Ah[buf][(wave + 4 * j) * 16 * 32], 16,
+                                                   voff, cc * 64, 0, 0);
+        }
       }
   };
 
@@ -156,13 +189,13 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
     const int row = (wave * NBJ + j) * 16 + (lane >> 2);
     woff[j] = (unsigned)(((size_t)min(n0 + row, N - 1) * 32 + ((lane & 3) ^ swz_p(row)) * 8) * 2);
   }
-  const int cpt = C / 32;
   const int wtile = N * 32 * 2;
-  int cc_lo = 0, cc_hi = cpt;
+  const int vcpt = S2D ? 4 * cpt : cpt;   // K chunks the loop walks (S2D: 4 phases x C / 32)
+  int cc_lo = 0, cc_hi = vcpt;
   if constexpr (SPLITK) {
-    const int per = (cpt + a.ksplit - 1) / a.ksplit;
-    cc_lo = min(cpt, zsplit * per);
-    cc_hi = min(cpt, cc_lo + per);
+    const int per = (vcpt + a.ksplit - 1) / a.ksplit;
+    cc_lo = min(vcpt, zsplit * per);
+    cc_hi = min(vcpt, cc_lo + per);
   }
   const int ncc = cc_hi - cc_lo;
 
@@ -249,8 +282,18 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
     for (int t = 0; t < NT; ++t) {
       const int f = t / TX, e = t - f * TX;
       const int ty = D > 0 ? f : TY - 1 - f, tx = D > 0 ? e : TX - 1 - e;
-      tapoff[t] = ((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * cpt * wtile;
+      if constexpr (S2D) tapoff[t] = ((2 * f) * a.KW + 2 * e) * cpt * wtile;   // + the chunk's phase (py, px): wrow_of
+      else tapoff[t] = ((ph.kh0 + ty * a.kst) * a.KW + (ph.kw0 + tx * a.kst)) * cpt * wtile;
     }
+    // byte offset of K chunk cc inside a tap's filter tiles (S2D: + the tap shift of the chunk's phase)
+    auto wrow_of = [&](int cc) __attribute__((always_inline)) {
+      if constexpr (S2D) {
+        const int q = cc / cpt, cq = cc - q * cpt;
+        return (((q >> 1) * a.KW + (q & 1)) * cpt + cq) * wtile;
+      } else {
+        return cc * wtile;
+      }
+    };
     // two fragment sets (the look-ahead reads of step k + 1 are issued before the MFMAs of step k) where the registers
     // allow it; the 128 x 64 wave tile (128 accumulator registers) keeps ONE set: reads after the MFMAs that consumed it
     constexpr int NSETS = MI == 4 ? 1 : 2;
@@ -297,8 +340,8 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
     constexpr std::integral_constant<int, 1> I1{};
     if (ncc > 0) {
       request_halo(cc_lo, 0);
-      request_b(I0, tapoff[0] + cc_lo * wtile);
-      request_b(I1, tapoff[1] + cc_lo * wtile);     // (NT >= 2)
+      request_b(I0, tapoff[0] + wrow_of(cc_lo));
+      request_b(I1, tapoff[1] + wrow_of(cc_lo));     // (NT >= 2)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
       read_step(fs[0], I0, I0, I0);
@@ -307,7 +350,7 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
     // register set and ring slot of a step are (H NT + T) & 1
     auto chunk = [&](auto Hc, int cc, bool has_next) __attribute__((always_inline)) {
       constexpr int H = decltype(Hc)::value;
-      const int wrow = cc * wtile;
+      const int wrow = wrow_of(cc), wrow_next = has_next ? wrow_of(cc + 1) : 0;
       static_for<NT>([&](auto Tc) __attribute__((always_inline)) {
         constexpr int T = decltype(Tc)::value;
         constexpr int SLOT = (H * NT + T) & 1;                   // ring slot of tile k (and of tile k + 2)
@@ -319,7 +362,7 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
         else land(fs[SET], WITH_BARRIER);
         // filter tile k + 2 -> the slot tile k was read from
         if constexpr (T + 2 < NT) request_b(SLOTc, tapoff[T + 2] + wrow);
-        else if (has_next) request_b(SLOTc, tapoff[T + 2 - NT] + wrow + wtile);
+        else if (has_next) request_b(SLOTc, tapoff[T + 2 - NT] + wrow_next);
         if constexpr (T == 0)
           if (has_next) request_halo(cc + 1, H ^ 1);
         if constexpr (NSETS == 1) {
@@ -348,7 +391,7 @@ __global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p
   constexpr std::integral_constant<int, 3> K3{};
   if constexpr (PH == 0) {
     kloop(K3, K3);
-  } else if constexpr (PH == 1) {
+  } else if constexpr (PH == 1 || PH == 3) {
     kloop(K2, K2);
   } else {
     if (nTy == 3 && nTx == 3) kloop(K3, K3);
@@ -405,8 +448,17 @@ static int ilog2p(int v) {
   return l;
 }
 
+static bool bf16p_s2d_shape(const ConvArgs& a) {   // 4x4 stride-2 SAME forward convolution (one phase, taps as stored)
+  const ConvPhase& p = a.ph[0];
+  return a.S == 2 && a.nphase == 1 && a.KW == 4 && p.Ty == 4 && p.Tx == 4 && a.kst == 1 && a.D == 1 && a.os == 1 && p.kh0 == 0 &&
+         p.kw0 == 0 && p.offy == -1 && p.offx == -1 && p.ophy == 0 && p.ophx == 0 && !a.reflect && a.IH == 2 * p.OHp &&
+         a.IW == 2 * p.OWp;
+}
+
 // tile geometry for PX output pixels per block and at most HR halo rows; false when the kernel does not take the shape
-static bool bf16p_geometry(const ConvArgs& a, int PX, int HR, PlaneGeom* g) {
+static bool bf16p_geometry(const ConvArgs& a_in, int PX, int HR, PlaneGeom* g) {
+  ConvArgs a = a_in;
+  if (bf16p_s2d_shape(a)) a.ph[0].Ty = a.ph[0].Tx = 2;   // the halo is that of the 2x2-tap space-to-depth form
   const int OH = a.ph[0].OHp, OW = a.ph[0].OWp;
   for (int p = 0; p < a.nphase; ++p)
     if (a.ph[p].OHp != OH || a.ph[p].OWp != OW) return false;
@@ -437,10 +489,12 @@ constexpr int kHR128 = 208, kHR256 = 400;
 bool conv_bf16p_eligible(const ConvArgs& a) {
   static const bool off = dbg_env("EG_NO_BF16P") != nullptr;
   if (off || !a.x_bf || !a.wgt_bf || a.limbs != 1 || a.shuf) return false;
-  if (a.S != 1 || !(a.D == 1 || a.D == -1) || a.C % 32 != 0 || a.N < 64 || a.N % 4 != 0) return false;
+  static const bool no_s2d = dbg_env("EG_NO_S2D") != nullptr;
+  const bool s2d = bf16p_s2d_shape(a) && !no_s2d;
+  if (!(a.S == 1 || s2d) || !(a.D == 1 || a.D == -1) || a.C % 32 != 0 || a.N < 64 || a.N % 4 != 0) return false;
   if (a.xbf_ps % 8 != 0 || a.y_ps % 4 != 0 || !a.xbf_bytes || !a.wbf_bytes) return false;
   if ((((uintptr_t)a.x_bf | (uintptr_t)a.y | (uintptr_t)a.wgt_bf) & 15) != 0 || (a.bias && (((uintptr_t)a.bias) & 15) != 0)) return false;
-  if (a.ksplit > 1 && a.ksplit > a.C / 32) return false;
+  if (a.ksplit > 1 && a.ksplit > (s2d ? 4 : 1) * (a.C / 32)) return false;
   PlaneGeom g;
   return bf16p_geometry(a, a.N >= 128 ? 128 : 256, a.N >= 128 ? kHR128 : kHR256, &g);
 }
@@ -470,6 +524,7 @@ static void bf16p_launch_ph(const ConvArgs& a, const PlaneGeom& g, dim3 grid, hi
 
 template <int MI, int WN, int HR>
 static void bf16p_launch_variant(const ConvArgs& a, const PlaneGeom& g, dim3 grid, hipStream_t s) {
+  if (bf16p_s2d_shape(a)) return bf16p_launch_ph<MI, WN, HR, 3>(a, g, grid, s);
   const int pc = bf16p_phase_class(a);
   if (pc == 0) bf16p_launch_ph<MI, WN, HR, 0>(a, g, grid, s);
   else if (pc == 1) bf16p_launch_ph<MI, WN, HR, 1>(a, g, grid, s);
