@@ -1003,6 +1003,10 @@ static bool wgrad_x3(const WgradArgs& a) {   // (limbs == 1: the same kernel wit
 
 int wgrad_pick_splits(const WgradArgs& a) {
   const long long M = (long long)a.NB * a.OH * a.OW;
+  if (const int pu = wgrad_bf16p_units(a)) {   // plane-fed kernel: 256-thread blocks, three per CU; a slab is >= 8 K steps of 32 pixels
+    const long long tiles = (long long)pu * ((a.N + 127) / 128);
+    return pick_balanced_splits(tiles, 768, std::min(256LL, (M + 255) / 256));
+  }
   if (wgrad_x3(a)) {   // ping-pong blocks: two (tap, 128-channel) units x 128 output channels, one block per CU
     const long long units = wgrad_x3_rowhalo_units(a) ? wgrad_x3_rowhalo_units(a)     // (filter row, column phase, 64-channel block)
                             : a.C == 64 ? (a.KH * a.KW + 1) / 2 : (long long)a.KH * a.KW * ((a.C + 127) / 128);
@@ -1045,7 +1049,9 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
                    (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0) && (a.ldw % 4 == 0) &&
                    (a.w_ts % 4 == 0) && (((uintptr_t)out & 15) == 0);
   const char* nm;
-  if (wgrad_x3(a) && (((uintptr_t)out & 15) == 0)) {
+  if (wgrad_bf16p_units(a) && (((uintptr_t)out & 15) == 0)) {
+    nm = launch_wgrad_bf16p(a, out, dense, s);
+  } else if (wgrad_x3(a) && (((uintptr_t)out & 15) == 0)) {
     nm = launch_wgrad_x3(a, out, dense, true, s);
   } else if (a.bf16 && vec && !wgrad_flatm(a)) {
     nm = launch_wgrad_bf16(a, out, dense, wgrad_big(a), s);

@@ -103,6 +103,11 @@ struct WgradArgs {
                      //    reduce_deferred when it left the reduction out: the float4 form applies)
   int reduce_deferred;
   int dbg;           // experiments build only: limiter probes of the filter-gradient kernel (k_gemm_x3.hip)
+  // bf16 mode: bf16 planes of both operands ([pixel][C] / [pixel][N] bf16, from the tensors' producers or launch_cvt_bf16);
+  // when both are there and the shape fits, the plane-fed kernel (k_wgrad_bf16p.hip) stages them by LDS-DMA
+  const unsigned short* x_bf;
+  const unsigned short* dy_bf;
+  unsigned xbf_bytes, dybf_bytes;
 };
 #ifdef __HIPCC__
 // XCD-aware block map (MI355X: 8 XCDs with private L2s; block b of a launch is observed on XCD b % 8): dispatch index ->
@@ -119,6 +124,10 @@ int wgrad_x3_rowhalo_units(const WgradArgs& a);   // k_gemm_x3.hip: units of the
 int wgrad_pick_splits(const WgradArgs& a);
 size_t wgrad_workspace_floats(const WgradArgs& a);
 double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name);
+
+// plane-fed bf16 filter gradient (k_wgrad_bf16p.hip): units > 0 when it takes the launch
+int wgrad_bf16p_units(const WgradArgs& a);
+const char* launch_wgrad_bf16p(const WgradArgs& a, float* out, int dense, hipStream_t s);
 
 // thin-layer kernels (k_thin.hip): 3x3 stride-1 convolution with <= 12 output channels as one product over the input
 // pixels + col2im in LDS

@@ -656,9 +656,13 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
   if (!a.accumulate) x->g_act_done = a.epi_applied != 0;   // (first writer: decides anew in every backward sweep)
 }
 
-static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, const float* dy, int OH, int OW,
+// xt / xgrad, dyt / dygrad: the tensors whose data (or gradient) the gathered and the dense operand are -- the bf16 mode's
+// plane-fed kernel reads their bf16 planes
+static void conv_wgrad(Ctx& c, T xt, bool xgrad, int NB, int IH, int IW, int C, T dyt, bool dygrad, int OH, int OW,
                        int N, WRef* w, int k, int stride, int pad_before, int reflect) {
   WgradArgs g{};
+  const float* xg = xgrad ? xt->g : xt->d;
+  const float* dy = dygrad ? dyt->g : dyt->d;
   g.x = xg;
   g.dy = dy;
   g.dw = w->g;
@@ -685,6 +689,18 @@ static void conv_wgrad(Ctx& c, const float* xg, int NB, int IH, int IW, int C, c
     const size_t xb = (size_t)NB * IH * IW * C * sizeof(float), yb = (size_t)NB * OH * OW * N * sizeof(float);
     g.x_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
     g.dy_bytes = yb < (1ull << 31) ? (unsigned)yb : 0u;
+  }
+  if (c.cfg.bf16 && g.limbs == 1 && xt->c == C && dyt->c == N) {
+    const size_t xb = xt->numel() * sizeof(unsigned short), yb = dyt->numel() * sizeof(unsigned short);
+    g.x_bf = g.dy_bf = reinterpret_cast<const unsigned short*>(uintptr_t(16));   // (placeholders: the shape test looks at alignment only)
+    g.xbf_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
+    g.dybf_bytes = yb < (1ull << 31) ? (unsigned)yb : 0u;
+    if (wgrad_bf16p_units(g)) {
+      g.x_bf = tensor_plane(c, xt, xgrad);
+      g.dy_bf = tensor_plane(c, dyt, dygrad);
+    } else {
+      g.x_bf = g.dy_bf = nullptr;
+    }
   }
   g.nsplit = wgrad_pick_splits(g);
   const size_t wsf = wgrad_workspace_floats(g);
@@ -799,10 +815,13 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
       Ctx& c = *cp;
       if (!y->g_set) return;
       if (fused && !y->g_act_done) launch_act_bwd(y->d, y->g, y->g, 0, y->numel(), fused_act, c.stream);   // in place: g *= act'(out)
+      // bf16 mode: the plane of y's gradient serves the filter gradient (leaf stream) AND the input gradient (this stream):
+      // if y's producer left none, make it here, before the leaf scope opens -- both streams may then read it
+      if (c.cfg.bf16 && y->c % 64 == 0 && w->want_grad && x->needs_grad && c.param_grad_enabled) (void)tensor_plane(c, y, true);
       if (c.param_grad_enabled && (w->want_grad || (bias && bias->want_grad))) {
         LeafScope leaf(c);
         if (w->want_grad)
-          conv_wgrad(c, x->d, x->n, x->h, x->w, Cin, y->g, OH, OW, N, w, k, stride, pt, pad == PAD_REFLECT);
+          conv_wgrad(c, x, false, x->n, x->h, x->w, Cin, y, true, OH, OW, N, w, k, stride, pt, pad == PAD_REFLECT);
         if (bias && bias->want_grad) bias_grad(c, bias, y->g, rows, N);
       }
       if (x->needs_grad) {
@@ -886,7 +905,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
       if (c.param_grad_enabled && (w->want_grad || (bias && bias->want_grad))) {
         LeafScope leaf(c);
         // dW[k][co][ci] = sum_i dy[2i+k-1][co] x[i][ci]: wgrad with the roles of x and dy swapped
-        if (w->want_grad) conv_wgrad(c, y->g, x->n, OH, OW, cout, x->d, x->h, x->w, Cin, w, 5, 2, 1, 0);
+        if (w->want_grad) conv_wgrad(c, y, true, x->n, OH, OW, cout, x, false, x->h, x->w, Cin, w, 5, 2, 1, 0);
         if (bias && bias->want_grad) bias_grad(c, bias, y->g, y->pixels(), cout);
       }
       if (x->needs_grad) {
