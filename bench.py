@@ -113,6 +113,68 @@ def _oracle_iteration(cfg_kwargs, batch, threads, substeps=None):
     return time.time() - t0
 
 
+def _cpu_shard_worker(rank, cores, threads, cfg_kwargs, batch, barrier, out):
+    """One process of the all-core CPU baseline: pinned to its own cores, its own shard of the batch."""
+    try:
+        if cores:
+            os.sched_setaffinity(0, cores)
+        os.environ['OMP_NUM_THREADS'] = str(threads)
+        for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch
+        torch.set_num_interop_threads(1)
+        _oracle_iteration(cfg_kwargs, batch, threads)      # untimed: thread pool, allocator, oneDNN primitives of these shapes
+        barrier.wait()
+        out.put((rank, _oracle_iteration(cfg_kwargs, batch, threads)))
+    except Exception as e:     # the parent must never wait for a worker that died
+        try:
+            barrier.abort()
+        except Exception:
+            pass
+        out.put((rank, repr(e)))
+
+
+def cpu_all_cores_sharded(cfg_kwargs, batch_all, threads, phys):
+    """All physical cores the way a CPU data-parallel run would use them: P = cores // threads processes, each pinned to its
+    own `threads` cores with 1/P of the batch (one torch process does not scale past ~16 threads on these convolution
+    shapes; one thread per core in ONE process thrashes its spin-waiting pool).  Returns (images/s, P, per-process batch, s)."""
+    import multiprocessing as mp
+    procs = max(1, phys // threads)
+    per = max(2, batch_all // procs)
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(phys))
+    ctx = mp.get_context('spawn')
+    barrier, out = ctx.Barrier(procs), ctx.Queue()
+    ps = []
+    for r in range(procs):
+        cores = set(avail[r * threads:(r + 1) * threads]) if len(avail) >= procs * threads else None
+        ps.append(ctx.Process(target=_cpu_shard_worker, args=(r, cores, threads, cfg_kwargs, per, barrier, out)))
+        ps[-1].start()
+    import queue
+    times, waited = [], 0.0
+    while len(times) < procs:
+        try:
+            r, t = out.get(timeout=2.0)
+        except queue.Empty:
+            waited += 2.0
+            if waited > 600 or any(p.exitcode not in (None, 0) for p in ps):     # a worker died without reporting / hung
+                for p in ps:
+                    p.terminate()
+                raise RuntimeError('cpu shard workers did not report (exit codes %s)' % [p.exitcode for p in ps])
+            continue
+        if not isinstance(t, float):
+            for p in ps:
+                p.terminate()
+            raise RuntimeError(f'cpu shard {r}: {t}')
+        times.append(t)
+    for p in ps:
+        p.join(timeout=60)
+    return procs * per / max(times), procs, per, max(times)
+
+
 def cpu_baseline(cfg_kwargs, batch_all=64, batch_one=2):
     """the CPU restatement of the identical iteration (`kind: port`, torch-CPU -- the reference's
     TF-1.14 CPU path cannot exist on this box), timed on this host's cores:
@@ -143,11 +205,29 @@ def cpu_baseline(cfg_kwargs, batch_all=64, batch_one=2):
     dt_one = _oracle_iteration(cfg_kwargs, batch_one, 1)
     dt_c0 = _oracle_iteration(dict(cfg_kwargs, num_classes=0), 4, best)
     torch.set_num_threads(ncpu)
-    return {'value': round(batch_all / dt_all, 3), 'unit': 'images/s', 'cores': best, 'kind': 'port',
+    # the best HONEST all-core number: batch shards on pinned processes
+    sharded = None
+    if phys >= 2 * best:
+        try:
+            ips, procs, per, dts = cpu_all_cores_sharded(cfg_kwargs, batch_all, best, phys)
+            sharded = {'value': round(ips, 3), 'unit': 'images/s', 'cores': procs * best,
+                       'sample': f'{procs} processes x {best} threads, each pinned to its own cores, one full iteration at batch '
+                                 f'{per} per process ({procs * per} images), {dts:.1f} s for the slowest'}
+        except Exception as e:
+            sharded = {'value': None, 'error': repr(e)}
+    if sharded and sharded.get('value') and sharded['value'] > batch_all / dt_all:
+        head = {'value': sharded['value'], 'cores': sharded['cores'], 'sample': sharded['sample'] + ' (torch-CPU fp32 oracle, BASELINE configs[2] shapes)'}
+    else:
+        head = {'value': round(batch_all / dt_all, 3), 'cores': best,
+                'sample': f'1 full iteration (7 sub-steps) at batch {batch_all} (BASELINE configs[2] shapes), torch-CPU fp32 '
+                          f'oracle, {best} threads (best of the sweep), {dt_all:.1f} s'}
+    return {'value': head['value'], 'unit': 'images/s', 'cores': head['cores'], 'kind': 'port',
             'kind_detail': 'torch-CPU fp32 restatement (oracle/edgegan_oracle.py), not the reference\'s TensorFlow 1.14',
             'cpu_model': cpu_model(), 'host_hardware_threads': hw,
-            'sample': f'1 full iteration (7 sub-steps) at batch {batch_all} (BASELINE configs[2] shapes), torch-CPU fp32 '
-                      f'oracle, {best} threads (best of the sweep), {dt_all:.1f} s',
+            'sample': head['sample'],
+            'one_process_best_threads': {'value': round(batch_all / dt_all, 3), 'unit': 'images/s', 'cores': best,
+                                         'sample': f'1 full iteration at batch {batch_all}, {best} threads, {dt_all:.1f} s'},
+            'all_cores_sharded': sharded,
             'thread_sweep_images_per_s_at_batch_16': sweep,
             'all_cores': {'value': round(allc_batch / dt_allc, 3), 'unit': 'images/s', 'cores': phys,
                           'sample': f'1 full iteration at batch {allc_batch} with one thread on each of the {phys} physical cores '

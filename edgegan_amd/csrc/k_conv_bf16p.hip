@@ -75,7 +75,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 //    straight from x's plane (a uniform phase offset + per-row validity of the 4 phases) and pairs with the filter taps
 //    (2 dY + py, 2 dX + px)
 template <int MI, int WN, bool SPLITK, bool SW16, int HR, int PH>
-__global__ __launch_bounds__(256, ((HR <= 208 && SW16) ? 3 : 2)) void conv_bf16p_kernel(const ConvArgs a, const PlaneGeom g) {
+__global__ __launch_bounds__(256, ((HR <= 288 && SW16) ? 3 : 2)) void conv_bf16p_kernel(const ConvArgs a, const PlaneGeom g) {
   constexpr int BN = 64 * WN;                // block tile: (4 / WN) waves x 32 MI pixels by WN waves x 64 channels
   constexpr int WROWS = 32 * MI;
   constexpr int NSB = 2;                     // ring slots: tile k + 1 is being read while tile k + 2 lands in tile k's slot
@@ -484,7 +484,24 @@ static bool bf16p_geometry(const ConvArgs& a_in, int PX, int HR, PlaneGeom* g) {
   return true;
 }
 
-constexpr int kHR128 = 208, kHR256 = 400;
+// halo rows of the 128-pixel form: 288 = 8 images of 4x4 outputs (6 x 6 halo each); 53 KB of LDS, still three blocks per CU
+constexpr int kHR128 = 288, kHR256 = 400;
+
+// K split of a plane-fed launch.  The kernel's time is (blocks x K steps) / 256 CUs x ~0.27 us whatever the split (measured:
+// profiles/r04h_layers_bf16.csv), so the split only has to give every CU two blocks -- each further slab is 4 bytes per output
+// element written and read again by the reduction (round 3's cost model, tuned for 256-pixel tiles at one block per CU,
+// chose 8 slabs for the classifier's last unit: 100 MB of slab traffic around a 43 GFLOP launch).
+int conv_bf16p_pick_ksplit(const ConvArgs& a) {
+  PlaneGeom g;
+  const bool n128 = a.N >= 128;
+  if (!bf16p_geometry(a, n128 ? 128 : 256, n128 ? kHR128 : kHR256, &g)) return 1;
+  const long long tiles = (long long)(a.NB / g.TI) * g.tiles_x * g.tiles_y * ((a.N + (n128 ? 127 : 63)) / (n128 ? 128 : 64)) * a.nphase;
+  const int chunks = (bf16p_s2d_shape(a) ? 4 : 1) * (a.C / 32);
+  if (tiles >= 448 || chunks < 4) return 1;
+  int ks = (int)((512 + tiles - 1) / tiles);
+  ks = std::min(ks, std::min(8, chunks / 2));
+  return ks < 2 ? 1 : ks;
+}
 
 bool conv_bf16p_eligible(const ConvArgs& a) {
   static const bool off = dbg_env("EG_NO_BF16P") != nullptr;

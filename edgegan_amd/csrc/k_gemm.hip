@@ -435,7 +435,9 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     fprintf(stderr, "edgegan_hip: conv launch without an fp32 filter that no limb / bf16 kernel accepts (N=%d C=%d)\n", a.N, a.C);
     abort();
   }
-  if (conv_scatter_eligible(a)) {
+  if (conv_pk_eligible(a)) {
+    nm = launch_conv_pk(a, s);
+  } else if (conv_scatter_eligible(a)) {
     nm = launch_conv_scatter(a, s);
   } else if (conv_smallc_eligible(a)) {
     nm = launch_conv_smallc(a, s);

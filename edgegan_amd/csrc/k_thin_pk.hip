@@ -1,0 +1,257 @@
+// Thin forward convolutions (3 or 8 input channels) with (tap, channel) PACKED into the MFMA's K -- VERDICT r3 item 4.
+//
+//   conv_pk_kernel<CP, KH, KW, S> : Y[oy][ox][n] (+)= b[n] + sum_{ky,kx,c} X[oy S + ky - pad][ox S + kx - pad][c] W[ky][kx][c][n]
+//       CP = 8: C == 8, 3x3 stride 1        (the classifier's Conv_1 / update gate of unit 1, edgegan/nn/modules/conv.py:185-224)
+//       CP = 4: C == 3, 3x3 stride 1 / 4x4 stride 2  (image-pyramid convolutions of the MRU units, conv.py:199-213; d_conv_0 of
+//               the three discriminators and the encoder stem, edgegan/models/discriminator.py:61-63, encoder.py:61-63)
+//
+// conv_smallc_kernel (k_thin.hip) builds these layers' MFMA operands element by element from a (tap, channel) table with a
+// padding predicate per element: ~5,000 issued instructions per 640 fp32 MFMAs, on neither roofline (r03x_smallc_limiter.txt).
+// Here the input tile is staged ONCE as a zero-padded halo image of bf16 limb planes [plane][row][col][CP] (the fp32 value is
+// the exact sum of its three limbs, k_gemm_x3.hip), and because a pixel's CP channels are 16 (CP = 8) or 8 (CP = 4) contiguous
+// bytes, the 8 K-values a lane feeds to v_mfma_f32_32x32x16_bf16 are ONE 16-byte LDS read: one tap's 8 channels (CP = 8) or two
+// horizontally adjacent taps' 4 + 4 channels (CP = 4) of the pixel under the lane's output pixel -- no table, no predicate,
+// no per-element work.  A K step of 16 is 2 taps (CP = 8: 5 steps for 3x3) or 4 taps (CP = 4: 3 steps for 3x3, 4 for 4x4).
+// The filter fragments (K steps x 3 limb planes) live in registers for the whole block; six limb products per step give
+// fp32 products (dropped terms < 2^-23), as everywhere in the f32x3 mode.  These layers then cost what their output costs to
+// write: the kernel is HBM-bound (algorithmic bytes = input + output + filter).
+//
+// Block = 256 threads = 4 waves on an output tile of TR = 8 rows x 32 columns x (32 NWN) channels, NWN = min(4, N / 32) waves
+// along the channels, the others along the rows.  Used by the f32x3 and bf16 modes (the exact-fp32 mode keeps conv_smallc).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace eg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ unsigned pk2(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_f(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// (x, y) -> packed limb pairs p0, p1, p2 with x = lo(p0) + lo(p1) + lo(p2) exactly (k_gemm_x3.hip: split_pair)
+__device__ __forceinline__ void split2(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = pk2(x, y);
+  const float rx = x - lo_f(p0), ry = y - hi_f(p0);
+  p1 = pk2(rx, ry);
+  p2 = pk2(rx - lo_f(p1), ry - hi_f(p1));
+}
+}  // namespace
+
+template <int CP, int KH, int KW, int S>
+__global__ __launch_bounds__(256, 2) void conv_pk_kernel(const ConvArgs a, int tiles_x, int tiles_y, int nwn) {
+  constexpr int TR = 8;                                   // output rows of a tile
+  constexpr int TPS = CP == 8 ? 2 : 4;                    // taps per K step of 16 (8 K-values per lane half)
+  constexpr int PR = (KW + 1) / 2;                        // CP = 4: horizontal tap pairs per filter row
+  constexpr int NS = CP == 8 ? (KH * KW + 1) / 2 : (KH * PR + 1) / 2;   // K steps
+  constexpr int HR = (TR - 1) * S + KH;                   // halo rows
+  constexpr int HC = ((31 * S + KW + 1) + 3) & ~3;        // halo columns (+1: the second tap of a pair past the last column)
+  constexpr int PB = CP * 2;                              // bytes of a pixel in a limb plane
+  constexpr int PLANE = HR * HC * PB;                     // bytes of a limb plane
+  constexpr bool B128 = (CP == 8) || (S == 2);            // a lane's 16 bytes are 16-byte aligned (else two 8-byte reads)
+  static_assert(TPS * CP == 16, "a K step of 16 = TPS taps x CP channels");
+  __shared__ __attribute__((aligned(16))) unsigned char Hs[3 * PLANE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int C = a.C, N = a.N, IH = a.IH, IW = a.IW;
+  const ConvPhase ph = a.ph[0];
+  const int OH = ph.OHp, OW = ph.OWp;
+  const int tpi = tiles_x * tiles_y;
+  const int nb = blockIdx.x / tpi, trem = blockIdx.x - nb * tpi;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int oy0 = ty * TR, ox0 = tx * 32;
+  const int iy0 = oy0 * S + ph.offy, ix0 = ox0 * S + ph.offx;   // input pixel of halo (0, 0)
+  const int wn = wave % nwn, wr = wave / nwn, nwr = 4 / nwn;
+  const int n0 = (blockIdx.y * nwn + wn) * 32;
+
+  // ---- filter fragments: lane (n = n0 + l31, K half lh) holds, per K step, the 8 K-values of its half as three limbs --------
+  bf16x8 bfr[NS][3];
+  {
+    const int n = n0 + l31;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int tap = -1, c = 0;
+        if constexpr (CP == 8) {
+          tap = 2 * s + lh;
+          c = e;
+          if (tap >= KH * KW) tap = -1;
+        } else {
+          const int pi = 2 * s + lh, ky = pi / PR, kx = 2 * (pi - ky * PR) + (e >> 2);
+          c = e & 3;
+          tap = (ky < KH && kx < KW) ? ky * KW + kx : -1;
+        }
+        v[e] = (tap >= 0 && c < C && n < N) ? a.wgt[(size_t)tap * a.w_ts + (size_t)c * a.ldw + n] : 0.f;
+      }
+      unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split2(v[2 * q], v[2 * q + 1], q0[q], q1[q], q2[q]);
+      bfr[s][0] = __builtin_bit_cast(bf16x8, (u32x4){q0[0], q0[1], q0[2], q0[3]});
+      bfr[s][1] = __builtin_bit_cast(bf16x8, (u32x4){q1[0], q1[1], q1[2], q1[3]});
+      bfr[s][2] = __builtin_bit_cast(bf16x8, (u32x4){q2[0], q2[1], q2[2], q2[3]});
+    }
+  }
+
+  // ---- halo image: every pixel (zero outside the image) as CP channels x 3 limb planes ------------------------------------
+  for (int p = tid; p < HR * HC; p += 256) {
+    const int hy = p / HC, hx = p - hy * HC;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool in = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+    const float* src = a.x + ((size_t)(nb * IH + (in ? iy : 0)) * IW + (in ? ix : 0)) * C;
+    if constexpr (CP == 8) {
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+      if (in) {
+        lo = *reinterpret_cast<const float4*>(src);
+        hi = *reinterpret_cast<const float4*>(src + 4);
+      }
+      unsigned q0[4], q1[4], q2[4];
+      split2(lo.x, lo.y, q0[0], q1[0], q2[0]);
+      split2(lo.z, lo.w, q0[1], q1[1], q2[1]);
+      split2(hi.x, hi.y, q0[2], q1[2], q2[2]);
+      split2(hi.z, hi.w, q0[3], q1[3], q2[3]);
+      *reinterpret_cast<u32x4*>(&Hs[p * PB]) = (u32x4){q0[0], q0[1], q0[2], q0[3]};
+      *reinterpret_cast<u32x4*>(&Hs[PLANE + p * PB]) = (u32x4){q1[0], q1[1], q1[2], q1[3]};
+      *reinterpret_cast<u32x4*>(&Hs[2 * PLANE + p * PB]) = (u32x4){q2[0], q2[1], q2[2], q2[3]};
+    } else {
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (in) {
+        v0 = src[0];
+        v1 = src[1];
+        v2 = src[2];
+      }
+      unsigned q0[2], q1[2], q2[2];
+      split2(v0, v1, q0[0], q1[0], q2[0]);
+      split2(v2, 0.f, q0[1], q1[1], q2[1]);
+      *reinterpret_cast<u32x2*>(&Hs[p * PB]) = (u32x2){q0[0], q0[1]};
+      *reinterpret_cast<u32x2*>(&Hs[PLANE + p * PB]) = (u32x2){q1[0], q1[1]};
+      *reinterpret_cast<u32x2*>(&Hs[2 * PLANE + p * PB]) = (u32x2){q2[0], q2[1]};
+    }
+  }
+  __syncthreads();
+
+  // ---- per-lane fragment offsets: K step s, half lh -> the tap (pair) the lane's 16 bytes start at ---------------------------
+  const unsigned hs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&Hs[0];
+  unsigned aoff[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    int ky, kx;
+    if constexpr (CP == 8) {
+      const int tap = min(2 * s + lh, KH * KW - 1);     // (a padded tap reads a valid pixel; its filter rows are zero)
+      ky = tap / KW;
+      kx = tap - ky * KW;
+    } else {
+      const int pi = 2 * s + lh;
+      ky = min(pi / PR, KH - 1);
+      kx = 2 * (pi % PR);
+    }
+    aoff[s] = hs_base + (unsigned)((ky * HC + l31 * S + kx) * PB);
+  }
+
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = wr; r < TR; r += nwr) {
+    const int oy = oy0 + r;
+    if (oy >= OH) break;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const unsigned rowoff = (unsigned)(r * S * HC * PB);
+    bf16x8 af[NS][3];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const __attribute__((address_space(3))) unsigned char* q =
+            (const __attribute__((address_space(3))) unsigned char*)(uintptr_t)(aoff[s] + rowoff + p * PLANE);
+        if constexpr (B128) {
+          af[s][p] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(q);
+        } else {
+          const u32x2 lo = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(q);
+          const u32x2 hi = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(q + 8);
+          const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+          af[s][p] = __builtin_bit_cast(bf16x8, v);
+        }
+      }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      // six limb products down to 2^-16 of the leading one: (0,0) (0,1) (0,2) (1,0) (1,1) (2,0)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[s][2], af[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[s][0], af[s][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[s][1], af[s][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[s][1], af[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[s][0], af[s][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[s][0], af[s][0], acc, 0, 0, 0);
+    }
+    // D^T layout: lane l holds output pixel ox0 + (l & 31) and, in registers 4q .. 4q+3, channels 8q + 4 (l >> 5) .. +3
+    const int ox = ox0 + l31;
+    if (ox < OW) {
+      float* yrow = a.y + ((size_t)(nb * a.OHf + oy) * a.OWf + ox) * a.y_ps;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + q * 8 + lh * 4;
+        if (n < N) {
+          float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+          const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + n) : zero4;
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          if (a.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(yrow + n);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          if (a.act == ACT_RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          } else if (a.act == ACT_LRELU) {
+            v.x = fmaxf(v.x, 0.2f * v.x); v.y = fmaxf(v.y, 0.2f * v.y); v.z = fmaxf(v.z, 0.2f * v.z); v.w = fmaxf(v.w, 0.2f * v.w);
+          }
+          *reinterpret_cast<float4*>(yrow + n) = v;
+        }
+      }
+    }
+  }
+}
+
+bool conv_pk_eligible(const ConvArgs& a) {
+  static const bool off = dbg_env("EG_NO_PK") != nullptr;
+  if (off || !a.pk || !a.wgt || a.nphase != 1 || a.reflect || a.shuf || a.ksplit > 1 || a.D != 1 || a.os != 1 || a.kst != 1) return false;
+  const ConvPhase& p = a.ph[0];
+  if (!(a.C == 3 || a.C == 8) || a.x_ps != a.C || p.kh0 != 0 || p.kw0 != 0 || p.ophy != 0 || p.ophx != 0) return false;
+  const bool k3 = a.S == 1 && a.KW == 3 && p.Ty == 3 && p.Tx == 3;
+  const bool k4 = a.S == 2 && a.KW == 4 && p.Ty == 4 && p.Tx == 4 && a.C == 3;
+  if (!(k3 || k4) || a.N < 8 || a.N % 4 != 0 || a.y_ps % 4 != 0) return false;
+  if (a.C == 8 && (((uintptr_t)a.x) & 15) != 0) return false;
+  if ((((uintptr_t)a.y) & 15) != 0 || (a.bias && (((uintptr_t)a.bias) & 15) != 0)) return false;
+  return (long long)a.NB * a.IH * a.IW * a.C < (1ll << 31);
+}
+
+const char* launch_conv_pk(const ConvArgs& a, hipStream_t s) {
+  const ConvPhase& p = a.ph[0];
+  const int tiles_x = (p.OWp + 31) / 32, tiles_y = (p.OHp + 7) / 8;
+  const int nb32 = (a.N + 31) / 32;
+  const int nwn = nb32 >= 4 ? 4 : nb32 >= 2 ? 2 : 1;
+  dim3 grid(a.NB * tiles_x * tiles_y, (nb32 + nwn - 1) / nwn);
+  if (a.C == 8) {
+    hipLaunchKernelGGL((conv_pk_kernel<8, 3, 3, 1>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, nwn);
+    return "conv_pk<c8,k3>";
+  }
+  if (a.S == 1) {
+    hipLaunchKernelGGL((conv_pk_kernel<4, 3, 3, 1>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, nwn);
+    return "conv_pk<c3,k3>";
+  }
+  hipLaunchKernelGGL((conv_pk_kernel<4, 4, 4, 2>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, nwn);
+  return "conv_pk<c3,k4s2>";
+}
+
+}  // namespace eg

@@ -72,6 +72,7 @@ struct ConvArgs {
   const float* epi_ref;
   int epi_act;
   int epi_applied;
+  int pk;            // f32x3 / bf16 modes: thin forward layers (3 or 8 input channels) may run the packed-K limb kernel (k_thin_pk.hip)
 };
 
 // flops (2*M*N*K summed over phases) are returned for the profiler.
@@ -133,6 +134,9 @@ const char* launch_wgrad_bf16p(const WgradArgs& a, float* out, int dense, hipStr
 // pixels + col2im in LDS
 bool conv_scatter_eligible(const ConvArgs& a);
 const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s);
+// thin forward convolutions (3 / 8 input channels; 3x3 stride 1, 4x4 stride 2) with (tap, channel) packed into K on limb MFMAs
+bool conv_pk_eligible(const ConvArgs& a);
+const char* launch_conv_pk(const ConvArgs& a, hipStream_t s);
 // convolution with <= 8 input channels: input rows and the whole filter staged in LDS, MFMA operands built from LDS
 bool conv_smallc_eligible(const ConvArgs& a);
 const char* launch_conv_smallc(const ConvArgs& a, hipStream_t s);
@@ -170,6 +174,7 @@ void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int 
 
 // plane-fed bf16 kernel for stride-1 layers (k_conv_bf16p.hip): the gathered operand arrives from a bf16 plane by LDS-DMA
 bool conv_bf16p_eligible(const ConvArgs& a);
+int conv_bf16p_pick_ksplit(const ConvArgs& a);
 const char* launch_conv_bf16p(const ConvArgs& a, hipStream_t s);
 
 // halo-staged limb / bf16 kernel for stride-1 layers (k_gemm_x3h.hip)

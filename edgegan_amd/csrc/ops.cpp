@@ -489,7 +489,6 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
     a.ksplit = ks;
     if (blocks * ks < 128 || !conv_x3h_eligible(a)) a = keep;
   }
-  a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
   WRef* alt_w = c.alt_w;
   c.alt_w = nullptr;
   if (c.cfg.bf16 && a.limbs == 0 && alt_w && xsrc && a.x == (xgrad ? xsrc->g : xsrc->d) && a.x_ps == xsrc->c) {
@@ -517,8 +516,12 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
     a.x_bf = reinterpret_cast<const unsigned short*>(uintptr_t(16));   // (placeholder: eligibility looks at alignment only)
     a.xbf_ps = xsrc->c;
     a.xbf_bytes = pb < (1ull << 31) ? (unsigned)pb : 0u;
+    ConvArgs b = a;
+    b.ksplit = conv_bf16p_pick_ksplit(a);   // (the split of the plane-fed kernel, not the 256-pixel-tile model's)
+    if (conv_bf16p_eligible(b)) a.ksplit = b.ksplit;
     a.x_bf = conv_bf16p_eligible(a) ? tensor_plane(c, xsrc, xgrad) : nullptr;
   }
+  a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
   const char* nm;
   static const bool x3_timing = dbg_env("EG_X3_TIMING") != nullptr;   // experiment: per-phase s_memtime stamps of block 0
   if (x3_timing && a.limbs == 3 && a.ksplit <= 1) {
@@ -780,13 +783,14 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   a.nphase = 1;
   a.ph[0] = ConvPhase{OH, OW, 0, 0, k, k, 0, 0, -pt, -pl};
   attach_bf16(c, a, w, true);    // rows = Cout, contracted = Cin
+  a.pk = (c.cfg.x3 || c.cfg.bf16) ? 1 : 0;   // thin layers: the packed-K limb kernel (fp32 results; the exact-fp32 mode keeps conv_smallc)
   // conv + ReLU / LeakyReLU in one pass where the small-C kernel runs the layer (its epilogue applies the activation; the
   // backward turns dL/d(out) into dL/d(pre) in place from the OUTPUT's sign, like act()): d_conv_0, the encoder stem
   bool fused = false;
   if (fused_act == ACT_RELU || fused_act == ACT_LRELU) {
     static const bool fuse_on = dbg_env("EG_NO_FUSED_ACT") == nullptr;
     a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
-    fused = fuse_on && !accumulate_into && !conv_scatter_eligible(a) && conv_smallc_eligible(a);
+    fused = fuse_on && !accumulate_into && (conv_pk_eligible(a) || (!conv_scatter_eligible(a) && conv_smallc_eligible(a)));
     if (fused) a.act = fused_act;
   }
   if (c.prof_on) c.cur_label = w->name + " fwd";
