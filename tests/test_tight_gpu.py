@@ -84,6 +84,21 @@ def test_substep_gradients_at_1e4_on_margin_selected_fixtures(name):
     _assert(rows, f'{name} (margin {margin:.1e})')
 
 
+# Tolerance of the full-batch rows: max(1e-3, SELF_DEV_FACTOR x the oracle's own fp32-vs-fp64 deviation on this fixture).  The
+# general factor is 2 (it had been raised to 3 right after two rows measured 2.04 x and 2.1 x).  The rows that need
+# more are listed by name with what was measured (profiles/r04n_tight_ratios.txt: every variable's error / self-deviation in
+# both fp32 modes; everything else is <= 1.9 x or below the 1e-3 floor): the two image-side thin convolutions of the classifier's
+# stem -- 3 -> 8 channels over 64 x 64 maps, each filter element a sum over 1.7e7 pixel terms of mixed sign behind ~1e8 PReLU /
+# min-max kinks -- where the oracle's fp32 run (torch CPU, its summation order depends on the host's thread count) is ONE sample
+# of the fp32 noise and the engine's another.
+SELF_DEV_FACTOR = 2.0
+# scalar PReLU slopes: tolerance kappa x this (kappa = sum|t_i| / |sum t_i| of the slope's gradient terms, _full_batch_oracle).
+# Round 3 used 1e-4; the 28 slope rows of both modes measure <= 0.029 of that (r04n), so it is 1e-5 now: a >= 3.4 x margin.
+SLOPE_KAPPA_TOL = 1e-5
+SELF_DEV_OUTLIERS = {
+    'D2/mru_conv_unit_t_1_layer_0/Conv/weights': 2.6,     # measured 2.04 (r03, two boxes), 2.12 (r04n)
+    'D2/Conv/weights': 2.6,                               # measured 1.95 (r04n): inside 2 x on that box, not by a margin
+}
 FULL_BATCH_SUBSTEPS = ['d_optim', 'd_optim_patch3', 'd_optim2', 'g_optim_u', 'e_optim']
 _FULL_BATCH_ORACLE = {}     # name -> (g64, l64, self_dev): the f32x3 re-run of these tests (test_x3_gpu.py) reuses the oracle's work
 
@@ -105,12 +120,12 @@ def _full_batch_oracle(name, cfg, values, b):
         # A scalar PReLU slope's gradient is ONE cancelling sum  sum_i t_i  (t_i = dy_i x_i over the layer's non-positive
         # inputs: 1e5 .. 1.7e7 terms of both signs).  Element-wise relative noise eps in the terms moves the SUM by up to
         # eps * kappa relative to itself, kappa = sum|t_i| / |sum t_i| (measured in the fp64 oracle: 12 .. 8e3 for the 14
-        # slopes).  Its tolerance is therefore kappa x 1e-4 -- a tenth of the 1e-3 the tensors are held to -- where that
-        # exceeds the general rule; expressed through the same per-variable table.
+        # slopes).  Its tolerance is therefore kappa x SLOPE_KAPPA_TOL (1e-5: a hundredth of the 1e-3 the tensors are held to)
+        # where that exceeds the general rule; expressed through the same per-variable table.
         for vn, l1 in getattr(om, 'last_slope_l1', {}).items():
             if vn in g64:
                 kappa = l1 / max(abs(float(g64[vn])), 1e-300)
-                self_dev[vn] = max(self_dev[vn], 1e-4 * kappa / 3.0)
+                self_dev[vn] = max(self_dev[vn], SLOPE_KAPPA_TOL * kappa / SELF_DEV_FACTOR)
         _FULL_BATCH_ORACLE[name] = ({k: v.detach() for k, v in g64.items()}, {k: float(v) for k, v in l64.items()}, self_dev)
     return _FULL_BATCH_ORACLE[name]
 
@@ -120,8 +135,8 @@ def test_full_batch_fp32_substep_against_fp64_oracle(name):
     """B=64, 14 classes, fp32 (BASELINE configs[2]) -- every optimised variable of the sub-step against fp64 autograd, incl.
     the classifier sub-step d_optim2 (edgegan/models/classifier.py:50-115: 54 % of the iteration's FLOPs; every one of its
     58 variables, among them Conv_2/weights of all four units and the update_gate filters).  Tolerance per variable:
-    max(1e-3, 3 x the ORACLE'S OWN fp32-vs-fp64 deviation on this very fixture) in relative L2 -- the rule of
-    parity.substep_checks(self_consistency=True).  Filter gradients here are sums over 64 x H x W pixels (up to 1e6
+    max(1e-3, 2 x the ORACLE'S OWN fp32-vs-fp64 deviation on this very fixture) in relative L2 (SELF_DEV_FACTOR; two named
+    outliers at 2.6 x, SELF_DEV_OUTLIERS) -- the rule of parity.substep_checks(self_consistency=True).  Filter gradients here are sums over 64 x H x W pixels (up to 1e6
     terms, mixed signs) and the batch holds ~30x more near-kink activations than the B=2 fixtures, so ANY fp32
     evaluation of this graph -- the reference's own included -- deviates from exact arithmetic by 1e-4 .. 3e-3; the
     oracle's fp32 run is ONE sample of that noise, the engine's another (measured on MI355X, exact-fp32 mode: d_optim
@@ -135,8 +150,8 @@ def test_full_batch_fp32_substep_against_fp64_oracle(name):
     g64, l64, self_dev = _full_batch_oracle(name, cfg, values, b)
     net = ea.EdgeGAN(cfg, values)
     net.upload_batch(b['images'], b['z'], b['alpha'], b['eps'])
-    rows = _grad_rows(net, None, None, name, 1e-3, 'B=64', var_tol={vn: 3.0 * d for vn, d in self_dev.items()},
-                      precomputed=(g64, l64))
+    rows = _grad_rows(net, None, None, name, 1e-3, 'B=64',
+                      var_tol={vn: SELF_DEV_OUTLIERS.get(vn, SELF_DEV_FACTOR) * d for vn, d in self_dev.items()}, precomputed=(g64, l64))
     net.close()
     if os.environ.get('EG_TIGHT_RATIOS'):     # tools: every variable's error over the oracle's own fp32-vs-fp64 deviation
         with open(os.environ['EG_TIGHT_RATIOS'], 'a') as f:
