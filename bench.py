@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = 93.551 - 2 * 0.3263
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (never the 2:1-sparse figure)
-PMC_SET = 'r03zz'                # the profile set profiles/pmc_utilisation_latest.csv was derived from (tools/gpu_round_profile.sh)
+PMC_SET = 'r04p'                # the profile set profiles/pmc_utilisation_latest.csv was derived from (tools/gpu_round_profile.sh)
 X3_LIMB_PRODUCTS = 6            # limb products issued per fp32 product in f32x3 mode (edgegan_amd/csrc/k_gemm_x3.hip)
 
 
@@ -45,6 +45,22 @@ def pmc_traffic(kernel_label):
             for r in csv.DictReader(f):
                 mk = re.match(r'conv_gemm_x3h_kernel<(\d+), (true|false)(?:, (\d+))?', r['kernel'])
                 if not mk or (int(mk.group(1)), mk.group(2)) != want[:2] or (mk.group(3) and mk.group(3) != want[2]):
+                    continue
+                if best is None or int(r['launches']) > int(best['launches']):
+                    best = r
+        if best:
+            return float(best['hbm_read_bytes_per_launch(2xFETCH_SIZE)']) + float(best['hbm_write_bytes_per_launch'])
+    # plane-fed bf16 kernels (round 4): conv_bf16p<PX,BN[,splitk]> = conv_bf16p_kernel<MI, WN, SPLITK, ...> with
+    # (PX, BN) -> (MI, WN): (128,128) -> (2,2), (256,128) -> (4,2), (256,64) -> (2,1); the bf16 round profile's table
+    mp = re.match(r'conv_bf16p<(\d+),(\d+)(,splitk)?>', kernel_label)
+    bpath = os.path.join(ROOT, 'profiles', 'pmc_utilisation_bf16_latest.csv')
+    if mp and os.path.exists(bpath):
+        mi_wn = {('128', '128'): ('2', '2'), ('256', '128'): ('4', '2'), ('256', '64'): ('2', '1')}.get((mp.group(1), mp.group(2)))
+        best = None
+        with open(bpath) as f:
+            for r in csv.DictReader(f):
+                mk = re.match(r'conv_bf16p_kernel<(\d+), (\d+), (true|false)', r['kernel'])
+                if not mk or not mi_wn or (mk.group(1), mk.group(2)) != mi_wn or (mk.group(3) == 'true') != bool(mp.group(3)):
                     continue
                 if best is None or int(r['launches']) > int(best['launches']):
                     best = r
