@@ -1017,6 +1017,7 @@ int wgrad_pick_splits(const WgradArgs& a) {
     // waves): filter-gradient kernels 7.05 -> 6.70 ms per iteration and half the partial slabs to write and reduce
     return pick_balanced_splits(tiles, 256, std::min(256LL, (M + 255) / 256));
   }
+  if (wgrad_pk_eligible(a)) return wgrad_pk_splits(a);
   if (wgrad_flatm(a)) {
     const long long tiles = (long long)((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64);
     // latency-bound (one gather round trip per 32-pixel step, prefetch distance 1): eight resident blocks per CU hide it
@@ -1055,6 +1056,8 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
     nm = launch_wgrad_bf16p(a, out, dense, s);
   } else if (wgrad_x3(a) && (((uintptr_t)out & 15) == 0)) {
     nm = launch_wgrad_x3(a, out, dense, true, s);
+  } else if (wgrad_pk_eligible(a) && (((uintptr_t)out & 15) == 0)) {
+    nm = launch_wgrad_pk(a, out, dense, s);
   } else if (a.bf16 && vec && !wgrad_flatm(a)) {
     nm = launch_wgrad_bf16(a, out, dense, wgrad_big(a), s);
   } else if (wgrad_flatm(a)) {

@@ -122,6 +122,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned total, int of
 // k_elem.hip: a memory-free v_mfma_f32_32x32x16_bf16 loop, blocks x 8 waves x iters x 16 MFMAs (scratch >= blocks * 512 floats)
 void launch_mfma_probe(float* scratch, int blocks, int iters, int random_operands, hipStream_t s);
 int wgrad_x3_rowhalo_units(const WgradArgs& a);   // k_gemm_x3.hip: units of the row-halo filter-gradient kernel (0: it does not apply)
+// k_thin_wgrad.hip: filter gradients with 3 / 8 gathered channels, (tap, channel) packed into the MFMA's rows
+bool wgrad_pk_eligible(const WgradArgs& a);
+int wgrad_pk_splits(const WgradArgs& a);
+const char* launch_wgrad_pk(const WgradArgs& a, float* out, int dense, hipStream_t s);
 int wgrad_pick_splits(const WgradArgs& a);
 size_t wgrad_workspace_floats(const WgradArgs& a);
 double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name);

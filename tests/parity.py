@@ -75,6 +75,14 @@ CONV_CASES = [
     ('cls mru Conv 3x3 C3->128 32x32 (image rows)', 2, 32, 32, 3, 128, 3, 1, 0, True),
     ('cls mru Conv 3x3 C3->512 8x8', 3, 8, 8, 3, 512, 3, 1, 0, False),
     ('d_conv_0-like 4x4s2 C3->64 64x128', 1, 64, 128, 3, 64, 4, 2, 0, False),
+    # ... and the remaining shapes of the packed filter-gradient kernel (k_thin_wgrad.hip): 8 / 3 gathered channels against 8
+    # output channels (one 16-column tile, four pixel sub-ranges per block), the 1x1 layer, 32-pixel segments of 64-wide rows
+    # under the 7x7 halo, REFLECT padding with 8 four-pixel rows per K step across 3 images
+    ('cls gate 3x3 C8->8 32x32 (hidden rows of unit 1)', 2, 32, 32, 8, 8, 3, 1, 0, True),
+    ('cls Conv_3 1x1 C8->128 16x16', 2, 16, 16, 8, 128, 1, 1, 0, True),
+    ('cls mru Conv 3x3 C3->8 64x64 (32-pixel segments)', 1, 64, 64, 3, 8, 3, 1, 0, True),
+    ('cls h0 7x7 C3->8 64x64', 1, 64, 64, 3, 8, 7, 1, 0, True),
+    ('thin REFLECT 3x3 C3->32 8x4 nb3', 3, 8, 4, 3, 32, 3, 1, 1, True),
     # stride-1 layers with >= 128 output channels: the halo-staged kernel (k_gemm_x3h.hip) in the f32x3 / bf16 modes --
     # one 16x16 tile per image, 2x2 tiles per image, 4 images per tile, and the 2x2-tap phases of a stride-2 input gradient
     ('cls Conv_2 3x3 C128->128 16x16', 2, 16, 16, 128, 128, 3, 1, 0, True),
