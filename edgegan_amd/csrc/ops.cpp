@@ -469,6 +469,7 @@ static unsigned short* producer_plane(Ctx& c, T t, bool grad) {
 // xsrc / xgrad: the tensor whose data (gradient) a.x is -- the bf16 mode's plane-fed kernel reads its bf16 plane instead
 static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
   a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
+  a.pk = (c.cfg.x3 || c.cfg.bf16) ? 1 : 0;   // thin layers: the packed-K limb kernel (fp32 results; the exact-fp32 mode keeps conv_smallc)
   {
     const size_t xb = (size_t)a.NB * a.IH * a.IW * a.x_ps * sizeof(float);
     a.x_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
