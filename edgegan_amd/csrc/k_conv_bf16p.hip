@@ -497,8 +497,9 @@ int conv_bf16p_pick_ksplit(const ConvArgs& a) {
   if (!bf16p_geometry(a, n128 ? 128 : 256, n128 ? kHR128 : kHR256, &g)) return 1;
   const long long tiles = (long long)(a.NB / g.TI) * g.tiles_x * g.tiles_y * ((a.N + (n128 ? 127 : 63)) / (n128 ? 128 : 64)) * a.nphase;
   const int chunks = (bf16p_s2d_shape(a) ? 4 : 1) * (a.C / 32);
-  if (tiles >= 448 || chunks < 4) return 1;
-  int ks = (int)((512 + tiles - 1) / tiles);
+  static const int target = dbg_env("EG_BF16P_KS_BLOCKS") ? atoi(dbg_env("EG_BF16P_KS_BLOCKS")) : 256;   // in-box 2,961 / 2,963 / 2,997 / 2,971 / 2,948 images/s at 512 / 384 / 256 / 192 / 128 (profiles/r04v_ab_ksplit.txt)
+  if (tiles >= target * 7 / 8 || chunks < 4) return 1;
+  int ks = (int)((target + tiles - 1) / tiles);
   ks = std::min(ks, std::min(8, chunks / 2));
   return ks < 2 ? 1 : ks;
 }

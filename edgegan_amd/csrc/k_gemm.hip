@@ -1005,9 +1005,12 @@ static bool wgrad_x3(const WgradArgs& a) {   // (limbs == 1: the same kernel wit
 
 int wgrad_pick_splits(const WgradArgs& a) {
   const long long M = (long long)a.NB * a.OH * a.OW;
-  if (const int pu = wgrad_bf16p_units(a)) {   // plane-fed kernel: 256-thread blocks, three per CU; a slab is >= 8 K steps of 32 pixels
+  if (const int pu = wgrad_bf16p_units(a)) {   // plane-fed kernel: 256-thread blocks, up to three per CU; a slab is >= 8 K steps of 32 pixels.  Target 384 blocks: with 768
+                                               // (three full waves) the slabs cost more in the second-stage reduction than the occupancy gained --
+                                               // in-box 2,870 / 2,885 / 2,944 / 2,943 images/s at 768 / 512 / 384 / 256 (profiles/r04u_ab_splits.txt)
     const long long tiles = (long long)pu * ((a.N + 127) / 128);
-    return pick_balanced_splits(tiles, 768, std::min(256LL, (M + 255) / 256));
+    static const int target = dbg_env("EG_WGRAD_BF16P_BLOCKS") ? atoi(dbg_env("EG_WGRAD_BF16P_BLOCKS")) : 384;
+    return pick_balanced_splits(tiles, target, std::min(256LL, (M + 255) / 256));
   }
   if (wgrad_x3(a)) {   // ping-pong blocks: two (tap, 128-channel) units x 128 output channels, one block per CU
     const long long units = wgrad_x3_rowhalo_units(a) ? wgrad_x3_rowhalo_units(a)     // (filter row, column phase, 64-channel block)
