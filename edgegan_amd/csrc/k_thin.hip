@@ -40,14 +40,20 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // reads its 8 B-operands of a column tile with two ds_read_b128.  Operands are swapped (D^T = B^T A^T): lane l ends up
 // with columns 16 ct + 4 g .. + 3 of pixel p -> one ds_write_b128 per tile and column tile.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int N>
+//
+// X3 (the f32x3 and bf16 modes; round 4): the same product on the bf16 MFMA with three-limb operands -- the lane's 8
+// channels ARE the 8 K-values v_mfma_f32_16x16x32_bf16 takes from lane (p, g), so the operand registers are split in place
+// (k_gemm_x3.hip: split_pair) and one K step of 32 channels is 6 limb MFMAs of 16 cycles per column tile instead of 8 fp32
+// MFMAs of 32; the filter image holds the three limb planes [limb][C / 8][NP][8] bf16 (one ds_read_b128 per plane).
+template <int N, bool X3>
 __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int S, int R, int lw) {
   constexpr int NT = (9 * N + 15) / 16;
   constexpr int NP = NT * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = a.C, H = a.IH, W = a.IW;
-  float* Wl = smem;                        // [C / 8][NP][8]
-  float* Pr = smem + (size_t)C * NP;       // [(2R + 2) rows][W][NP]
+  float* Wl = smem;                        // [C / 8][NP][8] fp32, or X3: [3][C / 8][NP][8] bf16
+  unsigned short* Wb = reinterpret_cast<unsigned short*>(smem);
+  float* Pr = smem + (X3 ? (size_t)C * NP * 3 / 2 : (size_t)C * NP);       // [(2R + 2) rows][W][NP]
   const int ring = 2 * R + 2;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) == 0;
@@ -77,15 +83,36 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
           dst[u] = ((c >> 3) * NP + tap * N + n) * 8 + (c & 7);
         }
       }
+      const int plane = C * NP;             // elements of a limb plane
+      auto bf = [](float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); };
+      auto bff = [](unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); };
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (dst[u] >= 0) Wl[dst[u]] = v[u];
+        if (dst[u] >= 0) {
+          if constexpr (X3) {
+            const unsigned short h0 = bf(v[u]);
+            const float r1 = v[u] - bff(h0);
+            const unsigned short h1 = bf(r1);
+            Wb[dst[u]] = h0;
+            Wb[plane + dst[u]] = h1;
+            Wb[2 * plane + dst[u]] = bf(r1 - bff(h1));
+          } else {
+            Wl[dst[u]] = v[u];
+          }
+        }
     }
     constexpr int PADC = NP - 9 * N;
     if constexpr (PADC > 0)
       for (int i = threadIdx.x; i < C * PADC; i += 512) {
         const int c = i / PADC, col = 9 * N + (i - c * PADC);
-        Wl[((c >> 3) * NP + col) * 8 + (c & 7)] = 0.f;
+        const int d = ((c >> 3) * NP + col) * 8 + (c & 7);
+        if constexpr (X3) {
+          Wb[d] = 0;
+          Wb[C * NP + d] = 0;
+          Wb[2 * C * NP + d] = 0;
+        } else {
+          Wl[d] = 0.f;
+        }
       }
   }
 
@@ -242,14 +269,31 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
   __syncthreads();   // filter image complete
 
   const float* wl_lane = Wl + ((size_t)g * NP + p15) * 8;
+  const unsigned short* wb_lane = Wb + ((size_t)g * NP + p15) * 8;
   int cur_k = 0, cur_j = 0, cur_ks = 0;
-  f32x4 bb[2][NT][2];   // filter fragments of the current / the next item (double buffered by item parity; PD is even)
-  auto load_b = [&](f32x4 (&b)[NT][2], int ks) __attribute__((always_inline)) {
-    const float* wk = wl_lane + (size_t)ks * 4 * NP * 8;
+  typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+  constexpr int NBR = X3 ? 3 : 2;   // filter registers per column tile: three limb planes / two fp32 quads
+  f32x4 bb[2][NT][NBR];   // filter fragments of the current / the next item (double buffered by item parity; PD is even)
+  auto load_b = [&](f32x4 (&b)[NT][NBR], int ks) __attribute__((always_inline)) {
+    if constexpr (X3) {
+      const unsigned short* wk = wb_lane + (size_t)ks * 4 * NP * 8;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) b[t][0] = *reinterpret_cast<const f32x4*>(wk + t * 16 * 8);
+      for (int l = 0; l < 3; ++l)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) b[t][1] = *reinterpret_cast<const f32x4*>(wk + t * 16 * 8 + 4);
+        for (int t = 0; t < NT; ++t) b[t][l] = *reinterpret_cast<const f32x4*>(wk + (size_t)l * C * NP + t * 16 * 8);
+    } else {
+      const float* wk = wl_lane + (size_t)ks * 4 * NP * 8;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t][0] = *reinterpret_cast<const f32x4*>(wk + t * 16 * 8);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t][1] = *reinterpret_cast<const f32x4*>(wk + t * 16 * 8 + 4);
+    }
+  };
+  auto pk2s = [](float lo, float hi) __attribute__((always_inline)) {
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+    const f32x2s v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2s));
   };
   load_b(bb[0], 0);
   for (int it = 0; it < items; it += PD) {
@@ -262,16 +306,43 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
         // this item's filter fragments were requested one item ago; request the next item's before multiplying
         const int nks = cur_ks + 1 == KS ? 0 : cur_ks + 1;
         load_b(bb[(u + 1) & 1], nks);
+        if constexpr (X3) {
+          // the lane's 8 channels as three limb octets: x = l0 + l1 + l2 exactly
+          u32x4 x0, x1, x2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int q = 0; q < 4; ++q) {
+            const float lo = q < 2 ? a0[2 * q] : a1[2 * q - 4], hi = q < 2 ? a0[2 * q + 1] : a1[2 * q - 3];
+            const unsigned p0 = pk2s(lo, hi);
+            const float rl = lo - __builtin_bit_cast(float, p0 << 16), rh = hi - __builtin_bit_cast(float, p0 & 0xffff0000u);
+            const unsigned p1 = pk2s(rl, rh);
+            x0[q] = p0;
+            x1[q] = p1;
+            x2[q] = pk2s(rl - __builtin_bit_cast(float, p1 << 16), rh - __builtin_bit_cast(float, p1 & 0xffff0000u));
+          }
+          const bf16x8s xa = __builtin_bit_cast(bf16x8s, x0), xb = __builtin_bit_cast(bf16x8s, x1), xc = __builtin_bit_cast(bf16x8s, x2);
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[u & 1][t][0][j], a0[j], acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) {   // six limb products down to 2^-16 of the leading one, smallest first
+            const bf16x8s w0 = __builtin_bit_cast(bf16x8s, bb[u & 1][t][0]), w1 = __builtin_bit_cast(bf16x8s, bb[u & 1][t][1]),
+                          w2 = __builtin_bit_cast(bf16x8s, bb[u & 1][t][2]);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, xa, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xc, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xb, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xa, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xb, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xa, acc[t], 0, 0, 0);
+          }
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[u & 1][t][1][j], a1[j], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[u & 1][t][0][j], a0[j], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[u & 1][t][1][j], a1[j], acc[t], 0, 0, 0);
+        }
         if (++cur_ks == KS) {   // tile complete: its NP columns -> ring
           cur_ks = 0;
           const int idx = ((wave + 4 * cur_j) << 4) + p15;
@@ -300,6 +371,11 @@ static int ilog2(int v) {
   return l;
 }
 
+static bool scatter_x3(const ConvArgs& a) {   // f32x3 / bf16 modes: limb products on the bf16 MFMA (fp32 results)
+  static const bool off = dbg_env("EG_SCATTER_F32") != nullptr;
+  return a.pk && !off;
+}
+
 static bool scatter_geometry(const ConvArgs& a, int* S, int* R, size_t* lds) {
   const int W = a.IW, H = a.IH;
   if (W < 4 || (W & (W - 1)) != 0) return false;
@@ -314,8 +390,9 @@ static bool scatter_geometry(const ConvArgs& a, int* S, int* R, size_t* lds) {
   s = (s + r - 1) / r * r;
   *S = s;
   *R = r;
-  *lds = ((size_t)a.C * NP + (size_t)(2 * r + 2) * W * NP) * sizeof(float);
-  return *lds <= 150 * 1024;
+  const bool x3 = scatter_x3(a);
+  *lds = ((x3 ? (size_t)a.C * NP * 3 / 2 : (size_t)a.C * NP) + (size_t)(2 * r + 2) * W * NP) * sizeof(float);
+  return *lds <= (x3 ? 160 : 150) * 1024;
 }
 
 bool conv_scatter_eligible(const ConvArgs& a) {
@@ -332,27 +409,36 @@ bool conv_scatter_eligible(const ConvArgs& a) {
   return scatter_geometry(a, &S, &R, &lds);
 }
 
-template <int N>
+template <int N, bool X3>
 static void scatter_launch(const ConvArgs& a, int S, int R, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_scatter_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_scatter_kernel<N, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr_set = true;
   }
   const int strips = (a.IH + S - 1) / S;
-  hipLaunchKernelGGL((conv_scatter_kernel<N>), dim3(a.NB * strips), dim3(512), lds, s, a, S, R, ilog2(a.IW));
+  hipLaunchKernelGGL((conv_scatter_kernel<N, X3>), dim3(a.NB * strips), dim3(512), lds, s, a, S, R, ilog2(a.IW));
 }
 
 const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s) {
   int S, R;
   size_t lds;
   scatter_geometry(a, &S, &R, &lds);
+  if (scatter_x3(a)) {
+    switch (a.N) {
+      case 3: scatter_launch<3, true>(a, S, R, lds, s); break;
+      case 4: scatter_launch<4, true>(a, S, R, lds, s); break;
+      case 8: scatter_launch<8, true>(a, S, R, lds, s); break;
+      default: scatter_launch<12, true>(a, S, R, lds, s); break;
+    }
+    return "conv_scatter<3x3,N<=12,limbs>";
+  }
   switch (a.N) {
-    case 3: scatter_launch<3>(a, S, R, lds, s); break;
-    case 4: scatter_launch<4>(a, S, R, lds, s); break;
-    case 8: scatter_launch<8>(a, S, R, lds, s); break;
-    default: scatter_launch<12>(a, S, R, lds, s); break;
+    case 3: scatter_launch<3, false>(a, S, R, lds, s); break;
+    case 4: scatter_launch<4, false>(a, S, R, lds, s); break;
+    case 8: scatter_launch<8, false>(a, S, R, lds, s); break;
+    default: scatter_launch<12, false>(a, S, R, lds, s); break;
   }
   return "conv_scatter<3x3,N<=12>";
 }
