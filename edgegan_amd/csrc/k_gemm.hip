@@ -362,7 +362,8 @@ static int pick_x3(ConvArgs& a) {
         steps = (double)per * (nk_t / chunks);
       }
       double t = (double)((blocks + slots - 1) / slots) * steps * (tile == 1 ? 2.0 : 0.76) + (tile == 1 ? 3.0 : 1.0);
-      if (ks > 1) t += (ks + 1) * out_bytes / 3.0e12 / 1.3e-6 + 4.0;   // slab reduction + its launch
+      static const double slab_w = dbg_env("EG_X3_SLAB_COST") ? atof(dbg_env("EG_X3_SLAB_COST")) : 1.0;
+      if (ks > 1) t += slab_w * ((ks + 1) * out_bytes / 3.0e12 / 1.3e-6 + 4.0);   // slab reduction + its launch
       if (t < best) {
         best = t;
         best_ks = ks;
