@@ -15,6 +15,7 @@ sub-step 3 on the other image half; sub-step 7 is sub-step 5 after the encoder's
 import importlib.util
 import json
 import os
+import re
 
 import numpy as np
 import pytest
@@ -99,6 +100,18 @@ SELF_DEV_OUTLIERS = {
     'D2/mru_conv_unit_t_1_layer_0/Conv/weights': 2.6,     # measured 2.04 (r03, two boxes), 2.12 (r04n)
     'D2/Conv/weights': 2.6,                               # measured 1.95 (r04n): inside 2 x on that box, not by a margin
 }
+# Kink flips in the full-batch rows.  At B = 64 the encoder's deep blocks (512 channels on 8x8 ... 2x2 maps: InstanceNorm over
+# 64 ... 4 pixels) hold ~1e6 ReLU inputs per sub-step and the fp64 oracle itself finds some within fp32 rounding of the kink
+# (e_optim on this fixture: |x| / rms = 2.5e-7, 1.1e-6, 1.6e-6, 2.4e-6 -- MARGIN is 3e-6).  Which side an fp32 evaluation lands
+# on depends on its rounding, not on its correctness: the oracle's own fp32 run flips some (its deviation from fp64 on the two
+# filters next to such an element: 1.6e-3 ... 2.8e-3), the engine's modes others (round 4: re-ordering the sums of the
+# generators' 3-channel output layer moved E/e_resnet_512_4/res1 and res2 from 1.8e-3 / 7e-4 to 5.5e-3 / 5.0e-3 in the f32x3
+# mode, error concentrated in a few elements: max-norm 10 x the L2 figure).  A flip costs the adjacent filters' gradients up to
+# ~5e-3 in relative L2, a wiring error >= 1e-1.  Rule: ONLY IF the oracle's fp64 pass records a small-extent ReLU input inside
+# MARGIN, the residual-branch filters of the encoder's two deepest blocks are judged at FLIP_TOL, the ordinary sub-step tests'
+# flip-tolerant bound (tests/parity.py:substep_checks); everything else keeps the tight rule.
+FLIP_TOL = 1e-2
+FLIP_EXPOSED = re.compile(r'^E/e_resnet_512_[34]/res[12]/conv2d/w$')
 FULL_BATCH_SUBSTEPS = ['d_optim', 'd_optim_patch3', 'd_optim2', 'g_optim_u', 'e_optim']
 _FULL_BATCH_ORACLE = {}     # name -> (g64, l64, self_dev): the f32x3 re-run of these tests (test_x3_gpu.py) reuses the oracle's work
 
@@ -112,9 +125,11 @@ def _full_batch_oracle(name, cfg, values, b):
         g32, _ = om32.compute_grads(name, inp32, inp32.eps[0])
         O._SLOPE_TERMS = {}          # record sum_i |t_i| of every PReLU slope's gradient terms (conditioning, below)
         try:
-            g64, l64 = om.compute_grads(name, inp, inp.eps[0])
+            with O.kink_recorder() as rec:
+                g64, l64 = om.compute_grads(name, inp, inp.eps[0])
         finally:
             O._SLOPE_TERMS = None
+        near_kink = rec.margin(SF.SMALL_EXTENT) < MARGIN
         gmax = max(float(g.abs().max()) for g in g64.values())
         self_dev = {vn: parity.rel_l2(g32[vn].double().numpy(), g.numpy(), 1e-5 * gmax) for vn, g in g64.items()}
         # A scalar PReLU slope's gradient is ONE cancelling sum  sum_i t_i  (t_i = dy_i x_i over the layer's non-positive
@@ -126,7 +141,7 @@ def _full_batch_oracle(name, cfg, values, b):
             if vn in g64:
                 kappa = l1 / max(abs(float(g64[vn])), 1e-300)
                 self_dev[vn] = max(self_dev[vn], SLOPE_KAPPA_TOL * kappa / SELF_DEV_FACTOR)
-        _FULL_BATCH_ORACLE[name] = ({k: v.detach() for k, v in g64.items()}, {k: float(v) for k, v in l64.items()}, self_dev)
+        _FULL_BATCH_ORACLE[name] = ({k: v.detach() for k, v in g64.items()}, {k: float(v) for k, v in l64.items()}, self_dev, near_kink)
     return _FULL_BATCH_ORACLE[name]
 
 
@@ -147,11 +162,15 @@ def test_full_batch_fp32_substep_against_fp64_oracle(name):
     cfg = ea.Config(batch_size=64)
     values = ea.init_variables(cfg, 0)
     b = ea.synthetic_batch(cfg)
-    g64, l64, self_dev = _full_batch_oracle(name, cfg, values, b)
+    g64, l64, self_dev, near_kink = _full_batch_oracle(name, cfg, values, b)
     net = ea.EdgeGAN(cfg, values)
     net.upload_batch(b['images'], b['z'], b['alpha'], b['eps'])
-    rows = _grad_rows(net, None, None, name, 1e-3, 'B=64',
-                      var_tol={vn: SELF_DEV_OUTLIERS.get(vn, SELF_DEV_FACTOR) * d for vn, d in self_dev.items()}, precomputed=(g64, l64))
+    var_tol = {vn: SELF_DEV_OUTLIERS.get(vn, SELF_DEV_FACTOR) * d for vn, d in self_dev.items()}
+    if near_kink:       # (see FLIP_TOL above)
+        for vn in var_tol:
+            if FLIP_EXPOSED.match(vn):
+                var_tol[vn] = max(var_tol[vn], FLIP_TOL)
+    rows = _grad_rows(net, None, None, name, 1e-3, 'B=64', var_tol=var_tol, precomputed=(g64, l64))
     net.close()
     if os.environ.get('EG_TIGHT_RATIOS'):     # tools: every variable's error over the oracle's own fp32-vs-fp64 deviation
         with open(os.environ['EG_TIGHT_RATIOS'], 'a') as f:
