@@ -269,6 +269,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
 #else
 #define EG_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #endif
+#ifndef EG_X3H_BURST
+#define EG_X3H_BURST 0
+#endif
 #define EG_WAIT4(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]))
 #define EG_WAIT2(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0][0]), "+v"(f[0][1]))
   // one limb product: 8 MFMAs of the wave's 2 x 2 accumulators over the K step's two 16-wide halves
@@ -393,10 +396,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
         read_a(a0, aa, P0);      // (after a chunk's last tap: stale rows, replaced by the re-read at t == 0)
         read_b(b0, bbn, P0);
       } else {
-        // LDS reads return in order: a1 (2 MI), a2 (2 MI), b1 (4), b2 (4), then the next b0 (4), then the next a0 (2 MI)
         bf16x8 b1[2][2], b2[2][2], a1[MI][2], a2[MI][2];
-        // the first product's MFMAs with the step's 12 / 16 fragment reads dealt out between them: eight waves issuing
-        // their reads in one burst fill the LDS queue, and an in-order wave cannot issue the MFMA behind a blocked read
+#if EG_X3H_BURST   // round 2-3 schedule, kept for the A/B: the step's 12 / 16 reads dealt out between the FIRST product's MFMAs
+        // LDS reads return in order: a1 (2 MI), a2 (2 MI), b1 (4), b2 (4), then the next b0 (4), then the next a0 (2 MI)
         {
           constexpr int NM = 4 * MI;   // MFMAs of a product
 #pragma unroll
@@ -443,6 +445,56 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
         read_a(a0, aa, P0);      // (after a chunk's last tap: stale rows, replaced by the re-read at t == 0)
         __builtin_amdgcn_sched_barrier(0);
         mm(a1, b1);
+#else
+        // Round 4: ONE fragment group per product, requested under that product's first two MFMAs and consumed by the NEXT
+        // product -- a1 | a2 | b1 | b2 | next b0 | next a0 under a0b0 | a1b0 | a2b0 | a0b1 | a0b2 | a1b1.  The earlier schedule
+        // put the step's 16 reads under the first product: eight waves then ask the LDS for 128 KB in the ~512 cycles that
+        // product lasts on a SIMD, twice what it delivers, and an in-order wave cannot issue the MFMA behind a read the full
+        // queue refuses -- the matrix pipe starved for ~500 of a step's ~3,100 cycles ("fragment reads 20 %").
+        // Spread, the LDS runs at an even ~50 %, and at most five fragment groups are live instead of six.
+        // `R0` / `R1`: the reads issued behind the product's first / second MFMA.
+#define EG_PROD(af, bf, R0, R1)                                                   \
+  do {                                                                            \
+    constexpr int NM_ = 4 * MI;                                                   \
+    _Pragma("unroll") for (int n_ = 0; n_ < NM_; ++n_) {                          \
+      const int kk_ = n_ / (2 * MI), i_ = (n_ / 2) % MI, j_ = n_ % 2;             \
+      mfma_acc(acc[i_][j_], bf[j_][kk_], af[i_][kk_]);                            \
+      if (n_ == 0) { R0 }                                                         \
+      if (n_ == 1) { R1 }                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+    }                                                                             \
+  } while (0)
+        const unsigned aa0 = aa[0], aa1 = aa[MI - 1];
+        // a0 b0, a1 arriving
+        EG_PROD(a0, b0, EG_DSR(a1[0][0], aa0, 1 * APL); EG_DSR(a1[0][1], aa0 ^ 32u, 1 * APL);,
+                if constexpr (MI == 2) { EG_DSR(a1[MI - 1][0], aa1, 1 * APL); EG_DSR(a1[MI - 1][1], aa1 ^ 32u, 1 * APL); });
+        if (k + 2 < nt) request_b();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MI == 2) EG_WAIT4(0, a1);
+        else EG_WAIT2(0, a1);
+        // a1 b0, a2 arriving
+        EG_PROD(a1, b0, EG_DSR(a2[0][0], aa0, 2 * APL); EG_DSR(a2[0][1], aa0 ^ 32u, 2 * APL);,
+                if constexpr (MI == 2) { EG_DSR(a2[MI - 1][0], aa1, 2 * APL); EG_DSR(a2[MI - 1][1], aa1 ^ 32u, 2 * APL); });
+        if constexpr (MI == 2) EG_WAIT4(0, a2);
+        else EG_WAIT2(0, a2);
+        // a2 b0, b1 arriving
+        EG_PROD(a2, b0, EG_DSR(b1[0][0], bb, 1 * BPL); EG_DSR(b1[0][1], bb ^ 32u, 1 * BPL);,
+                EG_DSR(b1[1][0], bb, 1 * BPL + 2048); EG_DSR(b1[1][1], bb ^ 32u, 1 * BPL + 2048););
+        EG_WAIT4(0, b1);
+        // a0 b1, b2 arriving
+        EG_PROD(a0, b1, EG_DSR(b2[0][0], bb, 2 * BPL); EG_DSR(b2[0][1], bb ^ 32u, 2 * BPL);,
+                EG_DSR(b2[1][0], bb, 2 * BPL + 2048); EG_DSR(b2[1][1], bb ^ 32u, 2 * BPL + 2048););
+        EG_WAIT4(0, b2);
+        // a0 b2, the next step's b0 arriving (tile k+1; after the last step: a stale slot, never used)
+        EG_PROD(a0, b2, EG_DSR(b0[0][0], bbn, 0); EG_DSR(b0[0][1], bbn ^ 32u, 0);,
+                EG_DSR(b0[1][0], bbn, 2048); EG_DSR(b0[1][1], bbn ^ 32u, 2048););
+        // a1 b1, the next tap's a0 arriving (after a chunk's last tap: stale rows, replaced by the re-read at t == 0)
+        tap_addr(ty, tx, aa);
+        const unsigned an0 = aa[0], an1 = aa[MI - 1];
+        EG_PROD(a1, b1, EG_DSR(a0[0][0], an0, 0); EG_DSR(a0[0][1], an0 ^ 32u, 0);,
+                if constexpr (MI == 2) { EG_DSR(a0[MI - 1][0], an1, 0); EG_DSR(a0[MI - 1][1], an1 ^ 32u, 0); });
+#undef EG_PROD
+#endif
       }
       slot = nslot;
     }
