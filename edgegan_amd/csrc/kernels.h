@@ -72,6 +72,8 @@ struct ConvArgs {
   const float* epi_ref;
   int epi_act;
   int epi_applied;
+  unsigned short* y_bf;   // bf16 mode, conv_pk only: also store the (activated) output's bf16 plane [pixel][y_ps] -- the next
+                          // convolution reads it by LDS-DMA and no conversion pass runs (d_conv_0 + LeakyReLU -> d_conv_1)
   int pk;            // f32x3 / bf16 modes: thin forward layers (3 or 8 input channels) may run the packed-K limb kernel (k_thin_pk.hip)
 };
 

@@ -793,6 +793,9 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
     fused = fuse_on && !accumulate_into && (conv_pk_eligible(a) || (!conv_scatter_eligible(a) && conv_smallc_eligible(a)));
     if (fused) a.act = fused_act;
+    // bf16 mode: the packed-K kernel also stores the activated output's plane (N % 4 == 0 and a 4-aligned pitch: its float4 path)
+    static const bool pk_plane = dbg_env("EG_NO_PK_PLANE") == nullptr;
+    if (fused && pk_plane && conv_pk_eligible(a) && N % 4 == 0 && a.y_ps % 4 == 0) a.y_bf = producer_plane(c, y, false);
   }
   if (c.prof_on) c.cur_label = w->name + " fwd";
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
