@@ -438,6 +438,10 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
   }
   if (conv_pk_eligible(a)) {
     nm = launch_conv_pk(a, s);
+#ifdef EG_EXPERIMENTS
+  } else if (a.x3q && a.N > 16 && conv_x3q_eligible(a)) {
+    nm = launch_conv_x3q(a, s);
+#endif
   } else if (conv_scatter_eligible(a)) {
     nm = launch_conv_scatter(a, s);
   } else if (conv_smallc_eligible(a)) {

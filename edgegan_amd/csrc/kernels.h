@@ -72,6 +72,7 @@ struct ConvArgs {
   const float* epi_ref;
   int epi_act;
   int epi_applied;
+  int x3q;           // experiments build: run_conv chose the two-blocks-per-CU halo kernel (k_gemm_x3q.hip) and ITS K split for this launch
   unsigned short* y_bf;   // bf16 mode, conv_pk only: also store the (activated) output's bf16 plane [pixel][y_ps] -- the next
                           // convolution reads it by LDS-DMA and no conversion pass runs (d_conv_0 + LeakyReLU -> d_conv_1)
   int pk;            // f32x3 / bf16 modes: thin forward layers (3 or 8 input channels) may run the packed-K limb kernel (k_thin_pk.hip)
@@ -80,6 +81,13 @@ struct ConvArgs {
 // flops (2*M*N*K summed over phases) are returned for the profiler.
 double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_name);
 int conv_pick_ksplit(ConvArgs& a);   // also sets a.x3_tile for limb-mode launches
+#ifdef EG_EXPERIMENTS
+// k_gemm_x3q.hip (experiments build, EG_X3Q=1): the f32x3 halo convolution at two blocks per CU (128 x 128 tiles, 16-channel
+// K chunks) -- built and parity-green in round 4, equal to the one-block kernel within +-5 % per layer: docs/experiments.md
+bool conv_x3q_eligible(const ConvArgs& a);
+int conv_x3q_pick_ksplit(const ConvArgs& a);
+const char* launch_conv_x3q(const ConvArgs& a, hipStream_t s);
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[wt(tap)][c][n] = sum_m X[pix_in(m,tap)][c] * dY[m][n], m over NB*OH*OW

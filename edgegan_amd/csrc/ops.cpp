@@ -490,6 +490,16 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
     a.ksplit = ks;
     if (blocks * ks < 128 || !conv_x3h_eligible(a)) a = keep;
   }
+#ifdef EG_EXPERIMENTS
+  if (a.limbs == 3 && a.x3_tile == 1) {   // EG_X3Q=1: the launches of the one-block-per-CU halo kernel that the two-block form takes
+    ConvArgs b = a;
+    b.ksplit = conv_x3q_pick_ksplit(a);
+    if (conv_x3q_eligible(b)) {
+      a.ksplit = b.ksplit;
+      a.x3q = 1;
+    }
+  }
+#endif
   WRef* alt_w = c.alt_w;
   c.alt_w = nullptr;
   if (c.cfg.bf16 && a.limbs == 0 && alt_w && xsrc && a.x == (xgrad ? xsrc->g : xsrc->d) && a.x_ps == xsrc->c) {
@@ -531,7 +541,7 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
   }
   ProfScope ps(c);
   const double fl = launch_conv_gemm(a, c.stream, &nm);
-  a.epi_applied = a.epi_act && (strncmp(nm, "conv_gemm_x3h<", 14) == 0 || strncmp(nm, "conv_gemm_bf16h<", 16) == 0 || strncmp(nm, "conv_bf16p<", 11) == 0) &&
+  a.epi_applied = a.epi_act && (strncmp(nm, "conv_gemm_x3h<", 14) == 0 || strncmp(nm, "conv_gemm_x3q<", 14) == 0 || strncmp(nm, "conv_gemm_bf16h<", 16) == 0 || strncmp(nm, "conv_bf16p<", 11) == 0) &&
                           !strstr(nm, "splitk") ? 1 : 0;   // (the kernels that honour ConvArgs::epi_act)
   if (x3_timing && a.limbs == 3 && a.ksplit <= 1 && a.ws) {
     long long h[128];
