@@ -436,6 +436,10 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     fprintf(stderr, "edgegan_hip: conv launch without an fp32 filter that no limb / bf16 kernel accepts (N=%d C=%d)\n", a.N, a.C);
     abort();
   }
+  if (a.y_bf && !conv_pk_eligible(a)) {   // (ops.cpp: conv2d asked for the output's bf16 plane, which only conv_pk writes)
+    fprintf(stderr, "edgegan_hip: output plane requested for a launch the packed-K kernel does not take (N=%d C=%d)\n", a.N, a.C);
+    abort();
+  }
   if (conv_pk_eligible(a)) {
     nm = launch_conv_pk(a, s);
 #ifdef EG_EXPERIMENTS
