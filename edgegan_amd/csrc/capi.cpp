@@ -774,6 +774,97 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
     io.down(0, w, ip[0]);
     io.down(1, ms, ip[0]);
     io.down(2, mom, ip[0]);
+  } else if (op == "mru_tail") {
+    // the tail of an MRU unit (conv.py:217-243) through the fused forms of round 5: Conv_1 + PReLU (second store of the
+    // convolution's epilogue, or the PReLU pass summing K-split slabs), Conv_2 read by pool2_add as slabs, the next unit's
+    // prelu(h) as pool2_add's second store; backward: K-split input-gradient slabs summed by prelu_bwd
+    // ip: NB,H,W,C1,C2 ; in: x,w1,b1,leak1,w2,b2,bp,leak2,dh,dhp ; out: h,hp,dx,dw1,db1,dleak1,dw2,db2,dbp,dleak2
+    need_ip(5);
+    const int NB = ip[0], H = ip[1], W = ip[2], C1 = ip[3], C2 = ip[4];
+    const bool bw = io.has(8);
+    T x = io.tensor(0, NB, H, W, C1, bw);
+    Param* w1 = io.param(1, bw);
+    Param* b1 = io.param(2, bw);
+    Param* l1 = io.param(3, bw);
+    Param* w2 = io.param(4, bw);
+    Param* b2 = io.param(5, bw);
+    T bp = io.tensor(6, NB, H / 2, W / 2, C2, bw);
+    Param* l2 = io.param(7, bw);
+    T c1 = conv2d(c, x, wref_param(c, w1, 9, C1, C2), b1, 3, 1, PAD_SAME, nullptr, 0, l1);
+    c.feeds_in = FEED_FLAT;
+    T c2 = conv2d(c, c1, wref_param(c, w2, 9, C2, C2), b2, 3, 1, PAD_SAME);
+    T hp = nullptr;
+    T h = pool2_add(c, c2, bp, l2, &hp);
+    io.down(0, h->d, h->numel());
+    io.down(1, hp->d, hp->numel());
+    if (bw) {
+      io.seed(h, 8);
+      io.seed(hp, 9);
+      c.tape.backward();
+      io.down_grad(2, x);
+      io.down_pgrad(3, w1);
+      io.down_pgrad(4, b1);
+      io.down_pgrad(5, l1);
+      io.down_pgrad(6, w2);
+      io.down_pgrad(7, b2);
+      io.down_grad(8, bp);
+      io.down_pgrad(9, l2);
+    }
+  } else if (op == "mru_gate") {
+    // the head of an MRU unit (conv.py:185-209): prelu(h), the update gate as image rows + hidden rows (the hidden-state
+    // convolution's K-split slabs summed by the min-max pass), gate + PReLU, and a convolution behind it whose input
+    // gradient may reach gate_prelu's backward as slabs
+    // ip: NB,H,W,Ch,N ; in: h,xin,leak0,wh,wx,bg,img,leak1,w1,dy ; out: y,dh,dxin,dimg,dleak0,dwh,dwx,dbg,dleak1,dw1
+    need_ip(5);
+    const int NB = ip[0], H = ip[1], W = ip[2], Ch = ip[3], N = ip[4];
+    const bool bw = io.has(9);
+    T h = io.tensor(0, NB, H, W, Ch, bw);
+    T xin = io.tensor(1, NB, H, W, 3, bw);
+    Param* l0 = io.param(2, bw);
+    Param* wh = io.param(3, bw);
+    Param* wx = io.param(4, bw);
+    Param* bg = io.param(5, bw);
+    T img = io.tensor(6, NB, H, W, Ch, bw);
+    Param* l1 = io.param(7, bw);
+    Param* w1 = io.param(8, bw);
+    T hp = prelu(c, h, l0, 0.f);
+    T rg = conv2d(c, xin, wref_param(c, wx, 9, 3, Ch), bg, 3, 1, PAD_SAME);
+    c.feeds_in = FEED_MINMAX;
+    conv2d(c, hp, wref_param(c, wh, 9, Ch, Ch), nullptr, 3, 1, PAD_SAME, rg);
+    rg = minmax(c, rg, 0.2f);
+    T hin = gate_prelu(c, h, rg, img, l1);
+    T y = conv2d(c, hin, wref_param(c, w1, 9, Ch, N), nullptr, 3, 1, PAD_SAME);
+    io.down(0, y->d, y->numel());
+    if (bw) {
+      io.seed(y, 9);
+      c.tape.backward();
+      io.down_grad(1, h);
+      io.down_grad(2, xin);
+      io.down_grad(3, img);
+      io.down_pgrad(4, l0);
+      io.down_pgrad(5, wh);
+      io.down_pgrad(6, wx);
+      io.down_pgrad(7, bg);
+      io.down_pgrad(8, l1);
+      io.down_pgrad(9, w1);
+    }
+  } else if (op == "act_conv") {
+    // x -> {in_act(LeakyReLU) | pool2} -> convolution: the convolution's input gradient, first writer of the middle tensor's
+    // gradient, may leave K-split slabs that in_bwd / pool2_bwd sum while loading
+    // ip: NB,H,W,C,N,k,stride,kind(0 in_act, 1 pool2) ; in: x,w,dy ; out: y,dx,dw
+    need_ip(8);
+    const bool bw = io.has(2);
+    T x = io.tensor(0, ip[0], ip[1], ip[2], ip[3], bw);
+    Param* w = io.param(1, bw);
+    T m = ip[7] == 0 ? in_act(c, x, ACT_LRELU) : pool2(c, x);
+    T y = conv2d(c, m, wref_param(c, w, ip[5] * ip[5], ip[3], ip[4]), nullptr, ip[5], ip[6], PAD_SAME);
+    io.down(0, y->d, y->numel());
+    if (bw) {
+      io.seed(y, 2);
+      c.tape.backward();
+      io.down_grad(1, x);
+      io.down_pgrad(2, w);
+    }
   } else if (op == "fault_mid_backward") {
     // test hook (tests/test_step_gpu.py): leave the context the way an exception in the middle of a concurrent
     // iteration's backward sweep does -- another lane active, its stream pointing at the lane's leaf stream with

@@ -133,7 +133,14 @@ struct Tensor {
   // (ops.cpp: conv2d / deconv2d with Ctx::feeds_in, in_act): d is then NOT written
   const float* slabs = nullptr;
   const float* slab_bias = nullptr;
+  const float* slab_base = nullptr;   // an accumulating convolution's slabs: the tensor they are added to (d itself)
   int nslab = 0;
+  // The same for the GRADIENT: an input-gradient convolution that is the first writer of g may leave its K-split slabs
+  // un-summed (g_slabs / g_nslab, stride numel()) when this tensor's producer declared that its backward reads them
+  // (g_slab_ok: prelu, in_act, gate_prelu, pool2 -- ops.cpp); a second writer sums them first (grad_acc)
+  const float* g_slabs = nullptr;
+  int g_nslab = 0;
+  bool g_slab_ok = false;
   // bf16 planes ([pixel][c] bf16) of d / g for the plane-fed kernels of the bf16 mode (k_conv_bf16p.hip).  Written by the
   // tensor's own producer kernel as a second store (then *_bf_stream == nullptr: the plane is visible wherever d / g is),
   // or on demand by launch_cvt_bf16 on the stream recorded here (ops.cpp: tensor_plane decides who else may read it)

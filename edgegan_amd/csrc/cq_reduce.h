@@ -2,11 +2,33 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "kernels.h"
+
 namespace eg {
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// quad at float index i (channel c) of a tensor that may still be K-split slabs (kernels.h: SlabSrc): bias + slabs in
+// conv_split_reduce's order, then the base
+__device__ __forceinline__ float4 slab_ld4(const SlabSrc& s, size_t i, int c) {
+  if (s.n <= 1) return ld4(s.p + i);
+  float4 v = s.bias ? ld4(s.bias + c) : f4_zero();
+  for (int k = 0; k < s.n; ++k) {
+    const float4 q = ld4(s.p + (size_t)k * s.stride + i);
+    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+  }
+  if (s.base) {
+    const float4 q = ld4(s.base + i);
+    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+  }
+  return v;
+}
+// the same for flat element-wise kernels: quad index i4 of an [..][C] tensor
+__device__ __forceinline__ float4 slab_ld4_flat(const SlabSrc& s, size_t i4) {
+  if (s.n <= 1) return reinterpret_cast<const float4*>(s.p)[i4];
+  return slab_ld4(s, i4 * 4, (int)(i4 % (size_t)(s.C >> 2)) * 4);
+}
 #define F4_OP(dst, expr_x, expr_y, expr_z, expr_w) \
   do { (dst).x = (expr_x); (dst).y = (expr_y); (dst).z = (expr_z); (dst).w = (expr_w); } while (0)
 

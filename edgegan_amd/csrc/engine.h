@@ -20,6 +20,7 @@ struct Config {
   int g_in() const { return z_dim + (multiclasses() ? num_classes : 0); }
 };
 
+enum Feeds { FEED_NONE = 0, FEED_IN = 1, FEED_FLAT = 2, FEED_MINMAX = 3 };   // Ctx::feeds_in
 enum GroupId { G_G1 = 0, G_G2, G_D2, G_D, G_DP2, G_DP3, G_E, G_COUNT };
 
 // One network's variables in flat HBM buffers: [live trainables | dead trainables | non-trainables].
@@ -99,7 +100,9 @@ struct Ctx {
   bool param_grad_enabled = true;
   // set by a caller right before a conv2d / deconv2d whose ONLY reader is in_act: a forward-only K-split launch then
   // leaves its slabs for the InstanceNorm load pass (consumed, i.e. reset, by that convolution)
-  bool feeds_in = false;
+  // FEED_FLAT / FEED_MINMAX: the same hand-over to a flat element-wise reader (prelu, pool2_add's full-resolution operand)
+  // and to the min-max gate (kernels.h: SlabSrc)
+  int feeds_in = 0;
   // inference only (set inside infer()): a residual block's 1x1 shortcut convolution runs on lane 1 beside the block's
   // two 3x3 convolutions on lane 0 -- the encoder trunk is ONE chain of small launches otherwise
   bool infer_lanes = false;
@@ -214,8 +217,11 @@ const float* wref_transposed(Ctx& c, WRef* w);
 
 enum PadMode { PAD_SAME = 0, PAD_REFLECT = 1 };
 // y = conv(x, w) (+ bias); with accumulate_into the result is added to an existing output (split-input convs)
+// post_prelu: returns prelu(conv(x) + bias, post_prelu) -- the convolution's epilogue stores it as a second output where its
+// kernel can, a K-split launch hands its slabs to the PReLU pass, everything else runs prelu() behind the convolution
 T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into = nullptr,
-         int fused_act = 0 /* ACT_RELU / ACT_LRELU applied by the conv where its kernel can (else by act()) */);
+         int fused_act = 0 /* ACT_RELU / ACT_LRELU applied by the conv where its kernel can (else by act()) */,
+         Param* post_prelu = nullptr);
 T deconv2d(Ctx& c, T x, WRef* w /*[25][Cout][Cin]*/, Param* bias, int cout);
 T linear(Ctx& c, T x, WRef* w /*[1][in][out]*/, Param* bias);
 T linear1(Ctx& c, T x, Param* w /*[K][1]*/, Param* bias /*nullable*/);
@@ -233,7 +239,8 @@ T pool2(Ctx& c, T x);
 // consumer: their gradients are then ONE shared buffer (both equal the up-sampled output gradient / 4)
 T add_pool2(Ctx& c, T a, T b);
 // pool2(a) + b, b at the pooled resolution and with no other consumer (its gradient IS the output's gradient buffer)
-T pool2_add(Ctx& c, T a, T b);
+// post_prelu / prelu_out: also returns prelu(result, post_prelu) from the same pass (conv.py:185: the next unit's prelu(h))
+T pool2_add(Ctx& c, T a, T b, Param* post_prelu = nullptr, T* prelu_out = nullptr);
 T gmean(Ctx& c, T x, bool pre_relu);
 T resize(Ctx& c, T x, int size);
 T concat_w(Ctx& c, T a, T b);

@@ -1,6 +1,7 @@
 // HBM-bound kernels of the EdgeGAN step: data movement, pooling, legacy-bicubic resize, PReLU,
 // min-max gate, spectral norm, losses, RMSProp.  NHWC fp32.  All reductions are fixed-order
 // (two-stage, no float atomics) so replicas stay bit-identical under data parallelism.
+#include "common.h"
 #include "kernels.h"
 #include "cq_reduce.h"
 
@@ -280,7 +281,7 @@ __global__ void pool2_fwd_v_kernel(const float* __restrict__ x, float* __restric
                                                   (a.z + b.z + d.z + e.z) * 0.25f, (a.w + b.w + d.w + e.w) * 0.25f);
   }
 }
-__global__ void pool2_bwd_v_kernel(const float* __restrict__ dy, float* __restrict__ dx, int acc, int H, int W, int C4,
+__global__ void pool2_bwd_v_kernel(const SlabSrc dy, float* __restrict__ dx, int acc, int H, int W, int C4,
                                    unsigned n4, unsigned short* __restrict__ dx_bf) {
   const int Ho = H / 2, Wo = W / 2;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
@@ -289,7 +290,7 @@ __global__ void pool2_bwd_v_kernel(const float* __restrict__ dy, float* __restri
     const unsigned ox = t % Wo;
     t /= Wo;
     const unsigned oy = t % Ho, nb = t / Ho;
-    const float4 g0 = reinterpret_cast<const float4*>(dy)[i];
+    const float4 g0 = slab_ld4(dy, (size_t)i * 4, (int)c * 4);
     const float4 g = make_float4(0.25f * g0.x, 0.25f * g0.y, 0.25f * g0.z, 0.25f * g0.w);
     float4* p = reinterpret_cast<float4*>(dx) + ((size_t)(nb * H + 2 * oy) * W + 2 * ox) * C4 + c;
     const size_t offs[4] = {0, (size_t)C4, (size_t)W * C4, (size_t)W * C4 + C4};
@@ -331,29 +332,43 @@ __global__ void add_pool2_fwd_v_kernel(const float* __restrict__ a, const float*
 }
 // y = pool2(a) + b, b already at the pooled resolution (the MRU unit's output with the 1x1 projection evaluated on the
 // pooled hidden state: ops.cpp pool2_add)
-__global__ void pool2_add_fwd_v_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
-                                       int H, int W, int C4, unsigned n4) {
+// a may still be the K-split slabs of the convolution that produced it (SlabSrc); lkp != null: y2 = prelu(y, *lkp) and its
+// bf16 plane are stored too (the next MRU unit's prelu(h): conv.py:185, activation.py:23-27)
+__global__ void pool2_add_fwd_v_kernel(const SlabSrc a, const float* __restrict__ b, float* __restrict__ y,
+                                       int H, int W, int C4, unsigned n4, const float* __restrict__ lkp, float* __restrict__ y2,
+                                       unsigned short* __restrict__ y2_bf) {
   const int Ho = H / 2, Wo = W / 2;
+  const float lk = lkp ? *lkp : 0.f;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
     const unsigned c = i % C4;
     unsigned t = i / C4;
     const unsigned ox = t % Wo;
     t /= Wo;
     const unsigned oy = t % Ho, nb = t / Ho;
-    const float4* pa = reinterpret_cast<const float4*>(a) + ((size_t)(nb * H + 2 * oy) * W + 2 * ox) * C4 + c;
-    const size_t o1 = (size_t)W * C4, o2 = C4, o3 = (size_t)W * C4 + C4;
-    const float4 a0 = pa[0], a1 = pa[o1], a2 = pa[o2], a3 = pa[o3], q = reinterpret_cast<const float4*>(b)[i];
-    reinterpret_cast<float4*>(y)[i] = make_float4((a0.x + a1.x + a2.x + a3.x) * 0.25f + q.x, (a0.y + a1.y + a2.y + a3.y) * 0.25f + q.y,
-                                                  (a0.z + a1.z + a2.z + a3.z) * 0.25f + q.z, (a0.w + a1.w + a2.w + a3.w) * 0.25f + q.w);
+    const size_t p0 = (((size_t)(nb * H + 2 * oy) * W + 2 * ox) * C4 + c) * 4;
+    const size_t o1 = (size_t)W * C4 * 4, o2 = (size_t)C4 * 4, o3 = o1 + o2;
+    const float4 a0 = slab_ld4(a, p0, (int)c * 4), a1 = slab_ld4(a, p0 + o1, (int)c * 4), a2 = slab_ld4(a, p0 + o2, (int)c * 4),
+                 a3 = slab_ld4(a, p0 + o3, (int)c * 4), q = reinterpret_cast<const float4*>(b)[i];
+    const float4 r = make_float4((a0.x + a1.x + a2.x + a3.x) * 0.25f + q.x, (a0.y + a1.y + a2.y + a3.y) * 0.25f + q.y,
+                                 (a0.z + a1.z + a2.z + a3.z) * 0.25f + q.z, (a0.w + a1.w + a2.w + a3.w) * 0.25f + q.w);
+    reinterpret_cast<float4*>(y)[i] = r;
+    if (lkp) {
+      const float4 o = make_float4(fmaxf(lk * r.x, r.x), fmaxf(lk * r.y, r.y), fmaxf(lk * r.z, r.z), fmaxf(lk * r.w, r.w));
+      if (y2) reinterpret_cast<float4*>(y2)[i] = o;
+      if (y2_bf) st_bf4(y2_bf, i, o);
+    }
   }
 }
-bool launch_pool2_add_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s) {
+bool launch_pool2_add_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s,
+                          const SlabSrc* a_slabs, const float* leak, float* y2, unsigned short* y2_bf) {
   const size_t n = (size_t)NB * (H / 2) * (W / 2) * C;
   if (!(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (size_t)NB * H * W * C < (1ull << 31) &&
-        ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0))
+        ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y) | ((uintptr_t)y2)) & 15) == 0)) {
+    EG_CHECK(!a_slabs && !leak, "pool2_add: slab input / second output requested from the two-pass form");
     return false;
-  hipLaunchKernelGGL(pool2_add_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, a, b, y, H, W, C / 4,
-                     (unsigned)(n / 4));
+  }
+  hipLaunchKernelGGL(pool2_add_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, a_slabs ? *a_slabs : plain_src(a), b, y,
+                     H, W, C / 4, (unsigned)(n / 4), leak, y2, y2_bf);
   return true;
 }
 bool launch_add_pool2_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s) {
@@ -374,18 +389,15 @@ void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hip
   hipLaunchKernelGGL(pool2_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, H, W, C, n);
 }
 void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s,
-                      unsigned short* dx_bf) {
+                      unsigned short* dx_bf, const SlabSrc* dy_slabs) {
   const size_t n = (size_t)NB * H * W * C;
   if (C % 4 == 0 && n < (1ull << 31) && H % 2 == 0 && W % 2 == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0) {
     const size_t no4 = n / 16;   // output quads
-    hipLaunchKernelGGL(pool2_bwd_v_kernel, dim3(ew_blocks(no4)), dim3(256), 0, s, dy, dx, accumulate, H, W, C / 4,
-                       (unsigned)no4, dx_bf);
+    hipLaunchKernelGGL(pool2_bwd_v_kernel, dim3(ew_blocks(no4)), dim3(256), 0, s, dy_slabs ? *dy_slabs : plain_src(dy), dx,
+                       accumulate, H, W, C / 4, (unsigned)no4, dx_bf);
     return;
   }
-  if (dx_bf) {
-    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from the scalar form of pool2_bwd\n");
-    abort();
-  }
+  EG_CHECK(!dx_bf && !dy_slabs, "pool2_bwd: a bf16 plane / a slab input was requested from the scalar form");
   hipLaunchKernelGGL(pool2_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, dy, dx, accumulate, H, W, C, n);
 }
 
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
   }
 }
 // float4 form (n % 4 == 0, 16-byte aligned buffers)
-__global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restrict__ x, const SlabSrc dy,
                                                           const float* __restrict__ leak_p, float leak_c,
                                                           float* __restrict__ dx, int acc_dx, float* __restrict__ part,
                                                           size_t n4, unsigned short* __restrict__ dx_bf) {
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restric
   const float lk = leak_p ? *leak_p : leak_c;
   float s = 0.f;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i], g = reinterpret_cast<const float4*>(dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(x)[i], g = slab_ld4_flat(dy, i);
     const bool f0 = lk * v.x >= v.x, f1 = lk * v.y >= v.y, f2 = lk * v.z >= v.z, f3 = lk * v.w >= v.w;
     if (dx) {
       float4 o = make_float4(f0 ? lk * g.x : g.x, f1 ? lk * g.y : g.y, f2 ? lk * g.z : g.z, f3 ? lk * g.w : g.w);
@@ -562,11 +574,12 @@ __global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restric
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
   }
 }
-__global__ void prelu_fwd_v_kernel(const float* __restrict__ x, const float* __restrict__ leak_p, float leak_c,
-                                   float* __restrict__ y, size_t n4, unsigned short* __restrict__ y_bf) {
+__global__ void prelu_fwd_v_kernel(const SlabSrc x, const float* __restrict__ leak_p, float leak_c,
+                                   float* __restrict__ y, size_t n4, unsigned short* __restrict__ y_bf, float* __restrict__ xsum) {
   const float lk = leak_p ? *leak_p : leak_c;
   GRID_STRIDE(i, n4) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 v = slab_ld4_flat(x, i);
+    if (xsum) reinterpret_cast<float4*>(xsum)[i] = v;
     const float4 o = make_float4(fmaxf(lk * v.x, v.x), fmaxf(lk * v.y, v.y), fmaxf(lk * v.z, v.z), fmaxf(lk * v.w, v.w));
     reinterpret_cast<float4*>(y)[i] = o;
     if (y_bf) st_bf4(y_bf, i, o);
@@ -583,33 +596,30 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, int np, floa
 static bool ew_vec_ok(size_t n, const void* a, const void* b, const void* c = nullptr) {
   return (n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
 }
-void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s, unsigned short* y_bf) {
-  if (y_bf && !ew_vec_ok(n, x, y)) {
-    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from the scalar form of prelu_fwd\n");
-    abort();
-  }
-  if (ew_vec_ok(n, x, y)) {
+void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s, unsigned short* y_bf,
+                      const SlabSrc* x_slabs, float* xsum) {
+  EG_CHECK(!(y_bf || x_slabs) || ew_vec_ok(n, x, y, xsum), "prelu_fwd: a bf16 plane / a slab input was requested from the scalar form");
+  if (ew_vec_ok(n, x, y, xsum)) {
     // (experiments: EG_DUP_PRELU_FWD = N extra, idempotent launches -- what does an HBM-bound pass on a lane cost the iteration?)
     static const int dup = dbg_env("EG_DUP_PRELU_FWD") ? atoi(dbg_env("EG_DUP_PRELU_FWD")) : 0;
     for (int r = 0; r <= dup; ++r)
-      hipLaunchKernelGGL(prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, leak_p, leak_c, y, n / 4, y_bf);
+      hipLaunchKernelGGL(prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x_slabs ? *x_slabs : plain_src(x), leak_p,
+                         leak_c, y, n / 4, y_bf, xsum);
     return;
   }
   hipLaunchKernelGGL(prelu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, leak_p, leak_c, y, n);
 }
 size_t prelu_scratch_floats() { return 2048; }
 void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, float leak_c, float* dx, int acc_dx,
-                      float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s, unsigned short* dx_bf) {
+                      float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s, unsigned short* dx_bf,
+                      const SlabSrc* dy_slabs) {
   int nb;
   if (ew_vec_ok(n, x, dy, dx)) {
     nb = ew_blocks(n / 4, 2048);
-    hipLaunchKernelGGL(prelu_bwd_v_kernel, dim3(nb), dim3(256), 0, s, x, dy, leak_p, leak_c, dx, acc_dx,
-                       dleak ? scratch : nullptr, n / 4, dx_bf);
+    hipLaunchKernelGGL(prelu_bwd_v_kernel, dim3(nb), dim3(256), 0, s, x, dy_slabs ? *dy_slabs : plain_src(dy), leak_p, leak_c, dx,
+                       acc_dx, dleak ? scratch : nullptr, n / 4, dx_bf);
   } else {
-    if (dx_bf) {
-      fprintf(stderr, "edgegan_hip: a bf16 plane was requested from the scalar form of prelu_bwd\n");
-      abort();
-    }
+    EG_CHECK(!dx_bf && !dy_slabs, "prelu_bwd: a bf16 plane / a slab input was requested from the scalar form");
     nb = ew_blocks(n, 1024);
     hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, s, x, dy, leak_p, leak_c, dx, acc_dx,
                        dleak ? scratch : nullptr, n);
@@ -697,17 +707,28 @@ __global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* __restrict
     }
   }
 }
+// xs.n > 1: x is still the K-split slabs of the gate's hidden-state convolution (+ the image-row convolution's output as
+// the base): the first pass sums them and stores the sum to xsum, which the second pass (the same thread re-reads its own
+// stores) and the backward read
 template <int CQ>
-__global__ __launch_bounds__(256) void minmax_fwd_v(const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(256) void minmax_fwd_v(const SlabSrc xs, float* __restrict__ xsum, float* __restrict__ y,
                                                     float* __restrict__ mm, int HW, int C, float lk) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[2 * 4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
   const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
   const size_t base = (size_t)n * HW * C + c;
+  const float* x = xs.n > 1 ? xsum : xs.p;
   float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
   for (int p = pl; p < HW; p += PL) {
-    const float4 v = mm_pre4(ld4(x + base + (size_t)p * C), lk);
+    float4 raw;
+    if (xs.n > 1) {
+      raw = slab_ld4(xs, base + (size_t)p * C, c);
+      st4(xsum + base + (size_t)p * C, raw);
+    } else {
+      raw = ld4(x + base + (size_t)p * C);
+    }
+    const float4 v = mm_pre4(raw, lk);
     mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
     mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
   }
@@ -773,13 +794,16 @@ __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x,
   }
 }
 
-void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s, float pre_leak) {
+void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s, float pre_leak,
+                       const SlabSrc* x_slabs, float* xsum) {
+  const SlabSrc xs = x_slabs ? *x_slabs : plain_src(x);
+  EG_CHECK(xs.n <= 1 || (C % 8 == 0 && xsum), "minmax_fwd: a slab input needs C %% 8 == 0 and a destination for the sum");
   if (C % 32 == 0) {
-    hipLaunchKernelGGL(minmax_fwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, y, mm, HW, C, pre_leak);
+    hipLaunchKernelGGL(minmax_fwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, xs, xsum, y, mm, HW, C, pre_leak);
     return;
   }
   if (C % 8 == 0) {
-    hipLaunchKernelGGL(minmax_fwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, y, mm, HW, C, pre_leak);
+    hipLaunchKernelGGL(minmax_fwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, xs, xsum, y, mm, HW, C, pre_leak);
     return;
   }
   hipLaunchKernelGGL(minmax_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, y, mm, HW, C, pre_leak);
@@ -790,10 +814,7 @@ void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* 
     hipLaunchKernelGGL(minmax_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, dx_bf);
     return;
   }
-  if (dx_bf) {
-    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from minmax_bwd with C %% 32 != 0\n");
-    abort();
-  }
+  EG_CHECK(!dx_bf, "minmax_bwd: a bf16 plane was requested with C %% 32 != 0");
   if (C % 8 == 0) {
     hipLaunchKernelGGL(minmax_bwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, nullptr);
     return;
@@ -871,7 +892,7 @@ __global__ void gate_prelu_fwd_v_kernel(const float* __restrict__ h, const float
 }
 __global__ __launch_bounds__(256) void gate_prelu_bwd_v_kernel(const float* __restrict__ h, const float* __restrict__ rg,
                                                                const float* __restrict__ img, const float* __restrict__ leak_p,
-                                                               const float* __restrict__ d, float* __restrict__ dh, int acc_h,
+                                                               const SlabSrc d, float* __restrict__ dh, int acc_h,
                                                                float* __restrict__ drg, float* __restrict__ dimg,
                                                                float* __restrict__ part, size_t n4) {
   __shared__ float sm[4];
@@ -879,7 +900,7 @@ __global__ __launch_bounds__(256) void gate_prelu_bwd_v_kernel(const float* __re
   float s = 0.f;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 a = reinterpret_cast<const float4*>(h)[i], r = reinterpret_cast<const float4*>(rg)[i],
-                 m = reinterpret_cast<const float4*>(img)[i], gy = reinterpret_cast<const float4*>(d)[i];
+                 m = reinterpret_cast<const float4*>(img)[i], gy = slab_ld4_flat(d, i);
     const float v[4] = {a.x + r.x * m.x, a.y + r.y * m.y, a.z + r.z * m.z, a.w + r.w * m.w};
     const float gg[4] = {gy.x, gy.y, gy.z, gy.w};
     float g[4];
@@ -916,21 +937,19 @@ void launch_gate_prelu_fwd(const float* h, const float* rg, const float* img, co
     hipLaunchKernelGGL(gate_prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, h, rg, img, leak, out, n / 4, out_bf);
     return;
   }
-  if (out_bf) {
-    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from the scalar form of gate_prelu_fwd\n");
-    abort();
-  }
+  EG_CHECK(!out_bf, "gate_prelu_fwd: a bf16 plane was requested from the scalar form");
   hipLaunchKernelGGL(gate_prelu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, h, rg, img, leak, out, n);
 }
 void launch_gate_prelu_bwd(const float* h, const float* rg, const float* img, const float* leak, const float* dout, float* dh,
                            int acc_h, float* drg, float* dimg, float* dleak, int acc_dleak, size_t n, float* scratch,
-                           hipStream_t s) {
+                           hipStream_t s, const SlabSrc* dout_slabs) {
   int nb;
   if (gp_vec_ok(n, h, rg, img, dout, dh, drg, dimg)) {
     nb = ew_blocks(n / 4, 2048);
-    hipLaunchKernelGGL(gate_prelu_bwd_v_kernel, dim3(nb), dim3(256), 0, s, h, rg, img, leak, dout, dh, acc_h, drg, dimg,
-                       dleak ? scratch : nullptr, n / 4);
+    hipLaunchKernelGGL(gate_prelu_bwd_v_kernel, dim3(nb), dim3(256), 0, s, h, rg, img, leak, dout_slabs ? *dout_slabs : plain_src(dout),
+                       dh, acc_h, drg, dimg, dleak ? scratch : nullptr, n / 4);
   } else {
+    EG_CHECK(!dout_slabs, "gate_prelu_bwd: a slab input was requested from the scalar form");
     nb = ew_blocks(n, 2048);
     hipLaunchKernelGGL(gate_prelu_bwd_kernel, dim3(nb), dim3(256), 0, s, h, rg, img, leak, dout, dh, acc_h, drg, dimg,
                        dleak ? scratch : nullptr, n);

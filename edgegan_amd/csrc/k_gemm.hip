@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "common.h"
 #include "kernels.h"
 
 namespace eg {
@@ -325,6 +326,15 @@ __global__ void conv_split_reduce_kernel(const float* __restrict__ ws, float* __
   }
 }
 
+void launch_conv_split_reduce(const float* ws, float* y, const float* bias, size_t total, int y_ps, int N, int ksplit,
+                              int accumulate, hipStream_t s) {
+  const size_t total4 = total / 4;   // split-K requires N % 4 == 0 and a 16-byte aligned, y_ps % 4 == 0 output
+  size_t blocks = (total4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, y, bias, (unsigned)total4, y_ps / 4,
+                     N / 4, ksplit, accumulate);
+}
+
 // K-split factor for launches that cannot fill the 256 CUs with output tiles (small M x N, long K)
 // Limb-mode (k_gemm_x3.hip) launches: tile family and K split from a small cost model.  Unit of time = one K step
 // (32 channels of one tap) of a 128x128 tile at the ping-pong kernel's rate (~1.3 us per CU).  The ping-pong block
@@ -416,8 +426,9 @@ static const char* conv_dispatch(const ConvArgs& a, int maxM, bool avec, bool bv
   return nf;
 }
 
-double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel_name) {
+double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name) {
   ConvArgs a = a_in;
+  int caps = 0;   // what the kernel that runs honours of the optional epilogue work (ConvArgs::epi_act, ::y2): set where it is chosen
   int maxM = 0;
   double flops = 0;
   for (int p = 0; p < a.nphase; ++p) {
@@ -432,19 +443,20 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     a.ksplit = 1;   // only the fully vectorised kernels have a split-K form
   const long long blocks128 = (long long)((maxM + 127) / 128) * ((a.N + 127) / 128) * a.nphase;
   const char* nm;
-  if (!a.wgt && !(a.N > 16 && (conv_bf16p_eligible(a) || conv_x3_eligible(a) || conv_bf16_eligible(a)))) {
-    fprintf(stderr, "edgegan_hip: conv launch without an fp32 filter that no limb / bf16 kernel accepts (N=%d C=%d)\n", a.N, a.C);
-    abort();
-  }
-  if (a.y_bf && !conv_pk_eligible(a)) {   // (ops.cpp: conv2d asked for the output's bf16 plane, which only conv_pk writes)
-    fprintf(stderr, "edgegan_hip: output plane requested for a launch the packed-K kernel does not take (N=%d C=%d)\n", a.N, a.C);
-    abort();
-  }
+  EG_CHECK(a.wgt || (a.N > 16 && (conv_bf16p_eligible(a) || conv_x3_eligible(a) || conv_bf16_eligible(a))),
+           "conv launch without an fp32 filter that no limb / bf16 kernel accepts (N=%d C=%d)", a.N, a.C);
+  // (ops.cpp: conv2d asked for the output's bf16 plane, which only conv_pk writes)
+  EG_CHECK(!a.y_bf || conv_pk_eligible(a), "output plane requested for a launch the packed-K kernel does not take (N=%d C=%d)", a.N, a.C);
   if (conv_pk_eligible(a)) {
+    a.y2_leak = nullptr;
     nm = launch_conv_pk(a, s);
+    // (ConvArgs::y2 is NOT taken here although the float4 epilogue could store it: this kernel is bound by its 32-byte
+    //  partial-line output writes, and a second output stream of the same shape cost 97 us on the classifier's 8 -> 128
+    //  layer at 64 x 64 where the separate PReLU pass costs 49 -- profiles/r05b_*)
 #ifdef EG_EXPERIMENTS
   } else if (a.x3q && a.N > 16 && conv_x3q_eligible(a)) {
     nm = launch_conv_x3q(a, s);
+    if (a.ksplit <= 1) caps |= CONV_CAP_EPI_ACT;
 #endif
   } else if (conv_scatter_eligible(a)) {
     nm = launch_conv_scatter(a, s);
@@ -470,10 +482,12 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
     };
     const double e128 = a.N >= 128 ? 0.95 * balance(t128) : 0.0;
     const double e64 = 0.80 * balance(t64);
-    if (conv_bf16p_eligible(a))   // bf16 mode, the operand's bf16 plane is there: staged by LDS-DMA (k_conv_bf16p.hip)
+    if (conv_bf16p_eligible(a)) {   // bf16 mode, the operand's bf16 plane is there: staged by LDS-DMA (k_conv_bf16p.hip)
       nm = launch_conv_bf16p(a, s);
-    else if (conv_x3_eligible(a))
-      nm = launch_conv_gemm_x3(a, maxM, a.x3_tile ? a.x3_tile == 1 : e128 >= e64, s);
+      if (a.ksplit <= 1) caps |= CONV_CAP_EPI_ACT | CONV_CAP_Y2;
+    } else if (conv_x3_eligible(a)) {
+      nm = launch_conv_gemm_x3(a, maxM, a.x3_tile ? a.x3_tile == 1 : e128 >= e64, s, &caps);
+    }
     else if (conv_bf16_eligible(a))
       nm = launch_conv_gemm_bf16(a, maxM, e128 >= e64, s);
     else if (e128 >= e64)
@@ -485,18 +499,14 @@ double launch_conv_gemm(const ConvArgs& a_in, hipStream_t s, const char** kernel
                                          a.ksplit > 1 ? "conv_gemm<64,64,vec,splitk>" : "conv_gemm<64,64,vec>",
                                          "conv_gemm<64,64,avec>", "conv_gemm<64,64,flat>");
   }
-  if (a.ksplit > 1 && !a.keep_slabs) {
-    const size_t total4 = a.y_total / 4;   // split-K requires N % 4 == 0 and a 16-byte aligned, y_ps % 4 == 0 output
-    size_t blocks = (total4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.ws, a.y, a.bias,
-                       (unsigned)total4, a.y_ps / 4, a.N / 4, a.ksplit, a.accumulate);
-  }
+  if (a.ksplit > 1 && !a.keep_slabs) launch_conv_split_reduce(a.ws, a.y, a.bias, a.y_total, a.y_ps, a.N, a.ksplit, a.accumulate, s);
   static const bool trace = dbg_env("EG_TRACE_GEMM") != nullptr;   // shape log for offline tile/split tuning
   if (trace)
     fprintf(stderr, "EG_GEMM conv maxM=%d N=%d C=%d nphase=%d taps0=%d ksplit=%d kernel=%s gflop=%.3f\n", maxM, a.N, a.C,
             a.nphase, a.ph[0].Ty * a.ph[0].Tx, a.ksplit, nm, flops * 1e-9);
   if (kernel_name) *kernel_name = nm;
+  a_in.caps = caps;
+  a_in.ksplit = a.ksplit;   // (the split that ran: the caller's slab bookkeeping must not assume the one it asked for)
   return flops;
 }
 

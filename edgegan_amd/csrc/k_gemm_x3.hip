@@ -690,10 +690,13 @@ static void conv_x3_launch(const ConvArgs& a, int maxM, hipStream_t s) {
   }
 }
 
-const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s) {
+const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s, int* caps) {
   const int np = x3_nprod();
   static const int pipe = dbg_env("EG_X3_PIPE") ? atoi(dbg_env("EG_X3_PIPE")) : 2;
-  if ((a.limbs == 1 || (big_tile && np == 6)) && conv_x3h_eligible(a)) return launch_conv_gemm_x3h(a, s);
+  if ((a.limbs == 1 || (big_tile && np == 6)) && conv_x3h_eligible(a)) {
+    if (caps && a.ksplit <= 1) *caps |= CONV_CAP_EPI_ACT | CONV_CAP_Y2;   // the un-split halo kernel's epilogue (k_gemm_x3h.hip)
+    return launch_conv_gemm_x3h(a, s);
+  }
   if (a.limbs == 1) {
     const int zs = a.ksplit > 1 ? a.ksplit : 1;
     dim3 grid((maxM + 255) / 256, (a.N + 127) / 128, a.nphase * zs);

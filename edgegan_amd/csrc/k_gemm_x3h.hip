@@ -511,6 +511,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
 
   // D^T layout of the 32x32 accumulator: lane l holds pixel row l & 31 and, in registers 4q .. 4q+3, the four consecutive
   // output channels 8q + 4 (l >> 5) .. +3 of its 32-channel block: one 16-byte store per register quad
+  const float y2lk = (!SPLITK && a.y2_leak) ? *a.y2_leak : 0.f;   // second output: PReLU of the stored value (kernels.h: conv_epi_y2)
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int r = wm * WROWS + i * 32 + l31;
@@ -545,6 +546,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
             }
           }
           *reinterpret_cast<float4*>(yrow + n) = v;
+          if constexpr (!SPLITK) {
+            if (a.y2_leak) conv_epi_y2(a, (size_t)(yrow - a.y) + n, v, y2lk);
+          }
         }
       }
   }

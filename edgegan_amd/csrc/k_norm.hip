@@ -10,6 +10,7 @@
 //
 // Block = 256 threads = 64 channels x 4 pixel lanes, one block per (sample, 64-channel group):
 // a wave reads 256-byte channel rows (coalesced), reductions over the 4 pixel lanes go through LDS.
+#include "common.h"
 #include "kernels.h"
 #include "cq_reduce.h"
 
@@ -370,9 +371,10 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
 
 // IN+act backward with e = dout * act'(out) and (x - mean) held in registers between the reduction and the apply
 // pass (HW <= 32 * NP): out / dout / x are read from memory once
+// v (the output gradient) may still be the K-split slabs of the input-gradient convolution that produced it (SlabSrc)
 template <int NP, int CQ>
 __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, const float* __restrict__ out,
-                                                 const float* __restrict__ v, const float* __restrict__ stats,
+                                                 const SlabSrc v, const float* __restrict__ stats,
                                                  float* __restrict__ dst, int accumulate, int HW, int C, int act,
                                                  unsigned short* __restrict__ dst_bf) {
   constexpr int PL = 256 / CQ;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
     xc[k] = f4_zero();
     if (p < HW) {
       const size_t i = base + (size_t)p * C;
-      float4 e = ld4(v + i);
+      float4 e = slab_ld4(v, i, c);
       const float4 g = actg4(ld4(out + i), act);
       e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w;
       const float4 xv = ld4(x + i);
@@ -424,10 +426,7 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
 
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s, int nslab,
                    size_t slab_stride, const float* slab_bias, float* xsum, unsigned short* out_bf) {
-  if (out_bf && C % 32 != 0) {
-    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from in_fwd with C %% 32 != 0\n");
-    abort();
-  }
+  EG_CHECK(!out_bf || C % 32 == 0, "in_fwd: a bf16 plane was requested with C %% 32 != 0");
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
 #define EG_IN_FWD(NP, CQ, G) hipLaunchKernelGGL((in_fwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, HW, C, act, nslab, slab_stride, slab_bias, xsum, out_bf)
@@ -443,21 +442,22 @@ void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int
 
   hipLaunchKernelGGL(in_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, stats, HW, C, act);
 }
+bool in_bwd_takes_slabs(int HW, int C) { return C % 32 == 0 && HW <= 1024; }   // the register-resident forms
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
-                   int accumulate, int NB, int HW, int C, int act, hipStream_t s, unsigned short* dx_bf) {
-  if (dx_bf && C % 32 != 0) {
-    fprintf(stderr, "edgegan_hip: a bf16 plane was requested from in_bwd with C %% 32 != 0\n");
-    abort();
-  }
+                   int accumulate, int NB, int HW, int C, int act, hipStream_t s, unsigned short* dx_bf,
+                   const SlabSrc* dout_slabs) {
+  EG_CHECK(!dx_bf || C % 32 == 0, "in_bwd: a bf16 plane was requested with C %% 32 != 0");
+  EG_CHECK(!dout_slabs || in_bwd_takes_slabs(HW, C), "in_bwd: a slab input needs C %% 32 == 0 and HW <= 1024");
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
-#define EG_IN_BWD(NP) hipLaunchKernelGGL((in_bwd_vr<NP, 8>), grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act, dx_bf)
+    const SlabSrc dsrc = dout_slabs ? *dout_slabs : plain_src(dout);
+#define EG_IN_BWD(NP) hipLaunchKernelGGL((in_bwd_vr<NP, 8>), grid, dim3(256), 0, s, x, out, dsrc, stats, dx, accumulate, HW, C, act, dx_bf)
     if (HW <= 64) EG_IN_BWD(2);
     else if (HW <= 128) EG_IN_BWD(4);
     else if (HW <= 256) EG_IN_BWD(8);
     else if (HW <= 512) EG_IN_BWD(16);
     else if (HW <= 1024)
-      hipLaunchKernelGGL((in_bwd_vr<16, 4>), dim3(NB, C / 16), dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW,
+      hipLaunchKernelGGL((in_bwd_vr<16, 4>), dim3(NB, C / 16), dim3(256), 0, s, x, out, dsrc, stats, dx, accumulate, HW,
                          C, act, dx_bf);
     else
       hipLaunchKernelGGL((in_japply_v<0, 8>), grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act, dx_bf);

@@ -76,10 +76,35 @@ struct ConvArgs {
   unsigned short* y_bf;   // bf16 mode, conv_pk only: also store the (activated) output's bf16 plane [pixel][y_ps] -- the next
                           // convolution reads it by LDS-DMA and no conversion pass runs (d_conv_0 + LeakyReLU -> d_conv_1)
   int pk;            // f32x3 / bf16 modes: thin forward layers (3 or 8 input channels) may run the packed-K limb kernel (k_thin_pk.hip)
+  // Second output of the epilogue (conv.py:217-220, activation.py:23-27: the PReLU that follows Conv_1 of an MRU unit):
+  // y2 = max(*y2_leak * y, y) of the value just stored to y, as fp32 (same layout as y; may be null) and / or as its bf16
+  // plane.  Written by the un-split launches of the kernels that report CONV_CAP_Y2 in `caps`; everybody else leaves it to
+  // the caller's prelu pass.
+  const float* y2_leak;
+  float* y2;
+  unsigned short* y2_bf;
+  int caps;          // OUT, set by launch_conv_gemm: what the kernel that ran honoured (CONV_CAP_*); ksplit is written back too
 };
+enum ConvCaps { CONV_CAP_EPI_ACT = 1, CONV_CAP_Y2 = 2 };
+
+// A tensor that may still be the K-split slabs of the convolution that produced it (ConvArgs::keep_slabs): its value is
+// bias[c] + slab 0 + slab 1 + ... (+ base), conv_split_reduce's order, formed by the CONSUMER's load instead of a
+// reduction pass of its own (one launch, one write and one read of the tensor less).  n <= 1: an ordinary tensor at p.
+struct SlabSrc {
+  const float* p;              // the tensor, or slab 0
+  int n;                       // slabs (0 / 1: plain tensor)
+  int C;                       // channels (the bias period), % 4 == 0 when n > 1
+  unsigned long long stride;   // floats between slabs
+  const float* bias;           // [C] or null
+  const float* base;           // added last (the tensor an accumulating convolution adds to), or null
+};
+inline SlabSrc plain_src(const float* p) { return SlabSrc{p, 1, 0, 0ull, nullptr, nullptr}; }
+// y (+)= bias + slab 0 + ... : the stand-alone reduction (k_gemm.hip), for readers that do not take a SlabSrc
+void launch_conv_split_reduce(const float* ws, float* y, const float* bias, size_t total, int y_ps, int N, int ksplit,
+                              int accumulate, hipStream_t s);
 
 // flops (2*M*N*K summed over phases) are returned for the profiler.
-double launch_conv_gemm(const ConvArgs& a, hipStream_t s, const char** kernel_name);
+double launch_conv_gemm(ConvArgs& a, hipStream_t s, const char** kernel_name);
 int conv_pick_ksplit(ConvArgs& a);   // also sets a.x3_tile for limb-mode launches
 #ifdef EG_EXPERIMENTS
 // k_gemm_x3q.hip (experiments build, EG_X3Q=1): the f32x3 halo convolution at two blocks per CU (128 x 128 tiles, 16-channel
@@ -127,6 +152,21 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned total, int of
   if (off) return b;
   const unsigned q = total >> 3, r = total & 7, x = b & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+// ConvArgs::y2 / y2_bf: PReLU of the quad just stored at element offset `off` of y (lk = *a.y2_leak, read once per kernel);
+// the plane is rounded to nearest even, the rounding of cvt_bf16 / st_bf4 (k_elem.hip)
+__device__ __forceinline__ void conv_epi_y2(const ConvArgs& a, size_t off, const float4& v, float lk) {
+  const float4 p = make_float4(fmaxf(lk * v.x, v.x), fmaxf(lk * v.y, v.y), fmaxf(lk * v.z, v.z), fmaxf(lk * v.w, v.w));
+  if (a.y2) *reinterpret_cast<float4*>(a.y2 + off) = p;
+  if (a.y2_bf) {
+    typedef __bf16 bf16x2_e __attribute__((ext_vector_type(2)));
+    typedef float f32x2_e __attribute__((ext_vector_type(2)));
+    const f32x2_e lo = {p.x, p.y}, hi = {p.z, p.w};
+    uint2 o;
+    o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_e));
+    o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_e));
+    *reinterpret_cast<uint2*>(a.y2_bf + off) = o;
+  }
 }
 #endif
 // k_elem.hip: a memory-free v_mfma_f32_32x32x16_bf16 loop, blocks x 8 waves x iters x 16 MFMAs (scratch >= blocks * 512 floats)
@@ -197,7 +237,7 @@ const char* launch_conv_gemm_x3h(const ConvArgs& a, hipStream_t s);
 
 // fp32-via-three-bf16-limbs kernels (k_gemm_x3.hip)
 bool conv_x3_eligible(const ConvArgs& a);
-const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s);
+const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s, int* caps = nullptr);   // caps |= CONV_CAP_* of the kernel chosen
 const char* launch_wgrad_x3(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s);
 // src [T][R][Cc] fp32 -> three bf16 limb planes, K-step-major [plane][T][K/32][Nrows][32]; (Nrows, K) = (R, Cc), or (Cc, R)
 // when transposed; K % 32 == 0
@@ -242,8 +282,11 @@ void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int
                    int nslab = 0, size_t slab_stride = 0, const float* slab_bias = nullptr, float* xsum = nullptr,
                    unsigned short* out_bf = nullptr);   // *_bf: also store the bf16 plane of the output (bf16 mode, C % 32 == 0)
 // dx (+)= J * (dout * act'(out))   (J = IN Jacobian, symmetric)
+// dout_slabs (C % 32 == 0 and HW <= 1024 only): dout is that SlabSrc instead
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
-                   int accumulate, int NB, int HW, int C, int act, hipStream_t s, unsigned short* dx_bf = nullptr);
+                   int accumulate, int NB, int HW, int C, int act, hipStream_t s, unsigned short* dx_bf = nullptr,
+                   const SlabSrc* dout_slabs = nullptr);
+bool in_bwd_takes_slabs(int HW, int C);
 // tangent forward: tout = act'(out_primal) * (J * tx)
 void launch_in_tangent_fwd(const float* x, const float* out, const float* stats, const float* tx, float* tout,
                            int NB, int HW, int C, int act, hipStream_t s, unsigned short* tout_bf = nullptr);
@@ -292,11 +335,16 @@ void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C,
 // 2x2 mean pool NHWC fwd / bwd
 void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hipStream_t s);
 void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s,
-                      unsigned short* dx_bf = nullptr);   // dx_bf: also store the bf16 plane of dx (k_elem.hip: st_bf4)
+                      unsigned short* dx_bf = nullptr,   // dx_bf: also store the bf16 plane of dx (k_elem.hip: st_bf4)
+                      const SlabSrc* dy_slabs = nullptr);   // float4 form only (ops.cpp: flat_slab_ok)
 // y = pool2(a + b), a/b [NB][H][W][C]; returns false (nothing launched) when the float4 form does not apply
 bool launch_add_pool2_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s);
 // y = pool2(a) + b with b [NB][H/2][W/2][C]; same return convention
-bool launch_pool2_add_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s);
+// a_slabs: a is that SlabSrc; leak / y2 / y2_bf: also store prelu(y, *leak) (the next MRU unit's prelu(h), conv.py:185) and
+// its bf16 plane
+bool launch_pool2_add_fwd(const float* a, const float* b, float* y, int NB, int H, int W, int C, hipStream_t s,
+                          const SlabSrc* a_slabs = nullptr, const float* leak = nullptr, float* y2 = nullptr,
+                          unsigned short* y2_bf = nullptr);
 // global spatial mean: y[n][c] = mean_hw act(x[n][hw][c]) ; pre_relu applies relu first
 void launch_gmean_fwd(const float* x, float* y, int NB, int HW, int C, int pre_relu, hipStream_t s);
 void launch_gmean_bwd(const float* x, const float* dy, float* dx, int accumulate, int NB, int HW, int C,
@@ -307,15 +355,19 @@ void launch_resize(const float* x, float* y, int accumulate, int NB, int IH, int
                    const int* ty_i, const float* ty_w, int tyn, const int* tx_i, const float* tx_w, int txn,
                    hipStream_t s);
 // prelu / fixed leak: y = max(leak*x, x); leak read from device scalar (leak_p) or constant
+// x_slabs (float4 form only): x is that SlabSrc; xsum != null also stores the summed x (what prelu_bwd reads)
 void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s,
-                      unsigned short* y_bf = nullptr);
+                      unsigned short* y_bf = nullptr, const SlabSrc* x_slabs = nullptr, float* xsum = nullptr);
 // dx (+)= ..., dleak (+)= sum(dy*x [x<0 or tie]) (when dleak != null)
 size_t prelu_scratch_floats();
 void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, float leak_c, float* dx, int acc_dx,
-                      float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s, unsigned short* dx_bf = nullptr);
+                      float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s, unsigned short* dx_bf = nullptr,
+                      const SlabSrc* dy_slabs = nullptr);
 // per-(n,c) spatial min-max normalisation (conv.py:197-198) fwd/bwd; mm[n][c] = {min,max}
 // pre_leak != 0: y = minmax(lrelu_{pre_leak}(x)) with the lrelu applied on load / its slope on the gradient store
-void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s, float pre_leak = 0.f);
+// x_slabs (C % 8 == 0 only): x is that SlabSrc and the summed value is stored to xsum (what the backward reads)
+void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s, float pre_leak = 0.f,
+                       const SlabSrc* x_slabs = nullptr, float* xsum = nullptr);
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
                        int HW, int C, hipStream_t s, float pre_leak = 0.f, unsigned short* dx_bf = nullptr);
 // gate merge: out = h + rg*img ; backward
@@ -327,7 +379,7 @@ void launch_gate_prelu_fwd(const float* h, const float* rg, const float* img, co
                            hipStream_t s, unsigned short* out_bf = nullptr);
 void launch_gate_prelu_bwd(const float* h, const float* rg, const float* img, const float* leak, const float* dout, float* dh,
                            int acc_h, float* drg, float* dimg, float* dleak, int acc_dleak, size_t n, float* scratch,
-                           hipStream_t s);
+                           hipStream_t s, const SlabSrc* dout_slabs = nullptr);
 // add bias over last dim in place (y[r][c] += b[c]), optional prelu/lrelu fused variants are separate ops
 void launch_bias_add(float* y, const float* b, size_t R, int C, hipStream_t s);
 

@@ -332,7 +332,7 @@ void api_enter(Ctx& c) {
   }
   use_lane(c, 0);
   c.infer_lanes = false;
-  c.feeds_in = false;
+  c.feeds_in = FEED_NONE;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -454,14 +454,17 @@ T classifier_forward(Ctx& c, T x) {
   // these thin, HBM-bound launches
   if (x->needs_grad)
     for (int i = 0; i < 4; ++i) level[i]->leaf_grad = true;
-  T h = conv2d(c, x, wref_sn(c, P(c, "D2/Conv/weights")), P(c, "D2/Conv/biases"), 7, 1, PAD_SAME);
-  h = prelu(c, h, P(c, "D2/Conv/prelu/param"), 0.f);
+  // (conv + PReLU pairs go through conv2d's post_prelu: the PReLU is a second store of the convolution's epilogue where its
+  //  kernel has one; the PReLU of a unit's OUTPUT -- the next unit's prelu(h), the final one -- is a second store of pool2_add)
+  T h = conv2d(c, x, wref_sn(c, P(c, "D2/Conv/weights")), P(c, "D2/Conv/biases"), 7, 1, PAD_SAME, nullptr, 0,
+               P(c, "D2/Conv/prelu/param"));
+  T hp = nullptr;
   int hidden = 8;
   for (int u = 1; u <= 4; ++u) {
     const std::string b = "D2/mru_conv_unit_t_" + std::to_string(u) + "_layer_0";
     const int depth = kMruDepth[u - 1];
     T xin = level[u - 1];
-    T hp = prelu(c, h, P(c, b + "/norm_activation_in/prelu/param"), 0.f);
+    if (!hp) hp = prelu(c, h, P(c, b + "/norm_activation_in/prelu/param"), 0.f);
     // update gate on concat([prelu(h), x]) (conv.py:185-198) without materialising the concat:
     // the SN filter is split by input-channel rows into a hidden part and an image part.
     Param* wg = P(c, b + "/update_gate/weights");
@@ -492,19 +495,24 @@ T classifier_forward(Ctx& c, T x) {
     }
     WRef* wr_h = wref_raw(c, w_h, g_h, f_h, full->want_grad, 9, hidden, hidden, wg->name + "[hidden rows]");
     WRef* wr_x = wref_raw(c, w_x, g_x, f_x, full->want_grad, 9, 3, hidden, wg->name + "[image rows]");
-    T rg = conv2d(c, hp, wr_h, P(c, b + "/update_gate/biases"), 3, 1, PAD_SAME);
-    conv2d(c, xin, wr_x, nullptr, 3, 1, PAD_SAME, rg);
+    // image rows (+ bias) first, the hidden rows add to them: a K-split launch of the hidden-state convolution then leaves
+    // its slabs to the min-max pass (FEED_MINMAX), which sums them on top of the image rows' output
+    T rg = conv2d(c, xin, wr_x, P(c, b + "/update_gate/biases"), 3, 1, PAD_SAME);
+    c.feeds_in = FEED_MINMAX;
+    conv2d(c, hp, wr_h, nullptr, 3, 1, PAD_SAME, rg);
     rg = minmax(c, rg, 0.2f);   // lrelu (activation.py:30-32) + the min-max gate of conv.py:197-198, one pass each way
     T img = conv2d(c, xin, wref_sn(c, P(c, b + "/Conv/weights")), P(c, b + "/Conv/biases"), 3, 1, PAD_SAME);
     T hin = gate_prelu(c, h, rg, img, P(c, b + "/norm_activation_merge_1/prelu/param"));   // conv.py:207-209
-    T c1 = conv2d(c, hin, wref_sn(c, P(c, b + "/Conv_1/weights")), P(c, b + "/Conv_1/biases"), 3, 1, PAD_SAME);
-    c1 = prelu(c, c1, P(c, b + "/Conv_1/prelu/param"), 0.f);
+    T c1 = conv2d(c, hin, wref_sn(c, P(c, b + "/Conv_1/weights")), P(c, b + "/Conv_1/biases"), 3, 1, PAD_SAME, nullptr, 0,
+                  P(c, b + "/Conv_1/prelu/param"));   // conv.py:217-220
+    static const bool proj_full = dbg_env("EG_PROJ_FULL_RES") != nullptr;   // A/B: the reference's evaluation order
+    if (!proj_full) c.feeds_in = FEED_FLAT;   // (pool2_add below reads Conv_2's output quad by quad: K-split slabs stay un-summed)
     T c2 = conv2d(c, c1, wref_sn(c, P(c, b + "/Conv_2/weights")), P(c, b + "/Conv_2/biases"), 3, 1, PAD_SAME);
     // conv.py:229-243: ht_new = mean_pool(conv1x1(ht) + h_new).  The projection is a per-pixel linear map (+ bias) and the
     // pool a per-channel mean over 2x2 pixels, so mean_pool(conv1x1(ht)) == conv1x1(mean_pool(ht)): the 1x1 convolution
     // (forward, input gradient, filter gradient) runs on a quarter of the pixels and its full-resolution output -- as
     // large as h_new -- is never written or read.  Same value up to fp32 summation order.
-    static const bool proj_full = dbg_env("EG_PROJ_FULL_RES") != nullptr;   // A/B: the reference's evaluation order
+    hp = nullptr;
     if (proj_full) {
       T pf = conv2d(c, h, wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
       h = add_pool2(c, pf, c2);   // pf and c2 are conv outputs with no other consumer
@@ -513,11 +521,14 @@ T classifier_forward(Ctx& c, T x) {
       //  -- 1,530 -> 1,476 images/s, profiles/r03f_ab_forward_leaves_negative.txt: thin persistent kernels beside the
       //  one-block-per-CU matrix kernels of the same chain take CUs from them)
       T proj = conv2d(c, pool2(c, h), wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
-      h = pool2_add(c, c2, proj);
+      // the PReLU of the unit's output rides along: the next unit's prelu(h) (conv.py:185), the final one after unit 4 (:353-355)
+      Param* next_leak = u < 4 ? P(c, "D2/mru_conv_unit_t_" + std::to_string(u + 1) + "_layer_0/norm_activation_in/prelu/param")
+                               : P(c, "D2/mru_conv_unit_last_norm/prelu/param");
+      h = pool2_add(c, c2, proj, next_leak, &hp);
     }
     hidden = depth;
   }
-  h = prelu(c, h, P(c, "D2/mru_conv_unit_last_norm/prelu/param"), 0.f);  // conv.py:353-355
+  h = hp ? hp : prelu(c, h, P(c, "D2/mru_conv_unit_last_norm/prelu/param"), 0.f);  // conv.py:353-355
   T feat = gmean(c, h, false);
   return linear(c, feat, wref_sn(c, P(c, "D2/fully_connected/weights")), P(c, "D2/fully_connected/biases"));
 }

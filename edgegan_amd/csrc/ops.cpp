@@ -128,8 +128,27 @@ static void defer_reduction(Ctx& c, const RedDesc& d) {
   if ((int)c.deferred.size() == kRedBatch) run_deferred(c, c.stream);
 }
 
+// SlabSrc views of a tensor's value / gradient (kernels.h), and the stand-alone sum for readers that want a plain tensor
+static SlabSrc data_src(T t) {
+  if (t->nslab > 1) return SlabSrc{t->slabs, t->nslab, t->c, (unsigned long long)t->numel(), t->slab_bias, t->slab_base};
+  return plain_src(t->d);
+}
+static SlabSrc grad_src(T t) {
+  if (t->g_nslab > 1) return SlabSrc{t->g_slabs, t->g_nslab, t->c, (unsigned long long)t->numel(), nullptr, nullptr};
+  return plain_src(t->g);
+}
+static void materialize_grad(Ctx& c, T t) {
+  if (t->g_nslab <= 1) return;
+  launch_conv_split_reduce(t->g_slabs, t->g, nullptr, t->numel(), t->c, t->c, t->g_nslab, 0, c.stream);
+  t->g_nslab = 0;
+  t->g_slabs = nullptr;
+}
+// flat element-wise readers (prelu, gate_prelu, pool2 in their float4 forms) take any [..][C] tensor with C % 4 == 0
+static bool flat_slab_ok(T t) { return t->c % 4 == 0 && t->numel() < (1ull << 31); }
+
 float* grad_acc(Ctx& c, T t, int* acc) {
   if (!t->g) t->g = c.arena.allocf(t->numel());
+  if (t->g_set) materialize_grad(c, t);   // (the first writer left K-split slabs: a second one adds to their sum)
   // ConvArgs::epi_act: the FIRST writer applied the fused activation's derivative in its epilogue and the producer will
   // skip its in-place pass -- exact only if that writer stays the ONLY one.  A second consumer accumulating a raw
   // dL/d(out) into the same buffer would go unmasked: refuse loudly (no graph of this engine does it today).
@@ -147,6 +166,8 @@ void reset_grads(Ctx& c) {
   for (auto& t : c.tensors) {
     t.g_set = t.g_act_done = false;
     t.g_bf = nullptr;   // (the plane of a gradient is as short-lived as the gradient)
+    t.g_nslab = 0;
+    t.g_slabs = nullptr;
   }
   for (auto& p : c.params) p->g_set = false;
   for (auto& s : c.sn) s.dWbar_set = false;
@@ -541,8 +562,7 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
   }
   ProfScope ps(c);
   const double fl = launch_conv_gemm(a, c.stream, &nm);
-  a.epi_applied = a.epi_act && (strncmp(nm, "conv_gemm_x3h<", 14) == 0 || strncmp(nm, "conv_gemm_x3q<", 14) == 0 || strncmp(nm, "conv_gemm_bf16h<", 16) == 0 || strncmp(nm, "conv_bf16p<", 11) == 0) &&
-                          !strstr(nm, "splitk") ? 1 : 0;   // (the kernels that honour ConvArgs::epi_act)
+  a.epi_applied = (a.epi_act && (a.caps & CONV_CAP_EPI_ACT)) ? 1 : 0;   // (reported by the launcher of the kernel that ran)
   if (x3_timing && a.limbs == 3 && a.ksplit <= 1 && a.ws) {
     long long h[128];
     EG_HIP(hipStreamSynchronize(c.stream));
@@ -602,6 +622,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
   a.S = 1;
   a.D = -1;
   attach_bf16(c, a, w, false);   // rows = Cin, contracted = Cout: the filter as stored
+  bool keep_ok = false;
   if (stride == 1) {
     a.kst = 1;
     a.os = 1;
@@ -627,6 +648,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
     a.OHf = x->h;
     a.OWf = x->w;
     a.ph[0] = ConvPhase{x->h, x->w, 0, 0, k, k, 0, 0, pt, pl};
+    keep_ok = !acc;
   } else {
     EG_CHECK(stride == 2 && x->h % 2 == 0 && x->w % 2 == 0, "stride-2 dgrad needs even extents");
     if (Cin == 3 && k == 4 && pt == 1 && pl == 1 && N % 16 == 0) {   // d_conv_0 / encoder stem: phase-merged form
@@ -645,6 +667,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
       a.epi_ref = x->d;
       a.epi_act = x->fused_act;
     }
+    keep_ok = !acc;
     a.OHf = x->h;
     a.OWf = x->w;
     a.kst = 2;
@@ -666,7 +689,15 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
         p.offx = (px + pl - kw0) / 2;
       }
   }
+  // first writer of the gradient of a tensor whose producer's backward reads K-split slabs (Tensor::g_slab_ok): a split
+  // launch leaves them un-summed
+  static const bool gslab_on = dbg_env("EG_NO_GRAD_SLABS") == nullptr;
+  a.keep_slabs = (gslab_on && keep_ok && !a.accumulate && x->g_slab_ok && !x->leaf_grad && !a.epi_act && Cin % 4 == 0) ? 1 : 0;
   run_conv(c, a, y, true);
+  if (a.keep_slabs && a.ksplit > 1) {
+    x->g_slabs = a.ws;
+    x->g_nslab = a.ksplit;
+  }
   if (!a.accumulate) x->g_act_done = a.epi_applied != 0;   // (first writer: decides anew in every backward sweep)
 }
 
@@ -752,7 +783,9 @@ static void bias_grad(Ctx& c, Param* b, const float* dy, size_t rows, int C) {
   b->g_set = true;
 }
 
-T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into, int fused_act) {
+static T prelu_tail(Ctx& c, T x, T out, Param* leak, float leak_const);
+
+T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into, int fused_act, Param* post_prelu) {
   const int Cin = x->c, N = w->Cc;
   EG_CHECK(w->T == k * k && w->R == Cin, "conv2d weight shape: T=%d R=%d vs k=%d Cin=%d", w->T, w->R, k, Cin);
   int OH, OW, pt, pl;
@@ -814,14 +847,45 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   // stores the sum as this tensor's value for the backward passes (in_act)
   static const bool slab_fusion = dbg_env("EG_NO_SLAB_IN") == nullptr;
   static const bool slab_train = dbg_env("EG_NO_SLAB_IN_TRAIN") == nullptr;   // A/B: the fusion in training graphs
-  const bool slabs_ok = c.feeds_in && slab_fusion && (!need || slab_train) && !accumulate_into && !fused_act && N % 32 == 0 && OH * OW <= 1024;
-  c.feeds_in = false;
+  static const bool slab_flat = dbg_env("EG_NO_SLAB_FLAT") == nullptr;        // A/B: the hand-over to prelu / pool2_add / minmax
+  const int feeds = post_prelu ? (int)FEED_FLAT : c.feeds_in;
+  c.feeds_in = FEED_NONE;
+  bool slabs_ok = false;
+  if (feeds == FEED_IN)
+    slabs_ok = slab_fusion && (!need || slab_train) && !accumulate_into && !fused_act && N % 32 == 0 && OH * OW <= 1024;
+  else if (feeds == FEED_FLAT)   // prelu / pool2_add read any [..][N] tensor quad by quad
+    slabs_ok = slab_flat && !accumulate_into && !fused_act && N % 4 == 0 && y->numel() < (1ull << 31);
+  else if (feeds == FEED_MINMAX)   // the gate's hidden-state convolution adds to the image-row convolution's output (the base)
+    slabs_ok = slab_flat && !fused_act && N % 8 == 0;
   a.keep_slabs = slabs_ok ? 1 : 0;
+  // conv -> PReLU (conv.py:217-220): second output of the epilogue where the kernel has one
+  T y2 = nullptr;
+  static const bool epi2_on = dbg_env("EG_NO_EPI_PRELU") == nullptr;
+  if (post_prelu) {
+    EG_CHECK(!accumulate_into && !fused_act, "conv2d: post_prelu excludes accumulate_into / fused_act");
+    y2 = new_tensor(c, x->n, OH, OW, N, false);
+    if (epi2_on && N % 4 == 0) {
+      a.y2_leak = post_prelu->w;
+      a.y2 = y2->d;
+      a.y2_bf = producer_plane(c, y2, false);
+    }
+  }
   run_conv(c, a, x, false);
   if (slabs_ok && a.ksplit > 1) {
     y->slabs = a.ws;
     y->nslab = a.ksplit;
     y->slab_bias = a.bias;
+    y->slab_base = accumulate_into ? y->d : nullptr;
+  }
+  if (post_prelu) {
+    if (y->nslab > 1) {   // the PReLU pass sums the slabs (and stores the sum: its backward reads the pre-activation)
+      const SlabSrc xs = data_src(y);
+      launch_prelu_fwd(y->d, post_prelu->w, 0.f, y2->d, y->numel(), c.stream, a.y2_leak ? a.y2_bf : producer_plane(c, y2, false),
+                       &xs, y->d);
+      y->nslab = 0;
+    } else if (!(a.y2_leak && (a.caps & CONV_CAP_Y2))) {
+      launch_prelu_fwd(y->d, post_prelu->w, 0.f, y2->d, y->numel(), c.stream, a.y2_leak ? a.y2_bf : producer_plane(c, y2, false));
+    }
   }
   if (need) {
     y->needs_grad = true;
@@ -853,6 +917,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     });
   }
   if (fused_act && !fused) return act(c, y, fused_act);
+  if (post_prelu) return prelu_tail(c, y, y2, post_prelu, 0.f);
   return y;
 }
 
@@ -905,8 +970,8 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
   const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
   static const bool slab_fusion = dbg_env("EG_NO_SLAB_IN") == nullptr;
   static const bool slab_train = dbg_env("EG_NO_SLAB_IN_TRAIN") == nullptr;
-  const bool slabs_ok = c.feeds_in && slab_fusion && (!need || slab_train) && !merged && cout % 32 == 0 && OH * OW <= 1024;   // see conv2d
-  c.feeds_in = false;
+  const bool slabs_ok = c.feeds_in == FEED_IN && slab_fusion && (!need || slab_train) && !merged && cout % 32 == 0 && OH * OW <= 1024;   // see conv2d
+  c.feeds_in = FEED_NONE;
   a.keep_slabs = slabs_ok ? 1 : 0;
   if (!merged) run_conv(c, a, x, false);
   if (slabs_ok && a.ksplit > 1) {
@@ -1027,13 +1092,16 @@ T in_act(Ctx& c, T x, int a, T* stats_out) {
     launch_in_fwd(x->d, out->d, st->d, x->n, HW, x->c, a, c.stream, 0, 0, nullptr, nullptr, producer_plane(c, out, false));
   if (stats_out) *stats_out = st;
   if (x->needs_grad) {
+    out->g_slab_ok = in_bwd_takes_slabs(HW, x->c);
     Ctx* cp = &c;
     c.tape.push([=]() {
       Ctx& c = *cp;
       if (!out->g_set) return;
       int acc;
       float* dx = grad_acc(c, x, &acc);
-      launch_in_bwd(x->d, out->d, out->g, st->d, dx, acc, x->n, HW, x->c, a, c.stream, producer_plane(c, x, true));
+      const SlabSrc ds = grad_src(out);
+      launch_in_bwd(x->d, out->d, out->g, st->d, dx, acc, x->n, HW, x->c, a, c.stream, producer_plane(c, x, true),
+                    ds.n > 1 ? &ds : nullptr);
     });
   }
   return out;
@@ -1153,6 +1221,7 @@ T pool2(Ctx& c, T x) {
   T out = new_tensor(c, x->n, x->h / 2, x->w / 2, x->c, x->needs_grad);
   launch_pool2_fwd(x->d, out->d, x->n, x->h, x->w, x->c, c.stream);
   if (x->needs_grad) {
+    out->g_slab_ok = !x->leaf_grad && flat_slab_ok(x) && flat_slab_ok(out);
     Ctx* cp = &c;
     c.tape.push([=]() {
       Ctx& c = *cp;
@@ -1163,7 +1232,8 @@ T pool2(Ctx& c, T x) {
         LeafScope leaf(c);
         launch_pool2_bwd(out->g, dx, acc, x->n, x->h, x->w, x->c, c.stream);
       } else {
-        launch_pool2_bwd(out->g, dx, acc, x->n, x->h, x->w, x->c, c.stream, producer_plane(c, x, true));
+        const SlabSrc ds = grad_src(out);
+        launch_pool2_bwd(out->g, dx, acc, x->n, x->h, x->w, x->c, c.stream, producer_plane(c, x, true), ds.n > 1 ? &ds : nullptr);
       }
     });
   }
@@ -1206,14 +1276,23 @@ T add_pool2(Ctx& c, T a, T b) {
   return out;
 }
 
-T pool2_add(Ctx& c, T a, T b) {
+T pool2_add(Ctx& c, T a, T b, Param* post_prelu, T* prelu_out) {
   EG_CHECK(a->h % 2 == 0 && a->w % 2 == 0, "pool2_add needs even extents");
   EG_CHECK(a->n == b->n && a->h == 2 * b->h && a->w == 2 * b->w && a->c == b->c, "pool2_add shapes");
   T out = new_tensor(c, b->n, b->h, b->w, b->c, a->needs_grad || b->needs_grad);
-  if (!launch_pool2_add_fwd(a->d, b->d, out->d, a->n, a->h, a->w, a->c, c.stream)) {
+  // one pass where the float4 form applies: `a` may still be K-split slabs (conv2d with FEED_FLAT) and the PReLU of the
+  // result -- the next unit's prelu(h) -- is a second store
+  static const bool fuse2 = dbg_env("EG_NO_POOL_PRELU") == nullptr;
+  const bool vec = a->c % 4 == 0 && a->numel() < (1ull << 31);
+  T out2 = (post_prelu && fuse2 && vec) ? new_tensor(c, b->n, b->h, b->w, b->c, false) : nullptr;
+  const SlabSrc as = data_src(a);
+  EG_CHECK(as.n <= 1 || vec, "pool2_add: slab operand without the float4 form");
+  if (!launch_pool2_add_fwd(a->d, b->d, out->d, a->n, a->h, a->w, a->c, c.stream, as.n > 1 ? &as : nullptr,
+                            out2 ? post_prelu->w : nullptr, out2 ? out2->d : nullptr, out2 ? producer_plane(c, out2, false) : nullptr)) {
     launch_pool2_fwd(a->d, out->d, a->n, a->h, a->w, a->c, c.stream);
     launch_axpy(b->d, out->d, 1.f, 1, out->numel(), c.stream);
   }
+  a->nslab = 0;   // (consumed; its own backward needs only its gradient)
   if (out->needs_grad) {
     Ctx* cp = &c;
     c.tape.push([=]() {
@@ -1236,6 +1315,7 @@ T pool2_add(Ctx& c, T a, T b) {
       }
     });
   }
+  if (post_prelu) *prelu_out = out2 ? prelu_tail(c, out, out2, post_prelu, 0.f) : prelu(c, out, post_prelu, 0.f);
   return out;
 }
 
@@ -1371,9 +1451,14 @@ T slice_w(Ctx& c, T x, int w0, int w1) {
 T prelu(Ctx& c, T x, Param* leak, float leak_const) {
   T out = new_tensor(c, x->n, x->h, x->w, x->c, false);
   launch_prelu_fwd(x->d, leak ? leak->w : nullptr, leak_const, out->d, x->numel(), c.stream, producer_plane(c, out, false));
+  return prelu_tail(c, x, out, leak, leak_const);
+}
+// the backward of out = prelu(x) (whoever computed out: prelu() above, a convolution's epilogue, pool2_add's second store)
+static T prelu_tail(Ctx& c, T x, T out, Param* leak, float leak_const) {
   const bool need = x->needs_grad || (leak && leak->want_grad);
   if (need) {
     out->needs_grad = true;
+    out->g_slab_ok = flat_slab_ok(out) && (x->numel() & 3) == 0;
     Ctx* cp = &c;
     c.tape.push([=]() {
       Ctx& c = *cp;
@@ -1383,8 +1468,10 @@ T prelu(Ctx& c, T x, Param* leak, float leak_const) {
       if (x->needs_grad) dx = grad_acc(c, x, &acc);
       const bool pg = leak && leak->want_grad && c.param_grad_enabled;
       if (!dx && !pg) return;
+      const SlabSrc ds = grad_src(out);
       launch_prelu_bwd(x->d, out->g, leak ? leak->w : nullptr, leak_const, dx, acc, pg ? leak->g : nullptr,
-                       pg && leak->g_set ? 1 : 0, x->numel(), c.scratch, c.stream, dx ? producer_plane(c, x, true) : nullptr);
+                       pg && leak->g_set ? 1 : 0, x->numel(), c.scratch, c.stream, dx ? producer_plane(c, x, true) : nullptr,
+                       ds.n > 1 ? &ds : nullptr);
       if (pg) leak->g_set = true;
     });
   }
@@ -1396,7 +1483,9 @@ T minmax(Ctx& c, T x, float pre_leak) {
   T out = new_tensor(c, x->n, x->h, x->w, x->c, x->needs_grad);
   T mm = new_tensor(c, x->n, 1, 1, 2 * x->c, false);
   const int HW = x->h * x->w;
-  launch_minmax_fwd(x->d, out->d, mm->d, x->n, HW, x->c, c.stream, pre_leak);
+  const SlabSrc xs = data_src(x);   // (conv2d with FEED_MINMAX: the pass sums the slabs and stores the sum to x->d)
+  launch_minmax_fwd(x->d, out->d, mm->d, x->n, HW, x->c, c.stream, pre_leak, xs.n > 1 ? &xs : nullptr, x->d);
+  x->nslab = 0;
   if (x->needs_grad) {
     Ctx* cp = &c;
     c.tape.push([=]() {
@@ -1436,6 +1525,7 @@ T gate(Ctx& c, T h, T rg, T img) {
 T gate_prelu(Ctx& c, T h, T rg, T img, Param* leak) {
   T out = new_tensor(c, h->n, h->h, h->w, h->c, true);
   launch_gate_prelu_fwd(h->d, rg->d, img->d, leak->w, out->d, h->numel(), c.stream, producer_plane(c, out, false));
+  out->g_slab_ok = flat_slab_ok(out);
   Ctx* cp = &c;
   c.tape.push([=]() {
     Ctx& c = *cp;
@@ -1447,8 +1537,9 @@ T gate_prelu(Ctx& c, T h, T rg, T img, Param* leak) {
     float* dimg = grad_acc(c, img, &a2);
     EG_CHECK(!a1 && !a2, "gate operands are single-use");
     const bool pg = leak->want_grad && c.param_grad_enabled;
+    const SlabSrc ds = grad_src(out);
     launch_gate_prelu_bwd(h->d, rg->d, img->d, leak->w, out->g, dh, acc_h, drg, dimg, pg ? leak->g : nullptr,
-                          pg && leak->g_set ? 1 : 0, h->numel(), c.scratch, c.stream);
+                          pg && leak->g_set ? 1 : 0, h->numel(), c.scratch, c.stream, ds.n > 1 ? &ds : nullptr);
     if (pg) leak->g_set = true;
   });
   return out;

@@ -591,3 +591,116 @@ def bf16_op_checks(net):
     for case in DECONV_CASES:
         rows += check_deconv(net, case, bf16=True)
     return rows + real_shape_checks(net, bf16=True) + long_m_checks(net, bf16=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: the fused forms of the MRU unit (conv + PReLU as a second epilogue store, K-split slabs summed by their consumer,
+# pool2_add's second store) and the input-gradient slabs read by in_bwd / pool2_bwd -- each through a composite test op that
+# builds the same op sequence classifier_forward / disc_forward build (capi.cpp: mru_tail, mru_gate, act_conv)
+# ------------------------------------------------------------------------------------------------
+def _pool_nhwc(t):
+    return O._nhwc(O.mean_pool_nchw(O._nchw(t)))
+
+
+class _slope_kappa:
+    """Records sum_i |t_i| of every scalar PReLU slope's gradient terms while the oracle differentiates (O._SLOPE_TERMS); a
+    slope's gradient is ONE cancelling sum, good to eps x kappa relative to itself, kappa = sum|t_i| / |sum t_i| -- the rule of
+    tests/test_tight_gpu.py (1e-5 x kappa)."""
+    def __enter__(self):
+        O._SLOPE_TERMS = {}
+        return self
+
+    def __exit__(self, *exc):
+        self.terms = O._SLOPE_TERMS
+        O._SLOPE_TERMS = None
+
+    def tol(self, leak_tensor, grad, base):
+        l1 = self.terms.get(id(leak_tensor), 0.0)
+        return max(base, 1e-5 * l1 / max(abs(float(grad)), 1e-300))
+
+
+def check_mru_tail(net, NB, H, W, C1, C2, seed=0, bf16=False, tol=(FWD_TOL, BWD_TOL)):
+    rng = np.random.RandomState(seed)
+    sc = 1.0 / np.sqrt(9.0)
+    a = dict(x=rng.normal(size=(NB, H, W, C1)), w1=rng.normal(size=(3, 3, C1, C2)) * sc / np.sqrt(C1), b1=rng.normal(size=(C2,)) * 0.1,
+             l1=np.array([0.2 + 0.1 * rng.rand()]), w2=rng.normal(size=(3, 3, C2, C2)) * sc / np.sqrt(C2), b2=rng.normal(size=(C2,)) * 0.1,
+             bp=rng.normal(size=(NB, H // 2, W // 2, C2)), l2=np.array([0.15 + 0.1 * rng.rand()]))
+    a = {k: v.astype(np.float32) for k, v in a.items()}
+    dh = rng.normal(size=(NB, H // 2, W // 2, C2)).astype(np.float32)
+    dhp = rng.normal(size=(NB, H // 2, W // 2, C2)).astype(np.float32)
+    t = {k: t64(v, True) for k, v in a.items()}
+    with O.bf16_operands(bf16), _slope_kappa() as sk:
+        c1 = O.prelu(O.conv2d(t['x'], t['w1'], 1, 'SAME', t['b1']), t['l1'])
+        c2 = O.conv2d(c1, t['w2'], 1, 'SAME', t['b2'])
+        h = _pool_nhwc(c2) + t['bp']
+        hp = O.prelu(h, t['l2'])
+        names = ['x', 'w1', 'b1', 'l1', 'w2', 'b2', 'bp', 'l2']
+        gr = torch.autograd.grad((h * t64(dh)).sum() + (hp * t64(dhp)).sum(), [t[n] for n in names])
+    shapes = [h.shape, hp.shape] + [a[n].shape for n in names]
+    out = net.test_op('mru_tail', [a[n] for n in names] + [dh, dhp], [NB, H, W, C1, C2], [tuple(s) for s in shapes])
+    tag = f'mru_tail[{NB}x{H}x{W} {C1}->{C2}{" bf16" if bf16 else ""}]'
+    rows = [(f'{tag} h', relerr(out[0], h.detach().numpy()), tol[0]), (f'{tag} prelu(h)', relerr(out[1], hp.detach().numpy()), tol[0])]
+    for i, n in enumerate(names):
+        rows.append((f'{tag} d{n}', relerr(out[2 + i], gr[i].detach().numpy()), sk.tol(t[n], gr[i], tol[1]) if n in ('l1', 'l2') else tol[1]))
+    return rows
+
+
+def check_mru_gate(net, NB, H, W, Ch, N, seed=0, bf16=False, tol=(FWD_TOL, BWD_TOL)):
+    rng = np.random.RandomState(seed)
+    sc = 1.0 / 3.0
+    a = dict(h=rng.normal(size=(NB, H, W, Ch)), xin=rng.normal(size=(NB, H, W, 3)), l0=np.array([0.2 + 0.1 * rng.rand()]),
+             wh=rng.normal(size=(3, 3, Ch, Ch)) * sc / np.sqrt(Ch), wx=rng.normal(size=(3, 3, 3, Ch)) * sc / np.sqrt(3.0),
+             bg=rng.normal(size=(Ch,)) * 0.1 + 0.5, img=rng.normal(size=(NB, H, W, Ch)), l1=np.array([0.2 + 0.1 * rng.rand()]),
+             w1=rng.normal(size=(3, 3, Ch, N)) * sc / np.sqrt(Ch))
+    a = {k: v.astype(np.float32) for k, v in a.items()}
+    dy = rng.normal(size=(NB, H, W, N)).astype(np.float32)
+    t = {k: t64(v, True) for k, v in a.items()}
+    with O.bf16_operands(bf16), _slope_kappa() as sk:
+        hp = O.prelu(t['h'], t['l0'])
+        rg = O.conv2d(t['xin'], t['wx'], 1, 'SAME', t['bg']) + O.conv2d(hp, t['wh'], 1, 'SAME')
+        rg = O.lrelu_leak(rg)
+        mn, mx = rg.amin(dim=(1, 2), keepdim=True), rg.amax(dim=(1, 2), keepdim=True)
+        rg = (rg - mn) / (mx - mn)
+        hin = O.prelu(t['h'] + rg * t['img'], t['l1'])
+        y = O.conv2d(hin, t['w1'], 1, 'SAME')
+        names = ['h', 'xin', 'img', 'l0', 'wh', 'wx', 'bg', 'l1', 'w1']
+        gr = torch.autograd.grad((y * t64(dy)).sum(), [t[n] for n in names])
+    ins = [a['h'], a['xin'], a['l0'], a['wh'], a['wx'], a['bg'], a['img'], a['l1'], a['w1'], dy]
+    out = net.test_op('mru_gate', ins, [NB, H, W, Ch, N], [tuple(y.shape)] + [a[n].shape for n in names])
+    tag = f'mru_gate[{NB}x{H}x{W} {Ch}->{N}{" bf16" if bf16 else ""}]'
+    rows = [(f'{tag} y', relerr(out[0], y.detach().numpy()), tol[0])]
+    for i, n in enumerate(names):
+        rows.append((f'{tag} d{n}', relerr(out[1 + i], gr[i].detach().numpy()), sk.tol(t[n], gr[i], tol[1]) if n in ('l0', 'l1') else tol[1]))
+    return rows
+
+
+def check_act_conv(net, NB, H, W, Cc, N, k, s, kind, seed=0, bf16=False, tol=(FWD_TOL, BWD_TOL)):
+    rng = np.random.RandomState(seed)
+    x = rng.normal(size=(NB, H, W, Cc)).astype(np.float32)
+    w = (rng.normal(size=(k, k, Cc, N)) / (k * np.sqrt(Cc))).astype(np.float32)
+    xt, wt = t64(x, True), t64(w, True)
+    with O.bf16_operands(bf16):
+        m = O.lrelu_leak(O.instance_norm(xt)) if kind == 0 else O.avg_pool2(xt)
+        y = O.conv2d(m, wt, s, 'SAME')
+        dy = rng.normal(size=tuple(y.shape)).astype(np.float32)
+        gr = torch.autograd.grad((y * t64(dy)).sum(), [xt, wt])
+    out = net.test_op('act_conv', [x, w, dy], [NB, H, W, Cc, N, k, s, kind], [tuple(y.shape), x.shape, w.shape])
+    tag = f'{"in_act" if kind == 0 else "pool2"}->conv[{NB}x{H}x{W} {Cc}->{N} k{k}s{s}{" bf16" if bf16 else ""}]'
+    return [(f'{tag} y', relerr(out[0], y.detach().numpy()), tol[0]), (f'{tag} dx', relerr(out[1], gr[0].detach().numpy()), tol[1]),
+            (f'{tag} dw', relerr(out[2], gr[1].detach().numpy()), tol[1])]
+
+
+def fused_chain_checks(net, bf16=False):
+    """Shapes chosen so that the K-split launches (few output tiles: small maps, many channels) and the un-split epilogue
+    forms (16x16 / 32x32 maps) are both hit in the f32x3 and bf16 modes; the exact-fp32 mode runs the same graphs on its own
+    kernels (every fusion falls back to the separate pass where a kernel has no such epilogue)."""
+    tol = (2e-2, 5e-2) if bf16 else (FWD_TOL, 2 * BWD_TOL)   # (bf16: a rounding-boundary flip of an intermediate costs 2^-8 of that element)
+    rows = []
+    for (NB, H, W, C1, C2) in [(2, 8, 8, 256, 256), (4, 16, 16, 128, 128), (3, 8, 8, 512, 768), (2, 32, 32, 128, 256), (2, 16, 16, 8, 128)]:
+        rows += check_mru_tail(net, NB, H, W, C1, C2, seed=C1 + NB, bf16=bf16, tol=tol)
+    for (NB, H, W, Ch, N) in [(2, 8, 8, 256, 256), (4, 16, 16, 128, 128), (2, 8, 8, 512, 512), (2, 16, 16, 8, 32)]:
+        rows += check_mru_gate(net, NB, H, W, Ch, N, seed=Ch + NB, bf16=bf16, tol=tol)
+    for (NB, H, W, Cc, N, k, s, kind) in [(4, 16, 16, 256, 512, 4, 2, 0), (2, 8, 8, 512, 512, 3, 1, 0), (2, 32, 32, 128, 256, 4, 2, 0),
+                                            (2, 8, 8, 512, 768, 1, 1, 1), (2, 16, 16, 256, 512, 1, 1, 1)]:
+        rows += check_act_conv(net, NB, H, W, Cc, N, k, s, kind, seed=Cc + k, bf16=bf16, tol=tol)
+    return rows

@@ -47,6 +47,15 @@ def test_bf16_ops_match_rounded_operand_oracle():
     net.close()
 
 
+def test_bf16_fused_mru_chains():
+    """The fused forms of the MRU unit on the plane-fed kernels (Conv_1's PReLU and its bf16 plane from conv_bf16p's epilogue,
+    K-split slabs summed by their consumer) against the oracle with the engine's operand rounding emulated; a chain's
+    tolerance allows a rounding-boundary flip of an intermediate value (2^-8 of that element)."""
+    net = ea.EdgeGAN(ea.Config(batch_size=2, compute_dtype='bf16'))
+    _assert(parity.fused_chain_checks(net, bf16=True))
+    net.close()
+
+
 @pytest.mark.parametrize('num_classes', [14, 0])
 def test_bf16_network_forwards(num_classes):
     cfg = ea.Config(batch_size=2, num_classes=num_classes, compute_dtype='bf16')

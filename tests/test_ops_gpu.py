@@ -53,6 +53,12 @@ def test_remaining_ops(net):
     _assert(rows)
 
 
+def test_fused_mru_chains(net):
+    """conv + PReLU, the update gate, pool2_add + PReLU and the activation -> convolution chains as the classifier / the
+    discriminators build them (round 5: second epilogue stores, K-split slabs summed by their consumer)."""
+    _assert(parity.fused_chain_checks(net))
+
+
 def test_bad_arguments_fail_loudly(net):
     with pytest.raises(ea.EdgeGANLibError):
         net.test_op('no_such_op', [np.zeros(4, np.float32)], [1], [(4,)])

@@ -37,6 +37,14 @@ def _assert(rows):
     assert not bad, '\n' + parity.format_rows(bad)
 
 
+def test_x3_fused_mru_chains():
+    """The fused forms of the MRU unit in the benched mode: Conv_1's PReLU from the halo kernel's epilogue, K-split slabs
+    summed by prelu / min-max / pool2_add / in_bwd / prelu_bwd / gate_prelu_bwd / pool2_bwd (tests/parity.py)."""
+    net = ea.EdgeGAN(ea.Config(batch_size=2, compute_dtype='f32x3'))
+    _assert(parity.fused_chain_checks(net))
+    net.close()
+
+
 def test_x3_ops_at_fp32_tolerances():
     net = ea.EdgeGAN(ea.Config(batch_size=2, compute_dtype='f32x3'))
     rows = []
