@@ -109,6 +109,28 @@ def physical_cores(hw):
         return hw
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup CPU bandwidth limit (v2 cpu.max / v1 cfs quota) if there is one, else None.
+    The GPU boxes of this pool run the job in a container limited to 16 CPUs on a 2 x 64-core host (`1600000 100000` in
+    /sys/fs/cgroup/cpu.max, measured round 5): with more runnable threads than that the scheduler throttles the whole group,
+    which is why "one thread per physical core" measured 0.7 images/s against 5.4 on 16 threads and why pinned shard processes
+    slowed each other down 10-fold (profiles/r05e_cpu_scale.txt)."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, per = f.read().split()
+        return None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+            q = float(f.read())
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def _oracle_iteration(cfg_kwargs, batch, threads, substeps=None):
     """Seconds of one training iteration (or of the listed sub-steps) of the torch-CPU fp32 oracle at `batch`."""
     import torch
@@ -208,24 +230,27 @@ def cpu_baseline(cfg_kwargs, batch_all=64, batch_one=2):
     import torch
     ncpu = torch.get_num_threads()
     hw = os.cpu_count() or ncpu
-    _oracle_iteration(cfg_kwargs, 2, min(ncpu, 16), ['e_optim'])          # untimed: thread pool / allocator warm-up
-    sweep = {th: round(16 / _oracle_iteration(cfg_kwargs, 16, th), 2) for th in (8, 16, 32, 64) if th <= hw} or \
-        {ncpu: 0.0}
-    best = max(sweep, key=sweep.get)
-    # "all cores" = every PHYSICAL core (one thread per core: with SMT siblings added torch's spin-waiting pool thrashes
-    # -- measured once on the 2 x 64-core box: 256 threads took 1034 s for the batch-16 iteration that 16 threads do in 1.7 s)
+    quota = cpu_quota()
+    # every CPU the process may use: the host's physical cores, or the container's CPU quota where that is smaller (then a
+    # thread count above it only gets the whole group throttled -- cpu_quota())
     phys = physical_cores(hw)
-    dt_allc = _oracle_iteration(cfg_kwargs, 8, phys) if phys not in sweep else 16 / max(sweep[phys], 1e-9)
-    allc_batch = 8 if phys not in sweep else 16
+    usable = phys if quota is None else max(1, min(phys, int(quota)))
+    _oracle_iteration(cfg_kwargs, 2, min(ncpu, 16, usable), ['e_optim'])          # untimed: thread pool / allocator warm-up
+    sweep = {th: round(16 / _oracle_iteration(cfg_kwargs, 16, th), 2) for th in sorted({8, 16, 32, 64, usable}) if th <= usable} or \
+        {usable: round(16 / _oracle_iteration(cfg_kwargs, 16, usable), 2)}
+    best = max(sweep, key=sweep.get)
+    # "all cores" = every USABLE core, one thread each (with SMT siblings added torch's spin-waiting pool thrashes)
+    dt_allc = _oracle_iteration(cfg_kwargs, 8, usable) if usable not in sweep else 16 / max(sweep[usable], 1e-9)
+    allc_batch = 8 if usable not in sweep else 16
     dt_all = _oracle_iteration(cfg_kwargs, batch_all, best)
     dt_one = _oracle_iteration(cfg_kwargs, batch_one, 1)
     dt_c0 = _oracle_iteration(dict(cfg_kwargs, num_classes=0), 4, best)
     torch.set_num_threads(ncpu)
     # the best HONEST all-core number: batch shards on pinned processes
     sharded = None
-    if phys >= 2 * best:
+    if usable >= 2 * best:
         try:
-            ips, procs, per, dts = cpu_all_cores_sharded(cfg_kwargs, batch_all, best, phys)
+            ips, procs, per, dts = cpu_all_cores_sharded(cfg_kwargs, batch_all, best, usable)
             sharded = {'value': round(ips, 3), 'unit': 'images/s', 'cores': procs * best,
                        'sample': f'{procs} processes x {best} threads, each pinned to its own cores, one full iteration at batch '
                                  f'{per} per process ({procs * per} images), {dts:.1f} s for the slowest'}
@@ -239,15 +264,20 @@ def cpu_baseline(cfg_kwargs, batch_all=64, batch_one=2):
                           f'oracle, {best} threads (best of the sweep), {dt_all:.1f} s'}
     return {'value': head['value'], 'unit': 'images/s', 'cores': head['cores'], 'kind': 'port',
             'kind_detail': 'torch-CPU fp32 restatement (oracle/edgegan_oracle.py), not the reference\'s TensorFlow 1.14',
-            'cpu_model': cpu_model(), 'host_hardware_threads': hw,
+            'cpu_model': cpu_model(), 'host_hardware_threads': hw, 'host_physical_cores': phys,
+            'cgroup_cpu_quota': quota, 'usable_cpus': usable,
+            'usable_cpus_note': ('the container is limited to %g CPUs by its cgroup CPU quota: `cores` below are ALL the CPUs this '
+                                 'process may use, not a subset of the host\'s %d' % (quota, phys)) if quota is not None and quota < phys
+            else 'no cgroup CPU quota below the host\'s physical core count',
+
             'sample': head['sample'],
             'one_process_best_threads': {'value': round(batch_all / dt_all, 3), 'unit': 'images/s', 'cores': best,
                                          'sample': f'1 full iteration at batch {batch_all}, {best} threads, {dt_all:.1f} s'},
             'all_cores_sharded': sharded,
             'thread_sweep_images_per_s_at_batch_16': sweep,
-            'all_cores': {'value': round(allc_batch / dt_allc, 3), 'unit': 'images/s', 'cores': phys,
-                          'sample': f'1 full iteration at batch {allc_batch} with one thread on each of the {phys} physical cores '
-                                    f'({hw} hardware threads), {dt_allc:.1f} s'},
+            'all_cores': {'value': round(allc_batch / dt_allc, 3), 'unit': 'images/s', 'cores': usable,
+                          'sample': f'1 full iteration at batch {allc_batch} with one thread on each of the {usable} usable CPUs '
+                                    f'(host: {phys} physical cores, {hw} hardware threads; cgroup quota {quota}), {dt_allc:.1f} s'},
             'single_core': {'value': round(batch_one / dt_one, 4), 'unit': 'images/s', 'cores': 1,
                             'sample': f'1 full iteration at batch {batch_one}, 1 thread, {dt_one:.1f} s'},
             'config0_single_class_b4': {'value': round(4 / dt_c0, 3), 'unit': 'images/s', 'cores': best,

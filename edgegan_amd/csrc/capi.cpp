@@ -865,7 +865,28 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
       io.down_grad(1, x);
       io.down_pgrad(2, w);
     }
-  } else if (op == "fault_mid_backward") {
+  } else if (op == "d_head") {
+    // d_conv_0 + LeakyReLU (fused into the convolution where its kernel can) followed by d_conv_1 (discriminator.py:61-66): the
+    // second convolution's input gradient is the ONLY writer of the activated tensor's gradient, so the activation's backward
+    // rides in its epilogue when the kernel that runs reports CONV_CAP_EPI_ACT (un-split halo kernel) and is the in-place
+    // pass of conv2d's backward otherwise (K-split / 64x64 kernels) -- both must give the same gradient
+    // ip: NB,H,W,N1,N2 ; in: x,w0,w1,dy ; out: y,dx,dw0,dw1
+    need_ip(5);
+    const bool bw = io.has(3);
+    T x = io.tensor(0, ip[0], ip[1], ip[2], 3, bw);
+    Param* w0 = io.param(1, bw);
+    Param* w1 = io.param(2, bw);
+    T a0 = conv2d(c, x, wref_param(c, w0, 16, 3, ip[3]), nullptr, 4, 2, PAD_SAME, nullptr, ACT_LRELU);
+    T y = conv2d(c, a0, wref_param(c, w1, 16, ip[3], ip[4]), nullptr, 4, 2, PAD_SAME);
+    io.down(0, y->d, y->numel());
+    if (bw) {
+      io.seed(y, 3);
+      c.tape.backward();
+      io.down_grad(1, x);
+      io.down_pgrad(2, w0);
+      io.down_pgrad(3, w1);
+    }
+  } else if (op == "fault_mid_backward" && getenv("EG_TEST_HOOKS")) {   // (only where the test suite asks for it)
     // test hook (tests/test_step_gpu.py): leave the context the way an exception in the middle of a concurrent
     // iteration's backward sweep does -- another lane active, its stream pointing at the lane's leaf stream with
     // un-joined work, a queued second-stage reduction of the abandoned sweep -- and fail.  The NEXT call has to recover

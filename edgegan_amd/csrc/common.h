@@ -141,6 +141,10 @@ struct Tensor {
   const float* g_slabs = nullptr;
   int g_nslab = 0;
   bool g_slab_ok = false;
+  // column sums of g (a bias gradient) may be taken from a SMALLER tensor with the same column sums: pool2_add's backward
+  // writes g = up-sample(out.g) / 4, whose column sums are those of out.g (a quarter of the rows); cleared by grad_acc
+  const float* g_colsum_src = nullptr;
+  size_t g_colsum_rows = 0;
   // bf16 planes ([pixel][c] bf16) of d / g for the plane-fed kernels of the bf16 mode (k_conv_bf16p.hip).  Written by the
   // tensor's own producer kernel as a second store (then *_bf_stream == nullptr: the plane is visible wherever d / g is),
   // or on demand by launch_cvt_bf16 on the stream recorded here (ops.cpp: tensor_plane decides who else may read it)

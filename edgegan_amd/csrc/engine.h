@@ -50,6 +50,11 @@ struct WRef {
   unsigned short* wlT = nullptr;  // three bf16 limb planes, per-tap transposed
   int T = 1, R = 0, Cc = 0;
   std::string name;          // variable name (profiler labels)
+  // persistent derived copies owned by somebody else (the gate-filter parts of an SNWeight): per-tap transpose + its valid
+  // flag, limb-plane caches [as stored, transposed]
+  float* extT = nullptr;
+  bool* extT_valid = nullptr;
+  LimbCache* extL = nullptr;
 };
 
 // persistent per-weight spectral-norm buffers (classifier)
@@ -62,6 +67,14 @@ struct SNWeight {
   bool wT_valid = false;
   LimbCache wL[2];   // limb planes of Wbar (as stored / transposed), rebuilt when Wbar is
   int K = 0, Co = 0, T = 1;
+  // update-gate filters only (conv.py:185-198: the gate convolves concat([prelu(h), x])): Wbar split by input-channel rows into
+  // its hidden-state part [9][split_rows][Co] and its image part [9][3][Co] -- persistent copies refreshed with Wbar
+  // (sn_prepare), with their own per-tap transposes and limb planes (same life cycle as WbarT / wL)
+  int split_rows = 0;
+  float* part[2] = {nullptr, nullptr};
+  float* partT[2] = {nullptr, nullptr};
+  bool partT_valid[2] = {false, false};
+  LimbCache partL[2][2];
 };
 
 struct ResizeTab {  // separable resampling taps, forward and transposed

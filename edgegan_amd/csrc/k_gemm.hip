@@ -384,8 +384,55 @@ static int pick_x3(ConvArgs& a) {
   return best_ks;
 }
 
+// Measured (tile family, K split) of the f32x3 convolution launches whose best choice the cost model misses: one row per launch
+// shape of the iteration (BASELINE configs[2], B = 64), generated by tools/tune_x3.py from per-layer HIP-event timings of every
+// candidate on MI355X (profiles/r05*_tune_*).  Shapes that are not listed -- other batch sizes, other resolutions -- use the model.
+struct X3Tuned {
+  int M, N, C, taps, nphase, S, tile, ks;
+};
+static const X3Tuned kX3Tuned[] = {
+#include "x3_tuned.h"
+    {0, 0, 0, 0, 0, 0, 0, 0}};
+
 int conv_pick_ksplit(ConvArgs& a) {
   if (a.N <= 16 || a.C % 32 != 0 || a.N % 4 != 0) return 1;
+  if (a.limbs == 3 && a.wgt_bf) {
+    int maxM = 0, taps = 0;
+    for (int p = 0; p < a.nphase; ++p) {
+      maxM = std::max(maxM, a.NB * a.ph[p].OHp * a.ph[p].OWp);
+      taps += a.ph[p].Ty * a.ph[p].Tx;
+    }
+#ifdef EG_EXPERIMENTS
+    // tools/tune_x3.py: "tile,ks" forces every limb-mode launch onto one candidate (clipped to what the shape allows)
+    static const char* force = dbg_env("EG_X3_FORCE");
+    if (force) {
+      int ft = 0, fk = 1;
+      if (sscanf(force, "%d,%d", &ft, &fk) == 2 && (ft == 1 || ft == 2)) {
+        int nk = 1 << 30;
+        for (int p = 0; p < a.nphase; ++p) nk = std::min(nk, a.ph[p].Ty * a.ph[p].Tx * (a.C / 32));
+        while (fk > 1 && nk / fk < 4) --fk;
+        if (ft == 1 && !(a.N >= 64 && a.x_bytes && a.wbf_bytes)) ft = 2;
+        if (ft == 1 && a.N < 128) {   // (below 128 output channels only the halo kernel has a 256-pixel form)
+          ConvArgs b = a;
+          b.x3_tile = 1;
+          b.ksplit = fk;
+          if (!conv_x3h_eligible(b)) ft = 2;
+        }
+        a.x3_tile = ft;
+        a.tuned = 1;
+        return fk;
+      }
+    }
+    static const bool no_table = dbg_env("EG_X3_NO_TABLE") != nullptr;
+    if (!no_table)
+#endif
+    for (const X3Tuned* t = kX3Tuned; t->M; ++t)
+      if (t->M == maxM && t->N == a.N && t->C == a.C && t->taps == taps && t->nphase == a.nphase && t->S == a.S) {
+        a.x3_tile = t->tile;
+        a.tuned = 1;
+        return t->ks;
+      }
+  }
   if ((a.limbs == 3 || a.limbs == 1) && a.wgt_bf) return pick_x3(a);
   int maxM = 0, minTiles = 1 << 30;
   for (int p = 0; p < a.nphase; ++p) {
@@ -1037,7 +1084,8 @@ int wgrad_pick_splits(const WgradArgs& a) {
     const long long tiles = ((units + 1) / 2) * ((a.N + 127) / 128);
     // one block per CU (512 threads, 100 KB LDS): 256 blocks = one full wave of blocks.  Measured against 512 (two
     // waves): filter-gradient kernels 7.05 -> 6.70 ms per iteration and half the partial slabs to write and reduce
-    return pick_balanced_splits(tiles, 256, std::min(256LL, (M + 255) / 256));
+    static const int x3_blocks = dbg_env("EG_WGRAD_X3_BLOCKS") ? atoi(dbg_env("EG_WGRAD_X3_BLOCKS")) : 256;   // (tools/tune_x3.py sweeps it)
+    return pick_balanced_splits(tiles, x3_blocks, std::min(256LL, (M + 255) / 256));
   }
   if (wgrad_pk_eligible(a)) return wgrad_pk_splits(a);
   if (wgrad_flatm(a)) {

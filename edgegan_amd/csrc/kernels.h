@@ -84,6 +84,7 @@ struct ConvArgs {
   float* y2;
   unsigned short* y2_bf;
   int caps;          // OUT, set by launch_conv_gemm: what the kernel that ran honoured (CONV_CAP_*); ksplit is written back too
+  int tuned;         // conv_pick_ksplit took (x3_tile, ksplit) from the measured per-shape table (x3_tuned.h): run_conv keeps them
 };
 enum ConvCaps { CONV_CAP_EPI_ACT = 1, CONV_CAP_Y2 = 2 };
 

@@ -226,6 +226,14 @@ void build_context(Ctx& c) {
       EG_HIP(hipMalloc(&s.dv, (size_t)s.K * 4));
       EG_HIP(hipMalloc(&s.sv, (size_t)sn_sv_floats(s.Co) * 4));
       EG_HIP(hipMalloc(&s.scal, 80 * 4));
+      if (scope.size() > 12 && scope.compare(scope.size() - 12, 12, "/update_gate") == 0) {   // [3,3,hidden+3,hidden]
+        s.split_rows = p->shape[2] - 3;
+        const size_t nh = (size_t)s.T * s.split_rows * s.Co, nx = (size_t)s.T * 3 * s.Co;
+        EG_HIP(hipMalloc(&s.part[0], nh * 4));
+        EG_HIP(hipMalloc(&s.partT[0], nh * 4));
+        EG_HIP(hipMalloc(&s.part[1], nx * 4));
+        EG_HIP(hipMalloc(&s.partT[1], nx * 4));
+      }
       c.sn_index[p] = (int)c.sn.size();
       c.sn.push_back(s);
       if (s.K > c.sn_maxK) c.sn_maxK = s.K;
@@ -470,10 +478,9 @@ T classifier_forward(Ctx& c, T x) {
     Param* wg = P(c, b + "/update_gate/weights");
     WRef* full = wref_sn(c, wg);
     const int ct = hidden + 3;
-    float* w_h = c.arena.allocf((size_t)9 * hidden * hidden);
-    float* w_x = c.arena.allocf((size_t)9 * 3 * hidden);
-    launch_copy_cols(w_h, const_cast<float*>(full->w), 9, 1, hidden, ct, 0, hidden, 0, 0, c.stream);
-    launch_copy_cols(w_x, const_cast<float*>(full->w), 9, 1, 3, ct, hidden, hidden, 0, 0, c.stream);
+    SNWeight& sw = c.sn[c.sn_index.at(wg)];   // its two parts are refreshed together with W / sigma (ops.cpp: sn_prepare)
+    EG_CHECK(sw.split_rows == hidden, "update gate %s: split rows %d vs hidden %d", wg->name.c_str(), sw.split_rows, hidden);
+    float *w_h = sw.part[0], *w_x = sw.part[1];
     float *g_h = nullptr, *g_x = nullptr;
     bool *f_h = nullptr, *f_x = nullptr;
     c.flags.push_back(false);
@@ -495,6 +502,13 @@ T classifier_forward(Ctx& c, T x) {
     }
     WRef* wr_h = wref_raw(c, w_h, g_h, f_h, full->want_grad, 9, hidden, hidden, wg->name + "[hidden rows]");
     WRef* wr_x = wref_raw(c, w_x, g_x, f_x, full->want_grad, 9, 3, hidden, wg->name + "[image rows]");
+    int pi = 0;
+    for (WRef* wr : {wr_h, wr_x}) {   // persistent per-tap transposes / limb planes, like Wbar's own
+      wr->extT = sw.partT[pi];
+      wr->extT_valid = &sw.partT_valid[pi];
+      wr->extL = sw.partL[pi];
+      ++pi;
+    }
     // image rows (+ bias) first, the hidden rows add to them: a K-split launch of the hidden-state convolution then leaves
     // its slabs to the min-max pass (FEED_MINMAX), which sums them on top of the image rows' output
     T rg = conv2d(c, xin, wr_x, P(c, b + "/update_gate/biases"), 3, 1, PAD_SAME);

@@ -156,6 +156,7 @@ float* grad_acc(Ctx& c, T t, int* acc) {
   *acc = t->g_set ? 1 : 0;
   t->g_set = true;
   t->g_bf = nullptr;   // whoever asks is about to write g: a plane of its previous value is stale (the writer may set a new one)
+  t->g_colsum_src = nullptr;
   return t->g;
 }
 void seed_grad(Ctx& c, T t) {
@@ -168,6 +169,7 @@ void reset_grads(Ctx& c) {
     t.g_bf = nullptr;   // (the plane of a gradient is as short-lived as the gradient)
     t.g_nslab = 0;
     t.g_slabs = nullptr;
+    t.g_colsum_src = nullptr;
   }
   for (auto& p : c.params) p->g_set = false;
   for (auto& s : c.sn) s.dWbar_set = false;
@@ -182,6 +184,7 @@ void reset_step(Ctx& c) {
   c.flags.clear();
   c.sn_prepared = false;
   c.param_grad_enabled = true;
+  c.alt_w = nullptr;   // (points into c.wrefs)
   for (auto& p : c.params) p->g_set = false;
   for (auto& s : c.sn) s.dWbar_set = false;
 }
@@ -243,6 +246,14 @@ WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_
 }
 const float* wref_transposed(Ctx& c, WRef* w) {
   if (w->wT) return w->wT;
+  if (w->extT) {
+    if (!*w->extT_valid) {
+      launch_tap_transpose(w->w, w->extT, w->T, w->R, w->Cc, nullptr, c.stream);
+      *w->extT_valid = true;
+    }
+    w->wT = w->extT;
+    return w->wT;
+  }
   if (w->param && w->param->cache_T) {
     Param* p = w->param;
     if (!p->wT) EG_HIP(hipMalloc(&p->wT, p->numel * sizeof(float)));
@@ -334,6 +345,8 @@ static unsigned short* limb_planes(Ctx& c, WRef* w, bool transposed, int nplanes
     lc = &w->param->wL[o];
   else if (w->sn)
     lc = &w->sn->wL[o];
+  else if (w->extL)
+    lc = &w->extL[o];
   if (lc) {
     if (lc->buf && lc->planes != nplanes) {
       (void)hipFree(lc->buf);
@@ -410,6 +423,7 @@ static unsigned short* limb_planes(Ctx& c, WRef* w, bool transposed, int nplanes
 }
 
 static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
+  c.alt_w = nullptr;   // (a hand-over to run_conv that an earlier caller never consumed must not reach this launch)
   if (c.cfg.x3) {   // three limb planes instead of one rounded copy (k_gemm_x3.hip)
     if (a.C % 32 != 0 || a.N <= 16 || a.N % 4 != 0) return;
     const size_t n = (size_t)w->T * w->R * w->Cc;
@@ -501,7 +515,7 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
   // splits over the channel chunks give every CU a block: 168-186 vs 111-139 TFLOP/s on the discriminators' conv3 / conv4
   // input gradients and the encoder's residual convolutions.
   static const bool halo_small = dbg_env("EG_NO_HALO_SMALL") == nullptr;
-  if (halo_small && a.limbs == 3 && a.x3_tile == 2 && a.N >= 64 && a.S == 1) {
+  if (halo_small && !a.tuned && a.limbs == 3 && a.x3_tile == 2 && a.N >= 64 && a.S == 1) {
     const ConvArgs keep = a;
     const int bn = a.N >= 128 ? 128 : 64;
     const long long blocks = (long long)((a.NB * a.ph[0].OHp * a.ph[0].OWp + 255) / 256) * ((a.N + bn - 1) / bn) * a.nphase;
@@ -800,6 +814,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   }
   T y = accumulate_into ? accumulate_into : new_tensor(c, x->n, OH, OW, N, false);
   EG_CHECK(y->n == x->n && y->h == OH && y->w == OW && y->c == N, "conv2d output shape");
+  if (accumulate_into) y->d_bf = nullptr;   // (a bf16 plane of the value this launch adds to is stale afterwards)
   ConvArgs a{};
   a.x = x->d;
   a.x_is_activation = 1;
@@ -896,15 +911,24 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     c.tape.push([=]() {
       Ctx& c = *cp;
       if (!y->g_set) return;
-      if (fused && !y->g_act_done) launch_act_bwd(y->d, y->g, y->g, 0, y->numel(), fused_act, c.stream);   // in place: g *= act'(out)
+      if (fused && !y->g_act_done) {
+        launch_act_bwd(y->d, y->g, y->g, 0, y->numel(), fused_act, c.stream);   // in place: g *= act'(out)
+        y->g_bf = nullptr;           // (a plane its writer stored holds the un-masked values)
+        y->g_colsum_src = nullptr;
+      }
       // bf16 mode: the plane of y's gradient serves the filter gradient (leaf stream) AND the input gradient (this stream):
-      // if y's producer left none, make it here, before the leaf scope opens -- both streams may then read it
-      if (c.cfg.bf16 && y->c % 64 == 0 && w->want_grad && x->needs_grad && c.param_grad_enabled) (void)tensor_plane(c, y, true);
+      // if y's producer left none, make it here, before the leaf scope opens -- both streams may then read it.  Only the
+      // multi-tap layers have plane-fed kernels (k_conv_bf16p.hip: 2 .. 3 taps per dimension; k_wgrad_bf16p.hip: 3x3, 4x4,
+      // 5x5): a 1x1 layer would pay the conversion for nothing
+      if (c.cfg.bf16 && k > 1 && y->c % 64 == 0 && w->want_grad && x->needs_grad && c.param_grad_enabled) (void)tensor_plane(c, y, true);
       if (c.param_grad_enabled && (w->want_grad || (bias && bias->want_grad))) {
         LeafScope leaf(c);
         if (w->want_grad)
           conv_wgrad(c, x, false, x->n, x->h, x->w, Cin, y, true, OH, OW, N, w, k, stride, pt, pad == PAD_REFLECT);
-        if (bias && bias->want_grad) bias_grad(c, bias, y->g, rows, N);
+        if (bias && bias->want_grad) {
+          if (y->g_colsum_src) bias_grad(c, bias, y->g_colsum_src, y->g_colsum_rows, N);   // (pool2_add: a quarter of the rows)
+          else bias_grad(c, bias, y->g, rows, N);
+        }
       }
       if (x->needs_grad) {
         if (x->leaf_grad) {   // gradient towards a leaf-side tensor (the classifier's image pyramid): off the dependent chain
@@ -1312,6 +1336,11 @@ T pool2_add(Ctx& c, T a, T b, Param* post_prelu, T* prelu_out) {
         int acc;
         float* d = grad_acc(c, a, &acc);
         launch_pool2_bwd(out->g, d, acc, a->n, a->h, a->w, a->c, c.stream, producer_plane(c, a, true));
+        static const bool colsum_small = dbg_env("EG_NO_POOLED_COLSUM") == nullptr;
+        if (!acc && colsum_small) {   // the column sums of d are those of out->g (each value appears 4 times, scaled by 1/4)
+          a->g_colsum_src = out->g;
+          a->g_colsum_rows = out->pixels();
+        }
       }
     });
   }
@@ -1570,7 +1599,15 @@ void sn_prepare(Ctx& c) {
   if (count == 0) return;
   if (!c.sn_valid) {  // the classifier's weights only change in sub-step 4: sub-steps 5 and 7 share one W/sigma
     launch_sn_fwd(c.sn_table, count, c.sn_maxK, c.sn_maxCo, c.stream);
-    for (auto& s : c.sn) s.wT_valid = s.wL[0].valid = s.wL[1].valid = false;
+    for (auto& s : c.sn) {
+      s.wT_valid = s.wL[0].valid = s.wL[1].valid = false;
+      if (!s.split_rows) continue;
+      // the update gate's filter by input-channel rows (hidden state | image): copies that live as long as Wbar does
+      const int ct = s.split_rows + 3;
+      launch_copy_cols(s.part[0], s.Wbar, s.T, 1, s.split_rows, ct, 0, s.Co, 0, 0, c.stream);
+      launch_copy_cols(s.part[1], s.Wbar, s.T, 1, 3, ct, s.split_rows, s.Co, 0, 0, c.stream);
+      for (int i = 0; i < 2; ++i) s.partT_valid[i] = s.partL[i][0].valid = s.partL[i][1].valid = false;
+    }
     c.sn_valid = true;
   }
   bool want = false;
@@ -1628,6 +1665,11 @@ Ctx::~Ctx() {
     (void)hipFree(s.Wbar);
     (void)hipFree(s.WbarT);
     for (int o = 0; o < 2; ++o) s.wL[o].release();
+    for (int i = 0; i < 2; ++i) {
+      (void)hipFree(s.part[i]);
+      (void)hipFree(s.partT[i]);
+      for (int o = 0; o < 2; ++o) s.partL[i][o].release();
+    }
     (void)hipFree(s.dWbar);
     (void)hipFree(s.t);
     (void)hipFree(s.sv);

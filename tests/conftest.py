@@ -11,6 +11,24 @@ for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The oracle (torch CPU) is what most of the suite's wall time goes to, and on the GPU boxes' 128-core hosts torch's default
+    # -- one thread per hardware thread -- is several times SLOWER than 16 threads on these small tensors (bench.py's
+    # cpu_baseline sweep: 5.4 images/s on 16 threads, 0.7 on 128; the B = 64 oracle sub-steps take 10-20 s on this container's 8
+    # cores and took 35-75 s there).  Cap it.
+    # (Round 5 found why: the pool's containers carry a cgroup CPU quota of 16 CPUs -- bench.py: cpu_quota -- and more runnable
+    # threads than that get the whole group throttled.)
+    try:
+        import torch
+        quota = None
+        try:
+            with open('/sys/fs/cgroup/cpu.max') as f:
+                q, per = f.read().split()
+            quota = None if q == 'max' else int(float(q) / float(per))
+        except (OSError, ValueError):
+            pass
+        torch.set_num_threads(max(1, min(os.cpu_count() or 8, 16, quota or 16)))
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope='session')

@@ -403,7 +403,7 @@ def _net_checks(net, values, seed, tol):
 # sub-step gradient + update checks
 # ------------------------------------------------------------------------------------------------
 def substep_checks(net: ea.EdgeGAN, values, batch, grad_tol=1e-2, iterations=1, bf16=False, loss_tol=1e-4,
-                   self_consistency=None):
+                   self_consistency=None, share_oracle=False):
     """bf16=True (engine created with compute_dtype='bf16'): the oracle runs under O.bf16_operands(), i.e. with the
     engine's operand rounding in all three maps of every qualifying contraction.  What remains between the two is
     (a) fp32-vs-fp64 noise in the values that GET rounded -- ~1e-4 of them land on the other side of a bf16 rounding
@@ -417,10 +417,71 @@ def substep_checks(net: ea.EdgeGAN, values, batch, grad_tol=1e-2, iterations=1, 
     L1 kink: the oracle's own fp32 run then deviates from its fp64 run by the same few percent the engine does)."""
     with O.bf16_operands(bf16):
         return _substep_checks(net, values, batch, grad_tol, iterations, loss_tol,
-                               self_consistency=bf16 if self_consistency is None else self_consistency)
+                               self_consistency=bf16 if self_consistency is None else self_consistency, share_oracle=share_oracle)
 
 
-def _substep_checks(net, values, batch, grad_tol, iterations, loss_tol, self_consistency=False):
+# The oracle's side of _substep_checks does not depend on the engine (before every sub-step the engine is put on the
+# oracle's state), so tests that run the same fixture in two compute modes (tests/test_step_gpu.py and their f32x3 re-runs in
+# tests/test_x3_gpu.py) share one oracle trace: computed by the first, consumed -- and dropped -- by the second.
+_ORACLE_TRACES = {}
+
+
+def _trace_key(cfg, values, batch, iterations, self_consistency):
+    import hashlib
+    h = hashlib.sha1(repr((oracle_config(cfg), iterations, bool(self_consistency), bool(O._BF16_OPERANDS))).encode())
+    for d in (values, batch):
+        for k in sorted(d):
+            h.update(k.encode())
+            h.update(np.ascontiguousarray(d[k]).tobytes())
+    return h.hexdigest()
+
+
+def _oracle_trace(cfg, values, batch, iterations, self_consistency):
+    """Per sub-step: the fp64 gradients and losses at the (fp32-representable) state the step starts from, the optional
+    per-variable tolerance from the oracle's own fp32 run, the weights / RMS slots before the update and the state every
+    optimised variable (and its two slots) is put on afterwards; at the end the generators' BatchNorm moving statistics."""
+    ocfg = oracle_config(cfg)
+    om = O.OracleModel(ocfg, values, dtype=DT)
+    inp = O.StepInputs(t64(batch['images']), t64(batch['z']), t64(batch['alpha']), t64(batch['eps']))
+    if self_consistency:
+        om32 = O.OracleModel(ocfg, values, dtype=torch.float32)
+        inp32 = O.StepInputs(*[torch.tensor(np.asarray(batch[k]), dtype=torch.float32) for k in ('images', 'z', 'alpha', 'eps')])
+    steps = []
+    for it in range(iterations):
+        for k, name in enumerate(O.SUBSTEPS, start=1):
+            if name == 'd_optim2' and not cfg.multiclasses:
+                continue
+            grads, losses = om.compute_grads(name, inp, inp.eps[0])
+            var_tol = {}
+            if self_consistency:
+                for d32, d64 in ((om32.p, om.p), (om32.ms, om.ms), (om32.mom, om.mom)):
+                    for vn in d32:
+                        d32[vn].copy_(d64[vn].float())
+                g32, _ = om32.compute_grads(name, inp32, inp32.eps[0])
+                for vn, g in grads.items():
+                    var_tol[vn] = 3.0 * rel_l2(g32[vn].double().numpy(), g.numpy(), 1e-5 * float(g.abs().max()) + 1e-300)
+            before = {vn: om.p[vn].numpy().astype(np.float32) for vn in grads}          # (fp32-representable by construction)
+            ms_before = {vn: om.ms[vn].numpy().astype(np.float32) for vn in grads}
+            om.apply_grads(grads)
+            om.update_bn_moving(om._GENS[name])
+            post = {}
+            for vn in grads:
+                for d in (om.p, om.ms, om.mom):
+                    d[vn].copy_(d[vn].float().double())
+                post[vn] = (om.p[vn].numpy().astype(np.float32), om.ms[vn].numpy().astype(np.float32),
+                            om.mom[vn].numpy().astype(np.float32))
+            steps.append(dict(it=it, k=k, name=name, grads={vn: g.numpy().copy() for vn, g in grads.items()},
+                              losses={lk: float(v) for lk, v in losses.items()}, var_tol=var_tol, before=before,
+                              ms_before=ms_before, post=post))
+    bn = {}
+    for g in ('G1', 'G2'):
+        for sname in ('moving_mean', 'moving_variance'):
+            vn = f'{g}/batch_norm/BatchNorm/{sname}'
+            bn[vn] = om.p[vn].numpy().copy()
+    return dict(steps=steps, bn=bn)
+
+
+def _substep_checks(net, values, batch, grad_tol, iterations, loss_tol, self_consistency=False, share_oracle=False):
     """The 7 sub-steps in update_model order.  Before each sub-step the engine is put on exactly the
     oracle's state (oracle values are kept fp32-representable), because the GAN trajectory at random
     init is chaotic: an fp32-vs-fp64 run of the ORACLE ITSELF drifts to 1e-1 relative gradient
@@ -437,80 +498,60 @@ def _substep_checks(net, values, batch, grad_tol, iterations, loss_tol, self_con
     occurs the engine agrees with fp64 autograd to ~2e-5 max-norm (the value in each row's name);
     smooth-regime accuracy is pinned separately by the op tests at 5e-5 max-norm."""
     cfg = net.config
-    ocfg = oracle_config(cfg)
-    om = O.OracleModel(ocfg, values, dtype=DT)
-    inp = O.StepInputs(t64(batch['images']), t64(batch['z']), t64(batch['alpha']), t64(batch['eps']))
+    # share_oracle: this fixture is run twice in one session (exact-fp32 and f32x3): the first run leaves its oracle trace for
+    # the second, which consumes it
+    key = _trace_key(cfg, values, batch, iterations, self_consistency) if share_oracle else None
+    trace = _ORACLE_TRACES.pop(key, None) if share_oracle else None
+    if trace is None:
+        trace = _oracle_trace(cfg, values, batch, iterations, self_consistency)
+        if share_oracle:
+            _ORACLE_TRACES[key] = trace
     net.set_variables(values)
     net.upload_batch(batch['images'], batch['z'], batch['alpha'], batch['eps'])
     rows = []
-    if self_consistency:
-        om32 = O.OracleModel(ocfg, values, dtype=torch.float32)
-        inp32 = O.StepInputs(*[torch.tensor(np.asarray(batch[k]), dtype=torch.float32) for k in ('images', 'z', 'alpha', 'eps')])
-
-    def sync(names):
-        for vn in names:
-            for d in (om.p, om.ms, om.mom):
-                d[vn].copy_(d[vn].float().double())
-            net.set_variable(vn, om.p[vn].numpy())
-            net.set_variable(vn + '/RMSProp', om.ms[vn].numpy())
-            net.set_variable(vn + '/RMSProp_1', om.mom[vn].numpy())
-
     loss_map = {1: ['joint_dis_dloss'], 2: ['image_dis_dloss'], 3: ['edge_dis_dloss'], 4: ['loss_d_ac'],
                 5: ['edge_gloss', 'image_gloss'], 6: ['zl_loss'], 7: ['edge_gloss', 'image_gloss']}
-    for it in range(iterations):
-        for k, name in enumerate(O.SUBSTEPS, start=1):
-            if name == 'd_optim2' and not cfg.multiclasses:
-                continue
-            tag = f'it{it} substep {k} {name}'
-            grads, losses = om.compute_grads(name, inp, inp.eps[0])
-            var_tol = {}
-            if self_consistency:
-                for d32, d64 in ((om32.p, om.p), (om32.ms, om.ms), (om32.mom, om.mom)):
-                    for vn in d32:
-                        d32[vn].copy_(d64[vn].float())
-                g32, _ = om32.compute_grads(name, inp32, inp32.eps[0])
-                for vn, g in grads.items():
-                    var_tol[vn] = 3.0 * rel_l2(g32[vn].double().numpy(), g.numpy(), 1e-5 * float(g.abs().max()) + 1e-300)
-            net.substep(k, apply=False)
-            gmax = max(float(g.abs().max()) for g in grads.values())
-            hip_g = {}
-            for vn, g in grads.items():
-                hip_g[vn] = net.get_variable(vn + '/grad')
-                if float(g.abs().max()) < 1e-9 * gmax:
-                    # structurally zero gradient (a bias in front of an InstanceNorm / min-max gate):
-                    # fp32 may only leave rounding noise, bounded by 1e-5 of the sub-step's largest gradient
-                    rows.append((f'{tag} grad {vn} (structural zero: noise/1e-5*gmax)',
-                                 float(np.abs(hip_g[vn]).max()) / (1e-5 * gmax), 1.0))
-                else:
-                    mx = relerr(hip_g[vn], g.numpy(), 1e-5 * gmax)
-                    rows.append((f'{tag} grad {vn} [L2; max-norm {mx:.1e}; |g|/gmax {float(g.abs().max()) / gmax:.0e}]',
-                                 rel_l2(hip_g[vn], g.numpy(), 1e-5 * gmax), max(grad_tol, var_tol.get(vn, 0.0))))
-            hl = net.losses()
-            for lk in loss_map[k]:
-                ref = float(losses[lk])
-                rows.append((f'{tag} loss {lk}', abs(hl[lk] - ref) / (abs(ref) + 1e-30), loss_tol))
-            # the optimizer: the engine must apply tf RMSProp (Appendix B.7) with ITS gradient to exactly
-            # these variables and slots (gradient parity is the rows above; RMSProp's g/sqrt(ms) would
-            # otherwise re-weight element errors by the 1e3 dynamic range of GAN gradients at init)
-            before = {vn: om.p[vn].clone() for vn in grads}
-            ms_before = {vn: om.ms[vn].clone() for vn in grads}
-            om.apply_grads(grads)
-            om.update_bn_moving(om._GENS[name])
-            net.substep(k, apply=True)
-            for vn in grads:
-                gh = torch.tensor(hip_g[vn].astype(np.float64)).reshape(before[vn].shape)
-                ms_new = ms_before[vn] + (gh * gh - ms_before[vn]) * (1.0 - 0.9)
-                w_new = before[vn] - cfg.learning_rate * gh / torch.sqrt(ms_new + 1e-10)
-                got = net.get_variable(vn).astype(np.float64)
-                ulp = float(np.spacing(np.float32(np.abs(w_new.numpy()).max())))
-                e = 0.0 if np.max(np.abs(got - w_new.numpy())) <= 2 * ulp else relerr(got, w_new.numpy())
-                rows.append((f'{tag} rmsprop-applied {vn}', e, 1e-5))
-                rows.append((f'{tag} rms-slot {vn}', relerr(net.get_variable(vn + '/RMSProp'), ms_new.numpy()), 1e-5))
-            sync(list(grads.keys()))
-    for g in ('G1', 'G2'):
-        for sname in ('moving_mean', 'moving_variance'):
-            vn = f'{g}/batch_norm/BatchNorm/{sname}'
-            rows.append((f'bn {vn}', relerr(net.get_variable(vn), om.p[vn].numpy()), 1e-4))
+    for st in trace['steps']:
+        k, name, grads, losses, var_tol = st['k'], st['name'], st['grads'], st['losses'], st['var_tol']
+        tag = f"it{st['it']} substep {k} {name}"
+        net.substep(k, apply=False)
+        gmax = max(float(np.abs(g).max()) for g in grads.values())
+        hip_g = {}
+        for vn, g in grads.items():
+            hip_g[vn] = net.get_variable(vn + '/grad')
+            if float(np.abs(g).max()) < 1e-9 * gmax:
+                # structurally zero gradient (a bias in front of an InstanceNorm / min-max gate):
+                # fp32 may only leave rounding noise, bounded by 1e-5 of the sub-step's largest gradient
+                rows.append((f'{tag} grad {vn} (structural zero: noise/1e-5*gmax)',
+                             float(np.abs(hip_g[vn]).max()) / (1e-5 * gmax), 1.0))
+            else:
+                mx = relerr(hip_g[vn], g, 1e-5 * gmax)
+                rows.append((f'{tag} grad {vn} [L2; max-norm {mx:.1e}; |g|/gmax {float(np.abs(g).max()) / gmax:.0e}]',
+                             rel_l2(hip_g[vn], g, 1e-5 * gmax), max(grad_tol, var_tol.get(vn, 0.0))))
+        hl = net.losses()
+        for lk in loss_map[k]:
+            ref = losses[lk]
+            rows.append((f'{tag} loss {lk}', abs(hl[lk] - ref) / (abs(ref) + 1e-30), loss_tol))
+        # the optimizer: the engine must apply tf RMSProp (Appendix B.7) with ITS gradient to exactly
+        # these variables and slots (gradient parity is the rows above; RMSProp's g/sqrt(ms) would
+        # otherwise re-weight element errors by the 1e3 dynamic range of GAN gradients at init)
+        net.substep(k, apply=True)
+        for vn in grads:
+            before, ms_before = st['before'][vn].astype(np.float64), st['ms_before'][vn].astype(np.float64)
+            gh = hip_g[vn].astype(np.float64).reshape(before.shape)
+            ms_new = ms_before + (gh * gh - ms_before) * (1.0 - 0.9)
+            w_new = before - cfg.learning_rate * gh / np.sqrt(ms_new + 1e-10)
+            got = net.get_variable(vn).astype(np.float64)
+            ulp = float(np.spacing(np.float32(np.abs(w_new).max())))
+            e = 0.0 if np.max(np.abs(got - w_new)) <= 2 * ulp else relerr(got, w_new)
+            rows.append((f'{tag} rmsprop-applied {vn}', e, 1e-5))
+            rows.append((f'{tag} rms-slot {vn}', relerr(net.get_variable(vn + '/RMSProp'), ms_new), 1e-5))
+        for vn, (pw, pms, pmom) in st['post'].items():      # put the engine on the oracle's (fp32-representable) state
+            net.set_variable(vn, pw)
+            net.set_variable(vn + '/RMSProp', pms)
+            net.set_variable(vn + '/RMSProp_1', pmom)
+    for vn, ref in trace['bn'].items():
+        rows.append((f'bn {vn}', relerr(net.get_variable(vn), ref), 1e-4))
     return rows
 
 
@@ -690,6 +731,24 @@ def check_act_conv(net, NB, H, W, Cc, N, k, s, kind, seed=0, bf16=False, tol=(FW
             (f'{tag} dw', relerr(out[2], gr[1].detach().numpy()), tol[1])]
 
 
+def check_d_head(net, NB, H, W, N1, N2, seed=0, bf16=False, tol=(FWD_TOL, BWD_TOL)):
+    """d_conv_0 + LeakyReLU + d_conv_1: the activation's backward in the second convolution's input-gradient epilogue (un-split
+    halo kernel) or as the in-place pass (every other kernel) -- capi.cpp: d_head."""
+    rng = np.random.RandomState(seed)
+    x = rng.normal(size=(NB, H, W, 3)).astype(np.float32)
+    w0 = (rng.normal(size=(4, 4, 3, N1)) / np.sqrt(48.0)).astype(np.float32)
+    w1 = (rng.normal(size=(4, 4, N1, N2)) / (4 * np.sqrt(N1))).astype(np.float32)
+    xt, w0t, w1t = t64(x, True), t64(w0, True), t64(w1, True)
+    with O.bf16_operands(bf16):
+        y = O.conv2d(O.lrelu_leak(O.conv2d(xt, w0t, 2, 'SAME')), w1t, 2, 'SAME')
+        dy = rng.normal(size=tuple(y.shape)).astype(np.float32)
+        gr = torch.autograd.grad((y * t64(dy)).sum(), [xt, w0t, w1t])
+    out = net.test_op('d_head', [x, w0, w1, dy], [NB, H, W, N1, N2], [tuple(y.shape), x.shape, w0.shape, w1.shape])
+    tag = f'd_head[{NB}x{H}x{W} 3->{N1}->{N2}{" bf16" if bf16 else ""}]'
+    return [(f'{tag} y', relerr(out[0], y.detach().numpy()), tol[0])] + \
+           [(f'{tag} d{n}', relerr(out[1 + i], gr[i].detach().numpy()), tol[1]) for i, n in enumerate(['x', 'w0', 'w1'])]
+
+
 def fused_chain_checks(net, bf16=False):
     """Shapes chosen so that the K-split launches (few output tiles: small maps, many channels) and the un-split epilogue
     forms (16x16 / 32x32 maps) are both hit in the f32x3 and bf16 modes; the exact-fp32 mode runs the same graphs on its own
@@ -703,4 +762,8 @@ def fused_chain_checks(net, bf16=False):
     for (NB, H, W, Cc, N, k, s, kind) in [(4, 16, 16, 256, 512, 4, 2, 0), (2, 8, 8, 512, 512, 3, 1, 0), (2, 32, 32, 128, 256, 4, 2, 0),
                                             (2, 8, 8, 512, 768, 1, 1, 1), (2, 16, 16, 256, 512, 1, 1, 1)]:
         rows += check_act_conv(net, NB, H, W, Cc, N, k, s, kind, seed=Cc + k, bf16=bf16, tol=tol)
+    # first writer with / without the activation-backward epilogue: few pixels (K-split or 64x64 tiles) and enough for the
+    # un-split halo kernel
+    for (NB, H, W, N1, N2) in [(2, 32, 32, 64, 128), (16, 64, 64, 64, 128), (4, 64, 128, 64, 128)]:
+        rows += check_d_head(net, NB, H, W, N1, N2, seed=NB, bf16=bf16, tol=tol)
     return rows

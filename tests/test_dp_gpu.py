@@ -156,6 +156,59 @@ def test_bench_launches_its_own_ranks(shim, tmp_path):
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith('{')]
 
 
+def test_eight_rank_rehearsal_replicas_identical_and_bench_plumbing(shim, tmp_path):
+    """what the driver's 8-GPU scaling leg will do, rehearsed on ONE device through the loop-back stand-in:
+    (a) eight engine ranks (file rendezvous with 8 ranks, 7 gradient all-reduces per iteration, averaging RMSProp) run two
+    iterations and every replica ends bit-identical; (b) plain `python bench.py --gpus 8 --batch 4` starts its own eight
+    ranks and prints ONE line with exchange.nranks == 8, 7 all-reduces per step, global batch 32; (c) a rank that cannot
+    come up takes the whole 8-rank launch down with a non-zero status.  RCCL's own 8-device transport over xGMI first runs in
+    the driver's SCALE leg -- nothing here can stand in for that (edgegan/train.py:77 is single-device)."""
+    ranks = _run_ranks(shim, tmp_path, 'iterations', 'eight', world=8)
+    for r in range(1, 8):
+        for k in filter(_replicated, ranks[0]):
+            assert np.array_equal(ranks[0][k], ranks[r][k]), f'replica {r} differs in {k}'
+    env = _env(shim, tmp_path, 'bench8', EG_FORCE_DEVICE='0')
+    env.pop('EG_RDZV_KEY')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '4',
+           '--profile-steps', '1']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['exchange']['nranks'] == 8 and out['config']['global_batch'] == 32
+    assert out['exchange']['allreduce_calls_per_step'] == 7 and out['losses_finite'] and out['value'] > 0
+    assert out['scaling'] == 'weak' and 'cpu_baseline' not in out
+    bad = subprocess.run(cmd, env=dict(env, EG_RCCL_LIB=str(tmp_path / 'no_such_librccl.so')), capture_output=True, text=True,
+                         timeout=300)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith('{')]
+
+
+def test_training_command_line_four_ranks(shim, tmp_path):
+    """python -m edgegan_amd.train under torch.distributed.run with FOUR ranks: 16 images / batch 2 / 4 ranks = 2 iterations
+    per rank, rank 0 prints and saves (the two-rank form of this test below checks the checkpoint's content)."""
+    from PIL import Image
+    rng = np.random.RandomState(1)
+    root = tmp_path / 'data'
+    for c in (0, 5):
+        os.makedirs(root / 'class14' / 'train' / str(c))
+        for i in range(8):
+            Image.fromarray(rng.randint(0, 256, size=(64, 128, 3)).astype(np.uint8)).save(
+                root / 'class14' / 'train' / str(c) / f'{i}.png')
+    env = _env(shim, tmp_path, 'train4', EG_FORCE_DEVICE='0', PYTHONPATH=ROOT)
+    env.pop('EG_RDZV_KEY')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
+           '--master-port', '29535', '-m', 'edgegan_amd.train', '--name=dp4', f'--dataroot={root}', '--batch_size=2', '--epoch=1',
+           '--save_checkpoint_frequency=3']
+    p = subprocess.run(cmd, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    progress = [l for l in p.stdout.splitlines() if l.startswith('Epoch:')]
+    assert len(progress) == 2 and '/   2]' in progress[0], p.stdout[-2000:]
+    assert (tmp_path / 'outputs' / 'dp4' / 'checkpoints' / 'EdgeGAN-Model-2.index').exists()
+
+
 def test_training_command_line_two_ranks(shim, tmp_path):
     """python -m edgegan_amd.train under torch.distributed.run with two ranks: one shared shuffle seed, the batches of an
     epoch partitioned over the ranks (4 batches -> 2 iterations per rank), rank 0 prints and writes the checkpoint

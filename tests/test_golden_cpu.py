@@ -49,3 +49,33 @@ def test_goldens_are_small_and_complete():
     # the dead classifier head (quirk N8) never gets a gradient and never moves
     assert not any('D2/Conv_1/' in k and '/grad/' in k for k in st.files)
     assert st['it1/delta/D2/Conv_1/weights'][1] == 0.0
+
+
+def test_full_batch_digest_is_rederived_from_the_oracle():
+    """tests/golden/full_batch.npz (digests of the oracle's full-size sub-step gradients, tests/full_batch_lib.py) is what the
+    GPU tests at B = 64 / bf16 B = 16 compare the engine with: one case -- the encoder's sub-step at BASELINE's full batch -- is
+    re-evaluated here from oracle/edgegan_oracle.py and must reproduce its committed digest (exactly stored small variables,
+    the Rademacher projections and norms of the large ones, the loss), so that neither side can drift silently.  The oracle's
+    fp32 self-deviation entries depend on the host's thread count and are not compared."""
+    import full_batch_lib as FB
+    spec2 = importlib.util.spec_from_file_location('make_full_batch_goldens', os.path.join(G.GOLDEN_DIR, 'make_full_batch_goldens.py'))
+    MF = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(MF)
+    key = 'b64/e_optim'
+    got = MF.entries(FB.CASE[key])
+    want = np.load(FB.GOLDEN)
+    checked = 0
+    for k, g in got.items():
+        parts = k.split('|')
+        if parts[1] in ('self_dev', 'kappa', 'near_kink'):
+            continue
+        w = want[k]
+        if parts[1] == 'v' and parts[3] == 'proj':
+            scale = float(want['|'.join(parts[:3] + ['norm'])][0])      # a projection is a cancelling sum: compare against ||g||
+        else:
+            scale = max(float(np.max(np.abs(w))), 1e-300)
+        noise = 1e-13 * float(want[key + '|gmax'][0])      # (structural zeros -- a bias in front of an InstanceNorm -- hold 1e-16 noise)
+        assert w.shape == g.shape and float(np.max(np.abs(w - g))) <= 1e-9 * scale + noise, k
+        checked += 1
+    assert checked >= 60
+    assert sorted(k for k in want.files if k.startswith(key + '|')) == sorted(got)

@@ -32,7 +32,7 @@ def test_substeps_14_classes():
     cfg = ea.Config(batch_size=2)
     values = ea.init_variables(cfg, 0)
     net = ea.EdgeGAN(cfg, values)
-    rows = parity.substep_checks(net, values, ea.synthetic_batch(cfg))
+    rows = parity.substep_checks(net, values, ea.synthetic_batch(cfg), share_oracle=True)   # (re-run in f32x3: test_x3_gpu.py)
     assert len(rows) > 400
     _assert(rows)
     net.close()
@@ -44,7 +44,7 @@ def test_substeps_odd_batch():
     cfg = ea.Config(batch_size=3)
     values = ea.init_variables(cfg, 11)
     net = ea.EdgeGAN(cfg, values)
-    _assert(parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=3)))
+    _assert(parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=3), share_oracle=True))
     net.close()
 
 
@@ -68,7 +68,7 @@ def test_substeps_single_class_batch4():
     cfg = ea.Config(batch_size=4, num_classes=0)
     values = ea.init_variables(cfg, 5)
     net = ea.EdgeGAN(cfg, values)
-    _assert(parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=99)))
+    _assert(parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=99), share_oracle=True))
     net.close()
 
 
@@ -132,10 +132,11 @@ def test_train_step_equals_sequential_substeps_and_is_deterministic():
     assert np.all(outs[0]['D2/Conv_1/weights/RMSProp'] == 1)
 
 
-def test_context_recovers_from_an_error_in_the_middle_of_a_backward_sweep():
+def test_context_recovers_from_an_error_in_the_middle_of_a_backward_sweep(monkeypatch):
     """an exception that unwinds out of a concurrent iteration's backward sweep leaves another lane active, the
     context's stream on that lane's LEAF stream and leaf_dirty set.  The next C-ABI call must start from a sane state
     (csrc/model.cpp: api_enter) -- after the injected fault two iterations must reproduce a fresh engine bit for bit."""
+    monkeypatch.setenv('EG_TEST_HOOKS', '1')   # (the fault-injection op exists only where this is set: capi.cpp)
     cfg = ea.Config(batch_size=2)
     values = ea.init_variables(cfg, 0)
     batch = ea.synthetic_batch(cfg)

@@ -135,7 +135,7 @@ def test_x3_odd_batch_with_the_kink_flip_accounted_for():
     cfg = ea.Config(batch_size=3)
     values = ea.init_variables(cfg, 11)
     net = ea.EdgeGAN(cfg, values)
-    rows = parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=3))
+    rows = parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=3), share_oracle=True)   # (test_substeps_odd_batch's fixture)
     net.close()
     fixed = []
     for name, err, tol in rows:
