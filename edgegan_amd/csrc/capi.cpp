@@ -790,6 +790,7 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
     Param* b2 = io.param(5, bw);
     T bp = io.tensor(6, NB, H / 2, W / 2, C2, bw);
     Param* l2 = io.param(7, bw);
+    c.prelu_plane_only = c.cfg.bf16;   // (as classifier_forward does)
     T c1 = conv2d(c, x, wref_param(c, w1, 9, C1, C2), b1, 3, 1, PAD_SAME, nullptr, 0, l1);
     c.feeds_in = FEED_FLAT;
     T c2 = conv2d(c, c1, wref_param(c, w2, 9, C2, C2), b2, 3, 1, PAD_SAME);
@@ -832,7 +833,7 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
     c.feeds_in = FEED_MINMAX;
     conv2d(c, hp, wref_param(c, wh, 9, Ch, Ch), nullptr, 3, 1, PAD_SAME, rg);
     rg = minmax(c, rg, 0.2f);
-    T hin = gate_prelu(c, h, rg, img, l1);
+    T hin = gate_prelu(c, h, rg, img, l1, c.cfg.bf16);
     T y = conv2d(c, hin, wref_param(c, w1, 9, Ch, N), nullptr, 3, 1, PAD_SAME);
     io.down(0, y->d, y->numel());
     if (bw) {

@@ -150,6 +150,9 @@ struct Tensor {
   // or on demand by launch_cvt_bf16 on the stream recorded here (ops.cpp: tensor_plane decides who else may read it)
   unsigned short* d_bf = nullptr;
   unsigned short* g_bf = nullptr;
+  // bf16 mode: d was never written -- the tensor exists as its plane only (its readers are plane-fed dense contractions, which
+  // round their operands to bf16 anyway).  A reader that wants fp32 widens the plane first (ops.cpp: need_f32; exact)
+  bool d_plane_only = false;
   hipStream_t d_bf_stream = nullptr, g_bf_stream = nullptr;
   size_t numel() const { return (size_t)n * h * w * c; }
   size_t pixels() const { return (size_t)n * h * w; }

@@ -116,6 +116,9 @@ struct Ctx {
   // FEED_FLAT / FEED_MINMAX: the same hand-over to a flat element-wise reader (prelu, pool2_add's full-resolution operand)
   // and to the min-max gate (kernels.h: SlabSrc)
   int feeds_in = 0;
+  // bf16 mode, set by a caller right before conv2d(..., post_prelu): the PReLU output is read by plane-fed contractions only,
+  // so it is stored as its bf16 plane alone (Tensor::d_plane_only; consumed by that convolution)
+  bool prelu_plane_only = false;
   // inference only (set inside infer()): a residual block's 1x1 shortcut convolution runs on lane 1 beside the block's
   // two 3x3 convolutions on lane 0 -- the encoder trunk is ONE chain of small launches otherwise
   bool infer_lanes = false;
@@ -253,7 +256,8 @@ T pool2(Ctx& c, T x);
 T add_pool2(Ctx& c, T a, T b);
 // pool2(a) + b, b at the pooled resolution and with no other consumer (its gradient IS the output's gradient buffer)
 // post_prelu / prelu_out: also returns prelu(result, post_prelu) from the same pass (conv.py:185: the next unit's prelu(h))
-T pool2_add(Ctx& c, T a, T b, Param* post_prelu = nullptr, T* prelu_out = nullptr);
+// plane_only (bf16 mode): that PReLU output is read by plane-fed contractions only and stored as its bf16 plane alone
+T pool2_add(Ctx& c, T a, T b, Param* post_prelu = nullptr, T* prelu_out = nullptr, bool plane_only = false);
 T gmean(Ctx& c, T x, bool pre_relu);
 T resize(Ctx& c, T x, int size);
 T concat_w(Ctx& c, T a, T b);
@@ -261,7 +265,7 @@ T slice_w(Ctx& c, T x, int w0, int w1);   // no gradient (inputs only)
 T prelu(Ctx& c, T x, Param* leak, float leak_const);
 T minmax(Ctx& c, T x, float pre_leak = 0.f);   // pre_leak != 0: minmax(lrelu(x)) in one pass each way
 T gate(Ctx& c, T h, T rg, T img);
-T gate_prelu(Ctx& c, T h, T rg, T img, Param* leak);   // prelu(h + rg * img, leak) in one pass each way
+T gate_prelu(Ctx& c, T h, T rg, T img, Param* leak, bool plane_only = false);   // prelu(h + rg * img, leak) in one pass each way
 T reparam(Ctx& c, T mu, T ls, const float* eps_dev);
 void sn_prepare(Ctx& c);                  // W/sigma for every live SN weight + tape entry for its backward
 void seed_grad(Ctx& c, T t);              // marks t->g as holding a value (after a loss kernel wrote it)

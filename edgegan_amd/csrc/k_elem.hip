@@ -581,7 +581,7 @@ __global__ void prelu_fwd_v_kernel(const SlabSrc x, const float* __restrict__ le
     const float4 v = slab_ld4_flat(x, i);
     if (xsum) reinterpret_cast<float4*>(xsum)[i] = v;
     const float4 o = make_float4(fmaxf(lk * v.x, v.x), fmaxf(lk * v.y, v.y), fmaxf(lk * v.z, v.z), fmaxf(lk * v.w, v.w));
-    reinterpret_cast<float4*>(y)[i] = o;
+    if (y) reinterpret_cast<float4*>(y)[i] = o;
     if (y_bf) st_bf4(y_bf, i, o);
   }
 }
@@ -599,6 +599,7 @@ static bool ew_vec_ok(size_t n, const void* a, const void* b, const void* c = nu
 void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s, unsigned short* y_bf,
                       const SlabSrc* x_slabs, float* xsum) {
   EG_CHECK(!(y_bf || x_slabs) || ew_vec_ok(n, x, y, xsum), "prelu_fwd: a bf16 plane / a slab input was requested from the scalar form");
+  EG_CHECK(y || (y_bf && ew_vec_ok(n, x, y, xsum)), "prelu_fwd: no output");
   if (ew_vec_ok(n, x, y, xsum)) {
     // (experiments: EG_DUP_PRELU_FWD = N extra, idempotent launches -- what does an HBM-bound pass on a lane cost the iteration?)
     static const int dup = dbg_env("EG_DUP_PRELU_FWD") ? atoi(dbg_env("EG_DUP_PRELU_FWD")) : 0;
@@ -886,7 +887,7 @@ __global__ void gate_prelu_fwd_v_kernel(const float* __restrict__ h, const float
                  m = reinterpret_cast<const float4*>(img)[i];
     const float v0 = a.x + r.x * m.x, v1 = a.y + r.y * m.y, v2 = a.z + r.z * m.z, v3 = a.w + r.w * m.w;
     const float4 y = make_float4(fmaxf(lk * v0, v0), fmaxf(lk * v1, v1), fmaxf(lk * v2, v2), fmaxf(lk * v3, v3));
-    reinterpret_cast<float4*>(o)[i] = y;
+    if (o) reinterpret_cast<float4*>(o)[i] = y;       // (null: the output lives as its bf16 plane only, Tensor::d_plane_only)
     if (o_bf) st_bf4(o_bf, i, y);
   }
 }
@@ -937,7 +938,7 @@ void launch_gate_prelu_fwd(const float* h, const float* rg, const float* img, co
     hipLaunchKernelGGL(gate_prelu_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, h, rg, img, leak, out, n / 4, out_bf);
     return;
   }
-  EG_CHECK(!out_bf, "gate_prelu_fwd: a bf16 plane was requested from the scalar form");
+  EG_CHECK(!out_bf && out, "gate_prelu_fwd: a bf16 plane / a plane-only output was requested from the scalar form");
   hipLaunchKernelGGL(gate_prelu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, h, rg, img, leak, out, n);
 }
 void launch_gate_prelu_bwd(const float* h, const float* rg, const float* img, const float* leak, const float* dout, float* dh,

@@ -471,6 +471,14 @@ __global__ void cvt_bf16_kernel(const float* __restrict__ in, unsigned short* __
     reinterpret_cast<uint2*>(out)[i] = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
   }
 }
+// the inverse (exact): a bf16 plane widened to fp32 -- for the rare reader of a tensor that was only ever stored as its plane
+__global__ void cvt_from_bf16_kernel(const unsigned short* __restrict__ in, float* __restrict__ out, size_t n4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const uint2 v = reinterpret_cast<const uint2*>(in)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                                     __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+  }
+}
 __global__ void tap_transpose_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int R, int Cc) {
   __shared__ float tile[32][33];
   const int t = blockIdx.z;
@@ -493,6 +501,13 @@ void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n4);
+}
+void launch_cvt_from_bf16(const unsigned short* in, float* out, size_t n, hipStream_t s) {   // n % 4 == 0
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cvt_from_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n4);
 }
 void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int R, int Cc, hipStream_t s) {
   dim3 grid((Cc + 31) / 32, (R + 31) / 32, T);

@@ -225,6 +225,7 @@ bool conv_bf16_eligible(const ConvArgs& a);
 const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s);
 const char* launch_wgrad_bf16(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s);
 void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);
+void launch_cvt_from_bf16(const unsigned short* in, float* out, size_t n, hipStream_t s);   // exact widening, n % 4 == 0
 void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int R, int Cc, hipStream_t s);
 
 // plane-fed bf16 kernel for stride-1 layers (k_conv_bf16p.hip): the gathered operand arrives from a bf16 plane by LDS-DMA
@@ -356,7 +357,8 @@ void launch_resize(const float* x, float* y, int accumulate, int NB, int IH, int
                    const int* ty_i, const float* ty_w, int tyn, const int* tx_i, const float* tx_w, int txn,
                    hipStream_t s);
 // prelu / fixed leak: y = max(leak*x, x); leak read from device scalar (leak_p) or constant
-// x_slabs (float4 form only): x is that SlabSrc; xsum != null also stores the summed x (what prelu_bwd reads)
+// x_slabs (float4 form only): x is that SlabSrc; xsum != null also stores the summed x (what prelu_bwd reads);
+// y == null (float4 form, y_bf given): only the bf16 plane of the output is stored
 void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* y, size_t n, hipStream_t s,
                       unsigned short* y_bf = nullptr, const SlabSrc* x_slabs = nullptr, float* xsum = nullptr);
 // dx (+)= ..., dleak (+)= sum(dy*x [x<0 or tie]) (when dleak != null)

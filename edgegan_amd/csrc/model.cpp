@@ -341,6 +341,7 @@ void api_enter(Ctx& c) {
   use_lane(c, 0);
   c.infer_lanes = false;
   c.feeds_in = FEED_NONE;
+  c.prelu_plane_only = false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -516,7 +517,9 @@ T classifier_forward(Ctx& c, T x) {
     conv2d(c, hp, wr_h, nullptr, 3, 1, PAD_SAME, rg);
     rg = minmax(c, rg, 0.2f);   // lrelu (activation.py:30-32) + the min-max gate of conv.py:197-198, one pass each way
     T img = conv2d(c, xin, wref_sn(c, P(c, b + "/Conv/weights")), P(c, b + "/Conv/biases"), 3, 1, PAD_SAME);
-    T hin = gate_prelu(c, h, rg, img, P(c, b + "/norm_activation_merge_1/prelu/param"));   // conv.py:207-209
+    // (bf16 mode: the gate's output is read by Conv_1's forward and filter gradient only -- plane-fed, so only its plane is stored)
+    T hin = gate_prelu(c, h, rg, img, P(c, b + "/norm_activation_merge_1/prelu/param"), c.cfg.bf16);   // conv.py:207-209
+    c.prelu_plane_only = c.cfg.bf16;   // (bf16 mode: prelu(Conv_1) is read by Conv_2's forward and filter gradient only -- plane-fed)
     T c1 = conv2d(c, hin, wref_sn(c, P(c, b + "/Conv_1/weights")), P(c, b + "/Conv_1/biases"), 3, 1, PAD_SAME, nullptr, 0,
                   P(c, b + "/Conv_1/prelu/param"));   // conv.py:217-220
     static const bool proj_full = dbg_env("EG_PROJ_FULL_RES") != nullptr;   // A/B: the reference's evaluation order
@@ -538,7 +541,8 @@ T classifier_forward(Ctx& c, T x) {
       // the PReLU of the unit's output rides along: the next unit's prelu(h) (conv.py:185), the final one after unit 4 (:353-355)
       Param* next_leak = u < 4 ? P(c, "D2/mru_conv_unit_t_" + std::to_string(u + 1) + "_layer_0/norm_activation_in/prelu/param")
                                : P(c, "D2/mru_conv_unit_last_norm/prelu/param");
-      h = pool2_add(c, c2, proj, next_leak, &hp);
+      // (bf16 mode: the next unit's prelu(h) is read by the gate's hidden-state convolution only; the LAST one feeds the global mean)
+      h = pool2_add(c, c2, proj, next_leak, &hp, c.cfg.bf16 && u < 4);
     }
     hidden = depth;
   }

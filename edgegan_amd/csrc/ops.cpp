@@ -488,6 +488,14 @@ static const unsigned short* tensor_plane(Ctx& c, T t, bool grad) {
   return q;
 }
 
+// A tensor stored as its bf16 plane only (Tensor::d_plane_only) and a reader that wants fp32 after all: widen the plane into d
+// (exact; every reader of such a tensor is a dense contraction that would round to bf16 itself)
+static void need_f32(Ctx& c, T t) {
+  if (!t->d_plane_only) return;
+  launch_cvt_from_bf16(t->d_bf, t->d, t->numel(), c.stream);
+  t->d_plane_only = false;
+}
+
 // Producer-side planes: in bf16 mode an element-wise kernel whose output (or output gradient) is shaped like a dense
 // contraction's operand (channels a multiple of 32) stores the bf16 plane next to the fp32 tensor -- 2 extra bytes per
 // element once instead of a conversion pass (4 B read + 2 B written) per consumer.  Returns the plane to write, or null.
@@ -567,6 +575,7 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
     if (conv_bf16p_eligible(b)) a.ksplit = b.ksplit;
     a.x_bf = conv_bf16p_eligible(a) ? tensor_plane(c, xsrc, xgrad) : nullptr;
   }
+  if (xsrc && !xgrad && !a.x_bf) need_f32(c, xsrc);   // (a plane-only operand and a kernel that gathers fp32)
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
   const char* nm;
   static const bool x3_timing = dbg_env("EG_X3_TIMING") != nullptr;   // experiment: per-phase s_memtime stamps of block 0
@@ -761,6 +770,10 @@ static void conv_wgrad(Ctx& c, T xt, bool xgrad, int NB, int IH, int IW, int C, 
       g.x_bf = g.dy_bf = nullptr;
     }
   }
+  if (!g.x_bf) {
+    if (!xgrad) need_f32(c, xt);
+    if (!dygrad) need_f32(c, dyt);
+  }
   g.nsplit = wgrad_pick_splits(g);
   const size_t wsf = wgrad_workspace_floats(g);
   g.ws = wsf ? c.arena.allocf(wsf) : nullptr;
@@ -875,16 +888,21 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   a.keep_slabs = slabs_ok ? 1 : 0;
   // conv -> PReLU (conv.py:217-220): second output of the epilogue where the kernel has one
   T y2 = nullptr;
+  unsigned short* y2_plane = nullptr;
   static const bool epi2_on = dbg_env("EG_NO_EPI_PRELU") == nullptr;
   if (post_prelu) {
     EG_CHECK(!accumulate_into && !fused_act, "conv2d: post_prelu excludes accumulate_into / fused_act");
     y2 = new_tensor(c, x->n, OH, OW, N, false);
+    y2_plane = producer_plane(c, y2, false);
+    static const bool plane_only_on = dbg_env("EG_NO_PLANE_ONLY") == nullptr;
+    y2->d_plane_only = plane_only_on && c.prelu_plane_only && y2_plane != nullptr;
     if (epi2_on && N % 4 == 0) {
       a.y2_leak = post_prelu->w;
-      a.y2 = y2->d;
-      a.y2_bf = producer_plane(c, y2, false);
+      a.y2 = y2->d_plane_only ? nullptr : y2->d;
+      a.y2_bf = y2_plane;
     }
   }
+  c.prelu_plane_only = false;
   run_conv(c, a, x, false);
   if (slabs_ok && a.ksplit > 1) {
     y->slabs = a.ws;
@@ -895,11 +913,10 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
   if (post_prelu) {
     if (y->nslab > 1) {   // the PReLU pass sums the slabs (and stores the sum: its backward reads the pre-activation)
       const SlabSrc xs = data_src(y);
-      launch_prelu_fwd(y->d, post_prelu->w, 0.f, y2->d, y->numel(), c.stream, a.y2_leak ? a.y2_bf : producer_plane(c, y2, false),
-                       &xs, y->d);
+      launch_prelu_fwd(y->d, post_prelu->w, 0.f, y2->d_plane_only ? nullptr : y2->d, y->numel(), c.stream, y2_plane, &xs, y->d);
       y->nslab = 0;
     } else if (!(a.y2_leak && (a.caps & CONV_CAP_Y2))) {
-      launch_prelu_fwd(y->d, post_prelu->w, 0.f, y2->d, y->numel(), c.stream, a.y2_leak ? a.y2_bf : producer_plane(c, y2, false));
+      launch_prelu_fwd(y->d, post_prelu->w, 0.f, y2->d_plane_only ? nullptr : y2->d, y->numel(), c.stream, y2_plane);
     }
   }
   if (need) {
@@ -1300,7 +1317,7 @@ T add_pool2(Ctx& c, T a, T b) {
   return out;
 }
 
-T pool2_add(Ctx& c, T a, T b, Param* post_prelu, T* prelu_out) {
+T pool2_add(Ctx& c, T a, T b, Param* post_prelu, T* prelu_out, bool plane_only) {
   EG_CHECK(a->h % 2 == 0 && a->w % 2 == 0, "pool2_add needs even extents");
   EG_CHECK(a->n == b->n && a->h == 2 * b->h && a->w == 2 * b->w && a->c == b->c, "pool2_add shapes");
   T out = new_tensor(c, b->n, b->h, b->w, b->c, a->needs_grad || b->needs_grad);
@@ -1311,8 +1328,11 @@ T pool2_add(Ctx& c, T a, T b, Param* post_prelu, T* prelu_out) {
   T out2 = (post_prelu && fuse2 && vec) ? new_tensor(c, b->n, b->h, b->w, b->c, false) : nullptr;
   const SlabSrc as = data_src(a);
   EG_CHECK(as.n <= 1 || vec, "pool2_add: slab operand without the float4 form");
+  unsigned short* plane2 = out2 ? producer_plane(c, out2, false) : nullptr;
+  static const bool plane_only_on = dbg_env("EG_NO_PLANE_ONLY") == nullptr;
+  if (out2) out2->d_plane_only = plane_only_on && plane_only && plane2 != nullptr;
   if (!launch_pool2_add_fwd(a->d, b->d, out->d, a->n, a->h, a->w, a->c, c.stream, as.n > 1 ? &as : nullptr,
-                            out2 ? post_prelu->w : nullptr, out2 ? out2->d : nullptr, out2 ? producer_plane(c, out2, false) : nullptr)) {
+                            out2 ? post_prelu->w : nullptr, out2 && !out2->d_plane_only ? out2->d : nullptr, plane2)) {
     launch_pool2_fwd(a->d, out->d, a->n, a->h, a->w, a->c, c.stream);
     launch_axpy(b->d, out->d, 1.f, 1, out->numel(), c.stream);
   }
@@ -1551,9 +1571,12 @@ T gate(Ctx& c, T h, T rg, T img) {
 
 // conv.py:207-209 in one pass: prelu(ht + rg * img_new, leak).  ht_plus is not materialised: the backward recomputes it
 // from its three inputs for the PReLU mask and the slope's gradient (exactly the values the two-pass form reads back)
-T gate_prelu(Ctx& c, T h, T rg, T img, Param* leak) {
+T gate_prelu(Ctx& c, T h, T rg, T img, Param* leak, bool plane_only) {
   T out = new_tensor(c, h->n, h->h, h->w, h->c, true);
-  launch_gate_prelu_fwd(h->d, rg->d, img->d, leak->w, out->d, h->numel(), c.stream, producer_plane(c, out, false));
+  unsigned short* plane = producer_plane(c, out, false);
+  static const bool plane_only_on = dbg_env("EG_NO_PLANE_ONLY") == nullptr;
+  out->d_plane_only = plane_only_on && plane_only && plane != nullptr && (h->numel() & 3) == 0;
+  launch_gate_prelu_fwd(h->d, rg->d, img->d, leak->w, out->d_plane_only ? nullptr : out->d, h->numel(), c.stream, plane);
   out->g_slab_ok = flat_slab_ok(out);
   Ctx* cp = &c;
   c.tape.push([=]() {
