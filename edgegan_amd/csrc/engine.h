@@ -119,6 +119,8 @@ struct Ctx {
   // bf16 mode, set by a caller right before conv2d(..., post_prelu): the PReLU output is read by plane-fed contractions only,
   // so it is stored as its bf16 plane alone (Tensor::d_plane_only; consumed by that convolution)
   bool prelu_plane_only = false;
+  T conv_out_into = nullptr;   // conv_into(): the next conv2d writes its result here and records nothing on the tape
+  bool conv_wrote_plane = false;   //   ... and reports here whether its kernel stored the output's bf16 plane
   // inference only (set inside infer()): a residual block's 1x1 shortcut convolution runs on lane 1 beside the block's
   // two 3x3 convolutions on lane 0 -- the encoder trunk is ONE chain of small launches otherwise
   bool infer_lanes = false;
@@ -242,6 +244,19 @@ T deconv2d(Ctx& c, T x, WRef* w /*[25][Cout][Cin]*/, Param* bias, int cout);
 T linear(Ctx& c, T x, WRef* w /*[1][in][out]*/, Param* bias);
 T linear1(Ctx& c, T x, Param* w /*[K][1]*/, Param* bias /*nullable*/);
 T reshape(Ctx& c, T src, int n, int h, int w, int ch);
+// ---- explicit (tape-free) pieces for schedules the linear tape cannot express: the stacked discriminator sub-step (model.cpp) ----
+// images [n0, n0 + n) of a tensor as a tensor of their own: data, gradient and bf16 planes alias the parent's (the parent's
+// gradient buffer is allocated here if needed); no tape entry, g_set is the view's own
+T view_rows(Ctx& c, T parent, int n0, int n);
+// y = conv(x, w) (SAME) (+ ReLU / LeakyReLU where the thin kernels fuse it), forward only, into y.  Returns bit 0: the activation
+// was applied, bit 1: the kernel also stored y's bf16 plane rows (bf16 mode, y->d_bf given)
+int conv_into(Ctx& c, T x, WRef* w, T y, int k, int stride, int fused_act = 0);
+// filter gradient (on the lane's leaf stream) / input gradient of y = conv(x, w) (SAME) from y->g; x->g first-written or added to
+void conv_backward_w(Ctx& c, T x, T y, WRef* w, int k, int stride);
+void conv_backward_x(Ctx& c, T x, T y, WRef* w, int k, int stride);
+// N == 1 head (linear1): dW (+)= sum over `rows` rows of x[r] dy[r]; the bias gradient sums the first bias_rows of them only (on
+// the lane's leaf stream)
+void linear1_backward_w(Ctx& c, const float* x, const float* dy, Param* w, Param* bias, int bias_rows, int rows, int K);
 WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_, int R, int Cc,
                const std::string& name = std::string());
 T in_act(Ctx& c, T x, int act, T* stats_out = nullptr);

@@ -342,6 +342,7 @@ void api_enter(Ctx& c) {
   c.infer_lanes = false;
   c.feeds_in = FEED_NONE;
   c.prelu_plane_only = false;
+  c.conv_out_into = nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -661,6 +662,168 @@ static void disc_substep(Ctx& c, int group, T real, T fake, const float* alpha_d
   set_want_grad(c, group, false);
 }
 
+// The same sub-step with the discriminator's four passes STACKED along the batch: rows [0,B) x_hat (primal), [B,2B) real,
+// [2B,3B) fake, [3B,4B) the tangent along v.  The first-order pass needs x_hat's forward before v exists, so the forward runs
+// in two phases (B rows, then 3B rows in one launch per layer); the reverse sweep then runs ONE filter-gradient and ONE
+// input-gradient launch per layer over all 4B rows -- convolutions are linear, the tangent of a convolution is the
+// convolution -- where the tape's sweep ran three of each on B / 2B / B rows and accumulated.  Only the InstanceNorm +
+// LeakyReLU stages see the row classes: in_fwd / in_bwd on the primal and real|fake rows, the linearisation (in_tangent_fwd)
+// and its reverse on the tangent rows.  The linear tape cannot express this order (per layer: every row class's norm backward,
+// then one convolution backward), so the sweep is written out here.  Same kernels, same mathematics as disc_substep; sums over
+// the batch are taken in one launch instead of three (fp32 summation order differs).  Measured per layer (f32x3, forward +
+// both gradients): d_conv_4 of the patch discriminators 1.08 -> 0.96 ms, of the joint one 0.64 -> 0.51
+// (tools/gpu_stack_probe.py, profiles/r05g_*).
+static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float* alpha_dev, int slot_d, int slot_gp,
+                                 bool apply) {
+  const Config& cfg = c.cfg;
+  const int B = cfg.B, R = 4 * B;
+  const std::string p = kGroupPrefix[group];
+  set_want_grad(c, group, true);
+  const int H = real->h, W = real->w, C0 = real->c;
+  const int ch[5] = {C0, cfg.df, cfg.df * 2, cfg.df * 4, cfg.df * 8};
+  WRef* w[4];
+  for (int i = 0; i < 4; ++i) w[i] = wref_param(c, P(c, p + "/" + kDiscNames[i] + "/conv2d/w"), 16, ch[i], ch[i + 1]);
+  Param* lw = P(c, p + "/d_linear_5/Matrix");
+  Param* lb = P(c, p + "/d_linear_5/bias");
+  // stacked activations: X = the four inputs, pre[i] / out[i] = layer i before / after its norm + activation
+  T X = new_tensor(c, R, H, W, C0, false);
+  T pre[4], out[4], st[4];
+  int hh = H, ww = W;
+  const bool planes = cfg.bf16;
+  for (int i = 0; i < 4; ++i) {
+    hh = (hh + 1) / 2;
+    ww = (ww + 1) / 2;
+    pre[i] = new_tensor(c, R, hh, ww, ch[i + 1], true);
+    out[i] = i == 0 ? pre[0] : new_tensor(c, R, hh, ww, ch[i + 1], true);     // layer 0: the activation is applied in place
+    st[i] = i == 0 ? nullptr : new_tensor(c, 3 * B, 1, 1, 2 * ch[i + 1], false);
+    if (planes && ch[i + 1] % 32 == 0 && out[i]->numel() * 2 < (1ull << 31)) {   // the next convolution's operand plane (bf16 mode)
+      out[i]->d_bf = reinterpret_cast<unsigned short*>(c.arena.allocf((out[i]->numel() + 1) / 2));
+      out[i]->d_bf_stream = nullptr;
+    }
+    pre[i]->g = c.arena.allocf(pre[i]->numel());
+    if (i > 0) out[i]->g = c.arena.allocf(out[i]->numel());
+  }
+  const size_t per = (size_t)H * W * C0;
+  auto rows = [&](T t, int n0, int n) { return view_rows(c, t, n0, n); };
+  launch_blend(real->d, fake->d, alpha_dev, X->d, B, per, c.stream);
+  launch_copy(real->d, X->d + (size_t)B * per, (size_t)B * per, c.stream);
+  launch_copy(fake->d, X->d + (size_t)2 * B * per, (size_t)B * per, c.stream);
+  const int K = (int)(out[3]->numel() / R);
+  EG_CHECK((size_t)K == lw->numel, "d_linear_5 K mismatch %d vs %zu", K, lw->numel);
+  float* dval = c.arena.allocf(R);     // the head's outputs: d(x_hat) | d(real) | d(fake) | tangent
+  float* dgrad = c.arena.allocf(R);    // ... and their gradients
+  // one forward pass over rows [n0, n0 + n): rows below 3B are evaluated points, rows from 3B on the tangent along v
+  auto forward = [&](int n0, int n) {
+    const int ne = std::min(n0 + n, 3 * B) - n0;       // evaluated rows in this pass
+    const int nt = n - ne;                              // tangent rows in this pass (0 or B)
+    T xin = rows(X, n0, n);
+    for (int i = 0; i < 4; ++i) {
+      T yv = rows(pre[i], n0, n);
+      if (i == 0) {
+        // d_conv_0 + LeakyReLU (fused where the thin kernel runs the layer); the tangent rows: the convolution alone, then the
+        // LeakyReLU's linearisation at the primal (rows [0,B) of the same tensor)
+        if (ne > 0) {
+          T xe = rows(X, n0, ne), ye = rows(pre[0], n0, ne);
+          const int r = conv_into(c, xe, w[0], ye, 4, 2, ACT_LRELU);
+          if (!(r & 1)) launch_act_fwd(ye->d, ye->d, ye->numel(), ACT_LRELU, c.stream);
+          if (ye->d_bf && !(r & 2)) launch_cvt_bf16(ye->d, ye->d_bf, ye->numel(), c.stream);   // (plane rows the kernel did not store)
+        }
+        if (nt > 0) {
+          T xt = rows(X, n0 + ne, nt), yt = rows(pre[0], n0 + ne, nt);
+          conv_into(c, xt, w[0], yt, 4, 2, 0);
+          launch_act_bwd(pre[0]->d, yt->d, yt->d, 0, yt->numel(), ACT_LRELU, c.stream);   // t_out = act'(out_primal) * t
+          if (yt->d_bf) launch_cvt_bf16(yt->d, yt->d_bf, yt->numel(), c.stream);
+        }
+      } else {
+        conv_into(c, xin, w[i], yv, 4, 2, 0);
+        const int HW = pre[i]->h * pre[i]->w, C = ch[i + 1];
+        const size_t img = (size_t)HW * C;
+        if (ne > 0)
+          launch_in_fwd(yv->d, out[i]->d + (size_t)n0 * img, st[i]->d + (size_t)n0 * 2 * C, ne, HW, C, ACT_LRELU, c.stream, 0, 0, nullptr,
+                        nullptr, out[i]->d_bf ? out[i]->d_bf + (size_t)n0 * img : nullptr);
+        if (nt > 0)   // the tangent rows: linearised at the primal rows [0,B) (x, out, statistics)
+          launch_in_tangent_fwd(pre[i]->d, out[i]->d, st[i]->d, yv->d + (size_t)ne * img, out[i]->d + (size_t)(n0 + ne) * img, nt, HW, C,
+                                ACT_LRELU, c.stream, out[i]->d_bf ? out[i]->d_bf + (size_t)(n0 + ne) * img : nullptr);
+      }
+      xin = rows(out[i], n0, n);
+    }
+    // d_linear_5: bias on the evaluated rows only (the tangent of a constant is zero)
+    const size_t feat = (size_t)K;
+    if (ne > 0) launch_gemv_fwd(out[3]->d + (size_t)n0 * feat, lw->w, lb->w, dval + n0, ne, K, c.stream);
+    if (nt > 0) launch_gemv_fwd(out[3]->d + (size_t)(n0 + ne) * feat, lw->w, nullptr, dval + n0 + ne, nt, K, c.stream);
+  };
+  // norm + activation backward of layer i for rows [n0, n0 + n) of the evaluated points: gout -> gpre
+  auto norm_bwd = [&](int i, int n0, int n, int acc) {
+    const int HW = pre[i]->h * pre[i]->w, C = ch[i + 1];
+    const size_t img = (size_t)HW * C, o = (size_t)n0 * img;
+    launch_in_bwd(pre[i]->d + o, out[i]->d + o, out[i]->g + o, st[i]->d + (size_t)n0 * 2 * C, pre[i]->g + o, acc, n, HW, C, ACT_LRELU,
+                  c.stream);
+  };
+  // ---- phase 1: x_hat, and the first-order gradient g = d/dx_hat sum_b [sigmoid(D) + D] (quirk N10) ----
+  forward(0, B);
+  {
+    launch_gp_head(dval, nullptr, dgrad, nullptr, B, 0, c.stream);
+    T o3 = rows(out[3], 0, B);
+    launch_gemv_bwd_x(dgrad, lw->w, o3->g, 0, B, K, c.stream);
+    o3->g_set = true;
+    for (int i = 3; i >= 1; --i) {
+      norm_bwd(i, 0, B, 0);
+      T yv = rows(pre[i], 0, B), xv = rows(out[i - 1], 0, B);
+      yv->g_set = true;
+      conv_backward_x(c, xv, yv, w[i], 4, 2);
+    }
+    T y0 = rows(pre[0], 0, B), x0 = rows(X, 0, B);
+    launch_act_bwd(y0->d, y0->g, y0->g, 0, y0->numel(), ACT_LRELU, c.stream);   // in place: g *= act'(out)
+    y0->g_set = true;
+    x0->needs_grad = true;
+    conv_backward_x(c, x0, y0, w[0], 4, 2);
+  }
+  float* norms = c.arena.allocf(B);
+  launch_gp_v(X->g, X->d + (size_t)3 * B * per, norms, c.d_losses + slot_gp, B, per, cfg.lambda_gp, c.stream);   // v -> the tangent rows of X
+  // ---- phase 2: real | fake | tangent in one pass ----
+  forward(B, 3 * B);
+  launch_mean_diff(dval + 2 * B, dval + B, c.d_losses + slot_d, B, c.stream);
+  // ---- the reverse sweep over all 4B rows ----
+  launch_gp_head(dval, dval + 3 * B, dgrad, dgrad + 3 * B, B, 1, c.stream);   // seeds of d(x_hat) and of the tangent
+  launch_fill(dgrad + B, -1.f / B, B, c.stream);
+  launch_fill(dgrad + 2 * B, 1.f / B, B, c.stream);
+  linear1_backward_w(c, out[3]->d, dgrad, lw, lb, 3 * B, R, K);   // (the tangent rows carry no bias)
+  launch_gemv_bwd_x(dgrad, lw->w, out[3]->g, 0, R, K, c.stream);
+  for (int i = 3; i >= 1; --i) {
+    const int HW = pre[i]->h * pre[i]->w, C = ch[i + 1];
+    const size_t img = (size_t)HW * C, ot = (size_t)3 * B * img;
+    norm_bwd(i, B, 2 * B, 0);                                  // real | fake
+    // the tangent rows: reverse of the linearisation -- gradient w.r.t. the tangent AND w.r.t. the primal pre-norm rows [0,B)
+    launch_in_tangent_bwd(pre[i]->d, out[i]->d, st[i]->d, pre[i]->d + ot, out[i]->g + ot, pre[i]->g + ot, 0, pre[i]->g, 0, B, HW, C,
+                          ACT_LRELU, c.stream);
+    norm_bwd(i, 0, B, 1);                                      // the primal rows add their own first-order term
+    pre[i]->g_set = true;
+    pre[i]->g_bf = nullptr;
+    conv_backward_w(c, out[i - 1], pre[i], w[i], 4, 2);
+    out[i - 1]->needs_grad = true;
+    out[i - 1]->g_set = false;
+    conv_backward_x(c, out[i - 1], pre[i], w[i], 4, 2);
+  }
+  {   // layer 0: LeakyReLU backward on the evaluated rows, its linearisation's reverse on the tangent rows (mask of the primal)
+    const size_t img = pre[0]->numel() / R;
+    launch_act_bwd(pre[0]->d, pre[0]->g, pre[0]->g, 0, (size_t)3 * B * img, ACT_LRELU, c.stream);
+    launch_act_bwd(pre[0]->d, pre[0]->g + (size_t)3 * B * img, pre[0]->g + (size_t)3 * B * img, 0, (size_t)B * img, ACT_LRELU, c.stream);
+    pre[0]->g_set = true;
+    pre[0]->g_bf = nullptr;
+    conv_backward_w(c, X, pre[0], w[0], 4, 2);
+  }
+  flush_deferred(c);
+  if (apply) apply_group(c, group);
+  set_want_grad(c, group, false);
+}
+
+// EG_D_TAPE=1 (experiments build): the tape-driven form, for A/B runs and as the reference the stacked form is tested against
+static void d_substep(Ctx& c, int group, T real, T fake, const float* alpha_dev, int slot_d, int slot_gp, bool apply) {
+  static const bool tape_form = dbg_env("EG_D_TAPE") != nullptr;
+  if (tape_form) disc_substep(c, group, real, fake, alpha_dev, slot_d, slot_gp, apply);
+  else disc_substep_stacked(c, group, real, fake, alpha_dev, slot_d, slot_gp, apply);
+}
+
 // G1(z) / G2(z) for the discriminator sub-steps: evaluated once per iteration and shared by sub-steps 1-3 (the
 // reference re-evaluates them in each sess.run; the generators are frozen until sub-step 5, so the values are the
 // same -- SURVEY 7.2).  The BatchNorm moving statistics still advance once per reference evaluation.
@@ -729,21 +892,21 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       T image = generator_output_nograd(c, G_G2, zin, bn2);
       if (opts && opts->record_after_gen) EG_HIP(hipEventRecord(opts->record_after_gen, c.stream));
       T joint = concat_w(c, edge, image);
-      disc_substep(c, G_D, images, joint, c.d_alpha, L_JOINT_D, L_JOINT_GP, apply);
+      d_substep(c, G_D, images, joint, c.d_alpha, L_JOINT_D, L_JOINT_GP, apply);
     } break;
     case 2: {  // d_optim_patch2: image discriminator on bicubic-resized right halves
       T zin = make_zin(c);
       T image = generator_output_nograd(c, G_G2, zin, bn2);
       T r_real = resize(c, right_half(c, images), cfg.dis_size);
       T r_fake = resize(c, image, cfg.dis_size);
-      disc_substep(c, G_DP2, r_real, r_fake, c.d_alpha + B, L_IMAGE_D, L_IMAGE_GP, apply);
+      d_substep(c, G_DP2, r_real, r_fake, c.d_alpha + B, L_IMAGE_D, L_IMAGE_GP, apply);
     } break;
     case 3: {  // d_optim_patch3: edge discriminator
       T zin = make_zin(c);
       T edge = generator_output_nograd(c, G_G1, zin, bn1);
       T r_real = resize(c, left_half(c, images), cfg.dis_size);
       T r_fake = resize(c, edge, cfg.dis_size);
-      disc_substep(c, G_DP3, r_real, r_fake, c.d_alpha + 2 * B, L_EDGE_D, L_EDGE_GP, apply);
+      d_substep(c, G_DP3, r_real, r_fake, c.d_alpha + 2 * B, L_EDGE_D, L_EDGE_GP, apply);
     } break;
     case 4: {  // d_optim2: classifier focal loss on the real right half (edgegan.py:238-239,325-330)
       set_want_grad(c, G_D2, true);

@@ -825,7 +825,9 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     same_pad(x->h, k, stride, &OH, &pt);
     same_pad(x->w, k, stride, &OW, &pl);
   }
-  T y = accumulate_into ? accumulate_into : new_tensor(c, x->n, OH, OW, N, false);
+  T into = c.conv_out_into;   // (conv_into: forward only, into a caller's tensor)
+  c.conv_out_into = nullptr;
+  T y = accumulate_into ? accumulate_into : (into ? into : new_tensor(c, x->n, OH, OW, N, false));
   EG_CHECK(y->n == x->n && y->h == OH && y->w == OW && y->c == N, "conv2d output shape");
   if (accumulate_into) y->d_bf = nullptr;   // (a bf16 plane of the value this launch adds to is stale afterwards)
   ConvArgs a{};
@@ -866,10 +868,11 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     if (fused) a.act = fused_act;
     // bf16 mode: the packed-K kernel also stores the activated output's plane (N % 4 == 0 and a 4-aligned pitch: its float4 path)
     static const bool pk_plane = dbg_env("EG_NO_PK_PLANE") == nullptr;
-    if (fused && pk_plane && conv_pk_eligible(a) && N % 4 == 0 && a.y_ps % 4 == 0) a.y_bf = producer_plane(c, y, false);
+    if (fused && pk_plane && conv_pk_eligible(a) && N % 4 == 0 && a.y_ps % 4 == 0)
+      a.y_bf = (into && y->d_bf) ? y->d_bf : producer_plane(c, y, false);   // (a view's rows of its parent's plane)
   }
   if (c.prof_on) c.cur_label = w->name + " fwd";
-  const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
+  const bool need = !into && (x->needs_grad || w->want_grad || (bias && bias->want_grad));
   // convolution read by an InstanceNorm alone (Ctx::feeds_in): a K-split launch keeps its slabs, the norm's load pass sums
   // them (bias + slabs in conv_split_reduce's order: same bits, one launch and one round trip less) and, in training,
   // stores the sum as this tensor's value for the backward passes (in_act)
@@ -957,9 +960,62 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
       }
     });
   }
+  if (into) {
+    y->fused_act = fused ? fused_act : 0;
+    c.conv_wrote_plane = a.y_bf != nullptr;
+    return y;
+  }
   if (fused_act && !fused) return act(c, y, fused_act);
   if (post_prelu) return prelu_tail(c, y, y2, post_prelu, 0.f);
   return y;
+}
+
+T view_rows(Ctx& c, T parent, int n0, int n) {
+  EG_CHECK(n0 >= 0 && n > 0 && n0 + n <= parent->n, "view_rows [%d, %d) of %d images", n0, n0 + n, parent->n);
+  const size_t off = (size_t)n0 * parent->h * parent->w * parent->c;
+  T v = new_tensor(c, n, parent->h, parent->w, parent->c, false, false);
+  v->d = parent->d + off;
+  if (!parent->g) parent->g = c.arena.allocf(parent->numel());
+  v->g = parent->g + off;
+  if (parent->d_bf) {
+    v->d_bf = parent->d_bf + off;
+    v->d_bf_stream = parent->d_bf_stream;
+  }
+  return v;
+}
+
+int conv_into(Ctx& c, T x, WRef* w, T y, int k, int stride, int fused_act) {
+  c.conv_out_into = y;
+  c.feeds_in = FEED_NONE;
+  c.conv_wrote_plane = false;
+  conv2d(c, x, w, nullptr, k, stride, PAD_SAME, nullptr, fused_act);
+  const int r = (y->fused_act != 0 ? 1 : 0) | (c.conv_wrote_plane ? 2 : 0);
+  y->fused_act = 0;   // (the caller applies / differentiates the activation itself)
+  return r;
+}
+
+void conv_backward_w(Ctx& c, T x, T y, WRef* w, int k, int stride) {
+  int OH, OW, pt, pl;
+  same_pad(x->h, k, stride, &OH, &pt);
+  same_pad(x->w, k, stride, &OW, &pl);
+  if (c.cfg.bf16 && k > 1 && y->c % 64 == 0) (void)tensor_plane(c, y, true);   // (made on the main stream: both gradients read it)
+  LeafScope leaf(c);
+  conv_wgrad(c, x, false, x->n, x->h, x->w, x->c, y, true, OH, OW, y->c, w, k, stride, pt, 0);
+}
+
+void linear1_backward_w(Ctx& c, const float* x, const float* dy, Param* w, Param* bias, int bias_rows, int rows, int K) {
+  LeafScope leaf(c);
+  launch_gemv_bwd_w(x, dy, w->g, w->g_set ? 1 : 0, bias->g, bias->g_set ? 1 : 0, bias_rows, K, c.stream);
+  if (rows > bias_rows)
+    launch_gemv_bwd_w(x + (size_t)bias_rows * K, dy + bias_rows, w->g, 1, nullptr, 0, rows - bias_rows, K, c.stream);
+  w->g_set = bias->g_set = true;
+}
+
+void conv_backward_x(Ctx& c, T x, T y, WRef* w, int k, int stride) {
+  int OH, OW, pt, pl;
+  same_pad(x->h, k, stride, &OH, &pt);
+  same_pad(x->w, k, stride, &OW, &pl);
+  conv_dgrad(c, x, y, w, k, stride, PAD_SAME, pt, pl);
 }
 
 // ---------------------------------------------------------------------------------------------
