@@ -88,6 +88,64 @@ def pmc_traffic(kernel_label):
     return float(best['HbmBytesPerLaunch']) if best else None
 
 
+def live_traffic(kernel_label, args):
+    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE:
+    counters only, one group per pass, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over a 2-iteration child run of
+    this same bench with the sub-steps serialised, averaged over that kernel's launches; read side x 2 (the guide's gfx950
+    correction: FETCH_SIZE reports half of a wide coalesced read), both counters in KiB.  None where rocprofv3 is missing, the
+    process already runs under a profiler, or the label has no known instantiation pattern -- the caller then falls back to
+    the committed profile set."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which('rocprofv3') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
+        return None
+    m = re.match(r'conv_gemm_(x3h|bf16h)<256,(\d+)(,s2d)?(,splitk)?>', kernel_label)
+    mp = re.match(r'conv_bf16p<(\d+),(\d+)(,splitk)?>', kernel_label)
+    if m:
+        pat = r'conv_gemm_x3h_kernel<%d, %s, %s, (true|false), %s>' % (6 if m.group(1) == 'x3h' else 1, 'true' if m.group(4) else 'false',
+                                                                        m.group(2), 'true' if m.group(3) else 'false')
+    elif mp:
+        mi_wn = {('128', '128'): (2, 2), ('256', '128'): (4, 2), ('256', '64'): (2, 1)}.get((mp.group(1), mp.group(2)))
+        if not mi_wn:
+            return None
+        pat = r'conv_bf16p_kernel<%d, %d, %s,' % (mi_wn[0], mi_wn[1], 'true' if mp.group(3) else 'false')
+    else:
+        return None
+    rx = re.compile(pat)
+    child = [sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--profile-steps', '0', '--no-cpu-baseline',
+             '--no-alt', '--no-live-traffic', '--batch', str(args.batch), '--classes', str(args.classes), '--height', str(args.height),
+             '--width', str(args.width), '--dtype', args.dtype]
+    env = dict(os.environ, EG_LANES='0', TMPDIR='/tmp')
+    avg = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='eg_pmc_', dir='/tmp')
+        try:
+            subprocess.run(['rocprofv3', '--pmc', counter, '-d', d, '-o', 'p', '--output-format', 'csv', '--'] + child, env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            n, tot = 0, 0.0
+            for f in files:
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get('Counter_Name') == counter and rx.search(r.get('Kernel_Name', '')):
+                            n += 1
+                            tot += float(r['Counter_Value'])
+            if n == 0:
+                return None
+            avg[counter] = (tot / n, n)
+        except (subprocess.SubprocessError, OSError, ValueError, KeyError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {'bytes': 2.0 * 1024.0 * avg['FETCH_SIZE'][0] + 1024.0 * avg['WRITE_SIZE'][0],
+            'read_bytes': 2.0 * 1024.0 * avg['FETCH_SIZE'][0], 'write_bytes': 1024.0 * avg['WRITE_SIZE'][0],
+            'launches_sampled': avg['FETCH_SIZE'][1]}
+
+
 def cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -514,6 +572,8 @@ def main():
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the side measurement of the exact-fp32-MFMA mode')
+    ap.add_argument('--no-live-traffic', action='store_true',
+                    help='roofline.traffic from the committed profile set instead of two rocprofv3 --pmc passes inside this run')
     ap.add_argument('--cpu-baseline-batch', type=int, default=64)
     ap.add_argument('--mode', choices=['train', 'infer', 'loop'], default='train',
                     help='train = BASELINE configs[2] (the headline metric); infer = configs[1]: single-class 64x128 bf16 '
@@ -683,8 +743,22 @@ def main():
                                                    batch_all=args.cpu_baseline_batch)
             except Exception as e:  # the baseline must never hide the GPU number
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+        if world == 1 and roof and not args.no_live_traffic:
+            # roofline.traffic measured HERE (the committed table meant the driver never observed traffic): the engine
+            # is closed first, the PMC child runs own a context of their own
+            net.close()
+            net = None
+            lt = live_traffic(roof['kernel'], args)
+            if lt:
+                roof['traffic'] = round(lt['bytes'], 1)
+                roof['traffic_read_bytes'] = round(lt['read_bytes'], 1)
+                roof['traffic_write_bytes'] = round(lt['write_bytes'], 1)
+                roof['traffic_source'] = ('measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each) over a '
+                                          '2-iteration child run with the sub-steps serialised, averaged over %d launches of this kernel; '
+                                          'read side x 2 (gfx950), KiB units' % lt['launches_sampled'])
         print(json.dumps(out))
-    net.close()
+    if net is not None:
+        net.close()
 
 
 if __name__ == '__main__':

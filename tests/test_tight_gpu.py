@@ -207,16 +207,21 @@ def test_full_batch_fp32_substep_against_fp64_oracle(name):
     cfg = ea.Config(**case[2])
     values = ea.init_variables(cfg, case[3])
     b = ea.synthetic_batch(cfg, seed=case[4])
-    live = bool(os.environ.get('EG_LIVE_ORACLE'))
-    if live:        # the oracle evaluated here and now: exact relative L2 on every variable, minutes of CPU time
-        g64, l64, self_dev, near_kink = _full_batch_oracle(name, cfg, values, b)
-        if os.environ.get('EG_F32_MODE') == 'f32x3' or name not in FULL_BATCH_EXACT_FP32:
-            _FULL_BATCH_ORACLE.pop(name, None)      # last user of this entry (tens of MB of fp64 gradients each)
-    else:           # the committed digests of exactly that evaluation (tests/golden/make_full_batch_goldens.py)
-        fb = FB.load('b64/' + name)
-        self_dev, near_kink = dict(fb['self_dev']), fb['near_kink']
-        for vn, kappa in fb.get('kappa', {}).items():
-            self_dev[vn] = max(self_dev[vn], SLOPE_KAPPA_TOL * kappa / SELF_DEV_FACTOR)
+    # The benched mode (f32x3, re-run from tests/test_x3_gpu.py) evaluates the oracle HERE AND NOW -- exact relative L2 on every
+    # variable, ~10 s of CPU per sub-step; the exact-fp32 mode compares with the committed digests of that same evaluation
+    # (tests/full_batch_lib.py).  EG_LIVE_ORACLE=1 / 0 forces one or the other.  Tolerances come from the digests' four fp32
+    # samples in both cases (plus the live run's own sample): one fp32 run is one draw of the kink decisions.
+    x3 = os.environ.get('EG_F32_MODE') == 'f32x3'
+    live = os.environ.get('EG_LIVE_ORACLE', '1' if x3 else '0') != '0'
+    fb = FB.load('b64/' + name)
+    self_dev, near_kink = dict(fb['self_dev']), fb['near_kink']
+    for vn, kappa in fb.get('kappa', {}).items():
+        self_dev[vn] = max(self_dev[vn], SLOPE_KAPPA_TOL * kappa / SELF_DEV_FACTOR)
+    if live:
+        g64, l64, live_dev, live_kink = _full_batch_oracle(name, cfg, values, b)
+        _FULL_BATCH_ORACLE.pop(name, None)      # (tens of MB of fp64 gradients each)
+        self_dev = {vn: max(d, live_dev.get(vn, 0.0)) for vn, d in self_dev.items()}
+        near_kink = near_kink or live_kink
     net = ea.EdgeGAN(cfg, values)
     net.upload_batch(b['images'], b['z'], b['alpha'], b['eps'])
     var_tol = {vn: SELF_DEV_OUTLIERS.get(vn, SELF_DEV_FACTOR) * d for vn, d in self_dev.items()}
