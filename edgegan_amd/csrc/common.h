@@ -145,6 +145,11 @@ struct Tensor {
   // writes g = up-sample(out.g) / 4, whose column sums are those of out.g (a quarter of the rows); cleared by grad_acc
   const float* g_colsum_src = nullptr;
   size_t g_colsum_rows = 0;
+  // ... or from per-block column partials [g_colpart_rows][c] that the FIRST writer of g stored next to it (kernels.h: colpart)
+  // because this tensor's producer -- a convolution with a trainable bias -- asked for them (want_colpart); cleared by grad_acc
+  bool want_colpart = false;
+  const float* g_colpart = nullptr;
+  int g_colpart_rows = 0;
   // bf16 planes ([pixel][c] bf16) of d / g for the plane-fed kernels of the bf16 mode (k_conv_bf16p.hip).  Written by the
   // tensor's own producer kernel as a second store (then *_bf_stream == nullptr: the plane is visible wherever d / g is),
   // or on demand by launch_cvt_bf16 on the stream recorded here (ops.cpp: tensor_plane decides who else may read it)

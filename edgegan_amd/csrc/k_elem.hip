@@ -547,14 +547,39 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
   }
 }
+// Column partials of a flat float4 kernel over an [..][C] tensor (kernels.h: colpart): with C4 = C / 4 a divisor of 256 and a
+// grid stride that is a multiple of 256 quads, thread t only ever touches channel quad t % C4; the block sums its threads'
+// running sums per quad (fixed order) and stores row blockIdx.x of the [blocks][C] table
+__device__ __forceinline__ void flat_colpart_store(const float4& cs, float4* redc /*[256]*/, float* __restrict__ colpart, int C4) {
+  redc[threadIdx.x] = cs;
+  __syncthreads();
+  if ((int)threadIdx.x < C4) {
+    float4 t = redc[threadIdx.x];
+    for (int j = threadIdx.x + C4; j < 256; j += C4) {
+      const float4 v = redc[j];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(colpart)[(size_t)blockIdx.x * C4 + threadIdx.x] = t;
+  }
+}
+constexpr int kFlatColpartBlocks = 512;   // rows of the table = blocks of the launch (second stage: 128 adds per lane)
+int flat_colpart_rows(size_t n, int C) {
+  if (C % 4 != 0 || 256 % (C / 4) != 0 || (n & 3) != 0 || n / 4 < 256) return 0;
+  const size_t b = (n / 4 + 255) / 256;
+  return (int)(b > (size_t)kFlatColpartBlocks ? kFlatColpartBlocks : b);
+}
+
 // float4 form (n % 4 == 0, 16-byte aligned buffers)
 __global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restrict__ x, const SlabSrc dy,
                                                           const float* __restrict__ leak_p, float leak_c,
                                                           float* __restrict__ dx, int acc_dx, float* __restrict__ part,
-                                                          size_t n4, unsigned short* __restrict__ dx_bf) {
+                                                          size_t n4, unsigned short* __restrict__ dx_bf,
+                                                          float* __restrict__ colpart, int C4) {
   __shared__ float sm[4];
+  __shared__ float4 redc[256];
   const float lk = leak_p ? *leak_p : leak_c;
   float s = 0.f;
+  float4 cs = f4_zero();
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(x)[i], g = slab_ld4_flat(dy, i);
     const bool f0 = lk * v.x >= v.x, f1 = lk * v.y >= v.y, f2 = lk * v.z >= v.z, f3 = lk * v.w >= v.w;
@@ -566,6 +591,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restric
       }
       reinterpret_cast<float4*>(dx)[i] = o;
       if (dx_bf) st_bf4(dx_bf, i, o);
+      cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
     }
     s += (f0 ? g.x * v.x : 0.f) + (f1 ? g.y * v.y : 0.f) + (f2 ? g.z * v.z : 0.f) + (f3 ? g.w * v.w : 0.f);
   }
@@ -573,6 +599,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restric
     const float tot = block_sum(s, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
   }
+  if (colpart) flat_colpart_store(cs, redc, colpart, C4);
 }
 __global__ void prelu_fwd_v_kernel(const SlabSrc x, const float* __restrict__ leak_p, float leak_c,
                                    float* __restrict__ y, size_t n4, unsigned short* __restrict__ y_bf, float* __restrict__ xsum) {
@@ -613,14 +640,15 @@ void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* 
 size_t prelu_scratch_floats() { return 2048; }
 void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, float leak_c, float* dx, int acc_dx,
                       float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s, unsigned short* dx_bf,
-                      const SlabSrc* dy_slabs) {
+                      const SlabSrc* dy_slabs, float* colpart, int C) {
   int nb;
   if (ew_vec_ok(n, x, dy, dx)) {
-    nb = ew_blocks(n / 4, 2048);
+    nb = colpart ? flat_colpart_rows(n, C) : ew_blocks(n / 4, 2048);
+    EG_CHECK(nb > 0 && (!colpart || dx), "prelu_bwd: column partials were requested from a form that has none");
     hipLaunchKernelGGL(prelu_bwd_v_kernel, dim3(nb), dim3(256), 0, s, x, dy_slabs ? *dy_slabs : plain_src(dy), leak_p, leak_c, dx,
-                       acc_dx, dleak ? scratch : nullptr, n / 4, dx_bf);
+                       acc_dx, dleak ? scratch : nullptr, n / 4, dx_bf, colpart, colpart ? C / 4 : 1);
   } else {
-    EG_CHECK(!dx_bf && !dy_slabs, "prelu_bwd: a bf16 plane / a slab input was requested from the scalar form");
+    EG_CHECK(!dx_bf && !dy_slabs && !colpart, "prelu_bwd: a bf16 plane / a slab input / column partials were requested from the scalar form");
     nb = ew_blocks(n, 1024);
     hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, s, x, dy, leak_p, leak_c, dx, acc_dx,
                        dleak ? scratch : nullptr, n);
@@ -749,7 +777,8 @@ __global__ __launch_bounds__(256) void minmax_fwd_v(const SlabSrc xs, float* __r
 template <int CQ>
 __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x, const float* __restrict__ mm,
                                                     const float* __restrict__ dy, float* __restrict__ dx, int acc,
-                                                    int HW, int C, float lk, unsigned short* __restrict__ dx_bf) {
+                                                    int HW, int C, float lk, unsigned short* __restrict__ dx_bf,
+                                                    float* __restrict__ colpart) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[4 * 4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -776,6 +805,7 @@ __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x,
     dmn[j] = (-S1[j] / d[j] + S2[j] / (d[j] * d[j])) / Cn[j];
     dmx[j] = (-S2[j] / (d[j] * d[j])) / Cx[j];
   }
+  float4 cs[1] = {f4_zero()};
   for (int p = pl; p < HW; p += PL) {
     const size_t i = base + (size_t)p * C;
     const float4 xv = ld4(x + i), v = mm_pre4(xv, lk), g = ld4(dy + i);
@@ -792,6 +822,11 @@ __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x,
     if (acc) { const float4 t = ld4(dx + i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
     st4(dx + i, o);
     if (dx_bf) st_bf4(dx_bf, i >> 2, o);
+    cs[0].x += o.x; cs[0].y += o.y; cs[0].z += o.z; cs[0].w += o.w;
+  }
+  if (colpart) {   // row n of the gate bias gradient's first stage (kernels.h: colpart)
+    cq_reduce<1, CQ>(cs, red);
+    if (pl == 0) st4(colpart + (size_t)n * C + c, cs[0]);
   }
 }
 
@@ -809,15 +844,17 @@ void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int 
   }
   hipLaunchKernelGGL(minmax_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, y, mm, HW, C, pre_leak);
 }
+int minmax_bwd_colpart_rows(int NB, int C) { return C % 8 == 0 ? NB : 0; }
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
-                       int HW, int C, hipStream_t s, float pre_leak, unsigned short* dx_bf) {
+                       int HW, int C, hipStream_t s, float pre_leak, unsigned short* dx_bf, float* colpart) {
+  EG_CHECK(!colpart || C % 8 == 0, "minmax_bwd: column partials need C %% 8 == 0");
   if (C % 32 == 0) {
-    hipLaunchKernelGGL(minmax_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, dx_bf);
+    hipLaunchKernelGGL(minmax_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, dx_bf, colpart);
     return;
   }
   EG_CHECK(!dx_bf, "minmax_bwd: a bf16 plane was requested with C %% 32 != 0");
   if (C % 8 == 0) {
-    hipLaunchKernelGGL(minmax_bwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, nullptr);
+    hipLaunchKernelGGL(minmax_bwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, nullptr, colpart);
     return;
   }
   hipLaunchKernelGGL(minmax_bwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak);
@@ -895,10 +932,13 @@ __global__ __launch_bounds__(256) void gate_prelu_bwd_v_kernel(const float* __re
                                                                const float* __restrict__ img, const float* __restrict__ leak_p,
                                                                const SlabSrc d, float* __restrict__ dh, int acc_h,
                                                                float* __restrict__ drg, float* __restrict__ dimg,
-                                                               float* __restrict__ part, size_t n4) {
+                                                               float* __restrict__ part, size_t n4, float* __restrict__ colpart,
+                                                               int C4) {
   __shared__ float sm[4];
+  __shared__ float4 redc[256];
   const float lk = *leak_p;
   float s = 0.f;
+  float4 cs = f4_zero();   // column sums of dimg: the image convolution's bias gradient (kernels.h: colpart)
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 a = reinterpret_cast<const float4*>(h)[i], r = reinterpret_cast<const float4*>(rg)[i],
                  m = reinterpret_cast<const float4*>(img)[i], gy = slab_ld4_flat(d, i);
@@ -920,12 +960,15 @@ __global__ __launch_bounds__(256) void gate_prelu_bwd_v_kernel(const float* __re
       reinterpret_cast<float4*>(dh)[i] = o;
     }
     reinterpret_cast<float4*>(drg)[i] = make_float4(g[0] * m.x, g[1] * m.y, g[2] * m.z, g[3] * m.w);
-    reinterpret_cast<float4*>(dimg)[i] = make_float4(g[0] * r.x, g[1] * r.y, g[2] * r.z, g[3] * r.w);
+    const float4 di = make_float4(g[0] * r.x, g[1] * r.y, g[2] * r.z, g[3] * r.w);
+    reinterpret_cast<float4*>(dimg)[i] = di;
+    cs.x += di.x; cs.y += di.y; cs.z += di.z; cs.w += di.w;
   }
   if (part) {
     const float tot = block_sum(s, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
   }
+  if (colpart) flat_colpart_store(cs, redc, colpart, C4);
 }
 static bool gp_vec_ok(size_t n, const void* a, const void* b, const void* c, const void* d, const void* e = nullptr,
                       const void* f = nullptr, const void* g = nullptr) {
@@ -943,14 +986,15 @@ void launch_gate_prelu_fwd(const float* h, const float* rg, const float* img, co
 }
 void launch_gate_prelu_bwd(const float* h, const float* rg, const float* img, const float* leak, const float* dout, float* dh,
                            int acc_h, float* drg, float* dimg, float* dleak, int acc_dleak, size_t n, float* scratch,
-                           hipStream_t s, const SlabSrc* dout_slabs) {
+                           hipStream_t s, const SlabSrc* dout_slabs, float* colpart_img, int C) {
   int nb;
   if (gp_vec_ok(n, h, rg, img, dout, dh, drg, dimg)) {
-    nb = ew_blocks(n / 4, 2048);
+    nb = colpart_img ? flat_colpart_rows(n, C) : ew_blocks(n / 4, 2048);
+    EG_CHECK(nb > 0, "gate_prelu_bwd: column partials were requested from a form that has none");
     hipLaunchKernelGGL(gate_prelu_bwd_v_kernel, dim3(nb), dim3(256), 0, s, h, rg, img, leak, dout_slabs ? *dout_slabs : plain_src(dout),
-                       dh, acc_h, drg, dimg, dleak ? scratch : nullptr, n / 4);
+                       dh, acc_h, drg, dimg, dleak ? scratch : nullptr, n / 4, colpart_img, colpart_img ? C / 4 : 1);
   } else {
-    EG_CHECK(!dout_slabs, "gate_prelu_bwd: a slab input was requested from the scalar form");
+    EG_CHECK(!dout_slabs && !colpart_img, "gate_prelu_bwd: a slab input / column partials were requested from the scalar form");
     nb = ew_blocks(n, 2048);
     hipLaunchKernelGGL(gate_prelu_bwd_kernel, dim3(nb), dim3(256), 0, s, h, rg, img, leak, dout, dh, acc_h, drg, dimg,
                        dleak ? scratch : nullptr, n);

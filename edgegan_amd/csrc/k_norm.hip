@@ -376,7 +376,7 @@ template <int NP, int CQ>
 __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, const float* __restrict__ out,
                                                  const SlabSrc v, const float* __restrict__ stats,
                                                  float* __restrict__ dst, int accumulate, int HW, int C, int act,
-                                                 unsigned short* __restrict__ dst_bf) {
+                                                 unsigned short* __restrict__ dst_bf, float* __restrict__ colpart) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[2 * 4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -407,6 +407,7 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
   const float4 eb = make_float4(s[0].x / hw, s[0].y / hw, s[0].z / hw, s[0].w / hw);
   const float4 k2 = make_float4(st.r.x * st.r.x * s[1].x / (hw * st.sigma.x), st.r.y * st.r.y * s[1].y / (hw * st.sigma.y),
                                 st.r.z * st.r.z * s[1].z / (hw * st.sigma.z), st.r.w * st.r.w * s[1].w / (hw * st.sigma.w));
+  float4 cs[1] = {f4_zero()};
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const int p = pl + k * PL;
@@ -420,7 +421,12 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
       }
       st4(dst + i, res);
       if (dst_bf) st_bf4n(dst_bf, i, res);
+      cs[0].x += res.x; cs[0].y += res.y; cs[0].z += res.z; cs[0].w += res.w;
     }
+  }
+  if (colpart) {   // this (n, channel quad)'s sum over H x W of the gradient just written: row n of the bias gradient's first stage
+    cq_reduce<1, CQ>(cs, red);
+    if (pl == 0) st4(colpart + (size_t)n * C + c, cs[0]);
   }
 }
 
@@ -443,22 +449,24 @@ void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int
   hipLaunchKernelGGL(in_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, stats, HW, C, act);
 }
 bool in_bwd_takes_slabs(int HW, int C) { return C % 32 == 0 && HW <= 1024; }   // the register-resident forms
+int in_bwd_colpart_rows(int NB, int HW, int C) { return in_bwd_takes_slabs(HW, C) ? NB : 0; }
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
                    int accumulate, int NB, int HW, int C, int act, hipStream_t s, unsigned short* dx_bf,
-                   const SlabSrc* dout_slabs) {
+                   const SlabSrc* dout_slabs, float* colpart) {
+  EG_CHECK(!colpart || in_bwd_colpart_rows(NB, HW, C), "in_bwd: column partials need C %% 32 == 0 and HW <= 1024");
   EG_CHECK(!dx_bf || C % 32 == 0, "in_bwd: a bf16 plane was requested with C %% 32 != 0");
   EG_CHECK(!dout_slabs || in_bwd_takes_slabs(HW, C), "in_bwd: a slab input needs C %% 32 == 0 and HW <= 1024");
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
     const SlabSrc dsrc = dout_slabs ? *dout_slabs : plain_src(dout);
-#define EG_IN_BWD(NP) hipLaunchKernelGGL((in_bwd_vr<NP, 8>), grid, dim3(256), 0, s, x, out, dsrc, stats, dx, accumulate, HW, C, act, dx_bf)
+#define EG_IN_BWD(NP) hipLaunchKernelGGL((in_bwd_vr<NP, 8>), grid, dim3(256), 0, s, x, out, dsrc, stats, dx, accumulate, HW, C, act, dx_bf, colpart)
     if (HW <= 64) EG_IN_BWD(2);
     else if (HW <= 128) EG_IN_BWD(4);
     else if (HW <= 256) EG_IN_BWD(8);
     else if (HW <= 512) EG_IN_BWD(16);
     else if (HW <= 1024)
       hipLaunchKernelGGL((in_bwd_vr<16, 4>), dim3(NB, C / 16), dim3(256), 0, s, x, out, dsrc, stats, dx, accumulate, HW,
-                         C, act, dx_bf);
+                         C, act, dx_bf, colpart);
     else
       hipLaunchKernelGGL((in_japply_v<0, 8>), grid, dim3(256), 0, s, x, out, dout, stats, dx, accumulate, HW, C, act, dx_bf);
 #undef EG_IN_BWD

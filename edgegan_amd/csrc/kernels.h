@@ -287,7 +287,12 @@ void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int
 // dout_slabs (C % 32 == 0 and HW <= 1024 only): dout is that SlabSrc instead
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
                    int accumulate, int NB, int HW, int C, int act, hipStream_t s, unsigned short* dx_bf = nullptr,
-                   const SlabSrc* dout_slabs = nullptr);
+                   const SlabSrc* dout_slabs = nullptr, float* colpart = nullptr);
+// colpart (here and in the other gradient writers below): per-block column sums of the gradient JUST WRITTEN -- the first
+// stage of the bias gradient of the convolution whose output gradient this is (conv.py:31-34: db = sum over pixels of dY), so
+// that no pass re-reads dY for it.  [rows][C] floats; the launcher returns `rows` through colpart_rows_* below (0: this form of
+// the kernel does not produce them, the caller runs col_sum_stage1 as before).  Only meaningful for a first writer.
+int in_bwd_colpart_rows(int NB, int HW, int C);
 bool in_bwd_takes_slabs(int HW, int C);
 // tangent forward: tout = act'(out_primal) * (J * tx)
 void launch_in_tangent_fwd(const float* x, const float* out, const float* stats, const float* tx, float* tout,
@@ -365,14 +370,16 @@ void launch_prelu_fwd(const float* x, const float* leak_p, float leak_c, float* 
 size_t prelu_scratch_floats();
 void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, float leak_c, float* dx, int acc_dx,
                       float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s, unsigned short* dx_bf = nullptr,
-                      const SlabSrc* dy_slabs = nullptr);
+                      const SlabSrc* dy_slabs = nullptr, float* colpart = nullptr, int C = 0);
+int flat_colpart_rows(size_t n, int C);   // prelu_bwd / gate_prelu_bwd (their float4 forms): partial rows for [..][C] tensors of n elements, 0 = no
 // per-(n,c) spatial min-max normalisation (conv.py:197-198) fwd/bwd; mm[n][c] = {min,max}
 // pre_leak != 0: y = minmax(lrelu_{pre_leak}(x)) with the lrelu applied on load / its slope on the gradient store
 // x_slabs (C % 8 == 0 only): x is that SlabSrc and the summed value is stored to xsum (what the backward reads)
 void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s, float pre_leak = 0.f,
                        const SlabSrc* x_slabs = nullptr, float* xsum = nullptr);
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
-                       int HW, int C, hipStream_t s, float pre_leak = 0.f, unsigned short* dx_bf = nullptr);
+                       int HW, int C, hipStream_t s, float pre_leak = 0.f, unsigned short* dx_bf = nullptr, float* colpart = nullptr);
+int minmax_bwd_colpart_rows(int NB, int C);
 // gate merge: out = h + rg*img ; backward
 void launch_gate_fwd(const float* h, const float* rg, const float* img, float* out, size_t n, hipStream_t s);
 void launch_gate_bwd(const float* rg, const float* img, const float* dout, float* dh, int acc_h, float* drg,
@@ -382,7 +389,7 @@ void launch_gate_prelu_fwd(const float* h, const float* rg, const float* img, co
                            hipStream_t s, unsigned short* out_bf = nullptr);
 void launch_gate_prelu_bwd(const float* h, const float* rg, const float* img, const float* leak, const float* dout, float* dh,
                            int acc_h, float* drg, float* dimg, float* dleak, int acc_dleak, size_t n, float* scratch,
-                           hipStream_t s, const SlabSrc* dout_slabs = nullptr);
+                           hipStream_t s, const SlabSrc* dout_slabs = nullptr, float* colpart_img = nullptr, int C = 0);
 // add bias over last dim in place (y[r][c] += b[c]), optional prelu/lrelu fused variants are separate ops
 void launch_bias_add(float* y, const float* b, size_t R, int C, hipStream_t s);
 

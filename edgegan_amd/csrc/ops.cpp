@@ -143,6 +143,32 @@ static void materialize_grad(Ctx& c, T t) {
   t->g_nslab = 0;
   t->g_slabs = nullptr;
 }
+// Column partials of the gradient a backward kernel is about to write as the FIRST writer (acc == 0) of tensor t, if t's producer
+// asked for them (a convolution with a trainable bias: Tensor::want_colpart) and the kernel form has `rows` > 0 of them
+static float* colpart_for(Ctx& c, T t, int acc, int rows) {
+  static const bool on = dbg_env("EG_NO_COLPART") == nullptr;
+  if (!on || acc || !t->want_colpart || rows <= 0 || !c.param_grad_enabled || !c.defer_on) return nullptr;
+  return c.arena.allocf((size_t)rows * t->c);
+}
+static void colpart_done(T t, float* part, int rows) {   // (after grad_acc, which cleared any older table)
+  if (!part) return;
+  t->g_colpart = part;
+  t->g_colpart_rows = rows;
+}
+// the bias gradient of a convolution from what its output's gradient carries: the first writer's column partials, a smaller
+// tensor with the same column sums (pool2_add), or a pass over the gradient itself
+static void bias_grad(Ctx& c, Param* b, const float* dy, size_t rows, int C);
+static void bias_grad_of(Ctx& c, Param* b, T y) {
+  if (y->g_colpart && c.defer_on) {
+    defer_reduction(c, RedDesc{y->g_colpart, b->g, 1, 0, y->c, 0, 0, 0, y->g_colpart_rows, b->g_set ? 1 : 0});
+    b->g_set = true;
+  } else if (y->g_colsum_src) {
+    bias_grad(c, b, y->g_colsum_src, y->g_colsum_rows, y->c);   // (pool2_add: a quarter of the rows)
+  } else {
+    bias_grad(c, b, y->g, y->pixels(), y->c);
+  }
+}
+
 // flat element-wise readers (prelu, gate_prelu, pool2 in their float4 forms) take any [..][C] tensor with C % 4 == 0
 static bool flat_slab_ok(T t) { return t->c % 4 == 0 && t->numel() < (1ull << 31); }
 
@@ -157,6 +183,7 @@ float* grad_acc(Ctx& c, T t, int* acc) {
   t->g_set = true;
   t->g_bf = nullptr;   // whoever asks is about to write g: a plane of its previous value is stale (the writer may set a new one)
   t->g_colsum_src = nullptr;
+  t->g_colpart = nullptr;
   return t->g;
 }
 void seed_grad(Ctx& c, T t) {
@@ -170,6 +197,7 @@ void reset_grads(Ctx& c) {
     t.g_nslab = 0;
     t.g_slabs = nullptr;
     t.g_colsum_src = nullptr;
+    t.g_colpart = nullptr;
   }
   for (auto& p : c.params) p->g_set = false;
   for (auto& s : c.sn) s.dWbar_set = false;
@@ -926,8 +954,8 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     y->needs_grad = true;
     y->g_inplace = fused;
     y->fused_act = fused ? fused_act : 0;
+    if (bias && bias->want_grad && !accumulate_into) y->want_colpart = true;   // (the writer of y's gradient may sum its columns)
     Ctx* cp = &c;
-    const size_t rows = y->pixels();
     c.tape.push([=]() {
       Ctx& c = *cp;
       if (!y->g_set) return;
@@ -935,6 +963,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
         launch_act_bwd(y->d, y->g, y->g, 0, y->numel(), fused_act, c.stream);   // in place: g *= act'(out)
         y->g_bf = nullptr;           // (a plane its writer stored holds the un-masked values)
         y->g_colsum_src = nullptr;
+        y->g_colpart = nullptr;
       }
       // bf16 mode: the plane of y's gradient serves the filter gradient (leaf stream) AND the input gradient (this stream):
       // if y's producer left none, make it here, before the leaf scope opens -- both streams may then read it.  Only the
@@ -945,10 +974,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
         LeafScope leaf(c);
         if (w->want_grad)
           conv_wgrad(c, x, false, x->n, x->h, x->w, Cin, y, true, OH, OW, N, w, k, stride, pt, pad == PAD_REFLECT);
-        if (bias && bias->want_grad) {
-          if (y->g_colsum_src) bias_grad(c, bias, y->g_colsum_src, y->g_colsum_rows, N);   // (pool2_add: a quarter of the rows)
-          else bias_grad(c, bias, y->g, rows, N);
-        }
+        if (bias && bias->want_grad) bias_grad_of(c, bias, y);
       }
       if (x->needs_grad) {
         if (x->leaf_grad) {   // gradient towards a leaf-side tensor (the classifier's image pyramid): off the dependent chain
@@ -1078,6 +1104,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
   }
   if (need) {
     y->needs_grad = true;
+    if (bias && bias->want_grad) y->want_colpart = true;
     Ctx* cp = &c;
     c.tape.push([=]() {
       Ctx& c = *cp;
@@ -1086,7 +1113,7 @@ T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
         LeafScope leaf(c);
         // dW[k][co][ci] = sum_i dy[2i+k-1][co] x[i][ci]: wgrad with the roles of x and dy swapped
         if (w->want_grad) conv_wgrad(c, y, true, x->n, OH, OW, cout, x, false, x->h, x->w, Cin, w, 5, 2, 1, 0);
-        if (bias && bias->want_grad) bias_grad(c, bias, y->g, y->pixels(), cout);
+        if (bias && bias->want_grad) bias_grad_of(c, bias, y);
       }
       if (x->needs_grad) {
         // dx[i] = sum_k dy[2i+k-1] w[k]: a stride-2 SAME conv of dy with the filter as stored
@@ -1197,8 +1224,11 @@ T in_act(Ctx& c, T x, int a, T* stats_out) {
       int acc;
       float* dx = grad_acc(c, x, &acc);
       const SlabSrc ds = grad_src(out);
+      const int prow = in_bwd_colpart_rows(x->n, HW, x->c);
+      float* part = colpart_for(c, x, acc, prow);
       launch_in_bwd(x->d, out->d, out->g, st->d, dx, acc, x->n, HW, x->c, a, c.stream, producer_plane(c, x, true),
-                    ds.n > 1 ? &ds : nullptr);
+                    ds.n > 1 ? &ds : nullptr, part);
+      colpart_done(x, part, prow);
     });
   }
   return out;
@@ -1574,9 +1604,12 @@ static T prelu_tail(Ctx& c, T x, T out, Param* leak, float leak_const) {
       const bool pg = leak && leak->want_grad && c.param_grad_enabled;
       if (!dx && !pg) return;
       const SlabSrc ds = grad_src(out);
+      const int prow = dx ? flat_colpart_rows(x->numel(), x->c) : 0;
+      float* part = dx ? colpart_for(c, x, acc, prow) : nullptr;
       launch_prelu_bwd(x->d, out->g, leak ? leak->w : nullptr, leak_const, dx, acc, pg ? leak->g : nullptr,
                        pg && leak->g_set ? 1 : 0, x->numel(), c.scratch, c.stream, dx ? producer_plane(c, x, true) : nullptr,
-                       ds.n > 1 ? &ds : nullptr);
+                       ds.n > 1 ? &ds : nullptr, part, x->c);
+      colpart_done(x, part, prow);
       if (pg) leak->g_set = true;
     });
   }
@@ -1598,7 +1631,10 @@ T minmax(Ctx& c, T x, float pre_leak) {
       if (!out->g_set) return;
       int acc;
       float* dx = grad_acc(c, x, &acc);
-      launch_minmax_bwd(x->d, mm->d, out->g, dx, acc, x->n, HW, x->c, c.stream, pre_leak, producer_plane(c, x, true));
+      const int prow = minmax_bwd_colpart_rows(x->n, x->c);
+      float* part = colpart_for(c, x, acc, prow);
+      launch_minmax_bwd(x->d, mm->d, out->g, dx, acc, x->n, HW, x->c, c.stream, pre_leak, producer_plane(c, x, true), part);
+      colpart_done(x, part, prow);
     });
   }
   return out;
@@ -1646,8 +1682,11 @@ T gate_prelu(Ctx& c, T h, T rg, T img, Param* leak, bool plane_only) {
     EG_CHECK(!a1 && !a2, "gate operands are single-use");
     const bool pg = leak->want_grad && c.param_grad_enabled;
     const SlabSrc ds = grad_src(out);
+    const int prow = flat_colpart_rows(img->numel(), img->c);
+    float* part = colpart_for(c, img, a2, prow);     // the image convolution's bias gradient: column sums of dimg
     launch_gate_prelu_bwd(h->d, rg->d, img->d, leak->w, out->g, dh, acc_h, drg, dimg, pg ? leak->g : nullptr,
-                          pg && leak->g_set ? 1 : 0, h->numel(), c.scratch, c.stream, ds.n > 1 ? &ds : nullptr);
+                          pg && leak->g_set ? 1 : 0, h->numel(), c.scratch, c.stream, ds.n > 1 ? &ds : nullptr, part, img->c);
+    colpart_done(img, part, prow);
     if (pg) leak->g_set = true;
   });
   return out;
