@@ -35,7 +35,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef EG_X3H_DBG
-#define EG_X3H_DBG 0   // timing experiments (wrong results): 1 no per-step barrier, 2 no halo store, 4 no filter DMA, 8 no MFMA, 16 A reads from row 0, 32 no fragment reads
+#define EG_X3H_DBG 0   // timing experiments (wrong results): 1 no per-step barrier, 2 no halo store, 4 no filter DMA, 8 no MFMA, 16 A reads from row 0, 32 no fragment reads, 128 no output stores
 #endif
 namespace {
 typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
               }
             }
           }
-          *reinterpret_cast<float4*>(yrow + n) = v;
+          if ((EG_X3H_DBG & 128) == 0 || v.x == 123.456f) *reinterpret_cast<float4*>(yrow + n) = v;   // (bit 7: timing without the output stores)
           if constexpr (!SPLITK) {
             if (a.y2_leak) conv_epi_y2(a, (size_t)(yrow - a.y) + n, v, y2lk);
           }

@@ -1063,9 +1063,11 @@ void train_step(Ctx& c) {
     return;
   }
   const bool cls = c.cfg.multiclasses();
+  static const bool early_cls_probe = dbg_env("EG_EARLY_CLS") != nullptr;   // timing probe: lane 3 does not wait for lane 0's tail
   auto fork = [&](int nl) {   // lanes 1..nl-1 start after everything already enqueued on lane 0
     EG_HIP(hipEventRecord(c.ev_fork, c.lanes[0].stream));
-    for (int i = 1; i < nl; ++i) EG_HIP(hipStreamWaitEvent(c.lanes[i].stream, c.ev_fork, 0));
+    for (int i = 1; i < nl; ++i)
+      if (!(early_cls_probe && i == 3 && nl == 4)) EG_HIP(hipStreamWaitEvent(c.lanes[i].stream, c.ev_fork, 0));
   };
   use_lane(c, 0);
   const bool conc_a = c.lanes_mask & 1, conc_c = c.lanes_mask & 2;
