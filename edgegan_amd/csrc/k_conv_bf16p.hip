@@ -495,6 +495,12 @@ constexpr int kHR128 = 288, kHR256 = 400;
 // profiles/r04h_layers_bf16.csv), so the split only has to give every CU two blocks -- each further slab is 4 bytes per output
 // element written and read again by the reduction (round 3's cost model, tuned for 256-pixel tiles at one block per CU,
 // chose 8 slabs for the classifier's last unit: 100 MB of slab traffic around a 43 GFLOP launch).
+struct X3Tuned {   // (as in k_gemm.hip)
+  int M, N, C, taps, nphase, S, tile, ks;
+};
+static const X3Tuned kBf16pTuned[] = {
+#include "bf16p_tuned.h"
+    {0, 0, 0, 0, 0, 0, 0, 0}};
 int conv_bf16p_pick_ksplit(const ConvArgs& a) {
   PlaneGeom g;
   const bool n128 = a.N >= 128;
@@ -502,6 +508,21 @@ int conv_bf16p_pick_ksplit(const ConvArgs& a) {
   const long long tiles = (long long)(a.NB / g.TI) * g.tiles_x * g.tiles_y * ((a.N + (n128 ? 127 : 63)) / (n128 ? 128 : 64)) * a.nphase;
   const int chunks = (bf16p_s2d_shape(a) ? 4 : 1) * (a.C / 32);
   static const int target = dbg_env("EG_BF16P_KS_BLOCKS") ? atoi(dbg_env("EG_BF16P_KS_BLOCKS")) : 256;   // in-box 2,961 / 2,963 / 2,997 / 2,971 / 2,948 images/s at 512 / 384 / 256 / 192 / 128 (profiles/r04v_ab_ksplit.txt)
+#ifdef EG_EXPERIMENTS
+  if (const char* f = dbg_env("EG_BF16P_FORCE_KS")) {   // tools/tune_x3.py bf16: every plane-fed launch on one K split (clipped)
+    const int fk = atoi(f);
+    return std::max(1, std::min(fk, std::min(8, chunks / 2)));
+  }
+#endif
+  for (const X3Tuned* t = kBf16pTuned; t->M; ++t) {   // measured per-shape splits where the rule below misses (tools/tune_x3.py)
+    int maxM = 0, taps = 0;
+    for (int p = 0; p < a.nphase; ++p) {
+      maxM = std::max(maxM, a.NB * a.ph[p].OHp * a.ph[p].OWp);
+      taps += a.ph[p].Ty * a.ph[p].Tx;
+    }
+    if (t->M == maxM && t->N == a.N && t->C == a.C && t->taps == taps && t->nphase == a.nphase && t->S == a.S)
+      return std::min(t->ks, std::max(1, chunks / 2));
+  }
   if (tiles >= target * 7 / 8 || chunks < 4) return 1;
   int ks = (int)((target + tiles - 1) / tiles);
   ks = std::min(ks, std::min(8, chunks / 2));

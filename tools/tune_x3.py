@@ -85,8 +85,51 @@ def table(out, min_gain=0.04):
             print(f'#   {b:4d}: {sum(v[0] for k, v in t.items() if k[0]):.3f}')
 
 
+def sweep_bf16(out):
+    """The bf16 mode's plane-fed convolutions: K split 1 .. 4 forced on every launch (EG_BF16P_FORCE_KS), per-layer timings."""
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(ROOT, 'edgegan_amd', 'libedgegan_hip_exp.so')
+    for name, env in [('bfdefault', {})] + [(f'bfks{k}', {'EG_BF16P_FORCE_KS': str(k)}) for k in (1, 2, 3, 4)]:
+        csvp = os.path.join(out, f'tune_{name}.csv')
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'layer_table.py'), csvp, '--dtype', 'bf16', '--steps', '2'],
+                           env=dict(os.environ, EG_LIB_PATH=lib, **env), capture_output=True, text=True)
+        print(name, r.stderr.strip().splitlines()[-1] if r.stderr.strip() else '', flush=True)
+
+
+def table_bf16(out, min_gain=0.05):
+    default = load(os.path.join(out, 'tune_bfdefault.csv'))
+    cands = {k: load(os.path.join(out, f'tune_bfks{k}.csv')) for k in (1, 2, 3, 4) if os.path.exists(os.path.join(out, f'tune_bfks{k}.csv'))}
+    rows, saved, total = [], 0.0, 0.0
+    for key, (ms, n, kern) in sorted(default.items(), key=lambda kv: -kv[1][0]):
+        wg, M, N, C, taps, nph = key
+        if wg or not any(k.startswith('conv_bf16p') for k, _ in kern):
+            continue
+        total += ms
+        best, bk = ms, None
+        for k, tab in cands.items():
+            if key in tab and tab[key][0] < best:
+                best, bk = tab[key][0], k
+        if bk and best < ms * (1.0 - min_gain) and cands[bk][key][2] != kern:
+            ks = max(s for _, s in cands[bk][key][2])
+            S = 2 if (nph == 1 and taps in (16, 25)) else 1
+            rows.append((M, N, C, taps, nph, S, 0, ks))
+            saved += ms - best
+            print(f'# M={M:7d} N={N:4d} C={C:4d} taps={taps:2d} ph={nph} n={n:4.1f}  {ms:.3f} -> {best:.3f} ms  '
+                  f"{'/'.join(sorted(f'{k}:{s}' for k, s in kern))}  ->  ks {ks}")
+    print(f'# plane-fed convolutions {total:.2f} ms per iteration (serialised), table saves {saved:.2f} ms')
+    with open(os.path.join(ROOT, 'edgegan_amd', 'csrc', 'bf16p_tuned.h'), 'w') as f:
+        f.write('// plane-fed bf16 convolutions: {M, N, C, taps, nphase, S, 0, ks},\n')
+        for r in rows:
+            f.write('    {%d, %d, %d, %d, %d, %d, %d, %d},\n' % r)
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'sweep':
+    cmd = sys.argv[1]
+    if cmd == 'sweep':
         sweep(sys.argv[2])
+    elif cmd == 'sweep_bf16':
+        sweep_bf16(sys.argv[2])
+    elif cmd == 'table_bf16':
+        table_bf16(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.05)
     else:
         table(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.04)
