@@ -165,6 +165,12 @@ int eg_mfma_probe(eg_ctx* ctx, int iters, int random_operands, double* tflops);
 /* ---- per-op / per-network test entry points (parity tests against oracle/) ----------------------
  * eg_test_op runs ONE tape op forward and, if a cotangent is supplied, backward, through exactly
  * the code the training step uses.  See tests/test_ops_gpu.py for the per-op argument lists.
+ * Composite ops (round 5) build the op SEQUENCES of the classifier's MRU unit / the discriminator head the way
+ * classifier_forward / disc_forward do, so that the fused forms are exercised as the graph uses them: "mru_tail"
+ * (conv.py:217-243: Conv_1 + PReLU, Conv_2, pool2_add + the next unit's PReLU), "mru_gate" (conv.py:185-209: prelu(h),
+ * the update gate as image rows + hidden rows, min-max, gate + PReLU, a convolution behind it), "act_conv" (InstanceNorm
+ * + LeakyReLU or pool2 in front of a convolution), "d_head" (discriminator.py:61-66: d_conv_0 + LeakyReLU, d_conv_1);
+ * argument lists in csrc/capi.cpp, oracle restatements in tests/parity.py.
  * eg_net_forward runs one network forward: net in {"G1","G2","D","D_patch2","D_patch3","E","D2"}. */
 int eg_test_op(eg_ctx* ctx, const char* op, int n_in, const float* const* inputs, const long long* in_numel,
                int n_iparam, const int* iparams, int n_out, float* const* outputs, const long long* out_numel);
