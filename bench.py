@@ -125,7 +125,7 @@ def live_traffic(kernel_label, args):
         d = tempfile.mkdtemp(prefix='eg_pmc_', dir='/tmp')
         try:
             subprocess.run(['rocprofv3', '--pmc', counter, '-d', d, '-o', 'p', '--output-format', 'csv', '--'] + child, env=env,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
             files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
             n, tot = 0, 0.0
             for f in files:
