@@ -792,10 +792,8 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
     Param* l2 = io.param(7, bw);
     c.prelu_plane_only = c.cfg.bf16;   // (as classifier_forward does)
     T c1 = conv2d(c, x, wref_param(c, w1, 9, C1, C2), b1, 3, 1, PAD_SAME, nullptr, 0, l1);
-    c.feeds_in = FEED_FLAT;
-    T c2 = conv2d(c, c1, wref_param(c, w2, 9, C2, C2), b2, 3, 1, PAD_SAME);
     T hp = nullptr;
-    T h = pool2_add(c, c2, bp, l2, &hp);
+    T h = conv2d_pool2_add(c, c1, wref_param(c, w2, 9, C2, C2), b2, 3, bp, l2, &hp);   // (pooled in Conv_2's epilogue where its kernel can)
     io.down(0, h->d, h->numel());
     io.down(1, hp->d, hp->numel());
     if (bw) {

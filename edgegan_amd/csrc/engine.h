@@ -120,6 +120,13 @@ struct Ctx {
   // so it is stored as its bf16 plane alone (Tensor::d_plane_only; consumed by that convolution)
   bool prelu_plane_only = false;
   T conv_out_into = nullptr;   // conv_into(): the next conv2d writes its result here and records nothing on the tape
+  // conv2d_pool2_add(): the pooled outputs the next conv2d offers to its kernel's epilogue, and whether the kernel took them
+  struct PoolEpi {
+    T b = nullptr, out = nullptr, out2 = nullptr;
+    Param* leak = nullptr;
+    unsigned short* plane2 = nullptr;
+    bool done = false;
+  } pool_epi;
   bool conv_wrote_plane = false;   //   ... and reports here whether its kernel stored the output's bf16 plane
   // inference only (set inside infer()): a residual block's 1x1 shortcut convolution runs on lane 1 beside the block's
   // two 3x3 convolutions on lane 0 -- the encoder trunk is ONE chain of small launches otherwise
@@ -273,6 +280,10 @@ T add_pool2(Ctx& c, T a, T b);
 // post_prelu / prelu_out: also returns prelu(result, post_prelu) from the same pass (conv.py:185: the next unit's prelu(h))
 // plane_only (bf16 mode): that PReLU output is read by plane-fed contractions only and stored as its bf16 plane alone
 T pool2_add(Ctx& c, T a, T b, Param* post_prelu = nullptr, T* prelu_out = nullptr, bool plane_only = false);
+// pool2_add(conv2d(x, w) + bias, b, ...) with the pooling done in the convolution's epilogue where its kernel can (the
+// full-resolution convolution output is then never stored; conv.py:229-243); otherwise the two ops as usual
+T conv2d_pool2_add(Ctx& c, T x, WRef* w, Param* bias, int k, T b, Param* post_prelu = nullptr, T* prelu_out = nullptr,
+                   bool plane_only = false);
 T gmean(Ctx& c, T x, bool pre_relu);
 T resize(Ctx& c, T x, int size);
 T concat_w(Ctx& c, T a, T b);

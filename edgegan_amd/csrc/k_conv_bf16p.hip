@@ -403,6 +403,28 @@ __global__ __launch_bounds__(256, ((HR <= 288 && SW16) ? 3 : 2)) void conv_bf16p
 
   // D^T layout of the 32x32 accumulator: lane l holds pixel row l & 31 and, in registers 4q .. 4q+3, the four consecutive
   // output channels 8q + 4 (l >> 5) .. +3 of its 32-channel block: one 16-byte store per register quad
+  if constexpr (!SPLITK) {
+    if (a.pool_y) {   // pool2_add in the epilogue (kernels.h: ConvArgs::pool_y): the full-resolution output is never stored
+      const float plk = a.pool_leak ? *a.pool_leak : 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * WROWS + i * 32 + l31;
+        const int ti = r >> (g.lTW + g.lTH), py = (r >> g.lTW) & (TH - 1), px = r & (TW - 1);
+        const int nb = img0 + ti, oy = oy0 + py, ox = ox0 + px;
+        const bool owner = ((py | px) & 1) == 0;
+        const size_t prow = ((size_t)(nb * (a.OHf >> 1) + (oy >> 1)) * (a.OWf >> 1) + (ox >> 1)) * a.y_ps;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * 64 + j * 32 + q * 8 + lh * 4;
+            const float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            conv_epi_pool(a, v, TW, owner && n < N, prow + n, n, plk);
+          }
+      }
+      return;
+    }
+  }
   const float y2lk = (!SPLITK && a.y2_leak) ? *a.y2_leak : 0.f;   // second output: PReLU of the stored value (kernels.h: conv_epi_y2)
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -574,7 +596,19 @@ static void bf16p_launch_variant(const ConvArgs& a, const PlaneGeom& g, dim3 gri
   else bf16p_launch_ph<MI, WN, HR, 2>(a, g, grid, s);
 }
 
-const char* launch_conv_bf16p(const ConvArgs& a, hipStream_t s) {
+// the pooled epilogue (kernels.h: ConvArgs::pool_y): see conv_x3h_pool_ok -- every tile form here has TW >= 4, TH >= 2
+bool conv_bf16p_pool_ok(const ConvArgs& a) {
+  if (!a.pool_y || a.ksplit > 1 || a.nphase != 1 || a.os != 1 || a.S != 1 || a.accumulate || a.epi_act || a.y2_leak) return false;
+  if ((a.OHf | a.OWf) & 1 || a.ph[0].ophy || a.ph[0].ophx || a.N % 4 != 0 || a.y_ps % 4 != 0) return false;
+  if (((uintptr_t)a.pool_y | (uintptr_t)a.pool_b | (uintptr_t)a.pool_y2 | (uintptr_t)a.pool_y2_bf) & 15) return false;
+  PlaneGeom g;
+  if (!bf16p_geometry(a, a.N >= 128 ? 128 : 256, a.N >= 128 ? kHR128 : kHR256, &g)) return false;
+  return g.lTW >= 1 && g.lTW <= 4 && g.lTH >= 1;
+}
+
+const char* launch_conv_bf16p(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
+  if (!conv_bf16p_pool_ok(a)) a.pool_y = nullptr;   // (the caller sees CONV_CAP_POOL missing and runs pool2_add itself)
   PlaneGeom g;
   const int zs = a.ksplit > 1 ? a.ksplit : 1;
   // 256 pixels x 128 channels, waves 2 x 2 with 128 x 64 wave tiles (16 MFMAs per 12 fragment reads, half the filter DMA

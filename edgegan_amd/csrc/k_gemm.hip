@@ -532,6 +532,7 @@ double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name)
     if (conv_bf16p_eligible(a)) {   // bf16 mode, the operand's bf16 plane is there: staged by LDS-DMA (k_conv_bf16p.hip)
       nm = launch_conv_bf16p(a, s);
       if (a.ksplit <= 1) caps |= CONV_CAP_EPI_ACT | CONV_CAP_Y2;
+      if (conv_bf16p_pool_ok(a)) caps |= CONV_CAP_POOL;
     } else if (conv_x3_eligible(a)) {
       nm = launch_conv_gemm_x3(a, maxM, a.x3_tile ? a.x3_tile == 1 : e128 >= e64, s, &caps);
     }

@@ -695,6 +695,7 @@ const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipS
   static const int pipe = dbg_env("EG_X3_PIPE") ? atoi(dbg_env("EG_X3_PIPE")) : 2;
   if ((a.limbs == 1 || (big_tile && np == 6)) && conv_x3h_eligible(a)) {
     if (caps && a.ksplit <= 1) *caps |= CONV_CAP_EPI_ACT | CONV_CAP_Y2;   // the un-split halo kernel's epilogue (k_gemm_x3h.hip)
+    if (caps && conv_x3h_pool_ok(a)) *caps |= CONV_CAP_POOL;
     return launch_conv_gemm_x3h(a, s);
   }
   if (a.limbs == 1) {

@@ -511,6 +511,28 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
 
   // D^T layout of the 32x32 accumulator: lane l holds pixel row l & 31 and, in registers 4q .. 4q+3, the four consecutive
   // output channels 8q + 4 (l >> 5) .. +3 of its 32-channel block: one 16-byte store per register quad
+  if constexpr (!SPLITK) {
+    if (a.pool_y) {   // pool2_add in the epilogue (kernels.h: ConvArgs::pool_y): the full-resolution output is never stored
+      const float plk = a.pool_leak ? *a.pool_leak : 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * WROWS + i * 32 + l31;
+        const int ti = r >> (g.lTW + g.lTH), py = (r >> g.lTW) & (TH - 1), px = r & (TW - 1);
+        const int nb = img0 + ti, oy = oy0 + py, ox = ox0 + px;
+        const bool owner = ((py | px) & 1) == 0;
+        const size_t prow = ((size_t)(nb * (a.OHf >> 1) + (oy >> 1)) * (a.OWf >> 1) + (ox >> 1)) * a.y_ps;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * 64 + j * 32 + q * 8 + lh * 4;
+            const float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            conv_epi_pool(a, v, TW, owner && n < N, prow + n, n, plk);
+          }
+      }
+      return;
+    }
+  }
   const float y2lk = (!SPLITK && a.y2_leak) ? *a.y2_leak : 0.f;   // second output: PReLU of the stored value (kernels.h: conv_epi_y2)
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -597,6 +619,17 @@ static bool x3h_geometry(const ConvArgs& a_in, HaloGeom* g) {
   return true;
 }
 
+// The pooled epilogue needs the 2x2 partners of every output pixel inside one 32-row MFMA tile of the block: even tile extents
+// (TW >= 2 columns, TH >= 2 rows, 32 / TW rows per MFMA tile is then even), one phase, stride-1 output grid, a plain store
+bool conv_x3h_pool_ok(const ConvArgs& a) {
+  if (!a.pool_y || a.ksplit > 1 || a.nphase != 1 || a.os != 1 || a.S != 1 || a.accumulate || a.epi_act || a.y2_leak) return false;
+  if ((a.OHf | a.OWf) & 1 || a.ph[0].ophy || a.ph[0].ophx || a.N % 4 != 0 || a.y_ps % 4 != 0) return false;
+  if (((uintptr_t)a.pool_y | (uintptr_t)a.pool_b | (uintptr_t)a.pool_y2 | (uintptr_t)a.pool_y2_bf) & 15) return false;
+  HaloGeom g;
+  if (!x3h_geometry(a, &g)) return false;
+  return g.lTW >= 1 && g.lTW <= 4 && g.lTH >= 1;
+}
+
 bool conv_x3h_eligible(const ConvArgs& a) {
   static const bool off = dbg_env("EG_NO_HALO") != nullptr;
   if (off || !a.wgt_bf || !(a.limbs == 3 || a.limbs == 1) || a.shuf) return false;
@@ -642,7 +675,9 @@ static const char* x3h_launch(const ConvArgs& a, const HaloGeom& g, hipStream_t 
                    : (a.ksplit > 1 ? "conv_gemm_x3h<256,64,splitk>" : "conv_gemm_x3h<256,64>");
 }
 
-const char* launch_conv_gemm_x3h(const ConvArgs& a, hipStream_t s) {
+const char* launch_conv_gemm_x3h(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
+  if (!conv_x3h_pool_ok(a)) a.pool_y = nullptr;   // (the caller sees CONV_CAP_POOL missing and runs pool2_add itself)
   HaloGeom g;
   x3h_geometry(a, &g);
   static const bool dispatch_order = dbg_env("EG_NO_XCD_MAP") != nullptr;

@@ -83,10 +83,19 @@ struct ConvArgs {
   const float* y2_leak;
   float* y2;
   unsigned short* y2_bf;
+  // pool2_add in the epilogue (conv.py:239-243: ht_new = mean_pool(... + h_new); un-split stride-1 launches of the kernels that
+  // report CONV_CAP_POOL): INSTEAD of y the kernel stores  pool_y = mean of each 2x2 block of (y incl. bias) + pool_b  at the
+  // pooled resolution ([NB][OHf/2][OWf/2][y_ps]) and, with pool_leak, prelu(pool_y, *pool_leak) as pool_y2 / its bf16 plane.
+  // The 2x2 partners of an accumulator sit in the SAME register of lanes l ^ 1 and l ^ TW of the 32-row MFMA tile.
+  float* pool_y;
+  const float* pool_b;
+  const float* pool_leak;
+  float* pool_y2;
+  unsigned short* pool_y2_bf;
   int caps;          // OUT, set by launch_conv_gemm: what the kernel that ran honoured (CONV_CAP_*); ksplit is written back too
   int tuned;         // conv_pick_ksplit took (x3_tile, ksplit) from the measured per-shape table (x3_tuned.h): run_conv keeps them
 };
-enum ConvCaps { CONV_CAP_EPI_ACT = 1, CONV_CAP_Y2 = 2 };
+enum ConvCaps { CONV_CAP_EPI_ACT = 1, CONV_CAP_Y2 = 2, CONV_CAP_POOL = 4 };
 
 // A tensor that may still be the K-split slabs of the convolution that produced it (ConvArgs::keep_slabs): its value is
 // bias[c] + slab 0 + slab 1 + ... (+ base), conv_split_reduce's order, formed by the CONSUMER's load instead of a
@@ -169,6 +178,37 @@ __device__ __forceinline__ void conv_epi_y2(const ConvArgs& a, size_t off, const
     *reinterpret_cast<uint2*>(a.y2_bf + off) = o;
   }
 }
+// ConvArgs::pool_y: one accumulator quad of the pooled epilogue.  v = the quad of output pixel (py, px) of a tile TW wide; on
+// return the lanes with even (py, px) have stored  0.25 * (sum over the 2x2 block) + bias + pool_b  (and its PReLU) at element
+// offset `poff` of the pooled tensors.  Every lane of the wave must call it (cross-lane reads).
+__device__ __forceinline__ void conv_epi_pool(const ConvArgs& a, float4 v, int xr /* = TW */, bool owner, size_t poff, int n, float plk) {
+  v.x += __shfl_xor(v.x, 1, 64); v.y += __shfl_xor(v.y, 1, 64); v.z += __shfl_xor(v.z, 1, 64); v.w += __shfl_xor(v.w, 1, 64);
+  v.x += __shfl_xor(v.x, xr, 64); v.y += __shfl_xor(v.y, xr, 64); v.z += __shfl_xor(v.z, xr, 64); v.w += __shfl_xor(v.w, xr, 64);
+  if (!owner) return;
+  float4 r = make_float4(0.25f * v.x, 0.25f * v.y, 0.25f * v.z, 0.25f * v.w);
+  if (a.bias) {
+    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);
+    r.x += b4.x; r.y += b4.y; r.z += b4.z; r.w += b4.w;
+  }
+  if (a.pool_b) {
+    const float4 q = *reinterpret_cast<const float4*>(a.pool_b + poff);
+    r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+  }
+  *reinterpret_cast<float4*>(a.pool_y + poff) = r;
+  if (a.pool_leak) {
+    const float4 p = make_float4(fmaxf(plk * r.x, r.x), fmaxf(plk * r.y, r.y), fmaxf(plk * r.z, r.z), fmaxf(plk * r.w, r.w));
+    if (a.pool_y2) *reinterpret_cast<float4*>(a.pool_y2 + poff) = p;
+    if (a.pool_y2_bf) {
+      typedef __bf16 bf16x2_p __attribute__((ext_vector_type(2)));
+      typedef float f32x2_p __attribute__((ext_vector_type(2)));
+      const f32x2_p lo = {p.x, p.y}, hi = {p.z, p.w};
+      uint2 o;
+      o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_p));
+      o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_p));
+      *reinterpret_cast<uint2*>(a.pool_y2_bf + poff) = o;
+    }
+  }
+}
 #endif
 // k_elem.hip: a memory-free v_mfma_f32_32x32x16_bf16 loop, blocks x 8 waves x iters x 16 MFMAs (scratch >= blocks * 512 floats)
 void launch_mfma_probe(float* scratch, int blocks, int iters, int random_operands, hipStream_t s);
@@ -235,6 +275,8 @@ const char* launch_conv_bf16p(const ConvArgs& a, hipStream_t s);
 
 // halo-staged limb / bf16 kernel for stride-1 layers (k_gemm_x3h.hip)
 bool conv_x3h_eligible(const ConvArgs& a);
+bool conv_x3h_pool_ok(const ConvArgs& a);      // this launch can take ConvArgs::pool_y (the pooled epilogue)
+bool conv_bf16p_pool_ok(const ConvArgs& a);
 const char* launch_conv_gemm_x3h(const ConvArgs& a, hipStream_t s);
 
 // fp32-via-three-bf16-limbs kernels (k_gemm_x3.hip)

@@ -343,6 +343,7 @@ void api_enter(Ctx& c) {
   c.feeds_in = FEED_NONE;
   c.prelu_plane_only = false;
   c.conv_out_into = nullptr;
+  c.pool_epi = Ctx::PoolEpi();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -524,8 +525,7 @@ T classifier_forward(Ctx& c, T x) {
     T c1 = conv2d(c, hin, wref_sn(c, P(c, b + "/Conv_1/weights")), P(c, b + "/Conv_1/biases"), 3, 1, PAD_SAME, nullptr, 0,
                   P(c, b + "/Conv_1/prelu/param"));   // conv.py:217-220
     static const bool proj_full = dbg_env("EG_PROJ_FULL_RES") != nullptr;   // A/B: the reference's evaluation order
-    if (!proj_full) c.feeds_in = FEED_FLAT;   // (pool2_add below reads Conv_2's output quad by quad: K-split slabs stay un-summed)
-    T c2 = conv2d(c, c1, wref_sn(c, P(c, b + "/Conv_2/weights")), P(c, b + "/Conv_2/biases"), 3, 1, PAD_SAME);
+    T c2 = proj_full ? conv2d(c, c1, wref_sn(c, P(c, b + "/Conv_2/weights")), P(c, b + "/Conv_2/biases"), 3, 1, PAD_SAME) : nullptr;
     // conv.py:229-243: ht_new = mean_pool(conv1x1(ht) + h_new).  The projection is a per-pixel linear map (+ bias) and the
     // pool a per-channel mean over 2x2 pixels, so mean_pool(conv1x1(ht)) == conv1x1(mean_pool(ht)): the 1x1 convolution
     // (forward, input gradient, filter gradient) runs on a quarter of the pixels and its full-resolution output -- as
@@ -538,12 +538,15 @@ T classifier_forward(Ctx& c, T x) {
       // (measured and not kept: this projection and the image convolution above on the leaf stream beside the gate chain
       //  -- 1,530 -> 1,476 images/s, profiles/r03f_ab_forward_leaves_negative.txt: thin persistent kernels beside the
       //  one-block-per-CU matrix kernels of the same chain take CUs from them)
+      // (the projection comes FIRST: Conv_2's epilogue pools its own output and adds it, so that h_new at full resolution -- as
+      //  large as Conv_1's output -- is never stored where the kernel can do that; a K-split launch leaves slabs to pool2_add)
       T proj = conv2d(c, pool2(c, h), wref_sn(c, P(c, b + "/Conv_3/weights")), P(c, b + "/Conv_3/biases"), 1, 1, PAD_SAME);
       // the PReLU of the unit's output rides along: the next unit's prelu(h) (conv.py:185), the final one after unit 4 (:353-355)
       Param* next_leak = u < 4 ? P(c, "D2/mru_conv_unit_t_" + std::to_string(u + 1) + "_layer_0/norm_activation_in/prelu/param")
                                : P(c, "D2/mru_conv_unit_last_norm/prelu/param");
       // (bf16 mode: the next unit's prelu(h) is read by the gate's hidden-state convolution only; the LAST one feeds the global mean)
-      h = pool2_add(c, c2, proj, next_leak, &hp, c.cfg.bf16 && u < 4);
+      h = conv2d_pool2_add(c, c1, wref_sn(c, P(c, b + "/Conv_2/weights")), P(c, b + "/Conv_2/biases"), 3, proj, next_leak, &hp,
+                           c.cfg.bf16 && u < 4);
     }
     hidden = depth;
   }

@@ -934,7 +934,17 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     }
   }
   c.prelu_plane_only = false;
+  Ctx::PoolEpi& pe = c.pool_epi;
+  static const bool pool_epi_on = dbg_env("EG_NO_POOL_EPI") == nullptr;
+  if (pe.out && pool_epi_on && !accumulate_into && !fused_act && !post_prelu && stride == 1) {
+    a.pool_y = pe.out->d;
+    a.pool_b = pe.b->d;
+    a.pool_leak = pe.out2 ? pe.leak->w : nullptr;
+    a.pool_y2 = pe.out2 && !pe.out2->d_plane_only ? pe.out2->d : nullptr;
+    a.pool_y2_bf = pe.out2 ? pe.plane2 : nullptr;
+  }
   run_conv(c, a, x, false);
+  pe.done = a.pool_y && (a.caps & CONV_CAP_POOL);
   if (slabs_ok && a.ksplit > 1) {
     y->slabs = a.ws;
     y->nslab = a.ksplit;
@@ -1403,24 +1413,57 @@ T add_pool2(Ctx& c, T a, T b) {
   return out;
 }
 
+// the output tensors of pool2_add(a-shaped, b): the pooled sum and, with post_prelu in its float4 form, its PReLU (+ plane)
+static void pool2_add_outputs(Ctx& c, int an, int ah, int aw, int ac, bool needs_grad, T b, Param* post_prelu, bool plane_only,
+                              Ctx::PoolEpi* pe) {
+  EG_CHECK(ah % 2 == 0 && aw % 2 == 0, "pool2_add needs even extents");
+  EG_CHECK(an == b->n && ah == 2 * b->h && aw == 2 * b->w && ac == b->c, "pool2_add shapes");
+  pe->b = b;
+  pe->leak = post_prelu;
+  pe->out = new_tensor(c, b->n, b->h, b->w, b->c, needs_grad || b->needs_grad);
+  static const bool fuse2 = dbg_env("EG_NO_POOL_PRELU") == nullptr;
+  const bool vec = ac % 4 == 0 && (size_t)an * ah * aw * ac < (1ull << 31);
+  pe->out2 = (post_prelu && fuse2 && vec) ? new_tensor(c, b->n, b->h, b->w, b->c, false) : nullptr;
+  pe->plane2 = pe->out2 ? producer_plane(c, pe->out2, false) : nullptr;
+  static const bool plane_only_on = dbg_env("EG_NO_PLANE_ONLY") == nullptr;
+  if (pe->out2) pe->out2->d_plane_only = plane_only_on && plane_only && pe->plane2 != nullptr;
+  pe->done = false;
+}
+static T pool2_add_finish(Ctx& c, T a, T b, Param* post_prelu, T* prelu_out, const Ctx::PoolEpi& pe);
+
 T pool2_add(Ctx& c, T a, T b, Param* post_prelu, T* prelu_out, bool plane_only) {
-  EG_CHECK(a->h % 2 == 0 && a->w % 2 == 0, "pool2_add needs even extents");
-  EG_CHECK(a->n == b->n && a->h == 2 * b->h && a->w == 2 * b->w && a->c == b->c, "pool2_add shapes");
-  T out = new_tensor(c, b->n, b->h, b->w, b->c, a->needs_grad || b->needs_grad);
+  Ctx::PoolEpi pe;
+  pool2_add_outputs(c, a->n, a->h, a->w, a->c, a->needs_grad, b, post_prelu, plane_only, &pe);
+  return pool2_add_finish(c, a, b, post_prelu, prelu_out, pe);
+}
+
+T conv2d_pool2_add(Ctx& c, T x, WRef* w, Param* bias, int k, T b, Param* post_prelu, T* prelu_out, bool plane_only) {
+  // the convolution's output shape (SAME, stride 1) is x's with w->Cc channels
+  Ctx::PoolEpi pe;
+  const bool need = x->needs_grad || w->want_grad || (bias && bias->want_grad);
+  pool2_add_outputs(c, x->n, x->h, x->w, w->Cc, need, b, post_prelu, plane_only, &pe);
+  c.pool_epi = pe;
+  c.feeds_in = FEED_FLAT;   // (a K-split launch cannot pool: its slabs go to the pool2_add pass)
+  T y = conv2d(c, x, w, bias, k, 1, PAD_SAME);
+  pe = c.pool_epi;
+  c.pool_epi = Ctx::PoolEpi();
+  return pool2_add_finish(c, y, b, post_prelu, prelu_out, pe);
+}
+
+// forward pass (unless the producing convolution's epilogue already did it: pe.done) + the backward of out = pool2(a) + b
+static T pool2_add_finish(Ctx& c, T a, T b, Param* post_prelu, T* prelu_out, const Ctx::PoolEpi& pe) {
+  T out = pe.out, out2 = pe.out2;
   // one pass where the float4 form applies: `a` may still be K-split slabs (conv2d with FEED_FLAT) and the PReLU of the
   // result -- the next unit's prelu(h) -- is a second store
-  static const bool fuse2 = dbg_env("EG_NO_POOL_PRELU") == nullptr;
-  const bool vec = a->c % 4 == 0 && a->numel() < (1ull << 31);
-  T out2 = (post_prelu && fuse2 && vec) ? new_tensor(c, b->n, b->h, b->w, b->c, false) : nullptr;
-  const SlabSrc as = data_src(a);
-  EG_CHECK(as.n <= 1 || vec, "pool2_add: slab operand without the float4 form");
-  unsigned short* plane2 = out2 ? producer_plane(c, out2, false) : nullptr;
-  static const bool plane_only_on = dbg_env("EG_NO_PLANE_ONLY") == nullptr;
-  if (out2) out2->d_plane_only = plane_only_on && plane_only && plane2 != nullptr;
-  if (!launch_pool2_add_fwd(a->d, b->d, out->d, a->n, a->h, a->w, a->c, c.stream, as.n > 1 ? &as : nullptr,
-                            out2 ? post_prelu->w : nullptr, out2 && !out2->d_plane_only ? out2->d : nullptr, plane2)) {
-    launch_pool2_fwd(a->d, out->d, a->n, a->h, a->w, a->c, c.stream);
-    launch_axpy(b->d, out->d, 1.f, 1, out->numel(), c.stream);
+  if (!pe.done) {
+    const bool vec = a->c % 4 == 0 && a->numel() < (1ull << 31);
+    const SlabSrc as = data_src(a);
+    EG_CHECK(as.n <= 1 || vec, "pool2_add: slab operand without the float4 form");
+    if (!launch_pool2_add_fwd(a->d, b->d, out->d, a->n, a->h, a->w, a->c, c.stream, as.n > 1 ? &as : nullptr,
+                              out2 ? post_prelu->w : nullptr, out2 && !out2->d_plane_only ? out2->d : nullptr, pe.plane2)) {
+      launch_pool2_fwd(a->d, out->d, a->n, a->h, a->w, a->c, c.stream);
+      launch_axpy(b->d, out->d, 1.f, 1, out->numel(), c.stream);
+    }
   }
   a->nslab = 0;   // (consumed; its own backward needs only its gradient)
   if (out->needs_grad) {
