@@ -129,6 +129,7 @@ struct Tensor {
   bool g_inplace = false;   // the producer's backward rewrites g in place (conv + fused activation): g must not be shared
   int fused_act = 0;        // ... that activation (Act enum); g_act_done: its derivative was already applied to g by the
   bool g_act_done = false;  //     input-gradient kernel that wrote it (ConvArgs::epi_act)
+  size_t g_epi_wrap = 0;    //     ... with the activation output of element i - g_epi_wrap for elements i >= g_epi_wrap (ConvArgs::epi_wrap)
   // forward-only convolution outputs left as their K-split slabs for the InstanceNorm pass that is their only reader
   // (ops.cpp: conv2d / deconv2d with Ctx::feeds_in, in_act): d is then NOT written
   const float* slabs = nullptr;

@@ -376,7 +376,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3q_kernel(const ConvArgs a, cons
               v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
             if (a.epi_act) {   // dL/d(pre-activation) = dL/d(out) * act'(out), slopes as act_grad_from_out (k_norm.hip)
-              const float4 o = *reinterpret_cast<const float4*>(a.epi_ref + (yrow - a.y) + n);
+              size_t ei = (size_t)(yrow - a.y) + n;
+              if (a.epi_wrap && ei >= a.epi_wrap) ei -= a.epi_wrap;
+              const float4 o = *reinterpret_cast<const float4*>(a.epi_ref + ei);
               const float neg = a.epi_act == ACT_LRELU ? 0.2f : 0.f;
               if (a.epi_act == ACT_LRELU) {
                 v.x *= o.x >= 0.f ? 1.f : neg; v.y *= o.y >= 0.f ? 1.f : neg; v.z *= o.z >= 0.f ? 1.f : neg; v.w *= o.w >= 0.f ? 1.f : neg;

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_v(const float* __restrict_
                                                         const float* __restrict__ stats, const float* __restrict__ tx,
                                                         const float* __restrict__ dtout, float* __restrict__ dtx,
                                                         int acc_dtx, float* __restrict__ dx, int acc_dx, int HW, int C,
-                                                        int act) {
+                                                        int act, unsigned short* __restrict__ dtx_bf) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[3 * 4 * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -550,16 +550,114 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_v(const float* __restrict_
     if (acc_dtx) { const float4 a = ld4(dtx + i); o1.x += a.x; o1.y += a.y; o1.z += a.z; o1.w += a.w; }
     if (acc_dx) { const float4 a = ld4(dx + i); o2.x += a.x; o2.y += a.y; o2.z += a.z; o2.w += a.w; }
     st4(dtx + i, o1);
+    if (dtx_bf) st_bf4n(dtx_bf, i, o1);
     st4(dx + i, o2);
+  }
+}
+
+// the same with e = dtout * act'(out), (x - mean) and the tangent held in registers between the three passes (HW <= NP * 256 /
+// CQ): out / dtout / tx / x are read from memory once instead of 3 + 3 + 3 + 2 times; per-thread summation order as
+// in_tangent_bwd_v.  dtx_bf: optional bf16 plane of the tangent's gradient (bf16 mode).
+template <int NP, int CQ>
+__global__ __launch_bounds__(256) void in_tangent_bwd_vr(const float* __restrict__ x, const float* __restrict__ out,
+                                                         const float* __restrict__ stats, const float* __restrict__ tx,
+                                                         const float* __restrict__ dtout, float* __restrict__ dtx,
+                                                         int acc_dtx, float* __restrict__ dx, int acc_dx, int HW, int C,
+                                                         int act, unsigned short* __restrict__ dtx_bf) {
+  constexpr int PL = 256 / CQ;
+  __shared__ float4 red[3 * 4 * CQ];
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+  const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
+  const size_t base = (size_t)n * HW * C + c;
+  const Stat4 st = load_stats4(stats, (size_t)n * C + c);
+  float4 ev[NP], xc[NP], tv[NP];
+  float4 m[2] = {f4_zero(), f4_zero()};
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = pl + k * PL;
+    ev[k] = f4_zero();
+    xc[k] = f4_zero();
+    tv[k] = f4_zero();
+    if (p < HW) {
+      const size_t i = base + (size_t)p * C;
+      const float4 g = actg4(ld4(out + i), act), d = ld4(dtout + i), t = ld4(tx + i), xv = ld4(x + i);
+      ev[k] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+      xc[k] = make_float4(xv.x - st.mean.x, xv.y - st.mean.y, xv.z - st.mean.z, xv.w - st.mean.w);
+      tv[k] = t;
+      m[0].x += ev[k].x; m[0].y += ev[k].y; m[0].z += ev[k].z; m[0].w += ev[k].w;
+      m[1].x += t.x; m[1].y += t.y; m[1].z += t.z; m[1].w += t.w;
+    }
+  }
+  cq_reduce<2, CQ>(m, red);
+  const float hw = (float)HW;
+  const float4 eb = make_float4(m[0].x / hw, m[0].y / hw, m[0].z / hw, m[0].w / hw);
+  const float4 ta = make_float4(m[1].x / hw, m[1].y / hw, m[1].z / hw, m[1].w / hw);
+  float4 s[3] = {f4_zero(), f4_zero(), f4_zero()};  // sum (e-eb)(t-ta), sum xc*t, sum e*xc
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    if (pl + k * PL < HW) {
+      const float4 e = ev[k], t = tv[k], q = xc[k];
+      s[0].x += (e.x - eb.x) * (t.x - ta.x); s[0].y += (e.y - eb.y) * (t.y - ta.y);
+      s[0].z += (e.z - eb.z) * (t.z - ta.z); s[0].w += (e.w - eb.w) * (t.w - ta.w);
+      s[1].x += q.x * t.x; s[1].y += q.y * t.y; s[1].z += q.z * t.z; s[1].w += q.w * t.w;
+      s[2].x += e.x * q.x; s[2].y += e.y * q.y; s[2].z += e.z * q.z; s[2].w += e.w * q.w;
+    }
+  }
+  cq_reduce<3, CQ>(s, red);
+  float c1[4], c2[4], c3[4], k2[4];
+  {
+    const float A_[4] = {s[0].x, s[0].y, s[0].z, s[0].w}, Sxt[4] = {s[1].x, s[1].y, s[1].z, s[1].w},
+                Sex[4] = {s[2].x, s[2].y, s[2].z, s[2].w}, sg[4] = {st.sigma.x, st.sigma.y, st.sigma.z, st.sigma.w},
+                rr[4] = {st.r.x, st.r.y, st.r.z, st.r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float B = Sxt[j] * Sex[j] / hw, r2 = rr[j] * rr[j];
+      c1[j] = (-A_[j] * r2 + 2.f * r2 * rr[j] * B / sg[j] + r2 * B / (sg[j] * sg[j])) / (hw * sg[j]);
+      c2[j] = -r2 * Sex[j] / (hw * sg[j]);
+      c3[j] = -r2 * Sxt[j] / (hw * sg[j]);
+      k2[j] = r2 * Sex[j] / (hw * sg[j]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = pl + k * PL;
+    if (p < HW) {
+      const size_t i = base + (size_t)p * C;
+      const float e[4] = {ev[k].x, ev[k].y, ev[k].z, ev[k].w}, q[4] = {xc[k].x, xc[k].y, xc[k].z, xc[k].w},
+                  tt[4] = {tv[k].x, tv[k].y, tv[k].z, tv[k].w}, ebv[4] = {eb.x, eb.y, eb.z, eb.w},
+                  tav[4] = {ta.x, ta.y, ta.z, ta.w}, rr[4] = {st.r.x, st.r.y, st.r.z, st.r.w};
+      float gt[4], gx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gt[j] = rr[j] * (e[j] - ebv[j]) - k2[j] * q[j];
+        gx[j] = c1[j] * q[j] + c2[j] * (tt[j] - tav[j]) + c3[j] * (e[j] - ebv[j]);
+      }
+      float4 o1 = make_float4(gt[0], gt[1], gt[2], gt[3]), o2 = make_float4(gx[0], gx[1], gx[2], gx[3]);
+      if (acc_dtx) { const float4 a = ld4(dtx + i); o1.x += a.x; o1.y += a.y; o1.z += a.z; o1.w += a.w; }
+      if (acc_dx) { const float4 a = ld4(dx + i); o2.x += a.x; o2.y += a.y; o2.z += a.z; o2.w += a.w; }
+      st4(dtx + i, o1);
+      if (dtx_bf) st_bf4n(dtx_bf, i, o1);
+      st4(dx + i, o2);
+    }
   }
 }
 
 void launch_in_tangent_bwd(const float* x, const float* out, const float* stats, const float* tx,
                            const float* dtout, float* dtx, int acc_dtx, float* dx, int acc_dx, int NB, int HW,
-                           int C, int act, hipStream_t s) {
+                           int C, int act, hipStream_t s, unsigned short* dtx_bf) {
+  EG_CHECK(!dtx_bf || C % 32 == 0, "in_tangent_bwd: a bf16 plane was requested with C %% 32 != 0");
   if (C % 32 == 0) {
-    hipLaunchKernelGGL(in_tangent_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, out, stats, tx, dtout, dtx, acc_dtx,
-                       dx, acc_dx, HW, C, act);
+    const dim3 grid(NB, C / 32);
+#define EG_IN_TBWD(NP, CQ, G) hipLaunchKernelGGL((in_tangent_bwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, tx, dtout, dtx, acc_dtx, dx, acc_dx, HW, C, act, dtx_bf)
+    if (HW <= 64) EG_IN_TBWD(2, 8, grid);
+    else if (HW <= 128) EG_IN_TBWD(4, 8, grid);
+    else if (HW <= 256) EG_IN_TBWD(8, 8, grid);
+    else if (HW <= 512) EG_IN_TBWD(16, 8, grid);
+    else if (HW <= 1024) EG_IN_TBWD(16, 4, dim3(NB, C / 16));
+    else
+      hipLaunchKernelGGL(in_tangent_bwd_v<8>, grid, dim3(256), 0, s, x, out, stats, tx, dtout, dtx, acc_dtx, dx, acc_dx, HW, C,
+                         act, dtx_bf);
+#undef EG_IN_TBWD
     return;
   }
   hipLaunchKernelGGL(in_tangent_bwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, out, stats, tx, dtout, dtx,

@@ -72,6 +72,8 @@ struct ConvArgs {
   const float* epi_ref;
   int epi_act;
   int epi_applied;
+  unsigned long long epi_wrap;   // > 0: output elements at or beyond this index take epi_ref[index - epi_wrap] (the stacked
+                                 // discriminator sub-step: the tangent rows are masked by the primal rows' activation)
   int x3q;           // experiments build: run_conv chose the two-blocks-per-CU halo kernel (k_gemm_x3q.hip) and ITS K split for this launch
   unsigned short* y_bf;   // bf16 mode, conv_pk only: also store the (activated) output's bf16 plane [pixel][y_ps] -- the next
                           // convolution reads it by LDS-DMA and no conversion pass runs (d_conv_0 + LeakyReLU -> d_conv_1)
@@ -342,7 +344,7 @@ void launch_in_tangent_fwd(const float* x, const float* out, const float* stats,
 // tangent backward: given dtout, produce dtx (+)= ..., dx_primal (+)= ...
 void launch_in_tangent_bwd(const float* x, const float* out, const float* stats, const float* tx,
                            const float* dtout, float* dtx, int acc_dtx, float* dx, int acc_dx, int NB, int HW,
-                           int C, int act, hipStream_t s);
+                           int C, int act, hipStream_t s, unsigned short* dtx_bf = nullptr);
 // plain activation (no norm): fwd, bwd (dx (+)= dout*act'(out)), tangent (tout = act'(out)*tx)
 void launch_act_fwd(const float* x, float* out, size_t n, int act, hipStream_t s);
 void launch_act_bwd(const float* out, const float* dout, float* dx, int accumulate, size_t n, int act,

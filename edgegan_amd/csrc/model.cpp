@@ -691,6 +691,7 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
   // stacked activations: X = the four inputs, pre[i] / out[i] = layer i before / after its norm + activation
   T X = new_tensor(c, R, H, W, C0, false);
   T pre[4], out[4], st[4];
+  unsigned short* gpl[4];
   int hh = H, ww = W;
   const bool planes = cfg.bf16;
   for (int i = 0; i < 4; ++i) {
@@ -705,6 +706,10 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
     }
     pre[i]->g = c.arena.allocf(pre[i]->numel());
     if (i > 0) out[i]->g = c.arena.allocf(out[i]->numel());
+    // bf16 mode: the gradient planes both gradient convolutions of layer i read, stored by the norm backward kernels
+    gpl[i] = nullptr;
+    if (planes && i > 0 && ch[i + 1] % 32 == 0 && pre[i]->numel() * 2 < (1ull << 31))
+      gpl[i] = reinterpret_cast<unsigned short*>(c.arena.allocf((pre[i]->numel() + 1) / 2));
   }
   const size_t per = (size_t)H * W * C0;
   auto rows = [&](T t, int n0, int n) { return view_rows(c, t, n0, n); };
@@ -760,7 +765,9 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
     const int HW = pre[i]->h * pre[i]->w, C = ch[i + 1];
     const size_t img = (size_t)HW * C, o = (size_t)n0 * img;
     launch_in_bwd(pre[i]->d + o, out[i]->d + o, out[i]->g + o, st[i]->d + (size_t)n0 * 2 * C, pre[i]->g + o, acc, n, HW, C, ACT_LRELU,
-                  c.stream);
+                  c.stream, gpl[i] ? gpl[i] + o : nullptr);
+    pre[i]->g_bf = gpl[i];            // (rows [n0, n0 + n) of the plane are current; view_rows hands them on)
+    pre[i]->g_bf_stream = nullptr;
   };
   // ---- phase 1: x_hat, and the first-order gradient g = d/dx_hat sum_b [sigmoid(D) + D] (quirk N10) ----
   forward(0, B);
@@ -769,14 +776,20 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
     T o3 = rows(out[3], 0, B);
     launch_gemv_bwd_x(dgrad, lw->w, o3->g, 0, B, K, c.stream);
     o3->g_set = true;
+    bool act0_done = false;
     for (int i = 3; i >= 1; --i) {
       norm_bwd(i, 0, B, 0);
       T yv = rows(pre[i], 0, B), xv = rows(out[i - 1], 0, B);
       yv->g_set = true;
+      if (i == 1) {   // layer 0's LeakyReLU backward rides in this launch's epilogue where the kernel that runs has one
+        xv->fused_act = ACT_LRELU;
+        xv->g_inplace = true;
+      }
       conv_backward_x(c, xv, yv, w[i], 4, 2);
+      if (i == 1) act0_done = xv->g_act_done;
     }
     T y0 = rows(pre[0], 0, B), x0 = rows(X, 0, B);
-    launch_act_bwd(y0->d, y0->g, y0->g, 0, y0->numel(), ACT_LRELU, c.stream);   // in place: g *= act'(out)
+    if (!act0_done) launch_act_bwd(y0->d, y0->g, y0->g, 0, y0->numel(), ACT_LRELU, c.stream);   // in place: g *= act'(out)
     y0->g_set = true;
     x0->needs_grad = true;
     conv_backward_x(c, x0, y0, w[0], 4, 2);
@@ -798,19 +811,25 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
     norm_bwd(i, B, 2 * B, 0);                                  // real | fake
     // the tangent rows: reverse of the linearisation -- gradient w.r.t. the tangent AND w.r.t. the primal pre-norm rows [0,B)
     launch_in_tangent_bwd(pre[i]->d, out[i]->d, st[i]->d, pre[i]->d + ot, out[i]->g + ot, pre[i]->g + ot, 0, pre[i]->g, 0, B, HW, C,
-                          ACT_LRELU, c.stream);
+                          ACT_LRELU, c.stream, gpl[i] ? gpl[i] + ot : nullptr);
     norm_bwd(i, 0, B, 1);                                      // the primal rows add their own first-order term
     pre[i]->g_set = true;
-    pre[i]->g_bf = nullptr;
     conv_backward_w(c, out[i - 1], pre[i], w[i], 4, 2);
     out[i - 1]->needs_grad = true;
     out[i - 1]->g_set = false;
+    if (i == 1) {   // layer 0's LeakyReLU backward in the epilogue: rows below 3B by their own output, the tangent rows by the primal's
+      out[0]->fused_act = ACT_LRELU;
+      out[0]->g_inplace = true;
+      out[0]->g_epi_wrap = (size_t)3 * B * (pre[0]->numel() / R);
+    }
     conv_backward_x(c, out[i - 1], pre[i], w[i], 4, 2);
   }
-  {   // layer 0: LeakyReLU backward on the evaluated rows, its linearisation's reverse on the tangent rows (mask of the primal)
+  if (!out[0]->g_act_done) {   // layer 0: LeakyReLU backward on the evaluated rows, its linearisation's reverse on the tangent rows (mask of the primal)
     const size_t img = pre[0]->numel() / R;
     launch_act_bwd(pre[0]->d, pre[0]->g, pre[0]->g, 0, (size_t)3 * B * img, ACT_LRELU, c.stream);
     launch_act_bwd(pre[0]->d, pre[0]->g + (size_t)3 * B * img, pre[0]->g + (size_t)3 * B * img, 0, (size_t)B * img, ACT_LRELU, c.stream);
+  }
+  {
     pre[0]->g_set = true;
     pre[0]->g_bf = nullptr;
     conv_backward_w(c, X, pre[0], w[0], 4, 2);

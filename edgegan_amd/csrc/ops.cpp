@@ -491,6 +491,7 @@ static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
     slot = reinterpret_cast<unsigned short*>(c.arena.allocf((n + 1) / 2));
     if (transposed) launch_tap_transpose_bf16(w->w, slot, w->T, w->R, w->Cc, c.stream);
     else launch_cvt_bf16(w->w, slot, n, c.stream);
+    if (dbg_env("EG_TRACE_CVT")) fprintf(stderr, "[cvt] weight n=%zu transposed=%d lane=%d\n", n, (int)transposed, c.cur_lane);
   }
   a.wgt_bf = slot;
   a.wbf_ts = (long long)a.C * a.N;
@@ -509,6 +510,9 @@ static const unsigned short* tensor_plane(Ctx& c, T t, bool grad) {
   if (p && (ps == nullptr || ps == c.stream || (c.stream == l.leaf && ps == l.stream))) return p;
   unsigned short* q = reinterpret_cast<unsigned short*>(c.arena.allocf((t->numel() + 1) / 2));
   launch_cvt_bf16(grad ? t->g : t->d, q, t->numel(), c.stream);
+  if (dbg_env("EG_TRACE_CVT"))
+    fprintf(stderr, "[cvt] tensor %s n=%d h=%d w=%d c=%d lane=%d leaf=%d had_plane=%d\n", grad ? "grad" : "data", t->n, t->h, t->w, t->c,
+            c.cur_lane, (int)(c.stream == l.leaf), (int)(p != nullptr));
   if (!p) {
     p = q;
     ps = c.stream;
@@ -717,6 +721,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
       // gradient, so the activation's backward rides in the epilogue (if the un-split halo kernel runs the layer)
       a.epi_ref = x->d;
       a.epi_act = x->fused_act;
+      a.epi_wrap = x->g_epi_wrap;
     }
     keep_ok = !acc;
     a.OHf = x->h;
@@ -1017,6 +1022,10 @@ T view_rows(Ctx& c, T parent, int n0, int n) {
     v->d_bf = parent->d_bf + off;
     v->d_bf_stream = parent->d_bf_stream;
   }
+  if (parent->g_bf) {
+    v->g_bf = parent->g_bf + off;
+    v->g_bf_stream = parent->g_bf_stream;
+  }
   return v;
 }
 
@@ -1034,7 +1043,8 @@ void conv_backward_w(Ctx& c, T x, T y, WRef* w, int k, int stride) {
   int OH, OW, pt, pl;
   same_pad(x->h, k, stride, &OH, &pt);
   same_pad(x->w, k, stride, &OW, &pl);
-  if (c.cfg.bf16 && k > 1 && y->c % 64 == 0) (void)tensor_plane(c, y, true);   // (made on the main stream: both gradients read it)
+  // (a plane made on the main stream is read by both gradients; a thin filter gradient -- 3 / 6 input channels -- reads fp32)
+  if (c.cfg.bf16 && k > 1 && y->c % 64 == 0 && x->c % 32 == 0) (void)tensor_plane(c, y, true);
   LeafScope leaf(c);
   conv_wgrad(c, x, false, x->n, x->h, x->w, x->c, y, true, OH, OW, y->c, w, k, stride, pt, 0);
 }

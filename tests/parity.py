@@ -194,6 +194,12 @@ def check_in_act(net, act, shape=(3, 8, 16, 128), seed=2):
             (f'in_act[{ACTS[act]} {shape}] dx', relerr(dx, gx.numpy()), BWD_TOL)]
 
 
+# every register-resident form of the tangent kernels (k_norm.hip: in_tangent_bwd_vr / in_bwd_vr<.., 1> -- H*W <= 64 / 128 / 256 /
+# 512 / 1024, ragged pixel counts) and the multi-pass forms behind them (H*W > 1024); 32- and 64-channel blocks
+TANGENT_SHAPES = [(2, 6, 7, 32), (1, 8, 16, 64), (2, 10, 10, 32), (1, 16, 16, 32), (1, 12, 25, 64), (1, 16, 32, 32), (1, 25, 28, 32),
+                  (1, 32, 32, 32), (1, 33, 32, 32)]
+
+
 def check_in_tangent(net, act=2, shape=(2, 8, 8, 64), seed=3):
     """Forward-mode tangent of IN+act and its reverse (used by the WGAN-GP second-order path)."""
     rng = np.random.RandomState(seed)
@@ -205,10 +211,10 @@ def check_in_tangent(net, act=2, shape=(2, 8, 8, 64), seed=3):
     yr, tyr = torch.autograd.functional.jvp(f, (xt,), (txt,), create_graph=True)
     gx, gtx = torch.autograd.grad((tyr * t64(dty)).sum(), [xt, txt])
     y, ty, dtx, dx = net.test_op('in_tangent', [x, tx, dty], list(shape) + [act], [shape] * 4)
-    return [(f'in_tangent[{ACTS[act]}] y', relerr(y, yr.detach().numpy()), FWD_TOL),
-            (f'in_tangent[{ACTS[act]}] ty', relerr(ty, tyr.detach().numpy()), FWD_TOL),
-            (f'in_tangent[{ACTS[act]}] dtx', relerr(dtx, gtx.numpy()), BWD_TOL),
-            (f'in_tangent[{ACTS[act]}] dx_primal', relerr(dx, gx.numpy()), BWD_TOL)]
+    return [(f'in_tangent[{ACTS[act]} {shape}] y', relerr(y, yr.detach().numpy()), FWD_TOL),
+            (f'in_tangent[{ACTS[act]} {shape}] ty', relerr(ty, tyr.detach().numpy()), FWD_TOL),
+            (f'in_tangent[{ACTS[act]} {shape}] dtx', relerr(dtx, gtx.numpy()), BWD_TOL),
+            (f'in_tangent[{ACTS[act]} {shape}] dx_primal', relerr(dx, gx.numpy()), BWD_TOL)]
 
 
 def check_simple(net, op, shape, extra, ref_fn, seed=4, positive=False):
@@ -337,6 +343,8 @@ def all_op_checks(net):
     rows += check_in_act(net, 2, shape=(2, 4, 8, 512))
     rows += check_in_tangent(net, 2)
     rows += check_in_tangent(net, 2, shape=(2, 4, 8, 128), seed=33)
+    for i, shape in enumerate(TANGENT_SHAPES):
+        rows += check_in_tangent(net, 2, shape=shape, seed=40 + i)
     rows += check_simple(net, 'act', (2, 4, 4, 32), 3, lambda t: torch.tanh(t))
     rows += check_simple(net, 'act', (2, 4, 4, 32), 2, lambda t: O.activation(t, 'lrelu'))
     rows += check_simple(net, 'resize', (2, 64, 64, 3), 128, lambda t: O.resize_bicubic(t, 128))

@@ -45,6 +45,8 @@ def test_instance_norm_act(net, act):
 def test_instance_norm_tangent_and_its_reverse(net):
     _assert(parity.check_in_tangent(net, 2))
     _assert(parity.check_in_tangent(net, 2, shape=(2, 4, 8, 128), seed=33))
+    for i, shape in enumerate(parity.TANGENT_SHAPES):
+        _assert(parity.check_in_tangent(net, 2, shape=shape, seed=40 + i))
 
 
 def test_remaining_ops(net):
