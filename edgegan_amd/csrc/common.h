@@ -129,6 +129,11 @@ struct Tensor {
   bool g_inplace = false;   // the producer's backward rewrites g in place (conv + fused activation): g must not be shared
   int fused_act = 0;        // ... that activation (Act enum); g_act_done: its derivative was already applied to g by the
   bool g_act_done = false;  //     input-gradient kernel that wrote it (ConvArgs::epi_act)
+  // The gradient of a tensor whose only reader is a 2x2 average pool (pool2_add behind a convolution: g_up_ok) is 0.25 x the 2x
+  // nearest-neighbour upsampling of the pooled tensor's gradient: g_up = that tensor, g itself is NOT written -- the convolution's
+  // two gradient kernels read the small tensor (ConvArgs::x_up, WgradArgs::dy_up; ops.cpp: materialize_up where they cannot)
+  bool g_up_ok = false;
+  Tensor* g_up = nullptr;
   size_t g_epi_wrap = 0;    //     ... with the activation output of element i - g_epi_wrap for elements i >= g_epi_wrap (ConvArgs::epi_wrap)
   // forward-only convolution outputs left as their K-split slabs for the InstanceNorm pass that is their only reader
   // (ops.cpp: conv2d / deconv2d with Ctx::feeds_in, in_act): d is then NOT written

@@ -143,7 +143,10 @@ __global__ __launch_bounds__(256, ((HR <= 288 && SW16) ? 3 : 2)) void conv_bf16p
         }
         if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) {
           const int sw = sw16 ? (hx >> 2) & 3 : swz_p(row);
-          off = (unsigned)(((((img0 + ti) * IH + iy) * IW + ix) * a.xbf_ps + (((lane & 3) ^ sw) * 8)) * 2);
+          if (a.x_up)   // (the source is the half-resolution plane: four output-side pixels read one of its pixels)
+            off = (unsigned)(((((img0 + ti) * (IH >> 1) + (iy >> 1)) * (IW >> 1) + (ix >> 1)) * a.xbf_ps + (((lane & 3) ^ sw) * 8)) * 2);
+          else
+            off = (unsigned)(((((img0 + ti) * IH + iy) * IW + ix) * a.xbf_ps + (((lane & 3) ^ sw) * 8)) * 2);
         }
       }
     }
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(256, ((HR <= 288 && SW16) ? 3 : 2)) void conv_bf16p
         const int n = n0 + wn * 64 + j * 32 + q * 8 + lh * 4;
         if (n < N) {
           float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          if (a.x_up) { v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f; }   // (exact: the pool's 1/4 applied to the sum)
           if constexpr (!SPLITK) {
             if (a.bias) {
               const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);

@@ -473,6 +473,46 @@ static const char* conv_dispatch(const ConvArgs& a, int maxM, bool avec, bool bv
   return nf;
 }
 
+// the tile choice of the 17+-output-channel kernels: by CU load balance -- the MFMA pipe is the bottleneck, so what matters is
+// how evenly the tiles divide over the 256 CUs (measured: 4 vs 3 resident blocks per CU changes nothing), times the per-tile
+// efficiency of each configuration (64x64 runs at ~0.8 of the 128x128 tile's rate)
+static bool conv_big_tile(const ConvArgs& a, int maxM) {
+  const long long blocks128 = (long long)((maxM + 127) / 128) * ((a.N + 127) / 128) * a.nphase;
+  const int ksp = a.ksplit > 1 ? a.ksplit : 1;
+  const long long t128 = blocks128 * ksp;
+  const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase * ksp;
+  auto balance = [](long long tiles) {
+    const long long per_cu = (tiles + 255) / 256;
+    return (double)tiles / (double)(per_cu * 256);
+  };
+  const double e128 = a.N >= 128 ? 0.95 * balance(t128) : 0.0;
+  const double e64 = 0.80 * balance(t64);
+  return e128 >= e64;
+}
+static int conv_max_m(const ConvArgs& a) {
+  int maxM = 0;
+  for (int p = 0; p < a.nphase; ++p) maxM = std::max(maxM, a.NB * a.ph[p].OHp * a.ph[p].OWp);
+  return maxM;
+}
+// only the fully vectorised kernels have a split-K form
+static void conv_fix_ksplit(ConvArgs& a) {
+  const bool avec = (a.C % 16 == 0) && (a.x_ps % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
+  const bool bvec = (a.N % 4 == 0) && (a.ldw % 4 == 0) && (a.w_ts % 4 == 0) && (((uintptr_t)a.wgt & 15) == 0);
+  if (!(avec && bvec) || a.N <= 16 || !a.ws || a.y_ps % 4 != 0 || (((uintptr_t)a.y | (uintptr_t)a.bias) & 15) != 0 ||
+      a.y_total / 4 >= (1ull << 32))
+    a.ksplit = 1;
+}
+// ConvArgs::x_up is honoured by the plane-fed kernel and the halo kernel (their stride-1 forms): would launch_conv_gemm run one
+// of them for these arguments?  (the same tests in the same order as the dispatch below)
+bool conv_up_kernel(const ConvArgs& a_in) {
+  ConvArgs a = a_in;
+  conv_fix_ksplit(a);
+  if (a.S != 1 || a.nphase != 1 || a.x3q || (a.IH & 1) || (a.IW & 1)) return false;
+  if (conv_pk_eligible(a) || conv_scatter_eligible(a) || conv_smallc_eligible(a) || a.N <= 16) return false;
+  if (conv_bf16p_eligible(a)) return true;
+  return conv_x3_eligible(a) && conv_x3_takes_halo(a, a.x3_tile ? a.x3_tile == 1 : conv_big_tile(a, conv_max_m(a)));
+}
+
 double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name) {
   ConvArgs a = a_in;
   int caps = 0;   // what the kernel that runs honours of the optional epilogue work (ConvArgs::epi_act, ::y2): set where it is chosen
@@ -483,12 +523,10 @@ double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name)
     if (M > maxM) maxM = M;
     flops += 2.0 * M * a.N * (double)(a.ph[p].Ty * a.ph[p].Tx) * a.C;
   }
+  EG_CHECK(!a.x_up || conv_up_kernel(a), "conv launch: x_up with a kernel that does not read the half-resolution operand (N=%d C=%d)", a.N, a.C);
   const bool avec = (a.C % 16 == 0) && (a.x_ps % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
   const bool bvec = (a.N % 4 == 0) && (a.ldw % 4 == 0) && (a.w_ts % 4 == 0) && (((uintptr_t)a.wgt & 15) == 0);
-  if (!(avec && bvec) || a.N <= 16 || !a.ws || a.y_ps % 4 != 0 || (((uintptr_t)a.y | (uintptr_t)a.bias) & 15) != 0 ||
-      a.y_total / 4 >= (1ull << 32))
-    a.ksplit = 1;   // only the fully vectorised kernels have a split-K form
-  const long long blocks128 = (long long)((maxM + 127) / 128) * ((a.N + 127) / 128) * a.nphase;
+  conv_fix_ksplit(a);
   const char* nm;
   EG_CHECK(a.wgt || (a.N > 16 && (conv_bf16p_eligible(a) || conv_x3_eligible(a) || conv_bf16_eligible(a))),
            "conv launch without an fp32 filter that no limb / bf16 kernel accepts (N=%d C=%d)", a.N, a.C);
@@ -517,28 +555,17 @@ double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name)
       nm = conv_dispatch<64, 16, 16, 16>(a, maxM, avec, bvec, s, "conv_gemm<64,16,vec>", "conv_gemm<64,16,avec>",
                                          "conv_gemm<64,16,flat>");
   } else {
-    // pick the tile by CU load balance: the MFMA pipe is the bottleneck, so what matters is how evenly the
-    // tiles divide over the 256 CUs (measured: 4 vs 3 resident blocks per CU changes nothing), times the
-    // per-tile efficiency of each configuration (64x64 runs at ~0.8 of the 128x128 tile's rate)
-    const int ksp = a.ksplit > 1 ? a.ksplit : 1;
-    const long long t128 = blocks128 * ksp;
-    const long long t64 = (long long)((maxM + 63) / 64) * ((a.N + 63) / 64) * a.nphase * ksp;
-    auto balance = [](long long tiles) {
-      const long long per_cu = (tiles + 255) / 256;
-      return (double)tiles / (double)(per_cu * 256);
-    };
-    const double e128 = a.N >= 128 ? 0.95 * balance(t128) : 0.0;
-    const double e64 = 0.80 * balance(t64);
+    const bool big = conv_big_tile(a, maxM);   // (tile by CU load balance, above)
     if (conv_bf16p_eligible(a)) {   // bf16 mode, the operand's bf16 plane is there: staged by LDS-DMA (k_conv_bf16p.hip)
       nm = launch_conv_bf16p(a, s);
       if (a.ksplit <= 1) caps |= CONV_CAP_EPI_ACT | CONV_CAP_Y2;
       if (conv_bf16p_pool_ok(a)) caps |= CONV_CAP_POOL;
     } else if (conv_x3_eligible(a)) {
-      nm = launch_conv_gemm_x3(a, maxM, a.x3_tile ? a.x3_tile == 1 : e128 >= e64, s, &caps);
+      nm = launch_conv_gemm_x3(a, maxM, a.x3_tile ? a.x3_tile == 1 : big, s, &caps);
     }
     else if (conv_bf16_eligible(a))
-      nm = launch_conv_gemm_bf16(a, maxM, e128 >= e64, s);
-    else if (e128 >= e64)
+      nm = launch_conv_gemm_bf16(a, maxM, big, s);
+    else if (big)
       nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s,
                                            a.ksplit > 1 ? "conv_gemm<128,128,vec,splitk>" : "conv_gemm<128,128,vec>",
                                            "conv_gemm<128,128,avec>", "conv_gemm<128,128,flat>");
@@ -1115,10 +1142,19 @@ static void wgrad_launch(const WgradArgs& a, float* out, int dense, hipStream_t 
     hipLaunchKernelGGL((wgrad_kernel<BM, BN, WTM, WTN, 16, false>), grid, dim3(256), 0, s, a, out, dense);
 }
 
+// WgradArgs::dy_up is honoured by the plane-fed kernel and the row-halo limb kernel: would launch_wgrad run one of them?
+bool wgrad_up_kernel(const WgradArgs& a) {
+  const float* out = a.nsplit == 1 ? a.dw : a.ws;
+  if ((((uintptr_t)out) & 15) != 0 || (a.OH & 1) || (a.OW & 1)) return false;
+  if (wgrad_bf16p_units(a)) return true;
+  return wgrad_x3(a) && wgrad_x3_rowhalo_units(a) > 0;
+}
+
 double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name) {
   const bool direct = (a.nsplit == 1);
   float* out = direct ? a.dw : a.ws;
   const int dense = direct ? 0 : 1;
+  EG_CHECK(!a.dy_up || wgrad_up_kernel(a), "wgrad launch: dy_up with a kernel that does not read the half-resolution operand (N=%d C=%d)", a.N, a.C);
   const bool vec = (a.C % 4 == 0) && (a.N % 4 == 0) && (a.x_ps % 4 == 0) && (a.dy_ps % 4 == 0) &&
                    (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0) && (a.ldw % 4 == 0) &&
                    (a.w_ts % 4 == 0) && (((uintptr_t)out & 15) == 0);

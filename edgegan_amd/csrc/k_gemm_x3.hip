@@ -690,10 +690,15 @@ static void conv_x3_launch(const ConvArgs& a, int maxM, hipStream_t s) {
   }
 }
 
+// does launch_conv_gemm_x3 hand the launch to the halo kernel (k_gemm_x3h.hip)?
+bool conv_x3_takes_halo(const ConvArgs& a, bool big_tile) {
+  return (a.limbs == 1 || (big_tile && x3_nprod() == 6)) && conv_x3h_eligible(a);
+}
+
 const char* launch_conv_gemm_x3(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s, int* caps) {
   const int np = x3_nprod();
   static const int pipe = dbg_env("EG_X3_PIPE") ? atoi(dbg_env("EG_X3_PIPE")) : 2;
-  if ((a.limbs == 1 || (big_tile && np == 6)) && conv_x3h_eligible(a)) {
+  if (conv_x3_takes_halo(a, big_tile)) {
     if (caps && a.ksplit <= 1) *caps |= CONV_CAP_EPI_ACT | CONV_CAP_Y2;   // the un-split halo kernel's epilogue (k_gemm_x3h.hip)
     if (caps && conv_x3h_pool_ok(a)) *caps |= CONV_CAP_POOL;
     return launch_conv_gemm_x3h(a, s);
@@ -1434,6 +1439,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
     const int m = p_lo + t * BKX + 2 * mp;
     unsigned r0 = m < p_hi ? (unsigned)(m * a.dy_ps * 4) : 0x80000000u;
     unsigned r1 = m + 1 < p_hi ? (unsigned)((m + 1) * a.dy_ps * 4) : 0x80000000u;
+    if (a.dy_up) {   // WgradArgs::dy_up: pixel (nb, oy, ox) reads the half-resolution tensor's (nb, oy / 2, ox / 2) -- m is even
+      const int row = m >> lOW, nb = row >> lOH, oy = row & (OH - 1), ox = m & (OW - 1);
+      const int hm = (((nb << (lOH - 1)) + (oy >> 1)) << (lOW - 1)) + (ox >> 1);
+      r0 = r1 = m < p_hi ? (unsigned)(hm * a.dy_ps * 4) : 0x80000000u;
+    }
 #ifdef EG_EXPERIMENTS
     if (a.dbg & 32) { r0 &= 0x80000fffu; r1 &= 0x80000fffu; }
 #endif
@@ -1720,6 +1730,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3r_kernel(const WgradArgs a, fl
         float* q = dense_out ? out + (((size_t)by * T + otap) * C + c) * N + n
                              : out + (size_t)otap * a.w_ts + (size_t)c * a.ldw + n;
         float4 v = make_float4(acc[d][i][4 * g], acc[d][i][4 * g + 1], acc[d][i][4 * g + 2], acc[d][i][4 * g + 3]);
+        if (a.dy_up) { v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f; }   // (exact: the pool's 1/4 applied to the sum)
         if (!dense_out && a.accumulate) {
           const float4 o = *reinterpret_cast<const float4*>(q);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;

@@ -150,8 +150,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
           iy = reflect_h(iy, IH);
           ix = reflect_h(ix, IW);
         }
-        if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW)
-          off = (unsigned)(((((img0 + ti) * IH + iy) * IW + ix) * a.x_ps + c4 * 4) * 4);
+        if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) {
+          if (a.x_up)   // (the source is the half-resolution tensor: four output-side pixels read one of its pixels)
+            off = (unsigned)(((((img0 + ti) * (IH >> 1) + (iy >> 1)) * (IW >> 1) + (ix >> 1)) * a.x_ps + c4 * 4) * 4);
+          else
+            off = (unsigned)(((((img0 + ti) * IH + iy) * IW + ix) * a.x_ps + c4 * 4) * 4);
+        }
       }
       const int row = ti * HPI + hy * HWP + hx;
       srow[j] = row | ((sw16 ? (hx >> 2) & 3 : swz_h(row)) << 16) | (vbits << 20);
@@ -548,6 +552,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
         const int n = n0 + wn * 64 + j * 32 + q * 8 + lh * 4;
         if (n < N) {
           float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          if (a.x_up) { v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f; }   // (exact: the pool's 1/4 applied to the sum)
           if constexpr (!SPLITK) {
             if (a.bias) {
               const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);

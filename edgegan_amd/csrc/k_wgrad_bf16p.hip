@@ -135,7 +135,13 @@ __global__ __launch_bounds__(256, (ND > 3 ? 2 : 3)) void wgrad_bf16p_kernel(cons
     const int m = p_lo + t * 32;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const unsigned voff = m + ypix[j] < p_hi ? (unsigned)((m + ypix[j]) * N * 2) + ych[j] : 0x80000000u;
+      int pm = m + ypix[j];
+      const bool in = pm < p_hi;
+      if (a.dy_up) {   // WgradArgs::dy_up: pixel (nb, oy, ox) reads the half-resolution plane's (nb, oy / 2, ox / 2)
+        const int row = pm >> lOW, nb = row >> lOH, oy = row & (OH - 1), ox = pm & (OW - 1);
+        pm = (((nb << (lOH - 1)) + (oy >> 1)) << (lOW - 1)) + (ox >> 1);
+      }
+      const unsigned voff = in ? (unsigned)(pm * N * 2) + ych[j] : 0x80000000u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(yres, (__attribute__((address_space(3))) void*)&Ys[buf][(wave + 4 * j) * 4 * 128], 16, voff, 0, 0,
                                                0);
     }
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(256, (ND > 3 ? 2 : 3)) void wgrad_bf16p_kernel(cons
         const int n = n0 + 32 * wave + q * 8 + lh * 4;
         if (n < N) {
           float4 v = make_float4(acc[d][cb][4 * q], acc[d][cb][4 * q + 1], acc[d][cb][4 * q + 2], acc[d][cb][4 * q + 3]);
+          if (a.dy_up) { v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f; }   // (exact: the pool's 1/4 applied to the sum)
           if (!dense_out && a.accumulate) {
             const float4 o = *reinterpret_cast<const float4*>(row + n);
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;

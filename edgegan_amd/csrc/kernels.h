@@ -72,6 +72,9 @@ struct ConvArgs {
   const float* epi_ref;
   int epi_act;
   int epi_applied;
+  int x_up;          // 1: the gathered operand is 0.25 x the 2x nearest-neighbour upsampling of a [NB][IH/2][IW/2][x_ps] tensor at x
+                     //    (x_bf: its plane) -- the gradient of a 2x2 average pool read without materialising it (halo kernel and
+                     //    plane-fed kernel, stride-1 launches; launch_conv_gemm checks).  x_bytes / xbf_bytes: the small tensor's.
   unsigned long long epi_wrap;   // > 0: output elements at or beyond this index take epi_ref[index - epi_wrap] (the stacked
                                  // discriminator sub-step: the tangent rows are masked by the primal rows' activation)
   int x3q;           // experiments build: run_conv chose the two-blocks-per-CU halo kernel (k_gemm_x3q.hip) and ITS K split for this launch
@@ -117,6 +120,8 @@ void launch_conv_split_reduce(const float* ws, float* y, const float* bias, size
 
 // flops (2*M*N*K summed over phases) are returned for the profiler.
 double launch_conv_gemm(ConvArgs& a, hipStream_t s, const char** kernel_name);
+bool conv_up_kernel(const ConvArgs& a);     // would launch_conv_gemm run a kernel that honours ConvArgs::x_up for these arguments?
+bool conv_x3_takes_halo(const ConvArgs& a, bool big_tile);
 int conv_pick_ksplit(ConvArgs& a);   // also sets a.x3_tile for limb-mode launches
 #ifdef EG_EXPERIMENTS
 // k_gemm_x3q.hip (experiments build, EG_X3Q=1): the f32x3 halo convolution at two blocks per CU (128 x 128 tiles, 16-channel
@@ -156,6 +161,8 @@ struct WgradArgs {
   const unsigned short* x_bf;
   const unsigned short* dy_bf;
   unsigned xbf_bytes, dybf_bytes;
+  int dy_up;         // 1: the dense operand is 0.25 x the 2x nearest-neighbour upsampling of a [NB][OH/2][OW/2][dy_ps] tensor at dy
+                     //    (dy_bf: its plane; ConvArgs::x_up) -- row-halo limb kernel and plane-fed kernel only (wgrad_up_kernel)
 };
 #ifdef __HIPCC__
 // XCD-aware block map (MI355X: 8 XCDs with private L2s; block b of a launch is observed on XCD b % 8): dispatch index ->
@@ -222,6 +229,7 @@ const char* launch_wgrad_pk(const WgradArgs& a, float* out, int dense, hipStream
 int wgrad_pick_splits(const WgradArgs& a);
 size_t wgrad_workspace_floats(const WgradArgs& a);
 double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name);
+bool wgrad_up_kernel(const WgradArgs& a);   // would launch_wgrad run a kernel that honours WgradArgs::dy_up for these arguments?
 
 // plane-fed bf16 filter gradient (k_wgrad_bf16p.hip): units > 0 when it takes the launch
 int wgrad_bf16p_units(const WgradArgs& a);

@@ -143,6 +143,13 @@ static void materialize_grad(Ctx& c, T t) {
   t->g_nslab = 0;
   t->g_slabs = nullptr;
 }
+// Tensor::g_up: write the gradient out after all (a reader without the half-resolution form)
+static void materialize_up(Ctx& c, T t) {
+  if (!t->g_up) return;
+  if (!t->g) t->g = c.arena.allocf(t->numel());
+  launch_pool2_bwd(t->g_up->g, t->g, 0, t->n, t->h, t->w, t->c, c.stream, nullptr);
+  t->g_up = nullptr;
+}
 // Column partials of the gradient a backward kernel is about to write as the FIRST writer (acc == 0) of tensor t, if t's producer
 // asked for them (a convolution with a trainable bias: Tensor::want_colpart) and the kernel form has `rows` > 0 of them
 static float* colpart_for(Ctx& c, T t, int acc, int rows) {
@@ -165,6 +172,7 @@ static void bias_grad_of(Ctx& c, Param* b, T y) {
   } else if (y->g_colsum_src) {
     bias_grad(c, b, y->g_colsum_src, y->g_colsum_rows, y->c);   // (pool2_add: a quarter of the rows)
   } else {
+    materialize_up(c, y);
     bias_grad(c, b, y->g, y->pixels(), y->c);
   }
 }
@@ -174,6 +182,7 @@ static bool flat_slab_ok(T t) { return t->c % 4 == 0 && t->numel() < (1ull << 31
 
 float* grad_acc(Ctx& c, T t, int* acc) {
   if (!t->g) t->g = c.arena.allocf(t->numel());
+  EG_CHECK(!t->g_up, "a second gradient contribution reached a tensor whose gradient is held as its pooled form");
   if (t->g_set) materialize_grad(c, t);   // (the first writer left K-split slabs: a second one adds to their sum)
   // ConvArgs::epi_act: the FIRST writer applied the fused activation's derivative in its epilogue and the producer will
   // skip its in-place pass -- exact only if that writer stays the ONLY one.  A second consumer accumulating a raw
@@ -198,6 +207,7 @@ void reset_grads(Ctx& c) {
     t.g_slabs = nullptr;
     t.g_colsum_src = nullptr;
     t.g_colpart = nullptr;
+    t.g_up = nullptr;
   }
   for (auto& p : c.params) p->g_set = false;
   for (auto& s : c.sn) s.dWbar_set = false;
@@ -306,7 +316,7 @@ const float* wref_transposed(Ctx& c, WRef* w) {
   return buf;
 }
 
-static void run_conv(Ctx& c, ConvArgs& a, T xsrc = nullptr, bool xgrad = false);
+static void run_conv(Ctx& c, ConvArgs& a, T xsrc = nullptr, bool xgrad = false, float* x_full = nullptr);
 
 // Phase-merged 3x3 filter [9][C][12] of a stride-2 filter [k*k][3][C] with 3 image channels (kernels.h:
 // launch_merge_phase_filter); kept per variable until the variable changes, like the per-tap transposes.
@@ -542,11 +552,11 @@ static unsigned short* producer_plane(Ctx& c, T t, bool grad) {
 
 // launch one implicit-GEMM conv; layers too small to fill the chip with output tiles split K over blocks.
 // xsrc / xgrad: the tensor whose data (gradient) a.x is -- the bf16 mode's plane-fed kernel reads its bf16 plane instead
-static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
+static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad, float* x_full) {
   a.y_total = (size_t)a.NB * a.OHf * a.OWf * a.y_ps;
   a.pk = (c.cfg.x3 || c.cfg.bf16) ? 1 : 0;   // thin layers: the packed-K limb kernel (fp32 results; the exact-fp32 mode keeps conv_smallc)
   {
-    const size_t xb = (size_t)a.NB * a.IH * a.IW * a.x_ps * sizeof(float);
+    const size_t xb = (size_t)a.NB * a.IH * a.IW * a.x_ps * sizeof(float) / (a.x_up ? 4 : 1);
     a.x_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
   }
   a.ksplit = conv_pick_ksplit(a);
@@ -615,6 +625,15 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad) {
     a.ws = c.arena.allocf(512);
     EG_HIP(hipMemsetAsync(a.ws, 0, 2048, c.stream));
   }
+  if (a.x_up && !conv_up_kernel(a)) {   // the kernel that will run gathers a full-resolution operand: write it out (Tensor::g_up)
+    EG_CHECK(x_full, "run_conv: x_up without a buffer to fall back to");
+    launch_pool2_bwd(a.x, x_full, 0, a.NB, a.IH, a.IW, a.x_ps, c.stream, nullptr);
+    a.x = x_full;
+    a.x_up = 0;
+    a.x_bf = nullptr;
+    const size_t xb = (size_t)a.NB * a.IH * a.IW * a.x_ps * sizeof(float);
+    a.x_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
+  }
   ProfScope ps(c);
   const double fl = launch_conv_gemm(a, c.stream, &nm);
   a.epi_applied = (a.epi_act && (a.caps & CONV_CAP_EPI_ACT)) ? 1 : 0;   // (reported by the launcher of the kernel that ran)
@@ -659,8 +678,12 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
   const bool limb_path = (c.cfg.x3 || c.cfg.bf16) && N % 32 == 0 && Cin > 16 && Cin % 4 == 0;
   const float* wT = limb_path ? nullptr : wref_transposed(c, w);
   if (c.prof_on) c.cur_label = w->name + " dgrad";
+  if (y->g_up && !(stride == 1 && !(pad == PAD_REFLECT && pt > 0))) materialize_up(c, y);
+  T up = y->g_up;   // y's gradient as its pooled form (Tensor::g_up): the kernel gathers from the half-resolution tensor
+  if (up && !y->g) y->g = c.arena.allocf(y->numel());   // (where run_conv falls back to)
   ConvArgs a{};
-  a.x = y->g;
+  a.x = up ? up->g : y->g;
+  a.x_up = up ? 1 : 0;
   a.wgt = wT;
   a.bias = nullptr;
   a.NB = x->n;
@@ -749,7 +772,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
   // launch leaves them un-summed
   static const bool gslab_on = dbg_env("EG_NO_GRAD_SLABS") == nullptr;
   a.keep_slabs = (gslab_on && keep_ok && !a.accumulate && x->g_slab_ok && !x->leaf_grad && !a.epi_act && Cin % 4 == 0) ? 1 : 0;
-  run_conv(c, a, y, true);
+  run_conv(c, a, up ? up : y, true, up ? y->g : nullptr);
   if (a.keep_slabs && a.ksplit > 1) {
     x->g_slabs = a.ws;
     x->g_nslab = a.ksplit;
@@ -762,8 +785,15 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
 static void conv_wgrad(Ctx& c, T xt, bool xgrad, int NB, int IH, int IW, int C, T dyt, bool dygrad, int OH, int OW,
                        int N, WRef* w, int k, int stride, int pad_before, int reflect) {
   WgradArgs g{};
+  T up = dygrad ? dyt->g_up : nullptr;   // the dense operand as its pooled form (Tensor::g_up)
+  if (up && (dyt->c != N || dyt->h != OH || dyt->w != OW)) {
+    materialize_up(c, dyt);
+    up = nullptr;
+  }
+  T dsrc = up ? up : dyt;                // the tensor whose gradient / plane the kernel reads
+  g.dy_up = up ? 1 : 0;
   const float* xg = xgrad ? xt->g : xt->d;
-  const float* dy = dygrad ? dyt->g : dyt->d;
+  const float* dy = dygrad ? dsrc->g : dyt->d;
   g.x = xg;
   g.dy = dy;
   g.dw = w->g;
@@ -787,18 +817,18 @@ static void conv_wgrad(Ctx& c, T xt, bool xgrad, int NB, int IH, int IW, int C, 
   g.bf16 = c.cfg.bf16 ? 1 : 0;
   if (c.cfg.x3 || c.cfg.bf16) {
     g.limbs = c.cfg.x3 ? 3 : 1;
-    const size_t xb = (size_t)NB * IH * IW * C * sizeof(float), yb = (size_t)NB * OH * OW * N * sizeof(float);
+    const size_t xb = (size_t)NB * IH * IW * C * sizeof(float), yb = (size_t)NB * OH * OW * N * sizeof(float) / (up ? 4 : 1);
     g.x_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
     g.dy_bytes = yb < (1ull << 31) ? (unsigned)yb : 0u;
   }
   if (c.cfg.bf16 && g.limbs == 1 && xt->c == C && dyt->c == N) {
-    const size_t xb = xt->numel() * sizeof(unsigned short), yb = dyt->numel() * sizeof(unsigned short);
+    const size_t xb = xt->numel() * sizeof(unsigned short), yb = dsrc->numel() * sizeof(unsigned short);
     g.x_bf = g.dy_bf = reinterpret_cast<const unsigned short*>(uintptr_t(16));   // (placeholders: the shape test looks at alignment only)
     g.xbf_bytes = xb < (1ull << 31) ? (unsigned)xb : 0u;
     g.dybf_bytes = yb < (1ull << 31) ? (unsigned)yb : 0u;
     if (wgrad_bf16p_units(g)) {
       g.x_bf = tensor_plane(c, xt, xgrad);
-      g.dy_bf = tensor_plane(c, dyt, dygrad);
+      g.dy_bf = tensor_plane(c, dsrc, dygrad);
     } else {
       g.x_bf = g.dy_bf = nullptr;
     }
@@ -810,6 +840,14 @@ static void conv_wgrad(Ctx& c, T xt, bool xgrad, int NB, int IH, int IW, int C, 
   g.nsplit = wgrad_pick_splits(g);
   const size_t wsf = wgrad_workspace_floats(g);
   g.ws = wsf ? c.arena.allocf(wsf) : nullptr;
+  if (g.dy_up && !wgrad_up_kernel(g)) {   // the kernel that will run reads a full-resolution operand: write it out, for this launch
+    float* full = c.arena.allocf(dyt->numel());   // (on the stream of this launch -- the leaf stream; conv_dgrad falls back on its own)
+    launch_pool2_bwd(up->g, full, 0, dyt->n, dyt->h, dyt->w, dyt->c, c.stream, nullptr);
+    g.dy = full;
+    g.dy_up = 0;
+    const size_t yb = dyt->numel() * sizeof(float);
+    g.dy_bytes = yb < (1ull << 31) ? (unsigned)yb : 0u;
+  }
   g.defer_reduce = c.defer_on ? 1 : 0;
   for (const RedDesc& q : c.deferred)   // a queued reduction into this filter's gradient comes first (summation order)
     if (q.dst == g.dw) {
@@ -975,6 +1013,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
       Ctx& c = *cp;
       if (!y->g_set) return;
       if (fused && !y->g_act_done) {
+        materialize_up(c, y);
         launch_act_bwd(y->d, y->g, y->g, 0, y->numel(), fused_act, c.stream);   // in place: g *= act'(out)
         y->g_bf = nullptr;           // (a plane its writer stored holds the un-masked values)
         y->g_colsum_src = nullptr;
@@ -984,7 +1023,8 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
       // if y's producer left none, make it here, before the leaf scope opens -- both streams may then read it.  Only the
       // multi-tap layers have plane-fed kernels (k_conv_bf16p.hip: 2 .. 3 taps per dimension; k_wgrad_bf16p.hip: 3x3, 4x4,
       // 5x5): a 1x1 layer would pay the conversion for nothing
-      if (c.cfg.bf16 && k > 1 && y->c % 64 == 0 && w->want_grad && x->needs_grad && c.param_grad_enabled) (void)tensor_plane(c, y, true);
+      if (c.cfg.bf16 && k > 1 && y->c % 64 == 0 && w->want_grad && x->needs_grad && c.param_grad_enabled)
+        (void)tensor_plane(c, y->g_up ? y->g_up : y, true);   // (Tensor::g_up: the pooled gradient is what both kernels read)
       if (c.param_grad_enabled && (w->want_grad || (bias && bias->want_grad))) {
         LeafScope leaf(c);
         if (w->want_grad)
@@ -1455,6 +1495,7 @@ T conv2d_pool2_add(Ctx& c, T x, WRef* w, Param* bias, int k, T b, Param* post_pr
   c.pool_epi = pe;
   c.feeds_in = FEED_FLAT;   // (a K-split launch cannot pool: its slabs go to the pool2_add pass)
   T y = conv2d(c, x, w, bias, k, 1, PAD_SAME);
+  y->g_up_ok = true;   // (y's only reader is the pool below, its producer's backward handles the pooled form of its gradient)
   pe = c.pool_epi;
   c.pool_epi = Ctx::PoolEpi();
   return pool2_add_finish(c, y, b, post_prelu, prelu_out, pe);
@@ -1492,10 +1533,23 @@ static T pool2_add_finish(Ctx& c, T a, T b, Param* post_prelu, T* prelu_out, con
         }
       }
       if (a->needs_grad) {
+        static const bool colsum_small = dbg_env("EG_NO_POOLED_COLSUM") == nullptr;
+        static const bool up_on = dbg_env("EG_NO_POOL_UP") == nullptr;
+        if (up_on && colsum_small && a->g_up_ok && !a->g_set && (c.cfg.x3 || c.cfg.bf16) && a->h % 2 == 0 && a->w % 2 == 0) {
+          // d(a) = 0.25 x the upsampling of d(out) is not written: the convolution behind a reads d(out) in both of its gradient
+          // kernels (Tensor::g_up) and takes its bias gradient from d(out)'s column sums
+          materialize_grad(c, out);
+          a->g_up = out;
+          a->g_set = true;
+          a->g_bf = nullptr;
+          a->g_colpart = nullptr;
+          a->g_colsum_src = out->g;
+          a->g_colsum_rows = out->pixels();
+          return;
+        }
         int acc;
         float* d = grad_acc(c, a, &acc);
         launch_pool2_bwd(out->g, d, acc, a->n, a->h, a->w, a->c, c.stream, producer_plane(c, a, true));
-        static const bool colsum_small = dbg_env("EG_NO_POOLED_COLSUM") == nullptr;
         if (!acc && colsum_small) {   // the column sums of d are those of out->g (each value appears 4 times, scaled by 1/4)
           a->g_colsum_src = out->g;
           a->g_colsum_rows = out->pixels();
