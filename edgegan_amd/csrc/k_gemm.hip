@@ -577,8 +577,8 @@ double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name)
   if (a.ksplit > 1 && !a.keep_slabs) launch_conv_split_reduce(a.ws, a.y, a.bias, a.y_total, a.y_ps, a.N, a.ksplit, a.accumulate, s);
   static const bool trace = dbg_env("EG_TRACE_GEMM") != nullptr;   // shape log for offline tile/split tuning
   if (trace)
-    fprintf(stderr, "EG_GEMM conv maxM=%d N=%d C=%d nphase=%d taps0=%d ksplit=%d kernel=%s gflop=%.3f\n", maxM, a.N, a.C,
-            a.nphase, a.ph[0].Ty * a.ph[0].Tx, a.ksplit, nm, flops * 1e-9);
+    fprintf(stderr, "EG_GEMM conv maxM=%d N=%d C=%d nphase=%d taps0=%d ksplit=%d keep=%d acc=%d kernel=%s gflop=%.3f\n", maxM, a.N, a.C,
+            a.nphase, a.ph[0].Ty * a.ph[0].Tx, a.ksplit, a.keep_slabs, a.accumulate, nm, flops * 1e-9);
   if (kernel_name) *kernel_name = nm;
   a_in.caps = caps;
   a_in.ksplit = a.ksplit;   // (the split that ran: the caller's slab bookkeeping must not assume the one it asked for)

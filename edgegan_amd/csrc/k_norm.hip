@@ -321,6 +321,14 @@ __device__ __forceinline__ Stat4 load_stats4(const float* stats, size_t nc) {
   return s;
 }
 
+// act'(out) of out = act((x - mean) r), recomputed from the pre-norm input with the forward pass's own arithmetic (in_fwd_v /
+// in_fwd_vr: the stored mean, r = 1 / (sigma + eps) from the stored sigma) -- the same bits as reading `out`, one tensor read
+// less per element in every backward / tangent kernel below
+__device__ __forceinline__ float4 actg_from_x(const float4& xv, const Stat4& st, int act) {
+  return actg4(act4(make_float4((xv.x - st.mean.x) * st.r.x, (xv.y - st.mean.y) * st.r.y, (xv.z - st.mean.z) * st.r.z,
+                                (xv.w - st.mean.w) * st.r.w), act), act);
+}
+
 template <int MODE, int CQ>
 __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, const float* __restrict__ out,
                                                    const float* __restrict__ v, const float* __restrict__ stats,
@@ -336,11 +344,11 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
   for (int p = pl; p < HW; p += PL) {
     const size_t i = base + (size_t)p * C;
     float4 e = ld4(v + i);
+    const float4 xv = ld4(x + i);
     if (MODE == 0) {
-      const float4 g = actg4(ld4(out + i), act);
+      const float4 g = actg_from_x(xv, st, act);
       e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w;
     }
-    const float4 xv = ld4(x + i);
     s[0].x += e.x; s[0].y += e.y; s[0].z += e.z; s[0].w += e.w;
     s[1].x += e.x * (xv.x - st.mean.x); s[1].y += e.y * (xv.y - st.mean.y);
     s[1].z += e.z * (xv.z - st.mean.z); s[1].w += e.w * (xv.w - st.mean.w);
@@ -352,11 +360,10 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
                                 st.r.z * st.r.z * s[1].z / (hw * st.sigma.z), st.r.w * st.r.w * s[1].w / (hw * st.sigma.w));
   for (int p = pl; p < HW; p += PL) {
     const size_t i = base + (size_t)p * C;
-    const float4 o = ld4(out + i);
-    const float4 g = actg4(o, act);
+    const float4 xv = ld4(x + i);
+    const float4 g = actg_from_x(xv, st, act);
     float4 e = ld4(v + i);
     if (MODE == 0) { e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w; }
-    const float4 xv = ld4(x + i);
     float4 res = make_float4(st.r.x * (e.x - eb.x) - k2.x * (xv.x - st.mean.x), st.r.y * (e.y - eb.y) - k2.y * (xv.y - st.mean.y),
                              st.r.z * (e.z - eb.z) - k2.z * (xv.z - st.mean.z), st.r.w * (e.w - eb.w) - k2.w * (xv.w - st.mean.w));
     if (MODE == 1) { res.x *= g.x; res.y *= g.y; res.z *= g.z; res.w *= g.w; }
@@ -393,9 +400,9 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
     if (p < HW) {
       const size_t i = base + (size_t)p * C;
       float4 e = slab_ld4(v, i, c);
-      const float4 g = actg4(ld4(out + i), act);
-      e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w;
       const float4 xv = ld4(x + i);
+      const float4 g = actg_from_x(xv, st, act);
+      e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w;
       ev[k] = e;
       xc[k] = make_float4(xv.x - st.mean.x, xv.y - st.mean.y, xv.z - st.mean.z, xv.w - st.mean.w);
       s[0].x += e.x; s[0].y += e.y; s[0].z += e.z; s[0].w += e.w;
@@ -499,7 +506,7 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_v(const float* __restrict_
   float4 m[2] = {f4_zero(), f4_zero()};
   for (int p = pl; p < HW; p += PL) {
     const size_t i = base + (size_t)p * C;
-    const float4 g = actg4(ld4(out + i), act), d = ld4(dtout + i), t = ld4(tx + i);
+    const float4 g = actg_from_x(ld4(x + i), st, act), d = ld4(dtout + i), t = ld4(tx + i);
     m[0].x += d.x * g.x; m[0].y += d.y * g.y; m[0].z += d.z * g.z; m[0].w += d.w * g.w;
     m[1].x += t.x; m[1].y += t.y; m[1].z += t.z; m[1].w += t.w;
   }
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_v(const float* __restrict_
   float4 s[3] = {f4_zero(), f4_zero(), f4_zero()};  // sum (e-eb)(t-ta), sum xc*t, sum e*xc
   for (int p = pl; p < HW; p += PL) {
     const size_t i = base + (size_t)p * C;
-    const float4 g = actg4(ld4(out + i), act), d = ld4(dtout + i), t = ld4(tx + i), xv = ld4(x + i);
+    const float4 d = ld4(dtout + i), t = ld4(tx + i), xv = ld4(x + i), g = actg_from_x(xv, st, act);
     const float ex = d.x * g.x, ey = d.y * g.y, ez = d.z * g.z, ew = d.w * g.w;
     const float cx = xv.x - st.mean.x, cy = xv.y - st.mean.y, cz = xv.z - st.mean.z, cw = xv.w - st.mean.w;
     s[0].x += (ex - eb.x) * (t.x - ta.x); s[0].y += (ey - eb.y) * (t.y - ta.y);
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_v(const float* __restrict_
   }
   for (int p = pl; p < HW; p += PL) {
     const size_t i = base + (size_t)p * C;
-    const float4 g = actg4(ld4(out + i), act), d = ld4(dtout + i), t = ld4(tx + i), xv = ld4(x + i);
+    const float4 d = ld4(dtout + i), t = ld4(tx + i), xv = ld4(x + i), g = actg_from_x(xv, st, act);
     const float e[4] = {d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w};
     const float xc[4] = {xv.x - st.mean.x, xv.y - st.mean.y, xv.z - st.mean.z, xv.w - st.mean.w};
     const float tt[4] = {t.x, t.y, t.z, t.w}, ebv[4] = {eb.x, eb.y, eb.z, eb.w}, tav[4] = {ta.x, ta.y, ta.z, ta.w},
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_vr(const float* __restrict
     tv[k] = f4_zero();
     if (p < HW) {
       const size_t i = base + (size_t)p * C;
-      const float4 g = actg4(ld4(out + i), act), d = ld4(dtout + i), t = ld4(tx + i), xv = ld4(x + i);
+      const float4 d = ld4(dtout + i), t = ld4(tx + i), xv = ld4(x + i), g = actg_from_x(xv, st, act);
       ev[k] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
       xc[k] = make_float4(xv.x - st.mean.x, xv.y - st.mean.y, xv.z - st.mean.z, xv.w - st.mean.w);
       tv[k] = t;
