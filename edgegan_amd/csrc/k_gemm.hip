@@ -1037,7 +1037,49 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const RedBatch b) {
       *q = t;
     }
   } else if (d.kind == 0) {
+#ifdef EG_REDUCE_LANES
     wgrad_reduce_v_body(red, block, d.src, d.dst, d.T, d.C, d.N, d.w_ts, d.ldw, d.n, d.accumulate);
+#else
+    // one element quad per thread, all slabs: 8 independent loads in flight, the partial sums combined in a fixed tree --
+    // no LDS stage, 4 KB contiguous per block and slab
+    const size_t total4 = (size_t)d.T * d.C * d.N / 4;
+    const size_t i4 = (size_t)block * 256 + threadIdx.x;
+    if (i4 < total4) {
+      const float4* p = reinterpret_cast<const float4*>(d.src) + i4;
+      float4 s[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      int z = 0;
+      for (; z + 8 <= d.n; z += 8) {
+        float4 a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = p[(size_t)(z + k) * total4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[k].x += a[k].x; s[k].y += a[k].y; s[k].z += a[k].z; s[k].w += a[k].w; }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (z + k < d.n) {
+          const float4 a = p[(size_t)(z + k) * total4];
+          s[k].x += a.x; s[k].y += a.y; s[k].z += a.z; s[k].w += a.w;
+        }
+      float4 t = make_float4(((s[0].x + s[1].x) + (s[2].x + s[3].x)) + ((s[4].x + s[5].x) + (s[6].x + s[7].x)),
+                             ((s[0].y + s[1].y) + (s[2].y + s[3].y)) + ((s[4].y + s[5].y) + (s[6].y + s[7].y)),
+                             ((s[0].z + s[1].z) + (s[2].z + s[3].z)) + ((s[4].z + s[5].z) + (s[6].z + s[7].z)),
+                             ((s[0].w + s[1].w) + (s[2].w + s[3].w)) + ((s[4].w + s[5].w) + (s[6].w + s[7].w)));
+      const size_t i = i4 * 4;
+      const int n = (int)(i % d.N);
+      const size_t t2 = i / d.N;
+      const int c = (int)(t2 % d.C);
+      const int tp = (int)(t2 / d.C);
+      float4* q = reinterpret_cast<float4*>(d.dst + (size_t)tp * d.w_ts + (size_t)c * d.ldw + n);
+      if (d.accumulate) {
+        const float4 o = *q;
+        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+      }
+      *q = t;
+    }
+#endif
   } else {   // col_sum_stage2 (k_elem.hip): 64 columns per block, 4 row lanes
     float* r = reinterpret_cast<float*>(&red[0][0]);
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
@@ -1055,7 +1097,11 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const RedBatch b) {
 }
 unsigned red_desc_blocks(const RedDesc& d) {
   if (d.kind == 0 && d.n >= kWideSplits) return (unsigned)(((size_t)d.T * d.C * d.N / 4 + 15) / 16);
+#ifdef EG_REDUCE_LANES
   if (d.kind == 0) return (unsigned)(((size_t)d.T * d.C * d.N / 4 + 63) / 64);
+#else
+  if (d.kind == 0) return (unsigned)(((size_t)d.T * d.C * d.N / 4 + 255) / 256);
+#endif
   return (unsigned)((d.C + 63) / 64);
 }
 void launch_reduce_batch(const RedBatch& b, hipStream_t s) {
