@@ -46,6 +46,8 @@ def pmc_traffic(kernel_label):
                 mk = re.match(r'conv_gemm_x3h_kernel<(\d+), (true|false)(?:, (\d+))?', r['kernel'])
                 if not mk or (int(mk.group(1)), mk.group(2)) != want[:2] or (mk.group(3) and mk.group(3) != want[2]):
                     continue
+                if re.search(r', true>', r['kernel']):   # (sixth template argument: the phase-pair form, another bucket)
+                    continue
                 if best is None or int(r['launches']) > int(best['launches']):
                     best = r
         if best:
@@ -106,8 +108,9 @@ def live_traffic(kernel_label, args):
     m = re.match(r'conv_gemm_(x3h|bf16h)<256,(\d+)(,s2d)?(,splitk)?>', kernel_label)
     mp = re.match(r'conv_bf16p<(\d+),(\d+)(,splitk)?>', kernel_label)
     if m:
-        pat = r'conv_gemm_x3h_kernel<%d, %s, %s, (true|false), %s>' % (6 if m.group(1) == 'x3h' else 1, 'true' if m.group(4) else 'false',
-                                                                        m.group(2), 'true' if m.group(3) else 'false')
+        # template arguments <NPROD, SPLITK, BN, SW16, S2D, PAIR>: the 2 x 64 phase-pair form (PAIR) has its own label and bucket
+        pat = r'conv_gemm_x3h_kernel<%d, %s, %s, (true|false), %s, false>' % (6 if m.group(1) == 'x3h' else 1, 'true' if m.group(4) else 'false',
+                                                                               m.group(2), 'true' if m.group(3) else 'false')
     elif mp:
         mi_wn = {('128', '128'): (2, 2), ('256', '128'): (4, 2), ('256', '64'): (2, 1)}.get((mp.group(1), mp.group(2)))
         if not mi_wn:

@@ -71,6 +71,7 @@ struct HaloGeom {
   int tiles_x, tiles_y;    // tiles per image
   int pitch;               // LDS row pitch of a halo row: 20 for 16-wide tiles (conflict-free layout), 0 = dense rows
   int dispatch_order;      // experiments: 1 = blockIdx as dispatched (no XCD-aware block map)
+  int pair;                // 1: the PAIR form runs the launch (kernel comment)
 };
 
 // S2D: a 4x4 stride-2 SAME convolution (the discriminators' forward layers) as a 2x2-tap STRIDE-1 convolution over the
@@ -79,8 +80,14 @@ struct HaloGeom {
 // of 32 channels lies inside ONE phase (py, px), so staging chunk (q = 2 py + px, cq) reads the halo pixels' phase-(py, px)
 // source pixels straight from x (per-row base offset + a uniform phase offset, per-row validity of the 4 phases), and
 // the chunk's filter tiles are those of taps (2 dY + py, 2 dX + px).  The halo image is shared by 4 taps (9 at 3x3).
-template <int NPROD, bool SPLITK, int BN, bool SW16, bool S2D = false>
+// PAIR (64-output-channel layers with phases in pairs that differ in the column phase only -- the 4x4 stride-2 input gradients
+// towards a 64-channel tensor): the two 64-column halves of the 128-wide block tile are the two PHASES (ph[2z], ph[2z + 1]) of one
+// pixel tile instead of two channel blocks.  Both phases read the same staged halo (one column wider), wave column wn takes the
+// filter rows, tap offsets and output pixels of phase wn: every wave keeps the 64 x 64 tile of the 128-channel form where the
+// 64-channel form (BN = 64) runs 32 x 64 tiles at 1.5 fragment reads per MFMA.
+template <int NPROD, bool SPLITK, int BN, bool SW16, bool S2D = false, bool PAIR = false>
 __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a, const HaloGeom g) {
+  static_assert(!PAIR || (BN == 128 && !S2D), "PAIR is a form of the 128-wide stride-1 tile");
   constexpr int NL = NPROD == 1 ? 1 : 3;
   constexpr int NSB = 3;
   constexpr int MI = BN / 64;                 // 32-row accumulator blocks per wave: wave tile 64 x 64 (BN = 128: waves 4 x 2)
@@ -104,7 +111,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   const int bx = bxy / (int)gridDim.y, by = bxy - bx * (int)gridDim.y;
   const int zphase = SPLITK ? bz / a.ksplit : bz;
   const int zsplit = SPLITK ? bz - zphase * a.ksplit : 0;
-  const ConvPhase ph = a.ph[zphase];
+  // (PAIR: zphase counts phase pairs; ph = the phase of this wave's accumulators, dkh0 / dkw0 = first tap of the phase whose filter rows its DMA brings)
+  const ConvPhase ph = a.ph[PAIR ? 2 * zphase + wn : zphase];
+  const int dkh0 = PAIR ? a.ph[2 * zphase + (wave >> 2)].kh0 : ph.kh0, dkw0 = PAIR ? a.ph[2 * zphase + (wave >> 2)].kw0 : ph.kw0;
   const int IH = a.IH, IW = a.IW, C = a.C, N = a.N, D = S2D ? 1 : a.D;
   const int nTy = S2D ? 2 : ph.Ty, nTx = S2D ? 2 : ph.Tx;   // taps the K loop walks
   const int TW = 1 << g.lTW, TH = 1 << g.lTH;
@@ -113,11 +122,17 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
   const int tn = bx / tpi, trem = bx - tn * tpi;
   const int tyy = trem / g.tiles_x, txx = trem - tyy * g.tiles_x;
   const int img0 = tn * g.TI, oy0 = tyy * TH, ox0 = txx * TW;
-  const int n0 = by * BN;
+  const int n0 = PAIR ? 0 : by * BN;
   // halo geometry of this phase (stride 1): input pixel of output (oy, ox), tap (ty, tx) = (oy + ty D + offy, ox + tx D + offx)
   const int offy = S2D ? 0 : ph.offy, offx = S2D ? 0 : ph.offx;   // (S2D: ph.off* is the source offset of phase 0, below)
-  const int dminy = min(offy, (nTy - 1) * D + offy), dminx = min(offx, (nTx - 1) * D + offx);
-  const int HH = TH + nTy - 1, HW = TW + nTx - 1, HU = g.TI * HH * HW;   // HU staged halo pixels
+  const int dminy = min(offy, (nTy - 1) * D + offy);
+  int dminx = min(offx, (nTx - 1) * D + offx), xspan = 0;
+  if constexpr (PAIR) {   // the halo covers both phases' taps (their column offsets differ by one)
+    const int ox0p = a.ph[2 * zphase].offx, ox1p = a.ph[2 * zphase + 1].offx;
+    dminx = min(min(ox0p, (nTx - 1) * D + ox0p), min(ox1p, (nTx - 1) * D + ox1p));
+    xspan = ox0p > ox1p ? ox0p - ox1p : ox1p - ox0p;
+  }
+  const int HH = TH + nTy - 1, HW = TW + nTx - 1 + xspan, HU = g.TI * HH * HW;   // HU staged halo pixels
   // LDS image: pixel (ti, hy, hx) lives in row ti HPI + hy HWP + hx.  16-wide tiles: pitch 20 (a multiple of 4, so a row's
   // bank quarter is hx mod 4) with the 16-byte chunk swizzled by (hx >> 2) & 3 -- the four rows of a ds_read_b128 lane
   // group that share a bank quarter are hx = h, h + 12 (one tile row) and h + 4, h + 8 (the next one): four different
@@ -204,7 +219,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
 
   // ---- filter ring: a wave's instruction fills rows wave*16 + lane/4 of a plane of the slot ----------------------------
   const int lsw = (((-((lane >> 4) & 3)) & 3) ^ (wave & 1));   // swz(wave*16 + lane/4)
-  const unsigned woff = (unsigned)(((size_t)min(n0 + wave * 16 + (lane >> 2), N - 1) * 32 + ((lane & 3) ^ lsw) * 8) * 2);
+  const unsigned woff =
+      (unsigned)(((size_t)min(n0 + (PAIR ? wave & 3 : wave) * 16 + (lane >> 2), N - 1) * 32 + ((lane & 3) ^ lsw) * 8) * 2);
   const int plane_bytes = (int)(a.wbf_plane * 2);
   const int ntaps = nTy * nTx;
   const int vcpt = S2D ? 4 * cpt : cpt;   // K chunks the loop walks (S2D: 4 phases x C / 32)
@@ -223,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
       const int q = rq_cc / cpt, cq = rq_cc - q * cpt;
       wsoff = (((2 * rq_ty + (q >> 1)) * a.KW + (2 * rq_tx + (q & 1))) * cpt + cq) * wtile;
     } else {
-      wsoff = (((ph.kh0 + rq_ty * a.kst) * a.KW + (ph.kw0 + rq_tx * a.kst)) * cpt + rq_cc) * wtile;
+      wsoff = (((dkh0 + rq_ty * a.kst) * a.KW + (dkw0 + rq_tx * a.kst)) * cpt + rq_cc) * wtile;
     }
     if (issuer && (EG_X3H_DBG & 4) == 0) {
 #pragma unroll
@@ -529,7 +545,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int n = n0 + wn * 64 + j * 32 + q * 8 + lh * 4;
+            const int n = n0 + (PAIR ? 0 : wn * 64) + j * 32 + q * 8 + lh * 4;
             const float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
             conv_epi_pool(a, v, TW, owner && n < N, prow + n, n, plk);
           }
@@ -549,7 +565,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + j * 32 + q * 8 + lh * 4;
+        const int n = n0 + (PAIR ? 0 : wn * 64) + j * 32 + q * 8 + lh * 4;
         if (n < N) {
           float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
           if (a.x_up) { v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f; }   // (exact: the pool's 1/4 applied to the sum)
@@ -596,6 +612,20 @@ static bool x3h_s2d_shape(const ConvArgs& a) {   // 4x4 stride-2 SAME forward co
          a.IW == 2 * p.OWp;
 }
 
+// PAIR form (kernel comment): 64 output channels, four phases in pairs (0, 1), (2, 3) that differ in their column phase only
+static bool x3h_pair_shape(const ConvArgs& a) {
+  static const bool off = dbg_env("EG_NO_HALO_PAIR") != nullptr;
+  if (off || a.nphase != 4 || a.N != 64 || a.S != 1 || a.pool_y || a.y2_leak) return false;
+  for (int z = 0; z < 2; ++z) {
+    const ConvPhase &p = a.ph[2 * z], &q = a.ph[2 * z + 1];
+    const int d = p.offx - q.offx;
+    if (p.OHp != q.OHp || p.OWp != q.OWp || p.Ty != q.Ty || p.Tx != q.Tx || p.kh0 != q.kh0 || p.offy != q.offy || p.ophy != q.ophy ||
+        d < -1 || d > 1)
+      return false;
+  }
+  return true;
+}
+
 static bool x3h_geometry(const ConvArgs& a_in, HaloGeom* g) {
   ConvArgs a = a_in;
   if (x3h_s2d_shape(a)) a.ph[0].Ty = a.ph[0].Tx = 2;   // the halo is that of the 2x2-tap space-to-depth form
@@ -623,6 +653,16 @@ static bool x3h_geometry(const ConvArgs& a_in, HaloGeom* g) {
   g->TI = TI;
   g->tiles_x = OW / TW;
   g->tiles_y = OH / TH;
+  g->pair = 0;
+  if (x3h_pair_shape(a)) {   // the shared halo is up to one column wider
+    bool fits = true;
+    for (int z = 0; z < 2; ++z) {
+      const ConvPhase &p = a.ph[2 * z], &q = a.ph[2 * z + 1];
+      const int span = p.offx > q.offx ? p.offx - q.offx : q.offx - p.offx, HW = TW + p.Tx - 1 + span;
+      if (TI * (TH + p.Ty - 1) * HW > HRMAX || (g->pitch && HW > 20)) fits = false;
+    }
+    g->pair = fits ? 1 : 0;
+  }
   return true;
 }
 
@@ -682,6 +722,19 @@ static const char* x3h_launch(const ConvArgs& a, const HaloGeom& g, hipStream_t 
                    : (a.ksplit > 1 ? "conv_gemm_x3h<256,64,splitk>" : "conv_gemm_x3h<256,64>");
 }
 
+template <int NPROD>
+static void x3h_launch_pair(const ConvArgs& a, const HaloGeom& g, hipStream_t s) {
+  const int zs = a.ksplit > 1 ? a.ksplit : 1;
+  dim3 grid((a.NB / g.TI) * g.tiles_x * g.tiles_y, 1, 2 * zs);
+  if (g.pitch) {
+    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<NPROD, true, 128, true, false, true>), grid, dim3(512), 0, s, a, g);
+    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<NPROD, false, 128, true, false, true>), grid, dim3(512), 0, s, a, g);
+  } else {
+    if (a.ksplit > 1) hipLaunchKernelGGL((conv_gemm_x3h_kernel<NPROD, true, 128, false, false, true>), grid, dim3(512), 0, s, a, g);
+    else hipLaunchKernelGGL((conv_gemm_x3h_kernel<NPROD, false, 128, false, false, true>), grid, dim3(512), 0, s, a, g);
+  }
+}
+
 const char* launch_conv_gemm_x3h(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
   if (!conv_x3h_pool_ok(a)) a.pool_y = nullptr;   // (the caller sees CONV_CAP_POOL missing and runs pool2_add itself)
@@ -689,6 +742,12 @@ const char* launch_conv_gemm_x3h(const ConvArgs& a_in, hipStream_t s) {
   x3h_geometry(a, &g);
   static const bool dispatch_order = dbg_env("EG_NO_XCD_MAP") != nullptr;
   g.dispatch_order = dispatch_order;
+  if (g.pair) {
+    if (a.limbs == 1) x3h_launch_pair<1>(a, g, s);
+    else x3h_launch_pair<6>(a, g, s);
+    if (a.limbs == 1) return a.ksplit > 1 ? "conv_gemm_bf16h<256,2x64,splitk>" : "conv_gemm_bf16h<256,2x64>";
+    return a.ksplit > 1 ? "conv_gemm_x3h<256,2x64,splitk>" : "conv_gemm_x3h<256,2x64>";
+  }
   return a.N >= 128 ? x3h_launch<128>(a, g, s) : x3h_launch<64>(a, g, s);
 }
 

@@ -70,6 +70,13 @@ def test_x3_ops_at_fp32_tolerances():
                  ('Dp conv_3 4x4s2 128->256 @32 nb64 (s2d halo, split K)', 64, 32, 32, 128, 256, 4, 2, 0, False),
                  ('D conv_4 4x4s2 256->512 8x16 nb64 (s2d halo, 8 images per tile)', 64, 8, 16, 256, 512, 4, 2, 0, False)]:
         rows += parity.check_conv(net, case, seed=7)
+    # input gradients towards a 64-channel tensor through a 4x4 stride-2 layer: the phase-PAIR form of the halo kernel (k_gemm_x3h.hip:
+    # PAIR) -- 16 x 16 tiles, 4 images of 8 x 8, 16 images of 4 x 4 per tile; with K split over the channel chunks
+    for case in [('pair 4x4s2 64->128 @64 nb8', 8, 64, 64, 64, 128, 4, 2, 0, False),
+                 ('pair 4x4s2 64->256 @16 nb8', 8, 16, 16, 64, 256, 4, 2, 0, False),
+                 ('pair 4x4s2 64->128 @8 nb32', 32, 8, 8, 64, 128, 4, 2, 0, False),
+                 ('pair 4x4s2 64->512 @32 nb4 (split K)', 4, 32, 32, 64, 512, 4, 2, 0, False)]:
+        rows += parity.check_conv(net, case, seed=13)
     # the row-halo filter-gradient kernel (k_gemm_x3.hip: wgrad_x3r -- 3x3 stride 1, 4x4 / 5x5 stride 2, 64-channel units)
     # at its edges: 8 image rows per K step across 3 images, ragged output-channel tile, 192 channels (3 blocks), the
     # 32-pixel segments of a 128-wide row, reflect and zero padding, odd image counts
