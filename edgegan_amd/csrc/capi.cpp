@@ -779,17 +779,19 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
     // convolution's epilogue, or the PReLU pass summing K-split slabs), Conv_2 read by pool2_add as slabs, the next unit's
     // prelu(h) as pool2_add's second store; backward: K-split input-gradient slabs summed by prelu_bwd
     // ip: NB,H,W,C1,C2 ; in: x,w1,b1,leak1,w2,b2,bp,leak2,dh,dhp ; out: h,hp,dx,dw1,db1,dleak1,dw2,db2,dbp,dleak2
+    // ip[5] (optional) = 1: the parameters are frozen, as the classifier's are in the generator sub-steps -- only dx and dbp are
+    // formed, and Conv_1's PReLU backward may ride in Conv_2's input-gradient epilogue (ConvArgs::epi_act = ACT_PRELU_X)
     need_ip(5);
     const int NB = ip[0], H = ip[1], W = ip[2], C1 = ip[3], C2 = ip[4];
-    const bool bw = io.has(8);
+    const bool bw = io.has(8), pg = bw && !(n_ip > 5 && ip[5]);
     T x = io.tensor(0, NB, H, W, C1, bw);
-    Param* w1 = io.param(1, bw);
-    Param* b1 = io.param(2, bw);
-    Param* l1 = io.param(3, bw);
-    Param* w2 = io.param(4, bw);
-    Param* b2 = io.param(5, bw);
+    Param* w1 = io.param(1, pg);
+    Param* b1 = io.param(2, pg);
+    Param* l1 = io.param(3, pg);
+    Param* w2 = io.param(4, pg);
+    Param* b2 = io.param(5, pg);
     T bp = io.tensor(6, NB, H / 2, W / 2, C2, bw);
-    Param* l2 = io.param(7, bw);
+    Param* l2 = io.param(7, pg);
     c.prelu_plane_only = c.cfg.bf16;   // (as classifier_forward does)
     T c1 = conv2d(c, x, wref_param(c, w1, 9, C1, C2), b1, 3, 1, PAD_SAME, nullptr, 0, l1);
     T hp = nullptr;
@@ -801,13 +803,15 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
       io.seed(hp, 9);
       c.tape.backward();
       io.down_grad(2, x);
-      io.down_pgrad(3, w1);
-      io.down_pgrad(4, b1);
-      io.down_pgrad(5, l1);
-      io.down_pgrad(6, w2);
-      io.down_pgrad(7, b2);
+      if (pg) {
+        io.down_pgrad(3, w1);
+        io.down_pgrad(4, b1);
+        io.down_pgrad(5, l1);
+        io.down_pgrad(6, w2);
+        io.down_pgrad(7, b2);
+      }
       io.down_grad(8, bp);
-      io.down_pgrad(9, l2);
+      if (pg) io.down_pgrad(9, l2);
     }
   } else if (op == "mru_gate") {
     // the head of an MRU unit (conv.py:185-209): prelu(h), the update gate as image rows + hidden rows (the hidden-state

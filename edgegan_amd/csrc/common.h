@@ -119,6 +119,7 @@ class Arena {
 // buffer, allocated on first use; `g_set` says whether it already holds a value (first writer
 // stores, later writers accumulate -- no memsets).
 // ---------------------------------------------------------------------------------------------
+struct Param;
 struct Tensor {
   float* d = nullptr;
   float* g = nullptr;
@@ -132,6 +133,11 @@ struct Tensor {
   // The gradient of a tensor whose only reader is a 2x2 average pool (pool2_add behind a convolution: g_up_ok) is 0.25 x the 2x
   // nearest-neighbour upsampling of the pooled tensor's gradient: g_up = that tensor, g itself is NOT written -- the convolution's
   // two gradient kernels read the small tensor (ConvArgs::x_up, WgradArgs::dy_up; ops.cpp: materialize_up where they cannot)
+  // out = prelu(x) with a learned slope (prelu_tail): x and the slope -- the single input-gradient convolution that writes out's
+  // gradient may apply the PReLU's backward in its epilogue (ConvArgs::epi_act = ACT_PRELU_X; then g_act_done, and x's gradient
+  // IS this buffer)
+  Tensor* prelu_pre = nullptr;
+  Param* prelu_leak = nullptr;
   bool g_up_ok = false;
   Tensor* g_up = nullptr;
   size_t g_epi_wrap = 0;    //     ... with the activation output of element i - g_epi_wrap for elements i >= g_epi_wrap (ConvArgs::epi_wrap)

@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256, ((HR <= 288 && SW16) ? 3 : 2)) void conv_bf16p
       return;
     }
   }
+  const float elk = (!SPLITK && a.epi_act == ACT_PRELU_X) ? *a.epi_leak : 0.f;
   const float y2lk = (!SPLITK && a.y2_leak) ? *a.y2_leak : 0.f;   // second output: PReLU of the stored value (kernels.h: conv_epi_y2)
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -458,7 +459,10 @@ __global__ __launch_bounds__(256, ((HR <= 288 && SW16) ? 3 : 2)) void conv_bf16p
               if (a.epi_wrap && ei >= a.epi_wrap) ei -= a.epi_wrap;
               const float4 o = *reinterpret_cast<const float4*>(a.epi_ref + ei);
               const float neg = a.epi_act == ACT_LRELU ? 0.2f : 0.f;
-              if (a.epi_act == ACT_LRELU) {
+              if (a.epi_act == ACT_PRELU_X) {   // (o = the PReLU's input; prelu_bwd's expression, k_elem.hip)
+                v.x = elk * o.x >= o.x ? elk * v.x : v.x; v.y = elk * o.y >= o.y ? elk * v.y : v.y;
+                v.z = elk * o.z >= o.z ? elk * v.z : v.z; v.w = elk * o.w >= o.w ? elk * v.w : v.w;
+              } else if (a.epi_act == ACT_LRELU) {
                 v.x *= o.x >= 0.f ? 1.f : neg; v.y *= o.y >= 0.f ? 1.f : neg; v.z *= o.z >= 0.f ? 1.f : neg; v.w *= o.w >= 0.f ? 1.f : neg;
               } else {
                 v.x *= o.x > 0.f ? 1.f : neg; v.y *= o.y > 0.f ? 1.f : neg; v.z *= o.z > 0.f ? 1.f : neg; v.w *= o.w > 0.f ? 1.f : neg;
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(256, ((HR <= 288 && SW16) ? 3 : 2)) void conv_bf16p
           if ((EG_BF16P_DBG & 32) == 0 || v.x == 123.456f) *reinterpret_cast<float4*>(yrow + n) = v;
           if constexpr (!SPLITK) {
             if (a.y2_leak) conv_epi_y2(a, (size_t)(yrow - a.y) + n, v, y2lk);
+            if (a.epi_bf) conv_epi_plane(a.epi_bf + (size_t)(yrow - a.y) + n, v);
           }
         }
       }

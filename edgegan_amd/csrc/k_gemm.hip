@@ -540,8 +540,9 @@ double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name)
     //  layer at 64 x 64 where the separate PReLU pass costs 49 -- profiles/r05b_*)
 #ifdef EG_EXPERIMENTS
   } else if (a.x3q && a.N > 16 && conv_x3q_eligible(a)) {
+    if (a.epi_act == ACT_PRELU_X) a.epi_act = 0;   // (that kernel's epilogue has the ReLU / LeakyReLU forms only)
     nm = launch_conv_x3q(a, s);
-    if (a.ksplit <= 1) caps |= CONV_CAP_EPI_ACT;
+    if (a.ksplit <= 1 && a.epi_act) caps |= CONV_CAP_EPI_ACT;
 #endif
   } else if (conv_scatter_eligible(a)) {
     nm = launch_conv_scatter(a, s);

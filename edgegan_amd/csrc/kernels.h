@@ -75,6 +75,11 @@ struct ConvArgs {
   int x_up;          // 1: the gathered operand is 0.25 x the 2x nearest-neighbour upsampling of a [NB][IH/2][IW/2][x_ps] tensor at x
                      //    (x_bf: its plane) -- the gradient of a 2x2 average pool read without materialising it (halo kernel and
                      //    plane-fed kernel, stride-1 launches; launch_conv_gemm checks).  x_bytes / xbf_bytes: the small tensor's.
+  const float* epi_leak;   // epi_act == ACT_PRELU_X: y holds dL/d(prelu output), epi_ref the PReLU's INPUT x, *epi_leak its slope lk; the
+                           //   kernel stores (lk x >= x ? lk y : y) -- prelu_bwd's expression (k_elem.hip) -- and, with epi_bf, its bf16 plane
+  unsigned short* epi_bf;
+  int epi_soft;            // run_conv: a K-split launch drops the epilogue request and keeps its slabs instead (keep_slabs_soft)
+  int keep_slabs_soft;
   unsigned long long epi_wrap;   // > 0: output elements at or beyond this index take epi_ref[index - epi_wrap] (the stacked
                                  // discriminator sub-step: the tangent rows are masked by the primal rows' activation)
   int x3q;           // experiments build: run_conv chose the two-blocks-per-CU halo kernel (k_gemm_x3q.hip) and ITS K split for this launch
@@ -186,6 +191,16 @@ __device__ __forceinline__ void conv_epi_y2(const ConvArgs& a, size_t off, const
     o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_e));
     *reinterpret_cast<uint2*>(a.y2_bf + off) = o;
   }
+}
+// bf16 plane of a stored quad (round to nearest even: cvt_bf16's rounding)
+__device__ __forceinline__ void conv_epi_plane(unsigned short* dst, const float4& v) {
+  typedef __bf16 bf16x2_e __attribute__((ext_vector_type(2)));
+  typedef float f32x2_e __attribute__((ext_vector_type(2)));
+  const f32x2_e lo = {v.x, v.y}, hi = {v.z, v.w};
+  uint2 o;
+  o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_e));
+  o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_e));
+  *reinterpret_cast<uint2*>(dst) = o;
 }
 // ConvArgs::pool_y: one accumulator quad of the pooled epilogue.  v = the quad of output pixel (py, px) of a tile TW wide; on
 // return the lanes with even (py, px) have stored  0.25 * (sum over the 2x2 block) + bias + pool_b  (and its PReLU) at element
@@ -326,7 +341,8 @@ void launch_tap_transpose(const float* in, float* out, int T, int R, int Cc, con
 // ---------------------------------------------------------------------------------------------
 // norm / activation kernels (k_norm.hip).  act: 0 none, 1 relu, 2 lrelu(max(x,0.2x)), 3 tanh
 // ---------------------------------------------------------------------------------------------
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3,
+           ACT_PRELU_X = 4 };   // ConvArgs::epi_act only: PReLU backward from the PRE-activation (epi_ref) and the learned slope (epi_leak)
 
 // InstanceNorm (x-mean)/(sqrt(var)+1e-5) + act, per (n,c) over H*W. stats[n][c] = {mean, sigma}.
 // nslab > 1: x is the first of nslab K-split slabs (slab_stride floats apart) of a convolution output that was never

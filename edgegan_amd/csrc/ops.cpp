@@ -618,6 +618,11 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad, float* x_full) {
     a.x_bf = conv_bf16p_eligible(a) ? tensor_plane(c, xsrc, xgrad) : nullptr;
   }
   if (xsrc && !xgrad && !a.x_bf) need_f32(c, xsrc);   // (a plane-only operand and a kernel that gathers fp32)
+  if (a.epi_soft && a.ksplit > 1) {   // a K-split launch has no epilogue: its consumer's pass sums the slabs (ConvArgs::epi_soft)
+    a.epi_act = 0;
+    a.epi_bf = nullptr;
+    a.keep_slabs = a.keep_slabs_soft;
+  }
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
   const char* nm;
   static const bool x3_timing = dbg_env("EG_X3_TIMING") != nullptr;   // experiment: per-phase s_memtime stamps of block 0
@@ -727,6 +732,18 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
     a.OWf = x->w;
     a.ph[0] = ConvPhase{x->h, x->w, 0, 0, k, k, 0, 0, pt, pl};
     keep_ok = !acc;
+    // x = prelu(pre) and this launch is the only writer of x's gradient: the PReLU's backward in the epilogue (un-split halo /
+    // plane-fed kernel), unless the slope or a bias behind `pre` trains in this sweep (their sums come from prelu_bwd's pass)
+    static const bool pepi_on = dbg_env("EG_NO_EPI_PRELU_BWD") == nullptr;
+    T pre = x->prelu_pre;
+    if (pepi_on && pre && !acc && !pre->g_set && !pre->g && !pre->g_inplace && !x->leaf_grad && !pre->leaf_grad &&
+        !(c.param_grad_enabled && (x->prelu_leak->want_grad || pre->want_colpart)) && x->numel() < (1ull << 31)) {
+      a.epi_ref = pre->d;
+      a.epi_act = ACT_PRELU_X;
+      a.epi_leak = x->prelu_leak->w;
+      a.epi_soft = 1;
+      if (c.cfg.bf16 && x->c % 32 == 0) a.epi_bf = reinterpret_cast<unsigned short*>(c.arena.allocf((x->numel() + 1) / 2));
+    }
   } else {
     EG_CHECK(stride == 2 && x->h % 2 == 0 && x->w % 2 == 0, "stride-2 dgrad needs even extents");
     if (Cin == 3 && k == 4 && pt == 1 && pl == 1 && N % 16 == 0) {   // d_conv_0 / encoder stem: phase-merged form
@@ -771,8 +788,14 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
   // first writer of the gradient of a tensor whose producer's backward reads K-split slabs (Tensor::g_slab_ok): a split
   // launch leaves them un-summed
   static const bool gslab_on = dbg_env("EG_NO_GRAD_SLABS") == nullptr;
-  a.keep_slabs = (gslab_on && keep_ok && !a.accumulate && x->g_slab_ok && !x->leaf_grad && !a.epi_act && Cin % 4 == 0) ? 1 : 0;
+  const bool slabs_wanted = gslab_on && keep_ok && !a.accumulate && x->g_slab_ok && !x->leaf_grad && Cin % 4 == 0;
+  a.keep_slabs = (slabs_wanted && !a.epi_act) ? 1 : 0;
+  a.keep_slabs_soft = slabs_wanted ? 1 : 0;
   run_conv(c, a, up ? up : y, true, up ? y->g : nullptr);
+  if (a.epi_act == ACT_PRELU_X && a.epi_applied && a.epi_bf) {   // the plane of what was stored = d(pre)
+    x->g_bf = a.epi_bf;
+    x->g_bf_stream = nullptr;
+  }
   if (a.keep_slabs && a.ksplit > 1) {
     x->g_slabs = a.ws;
     x->g_nslab = a.ksplit;
@@ -1701,10 +1724,23 @@ static T prelu_tail(Ctx& c, T x, T out, Param* leak, float leak_const) {
   if (need) {
     out->needs_grad = true;
     out->g_slab_ok = flat_slab_ok(out) && (x->numel() & 3) == 0;
+    if (leak && x->needs_grad) {   // (conv_dgrad may take the backward into its epilogue)
+      out->prelu_pre = x;
+      out->prelu_leak = leak;
+    }
     Ctx* cp = &c;
     c.tape.push([=]() {
       Ctx& c = *cp;
       if (!out->g_set) return;
+      if (out->g_act_done) {   // the convolution that wrote out's gradient applied this backward: the buffer holds d(x)
+        x->g = out->g;
+        x->g_set = true;
+        x->g_bf = out->g_bf;
+        x->g_bf_stream = out->g_bf_stream;
+        x->g_colsum_src = nullptr;
+        x->g_colpart = nullptr;
+        return;
+      }
       float* dx = nullptr;
       int acc = 0;
       if (x->needs_grad) dx = grad_acc(c, x, &acc);

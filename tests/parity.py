@@ -691,6 +691,13 @@ def check_mru_tail(net, NB, H, W, C1, C2, seed=0, bf16=False, tol=(FWD_TOL, BWD_
     rows = [(f'{tag} h', relerr(out[0], h.detach().numpy()), tol[0]), (f'{tag} prelu(h)', relerr(out[1], hp.detach().numpy()), tol[0])]
     for i, n in enumerate(names):
         rows.append((f'{tag} d{n}', relerr(out[2 + i], gr[i].detach().numpy()), sk.tol(t[n], gr[i], tol[1]) if n in ('l1', 'l2') else tol[1]))
+    # the same graph with its parameters frozen (the classifier inside the generator sub-steps): only the input gradients are formed,
+    # Conv_1's PReLU backward rides in Conv_2's input-gradient epilogue where that launch is un-split
+    frozen = [tuple(s) if n in ('x', 'bp') else None for s, n in zip(shapes[2:], names)]
+    out = net.test_op('mru_tail', [a[n] for n in names] + [dh, dhp], [NB, H, W, C1, C2, 1], [tuple(h.shape), tuple(hp.shape)] + frozen)
+    for i, n in enumerate(names):
+        if n in ('x', 'bp'):
+            rows.append((f'{tag} frozen d{n}', relerr(out[2 + i], gr[i].detach().numpy()), tol[1]))
     return rows
 
 
