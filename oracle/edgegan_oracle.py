@@ -121,15 +121,24 @@ def _bilinear(f, x: Tensor, w: Tensor, c_in: int, n_out: int, c_wgrad: Optional[
 # piecewise-linear activation records, per call, how close its argument comes to the kink relative to the
 # argument's RMS -- fixtures whose small-extent layers keep a margin can then be compared at tight tolerance.
 _KINK_REC = None
+_KINK_FLIP = None      # kink_flipper: {activation call index: LongTensor of flat element indices}
+_KINK_CALL = 0         # activation calls since the recorder / flipper was entered (the two count alike on the same graph)
 
 
 class kink_recorder:
-    """rec.rows: list of (tag, elements per (n, c) slice, numel, min|x|/rms(x))."""
+    """rec.rows: list of (tag, elements per (n, c) slice, numel, min|x|/rms(x)).
+    With collect=(max_extent, margin): rec.near additionally lists (call index, flat element index, |x|/rms, tag, shape) of every non-zero
+    argument closer than `margin` to the kink in calls whose per-(n, c) extent is <= max_extent -- the elements an fp32
+    evaluation may decide differently (tests/test_tight_gpu.py proves its flip tolerance with them through kink_flipper)."""
+
+    def __init__(self, collect=None):
+        self.collect = collect
 
     def __enter__(self):
-        global _KINK_REC
-        self.prev, self.rows = _KINK_REC, []
+        global _KINK_REC, _KINK_CALL
+        self.prev, self.rows, self.near = _KINK_REC, [], []
         _KINK_REC = self
+        _KINK_CALL = 0
         return self
 
     def __exit__(self, *exc):
@@ -142,9 +151,48 @@ class kink_recorder:
         return min(m) if m else float('inf')
 
 
-def _kink(tag: str, x: Tensor) -> None:
+class kink_flipper:
+    """Re-evaluate a graph with the listed arguments of its piecewise-linear activations on the OTHER side of the kink (mirrored:
+    the elements are within rounding of it): flips = [(call index, flat element index), ...] as recorded by
+    kink_recorder(collect=...) on the same graph.  ReLU and the fixed-slope LeakyReLU only."""
+
+    def __init__(self, flips):
+        self.flips = {}
+        for call, idx in flips:
+            self.flips.setdefault(int(call), []).append(int(idx))
+
+    def __enter__(self):
+        global _KINK_FLIP, _KINK_CALL
+        self.prev = _KINK_FLIP
+        _KINK_FLIP = self.flips
+        _KINK_CALL = 0
+        return self
+
+    def __exit__(self, *exc):
+        global _KINK_FLIP
+        _KINK_FLIP = self.prev
+
+
+def _flipped(x: Tensor, call: int) -> Tensor:
+    """The activation's argument with the elements kink_flipper lists for this call mirrored to the other side of the kink
+    (x_i -> -x_i: a change of ~1e-6 of the layer's scale, what an fp32 evaluation's rounding does to such an element).  The mask
+    of this activation AND of whatever consumes the value downstream (the encoder's relu -> avg_pool -> relu, whose second relu
+    sees an exact zero when all four inputs are negative) follow from the value, as they do in the engine."""
+    if _KINK_FLIP is None or call not in _KINK_FLIP:
+        return x
+    idx = torch.tensor(_KINK_FLIP[call], dtype=torch.long)
+    m = torch.zeros(x.numel(), dtype=x.dtype)
+    m[idx] = 2.0
+    return x - m.reshape(x.shape) * x.detach()
+
+
+def _kink(tag: str, x: Tensor) -> int:
+    """Returns the index of this activation call (for _flipped)."""
+    global _KINK_CALL
+    call = _KINK_CALL
+    _KINK_CALL += 1
     if _KINK_REC is None or x.numel() == 0:
-        return
+        return call
     d = x.detach()
     if d.dim() == 4:            # NHWC or NCHW: either way numel / (n * channels) elements per slice
         ch = d.shape[3] if tag.endswith('nhwc') else d.shape[1]
@@ -154,12 +202,17 @@ def _kink(tag: str, x: Tensor) -> None:
     rms = float(d.pow(2).mean().sqrt())
     nz = d[d != 0]      # exact zeros are structural (relu of an already rectified, pooled tensor), the same in fp32
     _KINK_REC.rows.append((tag, extent, d.numel(), (float(nz.abs().min()) if nz.numel() else float('inf')) / max(rms, 1e-300)))
+    if _KINK_REC.collect is not None and extent <= _KINK_REC.collect[0] and rms > 0:
+        a = d.reshape(-1).abs()
+        for i in torch.nonzero((a < _KINK_REC.collect[1] * rms) & (a != 0)).reshape(-1).tolist():
+            _KINK_REC.near.append((call, i, float(a[i]) / rms, tag, tuple(d.shape)))
+    return call
 
 
 def relu(x: Tensor) -> Tensor:
     """tf.nn.relu (slope 0 at 0)."""
-    _kink('relu/nhwc', x)
-    return torch.relu(x)
+    call = _kink('relu/nhwc', x)
+    return torch.relu(_flipped(x, call))
 
 
 # --------------------------------------------------------------------------------------
@@ -269,7 +322,7 @@ def activation(x: Tensor, name: Optional[str]) -> Tensor:
     if name == 'relu':
         return relu(x)
     if name == 'lrelu':
-        _kink('lrelu/nhwc', x)
+        x = _flipped(x, _kink('lrelu/nhwc', x))
         return torch.maximum(x, 0.2 * x)
     if name == 'tanh':
         return torch.tanh(x)
@@ -307,7 +360,7 @@ def prelu(x: Tensor, leak: Tensor) -> Tensor:
 
 def lrelu_leak(x: Tensor, leak: float = 0.2) -> Tensor:
     """activation.py:30-32."""
-    _kink('lrelu_leak/nchw', x)
+    x = _flipped(x, _kink('lrelu_leak/nchw', x))
     return torch.maximum(leak * x, x)
 
 

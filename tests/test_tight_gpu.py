@@ -140,6 +140,11 @@ SELF_DEV_OUTLIERS = {
 # ~5e-3 in relative L2, a wiring error >= 1e-1.  Rule: ONLY IF the oracle's fp64 pass records a small-extent ReLU input inside
 # MARGIN, the residual-branch filters of the encoder's two deepest blocks are judged at FLIP_TOL, the ordinary sub-step tests'
 # flip-tolerant bound (tests/parity.py:substep_checks); everything else keeps the tight rule.
+# Round 5: in the runs that evaluate the oracle live (the benched f32x3 mode) this tolerance is no longer what such a row
+# is judged by -- _flip_proof below replaces the row by one at the TIGHT tolerance against the oracle with the responsible near-kink
+# elements mirrored (e_optim: two inputs of block 512_4's last ReLU at 2.4e-6 / 2.8e-6 of the layer's rms, 5.5e-3 -> 1.1e-5;
+# d_optim_patch2: two LeakyReLU inputs of the last InstanceNorm layer, 1.2e-3 -> 1.3e-5).  FLIP_TOL stays for the runs against the
+# committed digests (exact-fp32 mode), which hold no fp64 gradients to re-evaluate.
 FLIP_TOL = 1e-2
 FLIP_EXPOSED = re.compile(r'^E/e_resnet_(256_2|512_[34])/res[12]/conv2d/w$')   # InstanceNorm extents 256 / 64 / 16 pixels (<= SF.SMALL_EXTENT)
 # Round 5 added d_optim_patch2 (so far argued from d_optim_patch3): the discriminators' InstanceNorm + LeakyReLU layers behind
@@ -169,7 +174,7 @@ def _full_batch_oracle(name, cfg, values, b):
         g32, _ = om32.compute_grads(name, inp32, inp32.eps[0])
         O._SLOPE_TERMS = {}          # record sum_i |t_i| of every PReLU slope's gradient terms (conditioning, below)
         try:
-            with O.kink_recorder() as rec:
+            with O.kink_recorder(collect=(SF.SMALL_EXTENT, FLIP_CANDIDATE_MARGIN)) as rec:
                 g64, l64 = om.compute_grads(name, inp, inp.eps[0])
         finally:
             O._SLOPE_TERMS = None
@@ -186,7 +191,57 @@ def _full_batch_oracle(name, cfg, values, b):
                 kappa = l1 / max(abs(float(g64[vn])), 1e-300)
                 self_dev[vn] = max(self_dev[vn], SLOPE_KAPPA_TOL * kappa / SELF_DEV_FACTOR)
         _FULL_BATCH_ORACLE[name] = ({k: v.detach() for k, v in g64.items()}, {k: float(v) for k, v in l64.items()}, self_dev, near_kink)
+        _FULL_BATCH_NEAR[name] = sorted(rec.near, key=lambda r: r[2])
     return _FULL_BATCH_ORACLE[name]
+
+
+# The flip tolerance, proven where it is used: when a flip-exposed variable misses its TIGHT tolerance, the deviation
+# must be the signature of single mask decisions.  Measured on d_optim_patch2 (tools/gpu_flip_probe.py, profiles/r05v_flip_probe.txt):
+# 98 % of the error of d_conv_4's filter gradient sits in ONE of its 512 output channels, and flipping ONE input of that channel's
+# LeakyReLU (|x| / rms = 5.0e-6 in the fp64 oracle; the layer's InstanceNorm runs over 16 pixels) in the oracle moves the error
+# from 1.17e-3 to 2.3e-4 -- while the eight globally closest-to-kink elements explain nothing.  So the candidates are chosen where
+# the error is: the oracle's small-extent activation inputs inside FLIP_CANDIDATE_MARGIN of the kink (relative to the layer's rms)
+# that lie in the worst output channels of a failing filter (same channel count), at most FLIP_MAX_CANDIDATES of them; the oracle
+# is re-evaluated with each mirrored to the other side of the kink (oracle/edgegan_oracle.py: kink_flipper -- a value change of
+# ~1e-6 of the layer's scale; the masks, also those of dependent activations downstream, follow from the value), and the engine must meet the tight tolerance against  oracle + sum of the flip differences  for SOME subset, the same
+# subset for every failing variable of the sub-step (the differences add: each flip changes one mask element of a
+# piecewise-linear graph).  A deviation that no such subset explains is not a kink flip, whatever its size, and fails.
+FLIP_CANDIDATE_MARGIN = 3e-5
+FLIP_MAX_CANDIDATES = 6
+_FULL_BATCH_NEAR = {}
+
+
+def _flip_proof(name, cfg, values, b, g64, need, tight, gmax):
+    """need: {failing flip-exposed variable: its gradient from the engine}; tight: {variable: tolerance}.  Returns (flipped
+    candidates, {variable: error against the flipped oracle}, all candidates)."""
+    import itertools
+    chans = {}      # channel count -> worst output channels of the failing filters with that many
+    for vn, h in need.items():
+        g = g64[vn].numpy()
+        if g.ndim != 4:
+            continue
+        per_n = np.sqrt(((h - g) ** 2).reshape(-1, g.shape[-1]).sum(0))
+        chans.setdefault(g.shape[-1], set()).update(int(n) for n in np.argsort(-per_n)[:2])
+    cand = [r for r in _FULL_BATCH_NEAR.get(name, []) if len(r[4]) == 4 and r[4][-1] in chans and int(r[1] % r[4][-1]) in chans[r[4][-1]]]
+    cand = cand[:FLIP_MAX_CANDIDATES]
+    om = O.OracleModel(parity.oracle_config(cfg), values, dtype=torch.float64)
+    inp = O.StepInputs(parity.t64(b['images']), parity.t64(b['z']), parity.t64(b['alpha']), parity.t64(b['eps']))
+    deltas = []
+    for call, idx, _, _, _ in cand:
+        with O.kink_flipper([(call, idx)]):
+            gf, _ = om.compute_grads(name, inp, inp.eps[0])
+        deltas.append({vn: (gf[vn] - g64[vn]).numpy() for vn in need})
+    best = None
+    for r in range(len(cand) + 1):
+        for sub in itertools.combinations(range(len(cand)), r):
+            errs = {}
+            for vn, h in need.items():
+                ref = g64[vn].numpy() + sum((deltas[i][vn] for i in sub), np.zeros_like(g64[vn].numpy()))
+                errs[vn] = parity.rel_l2(h, ref, 1e-5 * gmax)
+            score = max(errs[vn] / tight[vn] for vn in need)
+            if best is None or score < best[0]:
+                best = (score, sub, errs)
+    return [cand[i] for i in best[1]], best[2], cand
 
 
 @pytest.mark.parametrize('name', FULL_BATCH_EXACT_FP32)
@@ -225,6 +280,7 @@ def test_full_batch_fp32_substep_against_fp64_oracle(name):
     net = ea.EdgeGAN(cfg, values)
     net.upload_batch(b['images'], b['z'], b['alpha'], b['eps'])
     var_tol = {vn: SELF_DEV_OUTLIERS.get(vn, SELF_DEV_FACTOR) * d for vn, d in self_dev.items()}
+    tight_tol = {vn: max(1e-3, t) for vn, t in var_tol.items()}
     if near_kink:       # (see FLIP_TOL above)
         for vn in var_tol:
             if FLIP_EXPOSED.match(vn):
@@ -233,6 +289,25 @@ def test_full_batch_fp32_substep_against_fp64_oracle(name):
                 var_tol[vn] = max(var_tol[vn], FLIP_TOL_D)
     if live:
         rows = _grad_rows(net, None, None, name, 1e-3, 'B=64', var_tol=var_tol, precomputed=(g64, l64))
+        # rows that needed the flip tolerance: prove that flips of recorded near-kink elements explain them (_flip_proof)
+        gmax = max(float(g.abs().max()) for g in g64.values())
+        need = {}
+        for vn in var_tol:
+            if (FLIP_EXPOSED.match(vn) or FLIP_EXPOSED_D.match(vn)) and vn in g64 and float(g64[vn].abs().max()) >= 1e-9 * gmax:
+                h = net.get_variable(vn + '/grad').astype(np.float64)
+                if parity.rel_l2(h, g64[vn].numpy(), 1e-5 * gmax) > tight_tol[vn]:
+                    need[vn] = h
+        if need:
+            flipped, errs, cand = _flip_proof(name, cfg, values, b, g64, need, tight_tol, gmax)
+            what = ', '.join(f'{c[3]} {c[4]} element {c[1]} at {c[2]:.1e} rms' for c in flipped) or 'none'
+            if os.environ.get('EG_FLIP_REPORT'):
+                print(name, 'flip proof:', len(cand), 'candidates; flipped:', what,
+                      {vn: ('%.1e' % parity.rel_l2(need[vn], g64[vn].numpy(), 1e-5 * gmax), '%.1e' % errs[vn], '%.1e' % tight_tol[vn]) for vn in need})
+            # the proof row REPLACES the row judged at the flip tolerance: tight tolerance, against the oracle with the listed elements mirrored
+            rows = [r for r in rows if not any(f' grad {vn} [' in r[0] for vn in need)]
+            for vn in need:
+                rows.append((f'B=64 {name} grad {vn} against the oracle with {len(flipped)} of {len(cand)} near-kink candidates flipped ({what}) [L2]',
+                             errs[vn], tight_tol[vn]))
     else:
         rows = _grad_rows_digest(net, name, fb, 1e-3, 'B=64', var_tol=var_tol)
     net.close()
