@@ -154,7 +154,7 @@ class kink_recorder:
 class kink_flipper:
     """Re-evaluate a graph with the listed arguments of its piecewise-linear activations on the OTHER side of the kink (mirrored:
     the elements are within rounding of it): flips = [(call index, flat element index), ...] as recorded by
-    kink_recorder(collect=...) on the same graph.  ReLU and the fixed-slope LeakyReLU only."""
+    kink_recorder(collect=...) on the same graph."""
 
     def __init__(self, flips):
         self.flips = {}
@@ -347,7 +347,7 @@ _SLOPE_TERMS = None
 
 def prelu(x: Tensor, leak: Tensor) -> Tensor:
     """activation.py:23-27: tf.maximum(leak*x, x), scalar learnable `param` (init 0.2)."""
-    _kink('prelu/nchw', x)
+    x = _flipped(x, _kink('prelu/nchw', x))
     if _SLOPE_TERMS is not None and leak.requires_grad:
         le = leak * torch.ones_like(x)       # same value per element; its gradient holds the terms t_i
 
