@@ -266,7 +266,7 @@ void conv_backward_x(Ctx& c, T x, T y, WRef* w, int k, int stride);
 void linear1_backward_w(Ctx& c, const float* x, const float* dy, Param* w, Param* bias, int bias_rows, int rows, int K);
 WRef* wref_raw(Ctx& c, const float* w_, float* g, bool* g_set, bool want, int T_, int R, int Cc,
                const std::string& name = std::string());
-T in_act(Ctx& c, T x, int act, T* stats_out = nullptr);
+T in_act(Ctx& c, T x, int act, T* stats_out = nullptr, bool plane_only = false);
 T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int act);
 T act(Ctx& c, T x, int a);
 T act_tangent(Ctx& c, T tx, T out_prim, int a);

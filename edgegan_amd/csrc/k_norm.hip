@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void in_fwd_v(const float* __restrict__ x, flo
   for (int p = pl; p < HW; p += PL) {
     const float4 v = ld4(xp + (size_t)p * C);
     const float4 y = act4(make_float4((v.x - mean.x) * r.x, (v.y - mean.y) * r.y, (v.z - mean.z) * r.z, (v.w - mean.w) * r.w), act);
-    st4(op + (size_t)p * C, y);
+    if (out) st4(op + (size_t)p * C, y);   // (out == nullptr: the output is kept as its bf16 plane only, Tensor::d_plane_only)
     if (out_bf) st_bf4n(out_bf, (size_t)n * HW * C + c + (size_t)p * C, y);
   }
   if (pl == 0) {
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void in_fwd_vr(const float* __restrict__ x, fl
     if (p < HW) {
       const float4 y = act4(make_float4((xv[i].x - mean.x) * r.x, (xv[i].y - mean.y) * r.y, (xv[i].z - mean.z) * r.z,
                                         (xv[i].w - mean.w) * r.w), act);
-      st4(op + (size_t)p * C, y);
+      if (out) st4(op + (size_t)p * C, y);
       if (out_bf) st_bf4n(out_bf, (size_t)n * HW * C + c + (size_t)p * C, y);
     }
   }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
       const float4 d = ld4(dst + i);
       res.x += d.x; res.y += d.y; res.z += d.z; res.w += d.w;
     }
-    st4(dst + i, res);
+    if (dst) st4(dst + i, res);            // (the tangent-forward output may be plane-only too)
     if (dst_bf) st_bf4n(dst_bf, i, res);
   }
 }
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s, int nslab,
                    size_t slab_stride, const float* slab_bias, float* xsum, unsigned short* out_bf) {
   EG_CHECK(!out_bf || C % 32 == 0, "in_fwd: a bf16 plane was requested with C %% 32 != 0");
+  EG_CHECK(out || out_bf, "in_fwd: neither an fp32 output nor a plane");
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
 #define EG_IN_FWD(NP, CQ, G) hipLaunchKernelGGL((in_fwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, HW, C, act, nslab, slab_stride, slab_bias, xsum, out_bf)

@@ -386,7 +386,7 @@ T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_o
     T pre = conv2d(c, x, w, nullptr, 4, 2, PAD_SAME, nullptr, (i == 0 && !tangent_of) ? ACT_LRELU : 0);
     T out, st = nullptr;
     if (!tangent_of) {
-      out = (i == 0) ? pre : in_act(c, pre, ACT_LRELU, &st);
+      out = (i == 0) ? pre : in_act(c, pre, ACT_LRELU, &st, /*plane_only=*/cfg.bf16 && i < 3);   // (layer 3 feeds the linear head)
       if (save) {
         save->pre[i] = pre;
         save->out[i] = out;
@@ -703,6 +703,9 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
     if (planes && ch[i + 1] % 32 == 0 && out[i]->numel() * 2 < (1ull << 31)) {   // the next convolution's operand plane (bf16 mode)
       out[i]->d_bf = reinterpret_cast<unsigned short*>(c.arena.allocf((out[i]->numel() + 1) / 2));
       out[i]->d_bf_stream = nullptr;
+      // layers 1 and 2 are read by convolutions only (their own backward recomputes act'(out) from pre): the plane alone
+      static const bool po_on = dbg_env("EG_NO_PLANE_ONLY_IN") == nullptr;
+      out[i]->d_plane_only = po_on && (i == 1 || i == 2);
     }
     pre[i]->g = c.arena.allocf(pre[i]->numel());
     if (i > 0) out[i]->g = c.arena.allocf(out[i]->numel());
@@ -747,11 +750,12 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
         const int HW = pre[i]->h * pre[i]->w, C = ch[i + 1];
         const size_t img = (size_t)HW * C;
         if (ne > 0)
-          launch_in_fwd(yv->d, out[i]->d + (size_t)n0 * img, st[i]->d + (size_t)n0 * 2 * C, ne, HW, C, ACT_LRELU, c.stream, 0, 0, nullptr,
-                        nullptr, out[i]->d_bf ? out[i]->d_bf + (size_t)n0 * img : nullptr);
+          launch_in_fwd(yv->d, out[i]->d_plane_only ? nullptr : out[i]->d + (size_t)n0 * img, st[i]->d + (size_t)n0 * 2 * C, ne, HW, C,
+                        ACT_LRELU, c.stream, 0, 0, nullptr, nullptr, out[i]->d_bf ? out[i]->d_bf + (size_t)n0 * img : nullptr);
         if (nt > 0)   // the tangent rows: linearised at the primal rows [0,B) (x, out, statistics)
-          launch_in_tangent_fwd(pre[i]->d, out[i]->d, st[i]->d, yv->d + (size_t)ne * img, out[i]->d + (size_t)(n0 + ne) * img, nt, HW, C,
-                                ACT_LRELU, c.stream, out[i]->d_bf ? out[i]->d_bf + (size_t)(n0 + ne) * img : nullptr);
+          launch_in_tangent_fwd(pre[i]->d, out[i]->d, st[i]->d, yv->d + (size_t)ne * img,
+                                out[i]->d_plane_only ? nullptr : out[i]->d + (size_t)(n0 + ne) * img, nt, HW, C, ACT_LRELU, c.stream,
+                                out[i]->d_bf ? out[i]->d_bf + (size_t)(n0 + ne) * img : nullptr);
       }
       xin = rows(out[i], n0, n);
     }

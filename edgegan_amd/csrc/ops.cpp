@@ -1084,6 +1084,7 @@ T view_rows(Ctx& c, T parent, int n0, int n) {
   if (parent->d_bf) {
     v->d_bf = parent->d_bf + off;
     v->d_bf_stream = parent->d_bf_stream;
+    v->d_plane_only = parent->d_plane_only;   // (a reader of the view that wants fp32 widens the view's rows: need_f32)
   }
   if (parent->g_bf) {
     v->g_bf = parent->g_bf + off;
@@ -1285,18 +1286,24 @@ T linear1(Ctx& c, T x, Param* w, Param* bias) {
 }
 
 // normalization.py:13-18 + activation.py:4-15 (fused)
-T in_act(Ctx& c, T x, int a, T* stats_out) {
+T in_act(Ctx& c, T x, int a, T* stats_out, bool plane_only) {
   T out = new_tensor(c, x->n, x->h, x->w, x->c, x->needs_grad);
   T st = new_tensor(c, x->n, 1, 1, 2 * x->c, false);
   const int HW = x->h * x->w;
+  // plane_only (bf16 mode, the caller knows every reader is a dense contraction): the output is stored as its bf16 plane alone --
+  // the backward recomputes act'(out) from x (k_norm.hip: actg_from_x), a reader that wants fp32 widens the plane (need_f32)
+  unsigned short* plane = producer_plane(c, out, false);
+  static const bool po_on = dbg_env("EG_NO_PLANE_ONLY_IN") == nullptr;
+  out->d_plane_only = po_on && plane_only && plane != nullptr;
+  float* od = out->d_plane_only ? nullptr : out->d;
   EG_CHECK(x->nslab <= 1 || (x->c % 32 == 0 && HW <= 1024), "in_act: slab input needs C %% 32 == 0 and HW <= 1024");
   if (x->nslab > 1) {   // a K-split convolution output that was left as slabs for this pass (conv2d); in a training graph
                         // the pass also stores the sum into x->d: from here on x is an ordinary tensor
-    launch_in_fwd(x->slabs, out->d, st->d, x->n, HW, x->c, a, c.stream, x->nslab, x->numel(), x->slab_bias,
-                  x->needs_grad ? x->d : nullptr, producer_plane(c, out, false));
+    launch_in_fwd(x->slabs, od, st->d, x->n, HW, x->c, a, c.stream, x->nslab, x->numel(), x->slab_bias,
+                  x->needs_grad ? x->d : nullptr, plane);
     if (x->needs_grad) x->nslab = 0;
   } else
-    launch_in_fwd(x->d, out->d, st->d, x->n, HW, x->c, a, c.stream, 0, 0, nullptr, nullptr, producer_plane(c, out, false));
+    launch_in_fwd(x->d, od, st->d, x->n, HW, x->c, a, c.stream, 0, 0, nullptr, nullptr, plane);
   if (stats_out) *stats_out = st;
   if (x->needs_grad) {
     out->g_slab_ok = in_bwd_takes_slabs(HW, x->c);
