@@ -91,8 +91,8 @@ def test_bf16_substeps_14_classes():
 
 
 @pytest.mark.parametrize('name,B,H,W', [('d_optim', 16, 64, 128), ('d_optim2', 16, 64, 128), ('g_optim_u', 16, 64, 128),
-                                        ('d_optim2', 2, 256, 512)],
-                         ids=['d_optim-b16', 'd_optim2-b16', 'g_optim_u-b16', 'd_optim2-256x512-b2'])
+                                        ('d_optim2', 2, 256, 512), ('d_optim_patch3', 16, 64, 128), ('d_optim2', 64, 64, 128)],
+                         ids=['d_optim-b16', 'd_optim2-b16', 'g_optim_u-b16', 'd_optim2-256x512-b2', 'd_optim_patch3-b16', 'd_optim2-b64'])
 def test_bf16_substep_at_batch16_against_the_emulating_oracle(name, B, H, W):
     """the bf16 mode against the EMULATING oracle (operands of every qualifying contraction rounded to
     bf16 exactly as the engine rounds them, everything else fp64: edgegan/models/edgegan.py:109-116 evaluated under
@@ -107,10 +107,15 @@ def test_bf16_substep_at_batch16_against_the_emulating_oracle(name, B, H, W):
     variables, scalar PReLU slopes judged in absolute terms (below).  A wiring / stale-plane bug shows as >= 3e-1.
     Round 5: the generators' sub-step g_optim_u at batch 16 (all four critics' input-gradient chains, the
     transposed convolutions' phases) and the classifier's sub-step at configs[4]'s geometry (256x512, batch 2: 128x128 ...
-    16x16 maps, 2^2 more pixels per image than any 64x128 test) against the same emulating oracle."""
+    16x16 maps, 2^2 more pixels per image than any 64x128 test) against the same emulating oracle; later in round 5 the edge
+    discriminator's sub-step (bicubic resize in front of the stacked passes) at batch 16 and the classifier's sub-step at configs[3]'s
+    full per-GPU batch of 64.  (The encoder's sub-step is not in this list on purpose: at random init the emulating oracle's OWN
+    fp32-vs-fp64 deviation on it is 0.2 ... 0.3 for most filters -- bf16 rounding moves the signs inside its L1 loss and the ReLU
+    decisions of its 4 ... 16-pixel InstanceNorm layers -- so a tolerance derived from it proves nothing; measured engine error 0.21
+    median.  Its bf16 coverage is the batch-2 test above and the property tests below.)"""
     import full_batch_lib as FB
     import test_tight_gpu as TT
-    key = ('bf16_b16/' if (B, H, W) == (16, 64, 128) else f'bf16_{H}x{W}_b{B}/') + name
+    key = (f'bf16_b{B}/' if (H, W) == (64, 128) else f'bf16_{H}x{W}_b{B}/') + name
     case = FB.CASE[key]
     cfg = ea.Config(compute_dtype='bf16', **case[2])
     values = ea.init_variables(cfg, case[3])
