@@ -136,6 +136,11 @@ struct Tensor {
   // out = prelu(x) with a learned slope (prelu_tail): x and the slope -- the single input-gradient convolution that writes out's
   // gradient may apply the PReLU's backward in its epilogue (ConvArgs::epi_act = ACT_PRELU_X; then g_act_done, and x's gradient
   // IS this buffer)
+  // bf16 mode: the gradient of a convolution's output (g_plane_ok, set by conv2d) whose writer is an element-wise backward kernel
+  // with a plane store is kept as that plane alone (g_plane_only; kernels.h: GRAD_PLANE_ONLY) -- both gradient kernels of the
+  // convolution read planes; a reader that wants fp32 widens its own copy (ops.cpp: grad_f32_view), a second writer widens in place
+  bool g_plane_ok = false;
+  bool g_plane_only = false;
   Tensor* prelu_pre = nullptr;
   Param* prelu_leak = nullptr;
   bool g_up_ok = false;

@@ -585,11 +585,11 @@ __global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restric
     const bool f0 = lk * v.x >= v.x, f1 = lk * v.y >= v.y, f2 = lk * v.z >= v.z, f3 = lk * v.w >= v.w;
     if (dx) {
       float4 o = make_float4(f0 ? lk * g.x : g.x, f1 ? lk * g.y : g.y, f2 ? lk * g.z : g.z, f3 ? lk * g.w : g.w);
-      if (acc_dx) {
+      if (acc_dx & 1) {
         const float4 d = reinterpret_cast<const float4*>(dx)[i];
         o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
       }
-      reinterpret_cast<float4*>(dx)[i] = o;
+      if (!(acc_dx & 2)) reinterpret_cast<float4*>(dx)[i] = o;   // (GRAD_PLANE_ONLY)
       if (dx_bf) st_bf4(dx_bf, i, o);
       cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
     }
@@ -642,6 +642,7 @@ void launch_prelu_bwd(const float* x, const float* dy, const float* leak_p, floa
                       float* dleak, int acc_dleak, size_t n, float* scratch, hipStream_t s, unsigned short* dx_bf,
                       const SlabSrc* dy_slabs, float* colpart, int C) {
   int nb;
+  EG_CHECK(!(acc_dx & GRAD_PLANE_ONLY) || dx_bf, "prelu_bwd: GRAD_PLANE_ONLY without a plane");
   if (ew_vec_ok(n, x, dy, dx)) {
     nb = colpart ? flat_colpart_rows(n, C) : ew_blocks(n / 4, 2048);
     EG_CHECK(nb > 0 && (!colpart || dx), "prelu_bwd: column partials were requested from a form that has none");
@@ -819,8 +820,8 @@ __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x,
       r[j] *= mm_slope(xx[j], lk);
     }
     float4 o = make_float4(r[0], r[1], r[2], r[3]);
-    if (acc) { const float4 t = ld4(dx + i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
-    st4(dx + i, o);
+    if (acc & 1) { const float4 t = ld4(dx + i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+    if (!(acc & 2)) st4(dx + i, o);      // (bit 1 of the accumulate argument: the gradient is kept as its bf16 plane only, kernels.h: GRAD_PLANE_ONLY)
     if (dx_bf) st_bf4(dx_bf, i >> 2, o);
     cs[0].x += o.x; cs[0].y += o.y; cs[0].z += o.z; cs[0].w += o.w;
   }
@@ -848,6 +849,7 @@ int minmax_bwd_colpart_rows(int NB, int C) { return C % 8 == 0 ? NB : 0; }
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
                        int HW, int C, hipStream_t s, float pre_leak, unsigned short* dx_bf, float* colpart) {
   EG_CHECK(!colpart || C % 8 == 0, "minmax_bwd: column partials need C %% 8 == 0");
+  EG_CHECK(!(accumulate & GRAD_PLANE_ONLY) || dx_bf, "minmax_bwd: GRAD_PLANE_ONLY without a plane");
   if (C % 32 == 0) {
     hipLaunchKernelGGL(minmax_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, dx_bf, colpart);
     return;

@@ -367,11 +367,11 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
     float4 res = make_float4(st.r.x * (e.x - eb.x) - k2.x * (xv.x - st.mean.x), st.r.y * (e.y - eb.y) - k2.y * (xv.y - st.mean.y),
                              st.r.z * (e.z - eb.z) - k2.z * (xv.z - st.mean.z), st.r.w * (e.w - eb.w) - k2.w * (xv.w - st.mean.w));
     if (MODE == 1) { res.x *= g.x; res.y *= g.y; res.z *= g.z; res.w *= g.w; }
-    if (accumulate) {
+    if (accumulate & 1) {
       const float4 d = ld4(dst + i);
       res.x += d.x; res.y += d.y; res.z += d.z; res.w += d.w;
     }
-    if (dst) st4(dst + i, res);            // (the tangent-forward output may be plane-only too)
+    if (dst && !(accumulate & 2)) st4(dst + i, res);   // (plane-only: the tangent-forward output, or GRAD_PLANE_ONLY)
     if (dst_bf) st_bf4n(dst_bf, i, res);
   }
 }
@@ -422,11 +422,11 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
       const size_t i = base + (size_t)p * C;
       float4 res = make_float4(st.r.x * (ev[k].x - eb.x) - k2.x * xc[k].x, st.r.y * (ev[k].y - eb.y) - k2.y * xc[k].y,
                                st.r.z * (ev[k].z - eb.z) - k2.z * xc[k].z, st.r.w * (ev[k].w - eb.w) - k2.w * xc[k].w);
-      if (accumulate) {
+      if (accumulate & 1) {
         const float4 d = ld4(dst + i);
         res.x += d.x; res.y += d.y; res.z += d.z; res.w += d.w;
       }
-      st4(dst + i, res);
+      if (!(accumulate & 2)) st4(dst + i, res);   // (GRAD_PLANE_ONLY)
       if (dst_bf) st_bf4n(dst_bf, i, res);
       cs[0].x += res.x; cs[0].y += res.y; cs[0].z += res.z; cs[0].w += res.w;
     }
@@ -463,6 +463,7 @@ void launch_in_bwd(const float* x, const float* out, const float* dout, const fl
                    const SlabSrc* dout_slabs, float* colpart) {
   EG_CHECK(!colpart || in_bwd_colpart_rows(NB, HW, C), "in_bwd: column partials need C %% 32 == 0 and HW <= 1024");
   EG_CHECK(!dx_bf || C % 32 == 0, "in_bwd: a bf16 plane was requested with C %% 32 != 0");
+  EG_CHECK(!(accumulate & GRAD_PLANE_ONLY) || dx_bf, "in_bwd: GRAD_PLANE_ONLY without a plane");
   EG_CHECK(!dout_slabs || in_bwd_takes_slabs(HW, C), "in_bwd: a slab input needs C %% 32 == 0 and HW <= 1024");
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
@@ -555,9 +556,9 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_v(const float* __restrict_
       gx[j] = c1[j] * xc[j] + c2[j] * (tt[j] - tav[j]) + c3[j] * (e[j] - ebv[j]);
     }
     float4 o1 = make_float4(gt[0], gt[1], gt[2], gt[3]), o2 = make_float4(gx[0], gx[1], gx[2], gx[3]);
-    if (acc_dtx) { const float4 a = ld4(dtx + i); o1.x += a.x; o1.y += a.y; o1.z += a.z; o1.w += a.w; }
+    if (acc_dtx & 1) { const float4 a = ld4(dtx + i); o1.x += a.x; o1.y += a.y; o1.z += a.z; o1.w += a.w; }
     if (acc_dx) { const float4 a = ld4(dx + i); o2.x += a.x; o2.y += a.y; o2.z += a.z; o2.w += a.w; }
-    st4(dtx + i, o1);
+    if (!(acc_dtx & 2)) st4(dtx + i, o1);   // (GRAD_PLANE_ONLY)
     if (dtx_bf) st_bf4n(dtx_bf, i, o1);
     st4(dx + i, o2);
   }
@@ -641,9 +642,9 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_vr(const float* __restrict
         gx[j] = c1[j] * q[j] + c2[j] * (tt[j] - tav[j]) + c3[j] * (e[j] - ebv[j]);
       }
       float4 o1 = make_float4(gt[0], gt[1], gt[2], gt[3]), o2 = make_float4(gx[0], gx[1], gx[2], gx[3]);
-      if (acc_dtx) { const float4 a = ld4(dtx + i); o1.x += a.x; o1.y += a.y; o1.z += a.z; o1.w += a.w; }
+      if (acc_dtx & 1) { const float4 a = ld4(dtx + i); o1.x += a.x; o1.y += a.y; o1.z += a.z; o1.w += a.w; }
       if (acc_dx) { const float4 a = ld4(dx + i); o2.x += a.x; o2.y += a.y; o2.z += a.z; o2.w += a.w; }
-      st4(dtx + i, o1);
+      if (!(acc_dtx & 2)) st4(dtx + i, o1);   // (GRAD_PLANE_ONLY)
       if (dtx_bf) st_bf4n(dtx_bf, i, o1);
       st4(dx + i, o2);
     }
@@ -654,6 +655,7 @@ void launch_in_tangent_bwd(const float* x, const float* out, const float* stats,
                            const float* dtout, float* dtx, int acc_dtx, float* dx, int acc_dx, int NB, int HW,
                            int C, int act, hipStream_t s, unsigned short* dtx_bf) {
   EG_CHECK(!dtx_bf || C % 32 == 0, "in_tangent_bwd: a bf16 plane was requested with C %% 32 != 0");
+  EG_CHECK(!(acc_dtx & GRAD_PLANE_ONLY) || dtx_bf, "in_tangent_bwd: GRAD_PLANE_ONLY without a plane");
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
 #define EG_IN_TBWD(NP, CQ, G) hipLaunchKernelGGL((in_tangent_bwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, tx, dtout, dtx, acc_dtx, dx, acc_dx, HW, C, act, dtx_bf)

@@ -105,6 +105,10 @@ struct ConvArgs {
   int caps;          // OUT, set by launch_conv_gemm: what the kernel that ran honoured (CONV_CAP_*); ksplit is written back too
   int tuned;         // conv_pick_ksplit took (x3_tile, ksplit) from the measured per-shape table (x3_tuned.h): run_conv keeps them
 };
+// bit 1 of the `accumulate` argument of the gradient writers that can store a bf16 plane (in_bwd, in_tangent_bwd's tangent output,
+// prelu_bwd, minmax_bwd -- their float4 forms): compute, store the plane, do NOT store the fp32 gradient (bf16 mode: both
+// gradient kernels of the convolution behind it read the plane; ops.cpp: Tensor::g_plane_only)
+enum { GRAD_ACCUMULATE = 1, GRAD_PLANE_ONLY = 2 };
 enum ConvCaps { CONV_CAP_EPI_ACT = 1, CONV_CAP_Y2 = 2, CONV_CAP_POOL = 4 };
 
 // A tensor that may still be the K-split slabs of the convolution that produced it (ConvArgs::keep_slabs): its value is

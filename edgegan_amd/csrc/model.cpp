@@ -765,13 +765,17 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
     if (nt > 0) launch_gemv_fwd(out[3]->d + (size_t)(n0 + ne) * feat, lw->w, nullptr, dval + n0 + ne, nt, K, c.stream);
   };
   // norm + activation backward of layer i for rows [n0, n0 + n) of the evaluated points: gout -> gpre
+  static const bool gpo_on = dbg_env("EG_NO_PLANE_ONLY_GRAD") == nullptr;
+  const int gpo = gpo_on ? GRAD_PLANE_ONLY : 0;
   auto norm_bwd = [&](int i, int n0, int n, int acc) {
     const int HW = pre[i]->h * pre[i]->w, C = ch[i + 1];
     const size_t img = (size_t)HW * C, o = (size_t)n0 * img;
-    launch_in_bwd(pre[i]->d + o, out[i]->d + o, out[i]->g + o, st[i]->d + (size_t)n0 * 2 * C, pre[i]->g + o, acc, n, HW, C, ACT_LRELU,
-                  c.stream, gpl[i] ? gpl[i] + o : nullptr);
+    // (gpo: the fp32 gradient of pre[i] is not stored -- both gradient convolutions of layer i read the plane, Tensor::g_plane_only)
+    launch_in_bwd(pre[i]->d + o, out[i]->d + o, out[i]->g + o, st[i]->d + (size_t)n0 * 2 * C, pre[i]->g + o, acc | (gpl[i] ? gpo : 0), n, HW, C,
+                  ACT_LRELU, c.stream, gpl[i] ? gpl[i] + o : nullptr);
     pre[i]->g_bf = gpl[i];            // (rows [n0, n0 + n) of the plane are current; view_rows hands them on)
     pre[i]->g_bf_stream = nullptr;
+    pre[i]->g_plane_only = gpl[i] && gpo;
   };
   // ---- phase 1: x_hat, and the first-order gradient g = d/dx_hat sum_b [sigmoid(D) + D] (quirk N10) ----
   forward(0, B);
@@ -814,7 +818,7 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
     const size_t img = (size_t)HW * C, ot = (size_t)3 * B * img;
     norm_bwd(i, B, 2 * B, 0);                                  // real | fake
     // the tangent rows: reverse of the linearisation -- gradient w.r.t. the tangent AND w.r.t. the primal pre-norm rows [0,B)
-    launch_in_tangent_bwd(pre[i]->d, out[i]->d, st[i]->d, pre[i]->d + ot, out[i]->g + ot, pre[i]->g + ot, 0, pre[i]->g, 0, B, HW, C,
+    launch_in_tangent_bwd(pre[i]->d, out[i]->d, st[i]->d, pre[i]->d + ot, out[i]->g + ot, pre[i]->g + ot, gpl[i] ? gpo : 0, pre[i]->g, 0, B, HW, C,
                           ACT_LRELU, c.stream, gpl[i] ? gpl[i] + ot : nullptr);
     norm_bwd(i, 0, B, 1);                                      // the primal rows add their own first-order term
     pre[i]->g_set = true;

@@ -150,6 +150,21 @@ static void materialize_up(Ctx& c, T t) {
   launch_pool2_bwd(t->g_up->g, t->g, 0, t->n, t->h, t->w, t->c, c.stream, nullptr);
   t->g_up = nullptr;
 }
+// Tensor::g_plane_only.  plane_only_acc: the `accumulate` argument of a gradient writer that stores `plane` -- with GRAD_PLANE_ONLY
+// where the fp32 gradient of t need not exist; grad_f32_view: the fp32 gradient for a reader without a plane-fed form (its own
+// widened copy on its own stream: the filter gradient runs on the leaf stream, the input gradient on the main one).
+static int plane_only_acc(Ctx& c, T t, int acc, const unsigned short* plane) {
+  static const bool on = dbg_env("EG_NO_PLANE_ONLY_GRAD") == nullptr;
+  if (!on || !c.cfg.bf16 || !t->g_plane_ok || acc || !plane) return acc;
+  t->g_plane_only = true;
+  return GRAD_PLANE_ONLY;
+}
+static const float* grad_f32_view(Ctx& c, T t) {
+  if (!t->g_plane_only) return t->g;
+  float* full = c.arena.allocf(t->numel());
+  launch_cvt_from_bf16(t->g_bf, full, t->numel(), c.stream);
+  return full;
+}
 // Column partials of the gradient a backward kernel is about to write as the FIRST writer (acc == 0) of tensor t, if t's producer
 // asked for them (a convolution with a trainable bias: Tensor::want_colpart) and the kernel form has `rows` > 0 of them
 static float* colpart_for(Ctx& c, T t, int acc, int rows) {
@@ -173,7 +188,7 @@ static void bias_grad_of(Ctx& c, Param* b, T y) {
     bias_grad(c, b, y->g_colsum_src, y->g_colsum_rows, y->c);   // (pool2_add: a quarter of the rows)
   } else {
     materialize_up(c, y);
-    bias_grad(c, b, y->g, y->pixels(), y->c);
+    bias_grad(c, b, grad_f32_view(c, y), y->pixels(), y->c);
   }
 }
 
@@ -183,6 +198,8 @@ static bool flat_slab_ok(T t) { return t->c % 4 == 0 && t->numel() < (1ull << 31
 float* grad_acc(Ctx& c, T t, int* acc) {
   if (!t->g) t->g = c.arena.allocf(t->numel());
   EG_CHECK(!t->g_up, "a second gradient contribution reached a tensor whose gradient is held as its pooled form");
+  if (t->g_set && t->g_plane_only) launch_cvt_from_bf16(t->g_bf, t->g, t->numel(), c.stream);   // (a second writer adds to the fp32 value)
+  t->g_plane_only = false;
   if (t->g_set) materialize_grad(c, t);   // (the first writer left K-split slabs: a second one adds to their sum)
   // ConvArgs::epi_act: the FIRST writer applied the fused activation's derivative in its epilogue and the producer will
   // skip its in-place pass -- exact only if that writer stays the ONLY one.  A second consumer accumulating a raw
@@ -208,6 +225,7 @@ void reset_grads(Ctx& c) {
     t.g_colsum_src = nullptr;
     t.g_colpart = nullptr;
     t.g_up = nullptr;
+    t.g_plane_only = false;
   }
   for (auto& p : c.params) p->g_set = false;
   for (auto& s : c.sn) s.dWbar_set = false;
@@ -618,6 +636,7 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad, float* x_full) {
     a.x_bf = conv_bf16p_eligible(a) ? tensor_plane(c, xsrc, xgrad) : nullptr;
   }
   if (xsrc && !xgrad && !a.x_bf) need_f32(c, xsrc);   // (a plane-only operand and a kernel that gathers fp32)
+  if (xsrc && xgrad && !a.x_bf && xsrc->g_plane_only && a.x == xsrc->g) a.x = grad_f32_view(c, xsrc);
   if (a.epi_soft && a.ksplit > 1) {   // a K-split launch has no epilogue: its consumer's pass sums the slabs (ConvArgs::epi_soft)
     a.epi_act = 0;
     a.epi_bf = nullptr;
@@ -859,6 +878,8 @@ static void conv_wgrad(Ctx& c, T xt, bool xgrad, int NB, int IH, int IW, int C, 
   if (!g.x_bf) {
     if (!xgrad) need_f32(c, xt);
     if (!dygrad) need_f32(c, dyt);
+    if (dygrad && dsrc->g_plane_only) g.dy = grad_f32_view(c, dsrc);
+    if (xgrad && xt->g_plane_only) g.x = grad_f32_view(c, xt);
   }
   g.nsplit = wgrad_pick_splits(g);
   const size_t wsf = wgrad_workspace_floats(g);
@@ -1030,6 +1051,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     y->needs_grad = true;
     y->g_inplace = fused;
     y->fused_act = fused ? fused_act : 0;
+    y->g_plane_ok = c.cfg.bf16 && k > 1 && N % 64 == 0 && !fused && !accumulate_into;   // (the closure below reads y's gradient through planes)
     if (bias && bias->want_grad && !accumulate_into) y->want_colpart = true;   // (the writer of y's gradient may sum its columns)
     Ctx* cp = &c;
     c.tape.push([=]() {
@@ -1089,6 +1111,7 @@ T view_rows(Ctx& c, T parent, int n0, int n) {
   if (parent->g_bf) {
     v->g_bf = parent->g_bf + off;
     v->g_bf_stream = parent->g_bf_stream;
+    v->g_plane_only = parent->g_plane_only;
   }
   return v;
 }
@@ -1316,7 +1339,8 @@ T in_act(Ctx& c, T x, int a, T* stats_out, bool plane_only) {
       const SlabSrc ds = grad_src(out);
       const int prow = in_bwd_colpart_rows(x->n, HW, x->c);
       float* part = colpart_for(c, x, acc, prow);
-      launch_in_bwd(x->d, out->d, out->g, st->d, dx, acc, x->n, HW, x->c, a, c.stream, producer_plane(c, x, true),
+      unsigned short* gplane = producer_plane(c, x, true);
+      launch_in_bwd(x->d, out->d, out->g, st->d, dx, plane_only_acc(c, x, acc, gplane), x->n, HW, x->c, a, c.stream, gplane,
                     ds.n > 1 ? &ds : nullptr, part);
       colpart_done(x, part, prow);
     });
@@ -1756,8 +1780,9 @@ static T prelu_tail(Ctx& c, T x, T out, Param* leak, float leak_const) {
       const SlabSrc ds = grad_src(out);
       const int prow = dx ? flat_colpart_rows(x->numel(), x->c) : 0;
       float* part = dx ? colpart_for(c, x, acc, prow) : nullptr;
-      launch_prelu_bwd(x->d, out->g, leak ? leak->w : nullptr, leak_const, dx, acc, pg ? leak->g : nullptr,
-                       pg && leak->g_set ? 1 : 0, x->numel(), c.scratch, c.stream, dx ? producer_plane(c, x, true) : nullptr,
+      unsigned short* gplane = dx ? producer_plane(c, x, true) : nullptr;
+      launch_prelu_bwd(x->d, out->g, leak ? leak->w : nullptr, leak_const, dx, dx ? plane_only_acc(c, x, acc, gplane) : acc,
+                       pg ? leak->g : nullptr, pg && leak->g_set ? 1 : 0, x->numel(), c.scratch, c.stream, gplane,
                        ds.n > 1 ? &ds : nullptr, part, x->c);
       colpart_done(x, part, prow);
       if (pg) leak->g_set = true;
@@ -1783,7 +1808,8 @@ T minmax(Ctx& c, T x, float pre_leak) {
       float* dx = grad_acc(c, x, &acc);
       const int prow = minmax_bwd_colpart_rows(x->n, x->c);
       float* part = colpart_for(c, x, acc, prow);
-      launch_minmax_bwd(x->d, mm->d, out->g, dx, acc, x->n, HW, x->c, c.stream, pre_leak, producer_plane(c, x, true), part);
+      unsigned short* gplane = producer_plane(c, x, true);
+      launch_minmax_bwd(x->d, mm->d, out->g, dx, plane_only_acc(c, x, acc, gplane), x->n, HW, x->c, c.stream, pre_leak, gplane, part);
       colpart_done(x, part, prow);
     });
   }
