@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256, ((HR <= 288 && SW16) ? 3 : 2)) void conv_bf16p
               }
             }
           }
-          if ((EG_BF16P_DBG & 32) == 0 || v.x == 123.456f) *reinterpret_cast<float4*>(yrow + n) = v;
+          if (((EG_BF16P_DBG & 32) == 0 || v.x == 123.456f) && (SPLITK || !a.epi_skip_f32)) *reinterpret_cast<float4*>(yrow + n) = v;
           if constexpr (!SPLITK) {
             if (a.y2_leak) conv_epi_y2(a, (size_t)(yrow - a.y) + n, v, y2lk);
             if (a.epi_bf) conv_epi_plane(a.epi_bf + (size_t)(yrow - a.y) + n, v);

@@ -594,7 +594,8 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
               }
             }
           }
-          if ((EG_X3H_DBG & 128) == 0 || v.x == 123.456f) *reinterpret_cast<float4*>(yrow + n) = v;   // (bit 7: timing without the output stores)
+          if (((EG_X3H_DBG & 128) == 0 || v.x == 123.456f) && (SPLITK || !a.epi_skip_f32))
+            *reinterpret_cast<float4*>(yrow + n) = v;   // (bit 7: timing without the output stores)
           if constexpr (!SPLITK) {
             if (a.y2_leak) conv_epi_y2(a, (size_t)(yrow - a.y) + n, v, y2lk);
             if (a.epi_bf) conv_epi_plane(a.epi_bf + (size_t)(yrow - a.y) + n, v);

@@ -78,6 +78,7 @@ struct ConvArgs {
   const float* epi_leak;   // epi_act == ACT_PRELU_X: y holds dL/d(prelu output), epi_ref the PReLU's INPUT x, *epi_leak its slope lk; the
                            //   kernel stores (lk x >= x ? lk y : y) -- prelu_bwd's expression (k_elem.hip) -- and, with epi_bf, its bf16 plane
   unsigned short* epi_bf;
+  int epi_skip_f32;        // with epi_bf, un-split launches of the kernels that honour it: the fp32 output is NOT stored (its readers take the plane)
   int epi_soft;            // run_conv: a K-split launch drops the epilogue request and keeps its slabs instead (keep_slabs_soft)
   int keep_slabs_soft;
   unsigned long long epi_wrap;   // > 0: output elements at or beyond this index take epi_ref[index - epi_wrap] (the stacked

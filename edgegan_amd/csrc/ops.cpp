@@ -640,6 +640,7 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad, float* x_full) {
   if (a.epi_soft && a.ksplit > 1) {   // a K-split launch has no epilogue: its consumer's pass sums the slabs (ConvArgs::epi_soft)
     a.epi_act = 0;
     a.epi_bf = nullptr;
+    a.epi_skip_f32 = 0;
     a.keep_slabs = a.keep_slabs_soft;
   }
   a.ws = a.ksplit > 1 ? c.arena.allocf((size_t)a.ksplit * a.y_total) : nullptr;
@@ -761,7 +762,12 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
       a.epi_act = ACT_PRELU_X;
       a.epi_leak = x->prelu_leak->w;
       a.epi_soft = 1;
-      if (c.cfg.bf16 && x->c % 32 == 0) a.epi_bf = reinterpret_cast<unsigned short*>(c.arena.allocf((x->numel() + 1) / 2));
+      if (c.cfg.bf16 && x->c % 32 == 0) {
+        a.epi_bf = reinterpret_cast<unsigned short*>(c.arena.allocf((x->numel() + 1) / 2));
+        // d(pre) is read by the gradient kernels of the convolution behind `pre` only: the plane alone (Tensor::g_plane_only)
+        static const bool gpo_on = dbg_env("EG_NO_PLANE_ONLY_GRAD") == nullptr;
+        a.epi_skip_f32 = gpo_on && pre->g_plane_ok ? 1 : 0;
+      }
     }
   } else {
     EG_CHECK(stride == 2 && x->h % 2 == 0 && x->w % 2 == 0, "stride-2 dgrad needs even extents");
@@ -814,6 +820,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
   if (a.epi_act == ACT_PRELU_X && a.epi_applied && a.epi_bf) {   // the plane of what was stored = d(pre)
     x->g_bf = a.epi_bf;
     x->g_bf_stream = nullptr;
+    x->g_plane_only = a.epi_skip_f32 != 0;
   }
   if (a.keep_slabs && a.ksplit > 1) {
     x->g_slabs = a.ws;
@@ -1768,6 +1775,7 @@ static T prelu_tail(Ctx& c, T x, T out, Param* leak, float leak_const) {
         x->g_set = true;
         x->g_bf = out->g_bf;
         x->g_bf_stream = out->g_bf_stream;
+        x->g_plane_only = out->g_plane_only;
         x->g_colsum_src = nullptr;
         x->g_colpart = nullptr;
         return;
