@@ -119,6 +119,7 @@ struct Ctx {
   // bf16 mode, set by a caller right before conv2d(..., post_prelu): the PReLU output is read by plane-fed contractions only,
   // so it is stored as its bf16 plane alone (Tensor::d_plane_only; consumed by that convolution)
   bool prelu_plane_only = false;
+  bool conv_plane_only_next = false;   // the next conv2d stores its fused-activation output as the bf16 plane alone where the packed-K kernel writes one (ops.cpp)
   T conv_out_into = nullptr;   // conv_into(): the next conv2d writes its result here and records nothing on the tape
   // conv2d_pool2_add(): the pooled outputs the next conv2d offers to its kernel's epilogue, and whether the kernel took them
   struct PoolEpi {
@@ -254,6 +255,7 @@ T reshape(Ctx& c, T src, int n, int h, int w, int ch);
 // ---- explicit (tape-free) pieces for schedules the linear tape cannot express: the stacked discriminator sub-step (model.cpp) ----
 // images [n0, n0 + n) of a tensor as a tensor of their own: data, gradient and bf16 planes alias the parent's (the parent's
 // gradient buffer is allocated here if needed); no tape entry, g_set is the view's own
+void tensor_need_f32(Ctx& c, T t);   // widen a plane-only tensor (Tensor::d_plane_only) for a reader of its fp32 values
 T view_rows(Ctx& c, T parent, int n0, int n);
 // y = conv(x, w) (SAME) (+ ReLU / LeakyReLU where the thin kernels fuse it), forward only, into y.  Returns bit 0: the activation
 // was applied, bit 1: the kernel also stored y's bf16 plane rows (bf16 mode, y->d_bf given)

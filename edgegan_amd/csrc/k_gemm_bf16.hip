@@ -19,6 +19,7 @@
 // register -> LDS store: a thread owns 4 channels x 2 pixels and writes 4 dwords (2 pixels packed) to 4 rows.  A
 // half wave is 8 channel quads (one 128-byte line per pixel, so the global loads stay coalesced) x 4 pixel pairs;
 // the swizzle plus a per-lane order of the 4 row stores makes every ds_write_b32 hit 32 distinct banks.
+#include "common.h"
 #include "kernels.h"
 
 namespace eg {
@@ -501,6 +502,38 @@ void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n4);
+}
+__global__ void act_bwd_bf_kernel(const unsigned short* __restrict__ out_bf, const float* __restrict__ dout, float* __restrict__ dx,
+                                  unsigned short* __restrict__ dx_bf, size_t n4, int act) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const uint2 q = reinterpret_cast<const uint2*>(out_bf)[i];
+    const float o[4] = {__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xffff0000u),
+                        __builtin_bit_cast(float, q.y << 16), __builtin_bit_cast(float, q.y & 0xffff0000u)};
+    const float4 d = reinterpret_cast<const float4*>(dout)[i];
+    const float dv[4] = {d.x, d.y, d.z, d.w};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)   // slopes as act_grad_from_out (k_norm.hip): ReLU o > 0 ? 1 : 0, LeakyReLU o >= 0 ? 1 : 0.2
+      r[j] = dv[j] * (act == ACT_LRELU ? (o[j] >= 0.f ? 1.f : 0.2f) : (o[j] > 0.f ? 1.f : 0.f));
+    if (dx) reinterpret_cast<float4*>(dx)[i] = make_float4(r[0], r[1], r[2], r[3]);
+    if (dx_bf) {
+      typedef __bf16 bf16x2_a __attribute__((ext_vector_type(2)));
+      typedef float f32x2_a __attribute__((ext_vector_type(2)));
+      const f32x2_a lo = {r[0], r[1]}, hi = {r[2], r[3]};
+      uint2 w;
+      w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_a));
+      w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_a));
+      reinterpret_cast<uint2*>(dx_bf)[i] = w;
+    }
+  }
+}
+void launch_act_bwd_bf(const unsigned short* out_bf, const float* dout, float* dx, unsigned short* dx_bf, size_t n, int act, hipStream_t s) {
+  EG_CHECK(n % 4 == 0 && (act == ACT_RELU || act == ACT_LRELU), "act_bwd_bf: n %% 4 == 0, ReLU / LeakyReLU");
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(act_bwd_bf_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out_bf, dout, dx, dx_bf, n4, act);
 }
 void launch_cvt_from_bf16(const unsigned short* in, float* out, size_t n, hipStream_t s) {   // n % 4 == 0
   const size_t n4 = n / 4;

@@ -582,7 +582,14 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3h_kernel(const ConvArgs a,
             if (a.epi_act) {   // dL/d(pre-activation) = dL/d(out) * act'(out), slopes as act_grad_from_out (k_norm.hip)
               size_t ei = (size_t)(yrow - a.y) + n;
               if (a.epi_wrap && ei >= a.epi_wrap) ei -= a.epi_wrap;
-              const float4 o = *reinterpret_cast<const float4*>(a.epi_ref + ei);
+              float4 o;
+              if (a.epi_ref_bf) {   // (the output as its plane: exact widening, the sign is what the ReLU / LeakyReLU forms read)
+                const uint2 q = *reinterpret_cast<const uint2*>(a.epi_ref_bf + ei);
+                o = make_float4(__builtin_bit_cast(float, q.x << 16), __builtin_bit_cast(float, q.x & 0xffff0000u),
+                                __builtin_bit_cast(float, q.y << 16), __builtin_bit_cast(float, q.y & 0xffff0000u));
+              } else {
+                o = *reinterpret_cast<const float4*>(a.epi_ref + ei);
+              }
               const float neg = a.epi_act == ACT_LRELU ? 0.2f : 0.f;
               if (a.epi_act == ACT_PRELU_X) {   // (o = the PReLU's input; prelu_bwd's expression, k_elem.hip)
                 v.x = elk * o.x >= o.x ? elk * v.x : v.x; v.y = elk * o.y >= o.y ? elk * v.y : v.y;

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, (FLDS && (CP == 8 || KH == 5)) ? 1 : 2) void c
         } else if (a.act == ACT_LRELU) {
           v.x = fmaxf(v.x, 0.2f * v.x); v.y = fmaxf(v.y, 0.2f * v.y); v.z = fmaxf(v.z, 0.2f * v.z); v.w = fmaxf(v.w, 0.2f * v.w);
         }
-        *reinterpret_cast<float4*>(yrow + n) = v;
+        if (!a.y_skip) *reinterpret_cast<float4*>(yrow + n) = v;
         if (a.y_bf) {   // the plane of the value just stored, rounded to nearest even (k_elem.hip: st_bf4 -- what cvt_bf16 would make of it)
           const f32x2 lo2 = {v.x, v.y}, hi2 = {v.z, v.w};
           const u32x2 o = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf16x2)),

@@ -75,6 +75,7 @@ struct ConvArgs {
   int x_up;          // 1: the gathered operand is 0.25 x the 2x nearest-neighbour upsampling of a [NB][IH/2][IW/2][x_ps] tensor at x
                      //    (x_bf: its plane) -- the gradient of a 2x2 average pool read without materialising it (halo kernel and
                      //    plane-fed kernel, stride-1 launches; launch_conv_gemm checks).  x_bytes / xbf_bytes: the small tensor's.
+  const unsigned short* epi_ref_bf;   // ReLU / LeakyReLU forms: the activation's output as its bf16 plane (a plane-only tensor); the sign is all they need
   const float* epi_leak;   // epi_act == ACT_PRELU_X: y holds dL/d(prelu output), epi_ref the PReLU's INPUT x, *epi_leak its slope lk; the
                            //   kernel stores (lk x >= x ? lk y : y) -- prelu_bwd's expression (k_elem.hip) -- and, with epi_bf, its bf16 plane
   unsigned short* epi_bf;
@@ -84,6 +85,7 @@ struct ConvArgs {
   unsigned long long epi_wrap;   // > 0: output elements at or beyond this index take epi_ref[index - epi_wrap] (the stacked
                                  // discriminator sub-step: the tangent rows are masked by the primal rows' activation)
   int x3q;           // experiments build: run_conv chose the two-blocks-per-CU halo kernel (k_gemm_x3q.hip) and ITS K split for this launch
+  int y_skip;             // with y_bf (conv_pk): the fp32 output is NOT stored -- the tensor lives as its plane alone (Tensor::d_plane_only)
   unsigned short* y_bf;   // bf16 mode, conv_pk only: also store the (activated) output's bf16 plane [pixel][y_ps] -- the next
                           // convolution reads it by LDS-DMA and no conversion pass runs (d_conv_0 + LeakyReLU -> d_conv_1)
   int pk;            // f32x3 / bf16 modes: thin forward layers (3 or 8 input channels) may run the packed-K limb kernel (k_thin_pk.hip)
@@ -295,7 +297,10 @@ bool conv_bf16_eligible(const ConvArgs& a);
 const char* launch_conv_gemm_bf16(const ConvArgs& a, int maxM, bool big_tile, hipStream_t s);
 const char* launch_wgrad_bf16(const WgradArgs& a, float* out, int dense, bool big_tile, hipStream_t s);
 void launch_cvt_bf16(const float* in, unsigned short* out, size_t n, hipStream_t s);
-void launch_cvt_from_bf16(const unsigned short* in, float* out, size_t n, hipStream_t s);   // exact widening, n % 4 == 0
+void launch_cvt_from_bf16(const unsigned short* in, float* out, size_t n, hipStream_t s);
+// dx = dout * act'(out) with the activation's output given as its bf16 plane (ReLU / LeakyReLU: the sign decides); dx and / or its
+// plane dx_bf are stored (n % 4 == 0)
+void launch_act_bwd_bf(const unsigned short* out_bf, const float* dout, float* dx, unsigned short* dx_bf, size_t n, int act, hipStream_t s);   // exact widening, n % 4 == 0
 void launch_tap_transpose_bf16(const float* in, unsigned short* out, int T, int R, int Cc, hipStream_t s);
 
 // plane-fed bf16 kernel for stride-1 layers (k_conv_bf16p.hip): the gathered operand arrives from a bf16 plane by LDS-DMA

@@ -383,6 +383,7 @@ T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_o
     // (first block: conv + LeakyReLU, fused where the small-C kernel runs the conv; `pre` is then the activated output,
     //  which is all the tangent pass and the backward need of it)
     c.feeds_in = i > 0 && !tangent_of;   // conv_block: the InstanceNorm is the convolution's only forward reader
+    c.conv_plane_only_next = cfg.bf16 && i == 0 && !tangent_of && !save;   // (no tangent pass will read this output's values)
     T pre = conv2d(c, x, w, nullptr, 4, 2, PAD_SAME, nullptr, (i == 0 && !tangent_of) ? ACT_LRELU : 0);
     T out, st = nullptr;
     if (!tangent_of) {
@@ -735,15 +736,23 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
         // LeakyReLU's linearisation at the primal (rows [0,B) of the same tensor)
         if (ne > 0) {
           T xe = rows(X, n0, ne), ye = rows(pre[0], n0, ne);
+          // bf16 mode: layer 0's output -- the largest activation of the sub-step -- as its plane alone: read by d_conv_1 and its
+          // filter gradient (planes) and, for the LeakyReLU's backward, by its sign (ConvArgs::epi_ref_bf, launch_act_bwd_bf)
+          c.conv_plane_only_next = planes && out[0]->d_bf != nullptr;
           const int r = conv_into(c, xe, w[0], ye, 4, 2, ACT_LRELU);
+          if (ye->d_plane_only) pre[0]->d_plane_only = true;
           if (!(r & 1)) launch_act_fwd(ye->d, ye->d, ye->numel(), ACT_LRELU, c.stream);
           if (ye->d_bf && !(r & 2)) launch_cvt_bf16(ye->d, ye->d_bf, ye->numel(), c.stream);   // (plane rows the kernel did not store)
         }
         if (nt > 0) {
           T xt = rows(X, n0 + ne, nt), yt = rows(pre[0], n0 + ne, nt);
           conv_into(c, xt, w[0], yt, 4, 2, 0);
-          launch_act_bwd(pre[0]->d, yt->d, yt->d, 0, yt->numel(), ACT_LRELU, c.stream);   // t_out = act'(out_primal) * t
-          if (yt->d_bf) launch_cvt_bf16(yt->d, yt->d_bf, yt->numel(), c.stream);
+          if (pre[0]->d_plane_only) {     // t_out = act'(out_primal) * t: mask from the primal rows' plane, the result as its plane
+            launch_act_bwd_bf(pre[0]->d_bf, yt->d, nullptr, yt->d_bf, yt->numel(), ACT_LRELU, c.stream);
+          } else {
+            launch_act_bwd(pre[0]->d, yt->d, yt->d, 0, yt->numel(), ACT_LRELU, c.stream);
+            if (yt->d_bf) launch_cvt_bf16(yt->d, yt->d_bf, yt->numel(), c.stream);
+          }
         }
       } else {
         conv_into(c, xin, w[i], yv, 4, 2, 0);
@@ -797,7 +806,10 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
       if (i == 1) act0_done = xv->g_act_done;
     }
     T y0 = rows(pre[0], 0, B), x0 = rows(X, 0, B);
-    if (!act0_done) launch_act_bwd(y0->d, y0->g, y0->g, 0, y0->numel(), ACT_LRELU, c.stream);   // in place: g *= act'(out)
+    if (!act0_done) {
+      tensor_need_f32(c, y0);
+      launch_act_bwd(y0->d, y0->g, y0->g, 0, y0->numel(), ACT_LRELU, c.stream);   // in place: g *= act'(out)
+    }
     y0->g_set = true;
     x0->needs_grad = true;
     conv_backward_x(c, x0, y0, w[0], 4, 2);
@@ -834,6 +846,7 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
   }
   if (!out[0]->g_act_done) {   // layer 0: LeakyReLU backward on the evaluated rows, its linearisation's reverse on the tangent rows (mask of the primal)
     const size_t img = pre[0]->numel() / R;
+    tensor_need_f32(c, pre[0]);
     launch_act_bwd(pre[0]->d, pre[0]->g, pre[0]->g, 0, (size_t)3 * B * img, ACT_LRELU, c.stream);
     launch_act_bwd(pre[0]->d, pre[0]->g + (size_t)3 * B * img, pre[0]->g + (size_t)3 * B * img, 0, (size_t)B * img, ACT_LRELU, c.stream);
   }

@@ -555,6 +555,7 @@ static void need_f32(Ctx& c, T t) {
   launch_cvt_from_bf16(t->d_bf, t->d, t->numel(), c.stream);
   t->d_plane_only = false;
 }
+void tensor_need_f32(Ctx& c, T t) { need_f32(c, t); }
 
 // Producer-side planes: in bf16 mode an element-wise kernel whose output (or output gradient) is shaped like a dense
 // contraction's operand (channels a multiple of 32) stores the bf16 plane next to the fp32 tensor -- 2 extra bytes per
@@ -785,6 +786,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
       // x = act(conv(..)) with the activation fused in its producer (d_conv_0): this launch is the only writer of its
       // gradient, so the activation's backward rides in the epilogue (if the un-split halo kernel runs the layer)
       a.epi_ref = x->d;
+      a.epi_ref_bf = x->d_plane_only ? x->d_bf : nullptr;
       a.epi_act = x->fused_act;
       a.epi_wrap = x->g_epi_wrap;
     }
@@ -992,7 +994,15 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     static const bool pk_plane = dbg_env("EG_NO_PK_PLANE") == nullptr;
     if (fused && pk_plane && conv_pk_eligible(a) && N % 4 == 0 && a.y_ps % 4 == 0)
       a.y_bf = (into && y->d_bf) ? y->d_bf : producer_plane(c, y, false);   // (a view's rows of its parent's plane)
+    // Ctx::conv_plane_only_next: every reader of this output takes the plane (the next convolution, its filter gradient) or only the
+    // SIGN of the activated value (the fused activation's backward: ConvArgs::epi_ref_bf, launch_act_bwd_bf) -- no fp32 copy
+    static const bool po0_on = dbg_env("EG_NO_PLANE_ONLY_CONV") == nullptr;
+    if (a.y_bf && c.conv_plane_only_next && po0_on) {
+      a.y_skip = 1;
+      y->d_plane_only = true;
+    }
   }
+  c.conv_plane_only_next = false;
   if (c.prof_on) c.cur_label = w->name + " fwd";
   const bool need = !into && (x->needs_grad || w->want_grad || (bias && bias->want_grad));
   // convolution read by an InstanceNorm alone (Ctx::feeds_in): a K-split launch keeps its slabs, the norm's load pass sums
@@ -1066,6 +1076,7 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
       if (!y->g_set) return;
       if (fused && !y->g_act_done) {
         materialize_up(c, y);
+        need_f32(c, y);
         launch_act_bwd(y->d, y->g, y->g, 0, y->numel(), fused_act, c.stream);   // in place: g *= act'(out)
         y->g_bf = nullptr;           // (a plane its writer stored holds the un-masked values)
         y->g_colsum_src = nullptr;
