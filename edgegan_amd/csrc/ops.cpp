@@ -760,6 +760,7 @@ static void conv_dgrad(Ctx& c, T x, T y, WRef* w, int k, int stride, int pad, in
     if (pepi_on && pre && !acc && !pre->g_set && !pre->g && !pre->g_inplace && !x->leaf_grad && !pre->leaf_grad &&
         !(c.param_grad_enabled && (x->prelu_leak->want_grad || pre->want_colpart)) && x->numel() < (1ull << 31)) {
       a.epi_ref = pre->d;
+      a.epi_ref_bf = pre->d_plane_only ? pre->d_bf : nullptr;
       a.epi_act = ACT_PRELU_X;
       a.epi_leak = x->prelu_leak->w;
       a.epi_soft = 1;
@@ -936,6 +937,10 @@ static void bias_grad(Ctx& c, Param* b, const float* dy, size_t rows, int C) {
 
 static T prelu_tail(Ctx& c, T x, T out, Param* leak, float leak_const);
 
+static bool need_params(WRef* w, Param* bias, Param* leak) {
+  return w->want_grad || (bias && bias->want_grad) || (leak && leak->want_grad);
+}
+
 T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into, int fused_act, Param* post_prelu) {
   const int Cin = x->c, N = w->Cc;
   EG_CHECK(w->T == k * k && w->R == Cin, "conv2d weight shape: T=%d R=%d vs k=%d Cin=%d", w->T, w->R, k, Cin);
@@ -1035,6 +1040,13 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
       a.y2_leak = post_prelu->w;
       a.y2 = y2->d_plane_only ? nullptr : y2->d;
       a.y2_bf = y2_plane;
+      // bf16 mode, nothing behind this convolution trains in this sweep (the classifier inside the generator sub-steps): the
+      // pre-activation is read for the SIGN only (PReLU backward: ConvArgs::epi_ref_bf, or prelu_bwd after need_f32) -- its plane alone
+      static const bool po1_on = dbg_env("EG_NO_PLANE_ONLY_CONV") == nullptr;
+      if (po1_on && c.cfg.bf16 && y2->d_plane_only && !need_params(w, bias, post_prelu) && N % 32 == 0 && y->numel() * 2 < (1ull << 31)) {
+        a.epi_bf = reinterpret_cast<unsigned short*>(c.arena.allocf((y->numel() + 1) / 2));
+        a.epi_skip_f32 = 1;
+      }
     }
   }
   c.prelu_plane_only = false;
@@ -1048,6 +1060,11 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     a.pool_y2_bf = pe.out2 ? pe.plane2 : nullptr;
   }
   run_conv(c, a, x, false);
+  if (a.epi_skip_f32 && a.epi_bf && (a.caps & CONV_CAP_Y2)) {   // (the kernels with the second store are the ones with this one)
+    y->d_bf = a.epi_bf;
+    y->d_bf_stream = nullptr;
+    y->d_plane_only = true;
+  }
   pe.done = a.pool_y && (a.caps & CONV_CAP_POOL);
   if (slabs_ok && a.ksplit > 1) {
     y->slabs = a.ws;
@@ -1796,6 +1813,7 @@ static T prelu_tail(Ctx& c, T x, T out, Param* leak, float leak_const) {
       if (x->needs_grad) dx = grad_acc(c, x, &acc);
       const bool pg = leak && leak->want_grad && c.param_grad_enabled;
       if (!dx && !pg) return;
+      need_f32(c, x);   // (a pre-activation kept as its plane alone: this pass reads its values)
       const SlabSrc ds = grad_src(out);
       const int prow = dx ? flat_colpart_rows(x->numel(), x->c) : 0;
       float* part = dx ? colpart_for(c, x, acc, prow) : nullptr;
