@@ -163,6 +163,7 @@ static const float* grad_f32_view(Ctx& c, T t) {
   if (!t->g_plane_only) return t->g;
   float* full = c.arena.allocf(t->numel());
   launch_cvt_from_bf16(t->g_bf, full, t->numel(), c.stream);
+  if (dbg_env("EG_TRACE_CVT")) fprintf(stderr, "[widen] grad view n=%d h=%d w=%d c=%d lane=%d\n", t->n, t->h, t->w, t->c, c.cur_lane);
   return full;
 }
 // Column partials of the gradient a backward kernel is about to write as the FIRST writer (acc == 0) of tensor t, if t's producer
@@ -198,7 +199,10 @@ static bool flat_slab_ok(T t) { return t->c % 4 == 0 && t->numel() < (1ull << 31
 float* grad_acc(Ctx& c, T t, int* acc) {
   if (!t->g) t->g = c.arena.allocf(t->numel());
   EG_CHECK(!t->g_up, "a second gradient contribution reached a tensor whose gradient is held as its pooled form");
-  if (t->g_set && t->g_plane_only) launch_cvt_from_bf16(t->g_bf, t->g, t->numel(), c.stream);   // (a second writer adds to the fp32 value)
+  if (t->g_set && t->g_plane_only) {   // (a second writer adds to the fp32 value)
+    launch_cvt_from_bf16(t->g_bf, t->g, t->numel(), c.stream);
+    if (dbg_env("EG_TRACE_CVT")) fprintf(stderr, "[widen] grad second writer n=%d h=%d w=%d c=%d lane=%d\n", t->n, t->h, t->w, t->c, c.cur_lane);
+  }
   t->g_plane_only = false;
   if (t->g_set) materialize_grad(c, t);   // (the first writer left K-split slabs: a second one adds to their sum)
   // ConvArgs::epi_act: the FIRST writer applied the fused activation's derivative in its epilogue and the producer will
@@ -553,6 +557,7 @@ static const unsigned short* tensor_plane(Ctx& c, T t, bool grad) {
 static void need_f32(Ctx& c, T t) {
   if (!t->d_plane_only) return;
   launch_cvt_from_bf16(t->d_bf, t->d, t->numel(), c.stream);
+  if (dbg_env("EG_TRACE_CVT")) fprintf(stderr, "[widen] data n=%d h=%d w=%d c=%d lane=%d label=%s\n", t->n, t->h, t->w, t->c, c.cur_lane, c.cur_label.c_str());
   t->d_plane_only = false;
 }
 void tensor_need_f32(Ctx& c, T t) { need_f32(c, t); }
@@ -1085,7 +1090,9 @@ T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumu
     y->needs_grad = true;
     y->g_inplace = fused;
     y->fused_act = fused ? fused_act : 0;
-    y->g_plane_ok = c.cfg.bf16 && k > 1 && N % 64 == 0 && !fused && !accumulate_into;   // (the closure below reads y's gradient through planes)
+    // (the closure below reads y's gradient through planes -- where its kernels are the plane-fed ones: not the thin layers'
+    //  (3 / 8 input channels), not the REFLECT-padded input gradient, which goes through the padded tensor)
+    y->g_plane_ok = c.cfg.bf16 && k > 1 && N % 64 == 0 && Cin % 32 == 0 && pad != PAD_REFLECT && !fused && !accumulate_into;
     if (bias && bias->want_grad && !accumulate_into) y->want_colpart = true;   // (the writer of y's gradient may sum its columns)
     Ctx* cp = &c;
     c.tape.push([=]() {
