@@ -167,7 +167,8 @@ int eg_mfma_probe(eg_ctx* ctx, int iters, int random_operands, double* tflops);
  * the code the training step uses.  See tests/test_ops_gpu.py for the per-op argument lists.
  * Composite ops (round 5) build the op SEQUENCES of the classifier's MRU unit / the discriminator head the way
  * classifier_forward / disc_forward do, so that the fused forms are exercised as the graph uses them: "mru_tail"
- * (conv.py:217-243: Conv_1 + PReLU, Conv_2, pool2_add + the next unit's PReLU), "mru_gate" (conv.py:185-209: prelu(h),
+ * (conv.py:217-243: Conv_1 + PReLU, Conv_2, pool2_add + the next unit's PReLU; a sixth integer parameter of 1 freezes its
+ * parameters as the generator sub-steps freeze the classifier's: input gradients only), "mru_gate" (conv.py:185-209: prelu(h),
  * the update gate as image rows + hidden rows, min-max, gate + PReLU, a convolution behind it), "act_conv" (InstanceNorm
  * + LeakyReLU or pool2 in front of a convolution), "d_head" (discriminator.py:61-66: d_conv_0 + LeakyReLU, d_conv_1);
  * argument lists in csrc/capi.cpp, oracle restatements in tests/parity.py.
