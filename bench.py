@@ -90,7 +90,7 @@ def pmc_traffic(kernel_label):
     return float(best['HbmBytesPerLaunch']) if best else None
 
 
-def live_traffic(kernel_label, args):
+def live_traffic(kernel_label, args, mode='train'):
     """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE:
     counters only, one group per pass, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over a 2-iteration child run of
     this same bench with the sub-steps serialised, averaged over that kernel's launches; read side x 2 (the guide's gfx950
@@ -121,7 +121,7 @@ def live_traffic(kernel_label, args):
     rx = re.compile(pat)
     child = [sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--profile-steps', '0', '--no-cpu-baseline',
              '--no-alt', '--no-live-traffic', '--batch', str(args.batch), '--classes', str(args.classes), '--height', str(args.height),
-             '--width', str(args.width), '--dtype', args.dtype]
+             '--width', str(args.width), '--dtype', args.dtype, '--no-side-legs', '--mode', mode]
     env = dict(os.environ, EG_LANES='0', TMPDIR='/tmp')
     avg = {}
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -369,30 +369,104 @@ def alt_mode(ea, cfg_kwargs, values, batch, args):
 INFER_GFLOP_PER_IMAGE = 2.228     # E (1.575) + G1 + G2 (2 x 0.326), 64x128
 
 
-def infer_bench(args, ea, np, rank, world, local):
+def roofline_of(ks, profile_steps, batch, note=None):
+    """`roofline` object from the engine's per-kernel event records (eg_profile_end: every GEMM-shaped launch bracketed by HIP
+    events on the stream it runs on, sub-steps serialised): the dominant kernel = the bucket with the most time."""
+    if not ks:
+        return None
+    dom = max(ks, key=lambda k: k['ms'])
+    tot_ms = sum(k['ms'] for k in ks)
+    tot_fl = sum(k['flops'] for k in ks)
+    alg = dom['flops'] / (dom['ms'] * 1e-3) / 1e12       # algorithmic fp32 (or bf16) TFLOP/s of the kernel
+    limb = 'x3' in dom['name']         # limb kernels execute 6 bf16 MFMA flops per algorithmic fp32 flop
+    ach = alg * (X3_LIMB_PRODUCTS if limb else 1)
+    bf = limb or 'bf16' in dom['name']
+    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
+    r = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+         'traffic': None, 'kernel': dom['name'], 'launches_per_step': dom['launches'] / profile_steps,
+         'avg_launch_ms': round(dom['ms'] / dom['launches'], 4), 'flops_per_launch': dom['flops'] / dom['launches'],
+         'all_gemm_kernels': {'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), 'ms_per_step': round(tot_ms / profile_steps, 3),
+                              'frac_of_peak': round(tot_fl / (tot_ms * 1e-3) / 1e12 * (X3_LIMB_PRODUCTS if limb else 1) / peak, 4),
+                              'executed_gflop_per_image': round(tot_fl / profile_steps / batch / 1e9, 2)}}
+    if note:
+        r['note'] = note
+    return r
+
+
+def attach_live_traffic(roof, spec, mode, deadline):
+    """roofline.traffic of a side leg, measured like the headline's (two rocprofv3 --pmc child runs); skipped -- and said so --
+    once the whole bench has used its time budget."""
+    if not roof:
+        return
+    if time.time() > deadline:
+        roof['traffic_source'] = 'not measured: the run had used its time budget before this leg\'s PMC passes'
+        return
+    lt = live_traffic(roof['kernel'], spec, mode)
+    if lt:
+        roof['traffic'] = round(lt['bytes'], 1)
+        roof['traffic_read_bytes'] = round(lt['read_bytes'], 1)
+        roof['traffic_write_bytes'] = round(lt['write_bytes'], 1)
+        roof['traffic_source'] = ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) over a child run of this '
+                                  'leg with the launches serialised, averaged over %d launches of this kernel; read side x 2 (gfx950), '
+                                  'KiB units' % lt['launches_sampled'])
+
+
+def train_leg(ea, np, local, spec, steps, warmup, profile_steps, workload, deadline, live):
+    """One more BASELINE configuration measured in the same process, after the headline: the same 7-sub-step iteration on a
+    synthetic batch resident in HBM, timed over `steps` iterations (lanes on), then `profile_steps` serialised iterations for
+    the roofline of ITS dominant kernel, then (separate child runs) that kernel's HBM traffic."""
+    cfg = ea.Config(batch_size=spec.batch, num_classes=spec.classes, device=local, compute_dtype=spec.dtype, height=spec.height,
+                    width=spec.width)
+    net = ea.EdgeGAN(cfg, ea.init_variables(cfg, 0))
+    b = ea.synthetic_batch(cfg, seed=1234)
+    net.upload_batch(b['images'], b['z'], b['alpha'], b['eps'])
+    for _ in range(warmup):
+        net.train_step()
+    net.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        net.train_step()
+    net.sync()
+    dt = time.perf_counter() - t0
+    finite = all(np.isfinite(v) for v in net.losses().values())
+    roof = None
+    if profile_steps > 0:
+        net.profile_begin()
+        for _ in range(profile_steps):
+            net.train_step()
+        roof = roofline_of(net.profile_end()['kernels'], profile_steps, spec.batch)
+    mem = net.memory_stats()
+    net.close()
+    if live:
+        attach_live_traffic(roof, spec, 'train', deadline)
+    return {'value': round(spec.batch * steps / dt, 2), 'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps,
+            'warmup': warmup, 'dtype': spec.dtype, 'config': {'workload': workload, 'per_gpu_batch': spec.batch},
+            'losses_finite': bool(finite), 'memory': mem, 'roofline': roof}
+
+
+def infer_leg(ea, np, rank, world, local, spec, steps, warmup, profile_steps, deadline, live):
     """BASELINE configs[1]: single-class 64x128, batch 64, generator-only inference (edgegan.test: E -> G1, E -> G2 = the
     two sess.run calls of edgegan/models/edgegan.py:606-609), bf16 contractions, inputs resident in HBM.  A step = one
     batch through both runs.  N > 1: independent replicas (inference has no exchange step)."""
-    dtype = 'bf16' if '--dtype' not in sys.argv else args.dtype
-    cfg = ea.Config(batch_size=args.batch, num_classes=0 if '--classes' not in sys.argv else args.classes, device=local,
-                    compute_dtype=dtype, height=args.height, width=args.width)
+    cfg = ea.Config(batch_size=spec.batch, num_classes=spec.classes, device=local, compute_dtype=spec.dtype, height=spec.height,
+                    width=spec.width)
     net = ea.EdgeGAN(cfg, ea.init_variables(cfg, 0))
     if world > 1:
         from edgegan_amd import rendezvous
         rendezvous.init_data_parallel(net, rank, world)
     b = ea.synthetic_batch(cfg, seed=1234, rank=rank)
-    cls = (np.arange(args.batch) % max(cfg.num_classes, 1)).astype(np.int32)
+    cls = (np.arange(spec.batch) % max(cfg.num_classes, 1)).astype(np.int32)
     net.infer_upload(b['images'], cls, eps2=[0.1, 0.2])
 
     def sync():
         net.sync()
         net.comm_barrier()
         net.sync()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         net.infer_run()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         net.infer_run()
     t_enq = time.perf_counter() - t0
     sync()
@@ -400,37 +474,43 @@ def infer_bench(args, ea, np, rank, world, local):
     if world > 1:
         dt = float(net.comm_reduce_scalars([dt], 'max')[0])
     roof = None
-    if rank == 0 and args.profile_steps > 0:
+    if rank == 0 and profile_steps > 0:
         net.profile_begin()
-        for _ in range(args.profile_steps):
+        for _ in range(profile_steps):
             net.infer_run()
-        ks = net.profile_end()['kernels']
-        if ks:
-            dom = max(ks, key=lambda k: k['ms'])
-            ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            peak = PEAK_BF16_MFMA_TFLOPS if 'bf16' in dom['name'] else PEAK_FP32_MFMA_TFLOPS
-            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                    'traffic': None, 'kernel': dom['name'], 'avg_launch_ms': round(dom['ms'] / dom['launches'], 4),
-                    'flops_per_launch': dom['flops'] / dom['launches'],
-                    'all_gemm_kernels': {'ms_per_step': round(sum(k['ms'] for k in ks) / args.profile_steps, 3),
-                                         'tflops': round(sum(k['flops'] for k in ks) / (sum(k['ms'] for k in ks) * 1e-3) / 1e12, 2)},
-                    'note': 'a batch-64 forward of E, G1, G2 is ~75 launches of 5-60 us: launch/latency-bound, not MFMA-bound'}
+        roof = roofline_of(net.profile_end()['kernels'], profile_steps, spec.batch,
+                           note='a batch-64 forward of E, G1, G2: small maps (4x4 .. 64x64), bounded by launch count and per-launch '
+                                'latency before it is bounded by the matrix pipe')
     e, i = net.infer_download()
-    if rank == 0:
-        value = args.batch * world * args.steps / dt
-        print(json.dumps({
-            'metric': f'inference images/sec (E -> G1, G2) at {args.height}x{args.width}', 'value': round(value, 1),
-            'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': dtype, 'data': 'synthetic',
-            'config': {'workload': f'configs[1]: {"single-class" if cfg.num_classes == 0 else str(cfg.num_classes) + "-class"} '
-                                   f'{args.height}x{args.width} {dtype} generator-only inference (edgegan.test path), batch '
-                                   f'{args.batch} per GPU, inputs resident in HBM', 'per_gpu_batch': args.batch,
-                       'parallelism': f'replicas x{world}'},
-            'algorithmic_tflops_per_gpu': round(INFER_GFLOP_PER_IMAGE * value / world / 1e3, 2) if (args.height, args.width) == (64, 128) else None,
-            'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
-            'outputs_finite': bool(np.all(np.isfinite(e)) and np.all(np.isfinite(i))), 'roofline': roof}))
+    finite = bool(np.all(np.isfinite(e)) and np.all(np.isfinite(i)))
     net.close()
+    if live and rank == 0 and world == 1:
+        attach_live_traffic(roof, spec, 'infer', deadline)
+    value = spec.batch * world * steps / dt
+    return {'value': round(value, 1), 'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps, 'warmup': warmup,
+            'dtype': spec.dtype,
+            'config': {'workload': f'configs[1]: {"single-class" if cfg.num_classes == 0 else str(cfg.num_classes) + "-class"} '
+                                   f'{spec.height}x{spec.width} {spec.dtype} generator-only inference (edgegan.test path), batch '
+                                   f'{spec.batch} per GPU, inputs resident in HBM', 'per_gpu_batch': spec.batch,
+                       'parallelism': f'replicas x{world}'},
+            'algorithmic_tflops_per_gpu': round(INFER_GFLOP_PER_IMAGE * value / world / 1e3, 2) if (spec.height, spec.width) == (64, 128) else None,
+            'host_enqueue_ms_per_step': round(t_enq / steps * 1e3, 3), 'outputs_finite': finite, 'roofline': roof}
+
+
+
+def infer_bench(args, ea, np, rank, world, local):
+    """python bench.py --mode infer: the configs[1] leg on its own (one JSON line in the contract's shape)."""
+    from types import SimpleNamespace
+    spec = SimpleNamespace(batch=args.batch, classes=0 if '--classes' not in sys.argv else args.classes, height=args.height,
+                           width=args.width, dtype='bf16' if '--dtype' not in sys.argv else args.dtype)
+    leg = infer_leg(ea, np, rank, world, local, spec, args.steps, args.warmup, args.profile_steps, time.time() + 120,
+                    live=not args.no_live_traffic)
+    if rank == 0:
+        out = {'metric': f'inference images/sec (E -> G1, G2) at {args.height}x{args.width}', 'value': leg['value'], 'unit': 'images/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': leg['ms_per_step'], 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': spec.dtype, 'data': 'synthetic'}
+        out.update({k: v for k, v in leg.items() if k not in out})
+        print(json.dumps(out))
 
 
 def loop_bench(args, ea, np, local):
@@ -575,6 +655,9 @@ def main():
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the side measurement of the exact-fp32-MFMA mode')
+    ap.add_argument('--no-side-legs', action='store_true',
+                    help='skip the side legs of the default run (bf16_mode = configs[3] arithmetic at batch 64, '
+                         'config4_256x512_b16_bf16, config1_infer_b64), each with its own roofline object')
     ap.add_argument('--no-live-traffic', action='store_true',
                     help='roofline.traffic from the committed profile set instead of two rocprofv3 --pmc passes inside this run')
     ap.add_argument('--cpu-baseline-batch', type=int, default=64)
@@ -589,6 +672,7 @@ def main():
                          "f32 uses the exact-fp32 MFMA instruction; bf16 = configs[3]'s arithmetic: bf16 MFMA "
                          "operands with fp32 accumulation / storage")
     args = ap.parse_args()
+    t_start = time.time()
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -625,15 +709,10 @@ def main():
     net.upload_batch(batch['images'], batch['z'], batch['alpha'], batch['eps'])
 
     def barrier_sync():
+        # (eg_sync = hipDeviceSynchronize behind the engine's pending exchanges: what torch.cuda.synchronize() is to a torch
+        #  program -- this process never loads torch)
         net.sync()
-        net.comm_barrier()          # RCCL all-reduce of one scalar + stream sync: returns when every rank has arrived
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.set_device(local)
-                torch.cuda.synchronize()
-        except Exception:
-            pass
+        net.comm_barrier()          # RCCL all-reduce of one scalar + device sync: returns when every rank has arrived
         net.sync()
 
     for _ in range(args.warmup):
@@ -685,6 +764,7 @@ def main():
                     'avg_launch_ms': round(dom['ms'] / dom['launches'], 4),
                     'flops_per_launch': dom['flops'] / dom['launches'],
                     'all_gemm_kernels': {'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                         'frac_of_peak': round(tot_fl / (tot_ms * 1e-3) / 1e12 * (X3_LIMB_PRODUCTS if limb else 1) / peak, 4),
                                          'ms_per_step': round(tot_ms / args.profile_steps, 3),
                                          'executed_gflop_per_image': round(tot_fl / args.profile_steps / args.batch / 1e9, 2)},
                     'per_kernel': {k['name']: {'ms_per_step': round(k['ms'] / args.profile_steps, 3),
@@ -759,6 +839,29 @@ def main():
                 roof['traffic_source'] = ('measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each) over a '
                                           '2-iteration child run with the sub-steps serialised, averaged over %d launches of this kernel; '
                                           'read side x 2 (gfx950), KiB units' % lt['launches_sampled'])
+        if (world == 1 and not args.no_side_legs and args.dtype == 'f32x3'
+                and (args.height, args.width, args.batch, args.classes) == (64, 128, 64, 14)):
+            # the other BASELINE configurations, in the driver's one line: each leg = its own engine, its
+            # own timed region, its own roofline object.  PMC child runs of a leg are skipped once the run is past its budget.
+            from types import SimpleNamespace
+            if net is not None:
+                net.close()
+                net = None
+            deadline = t_start + 105
+            live = not args.no_live_traffic
+            try:
+                out['bf16_mode'] = train_leg(
+                    ea, np, local, SimpleNamespace(batch=64, classes=14, height=64, width=128, dtype='bf16'), 10, 3, 2,
+                    'configs[3] arithmetic (bf16 MFMA operands, fp32 accumulate / storage): 14-class 64x128 full training iteration '
+                    '(7 RMSProp sub-steps), batch 64 per GPU (the per-GPU workload of the 8-GPU DP configuration)', deadline, live)
+                out['config4_256x512_b16_bf16'] = train_leg(
+                    ea, np, local, SimpleNamespace(batch=16, classes=14, height=256, width=512, dtype='bf16'), 5, 2, 1,
+                    'configs[4]: 14-class 256x512 bf16 full training iteration, batch 16 per GPU (its per-GPU workload)', deadline, live)
+                out['config1_infer_b64'] = infer_leg(
+                    ea, np, 0, 1, local, SimpleNamespace(batch=64, classes=0, height=64, width=128, dtype='bf16'), 50, 5, 3, deadline, live)
+            except Exception as e:   # a side leg must never hide the headline
+                out['side_legs_error'] = repr(e)
+            out['bench_seconds'] = round(time.time() - t_start, 1)
         print(json.dumps(out))
     if net is not None:
         net.close()

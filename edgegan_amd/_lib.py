@@ -4,7 +4,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 
@@ -17,9 +17,14 @@ class EdgeGANLibError(RuntimeError):
 
 
 class _CConfig(C.Structure):
-    _fields_ = [('batch_size', C.c_int), ('height', C.c_int), ('width', C.c_int), ('num_classes', C.c_int),
+    # include/edgegan_hip.h: eg_config.  struct_size = sizeof(eg_config) as THIS binding lays it out; the library rejects
+    # any other value, so a stale field list here fails at the first call instead of reading shifted fields
+    _fields_ = [('struct_size', C.c_uint),
+                ('batch_size', C.c_int), ('height', C.c_int), ('width', C.c_int), ('num_classes', C.c_int),
                 ('z_dim', C.c_int), ('gf_dim', C.c_int), ('df_dim', C.c_int), ('c_dim', C.c_int),
-                ('dis_size', C.c_int), ('lambda_gp', C.c_float), ('zl_weight', C.c_float),
+                ('use_image_discriminator', C.c_int), ('image_dis_size', C.c_int),
+                ('use_edge_discriminator', C.c_int), ('edge_dis_size', C.c_int),
+                ('lambda_gp', C.c_float), ('zl_weight', C.c_float),
                 ('learning_rate', C.c_float), ('joint_dweight', C.c_float), ('image_dweight', C.c_float),
                 ('edge_dweight', C.c_float), ('device', C.c_int), ('compute_dtype', C.c_int)]
 
@@ -35,7 +40,7 @@ class Config:
     gf_dim: int = 64
     df_dim: int = 64
     c_dim: int = 3
-    dis_size: int = 128
+    dis_size: int = 128        # image_dis_size and edge_dis_size (train.py:63-67) when those are not given separately
     lambda_gp: float = 10.0
     zl_weight: float = 10.0
     learning_rate: float = 2e-4
@@ -44,6 +49,18 @@ class Config:
     edge_dweight: float = 1.0
     device: int = 0
     compute_dtype: str = 'f32'  # 'bf16': dense contractions on the bf16 MFMA (fp32 accumulate / storage)
+    use_image_discriminator: bool = True   # train.py:61-62
+    use_edge_discriminator: bool = True    # train.py:65-66
+    image_dis_size: Optional[int] = None   # train.py:63-64 (None: dis_size)
+    edge_dis_size: Optional[int] = None    # train.py:67    (None: dis_size)
+
+    @property
+    def image_dis(self) -> int:
+        return self.dis_size if self.image_dis_size is None else self.image_dis_size
+
+    @property
+    def edge_dis(self) -> int:
+        return self.dis_size if self.edge_dis_size is None else self.edge_dis_size
 
     @property
     def multiclasses(self) -> bool:
@@ -54,8 +71,9 @@ class Config:
         return self.z_dim + (1 if self.multiclasses else 0)
 
     def to_c(self) -> _CConfig:
-        return _CConfig(self.batch_size, self.height, self.width, self.num_classes, self.z_dim, self.gf_dim,
-                        self.df_dim, self.c_dim, self.dis_size, self.lambda_gp, self.zl_weight,
+        return _CConfig(C.sizeof(_CConfig), self.batch_size, self.height, self.width, self.num_classes, self.z_dim, self.gf_dim,
+                        self.df_dim, self.c_dim, int(self.use_image_discriminator), self.image_dis,
+                        int(self.use_edge_discriminator), self.edge_dis, self.lambda_gp, self.zl_weight,
                         self.learning_rate, self.joint_dweight, self.image_dweight, self.edge_dweight, self.device,
                         {'f32': 0, 'bf16': 1, 'f32x3': 2}[_dtype_override(self.compute_dtype)])
 

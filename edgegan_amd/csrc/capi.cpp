@@ -16,6 +16,10 @@ struct eg_ctx {
 static thread_local std::string g_create_error;
 
 static Config to_config(const eg_config* k) {
+  EG_CHECK(k, "null eg_config");
+  if (k->struct_size != (unsigned)sizeof(eg_config))
+    fail(3, "eg_config layout mismatch: struct_size %u, this library was built with sizeof(eg_config) = %u (call eg_default_config "
+            "first, and rebuild the binding against include/edgegan_hip.h)", k->struct_size, (unsigned)sizeof(eg_config));
   Config c;
   c.B = k->batch_size;
   c.H = k->height;
@@ -25,7 +29,10 @@ static Config to_config(const eg_config* k) {
   c.gf = k->gf_dim;
   c.df = k->df_dim;
   c.c_dim = k->c_dim;
-  c.dis_size = k->dis_size;
+  c.use_image_dis = k->use_image_discriminator != 0;
+  c.image_dis = k->image_dis_size;
+  c.use_edge_dis = k->use_edge_discriminator != 0;
+  c.edge_dis = k->edge_dis_size;
   c.lambda_gp = k->lambda_gp;
   c.zl_weight = k->zl_weight;
   c.lr = k->learning_rate;
@@ -60,7 +67,7 @@ extern "C" {
 
 int eg_default_config(eg_config* k) {
   if (!k) return 1;
-  *k = eg_config{64, 64, 128, 14, 100, 64, 64, 3, 128, 10.f, 10.f, 2e-4f, 1.f, 1.f, 1.f, 0, 0};
+  *k = eg_config{(unsigned)sizeof(eg_config), 64, 64, 128, 14, 100, 64, 64, 3, 1, 128, 1, 128, 10.f, 10.f, 2e-4f, 1.f, 1.f, 1.f, 0, 0};
   return 0;
 }
 
@@ -94,12 +101,13 @@ int eg_create(const eg_config* k, eg_ctx** out) {
   eg_ctx* ctx = nullptr;
   try {
     EG_CHECK(k && out, "null argument");
+    const Config cfg = to_config(k);   // (first: a layout mismatch is reported as such, with or without a device)
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
       fail(2, "no HIP device available (%s); the engine has no CPU fallback", hipGetErrorString(e));
     ctx = new eg_ctx();
-    ctx->c.cfg = to_config(k);
+    ctx->c.cfg = cfg;
     build_context(ctx->c);
     *out = ctx;
     return 0;
@@ -304,14 +312,16 @@ int eg_eval_losses(eg_ctx* ctx, const float* alpha, float eps, int bn_updates, c
   };
   down(out->losses12, c.d_eval, L_COUNT);
   down(out->d_logits, c.d_eval + 16, (size_t)6 * B);
-  const size_t half = (size_t)B * cfg.H * (cfg.W / 2) * cfg.c_dim, rs = (size_t)B * cfg.dis_size * cfg.dis_size * cfg.c_dim;
+  const size_t half = (size_t)B * cfg.H * (cfg.W / 2) * cfg.c_dim;
   down(out->edge_output, r.edge, half);
   down(out->image_output, r.image, half);
-  const bool same = cfg.H == cfg.dis_size && cfg.W / 2 == cfg.dis_size;   // resize is the identity then
-  down(out->resized_inputs, r.resized[0], same ? half : rs);
-  down(out->resized_image_output, r.resized[1], same ? half : rs);
-  down(out->resized_edges, r.resized[2], same ? half : rs);
-  down(out->resized_edge_output, r.resized[3], same ? half : rs);
+  // a resize to the tensor's own size is the identity (the half image itself); a disabled patch discriminator has no resized
+  // tensors (models/edgegan.py:253-274): those outputs are left untouched
+  auto rs = [&](int size) { return (cfg.H == size && cfg.W / 2 == size) ? half : (size_t)B * size * size * cfg.c_dim; };
+  if (r.resized[0]) down(out->resized_inputs, r.resized[0], rs(cfg.image_dis));
+  if (r.resized[1]) down(out->resized_image_output, r.resized[1], rs(cfg.image_dis));
+  if (r.resized[2]) down(out->resized_edges, r.resized[2], rs(cfg.edge_dis));
+  if (r.resized[3]) down(out->resized_edge_output, r.resized[3], rs(cfg.edge_dis));
   EG_HIP(hipStreamSynchronize(c.stream));
   EG_API_END(ctx)
 }
@@ -386,6 +396,7 @@ int eg_sync(eg_ctx* ctx) {
   EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
+  EG_HIP(hipDeviceSynchronize());   // every lane, leaf and exchange stream of this device: the host-side "everything is done"
   EG_API_END(ctx)
 }
 

@@ -10,7 +10,9 @@ namespace eg {
 struct Config {
   int B = 64, H = 64, W = 128;
   int num_classes = 14;  // 0 => --nomulticlasses
-  int z_dim = 100, gf = 64, df = 64, c_dim = 3, dis_size = 128;
+  int z_dim = 100, gf = 64, df = 64, c_dim = 3;
+  bool use_image_dis = true, use_edge_dis = true;   // train.py:61-67: a patch discriminator that is off is never built
+  int image_dis = 128, edge_dis = 128;
   float lambda_gp = 10.f, zl_weight = 10.f, lr = 2e-4f;
   float joint_dweight = 1.f, image_dweight = 1.f, edge_dweight = 1.f;
   int device = 0;

@@ -118,8 +118,9 @@ std::vector<VarInfo> enumerate_variables(const Config& cfg) {
   gen_vars(v, cfg, G_G2);
   if (cfg.multiclasses()) cls_vars(v, cfg);
   disc_vars(v, cfg, G_D, cfg.H, cfg.W);
-  disc_vars(v, cfg, G_DP2, cfg.dis_size, cfg.dis_size);
-  disc_vars(v, cfg, G_DP3, cfg.dis_size, cfg.dis_size);
+  // edgegan.py:164-174: a patch discriminator that is switched off is never constructed (no variables, no optimizer slots)
+  if (cfg.use_image_dis) disc_vars(v, cfg, G_DP2, cfg.image_dis, cfg.image_dis);
+  if (cfg.use_edge_dis) disc_vars(v, cfg, G_DP3, cfg.edge_dis, cfg.edge_dis);
   enc_vars(v, cfg);
   return v;
 }
@@ -135,6 +136,8 @@ void build_context(Ctx& c) {
   EG_CHECK(cfg.H % 16 == 0 && (cfg.W / 2) % 16 == 0 && cfg.W % 2 == 0, "H and W/2 must be multiples of 16");
   EG_CHECK(cfg.B >= 1 && cfg.B <= 1024, "batch size out of range");
   EG_CHECK(cfg.num_classes <= 64, "num_classes <= 64");
+  EG_CHECK((!cfg.use_image_dis || (cfg.image_dis >= 16 && cfg.image_dis <= 1024)) && (!cfg.use_edge_dis || (cfg.edge_dis >= 16 && cfg.edge_dis <= 1024)),
+           "image_dis_size / edge_dis_size out of range (16..1024)");
   EG_HIP(hipSetDevice(cfg.device));
   EG_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   for (int g = 0; g < G_COUNT; ++g) c.groups[g].prefix = kGroupPrefix[g];
@@ -898,6 +901,7 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
   const int B = cfg.B;
   EG_CHECK(k >= 1 && k <= 7, "sub-step index 1..7");
   if (k == 4 && !cfg.multiclasses()) return;  // d_optim2 only registered with multiclasses (edgegan.py:115-116)
+  if ((k == 2 && !cfg.use_image_dis) || (k == 3 && !cfg.use_edge_dis)) return;   // register_optim_if(..., use_*_discriminator), edgegan.py:111-114
   {  // weights (and flat gradient buffers) this sub-step touches must have their pending update applied
     static const unsigned reads[8] = {0,
                                       1u << G_G1 | 1u << G_G2 | 1u << G_D,
@@ -940,15 +944,15 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
     case 2: {  // d_optim_patch2: image discriminator on bicubic-resized right halves
       T zin = make_zin(c);
       T image = generator_output_nograd(c, G_G2, zin, bn2);
-      T r_real = resize(c, right_half(c, images), cfg.dis_size);
-      T r_fake = resize(c, image, cfg.dis_size);
+      T r_real = resize(c, right_half(c, images), cfg.image_dis);
+      T r_fake = resize(c, image, cfg.image_dis);
       d_substep(c, G_DP2, r_real, r_fake, c.d_alpha + B, L_IMAGE_D, L_IMAGE_GP, apply);
     } break;
     case 3: {  // d_optim_patch3: edge discriminator
       T zin = make_zin(c);
       T edge = generator_output_nograd(c, G_G1, zin, bn1);
-      T r_real = resize(c, left_half(c, images), cfg.dis_size);
-      T r_fake = resize(c, edge, cfg.dis_size);
+      T r_real = resize(c, left_half(c, images), cfg.edge_dis);
+      T r_fake = resize(c, edge, cfg.edge_dis);
       d_substep(c, G_DP3, r_real, r_fake, c.d_alpha + 2 * B, L_EDGE_D, L_EDGE_GP, apply);
     } break;
     case 4: {  // d_optim2: classifier focal loss on the real right half (edgegan.py:238-239,325-330)
@@ -976,10 +980,12 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       T edge = generator_forward(c, G_G1, zin, bn1);
       const size_t mcat = c.tape.ops.size();   // concat: entries mcat (edge's part), mcat + 1 (image's part)
       T joint = concat_w(c, edge, image);
+      // (a patch discriminator that is switched off contributes neither a branch nor a loss term: edge_dis_gloss /
+      //  image_dis_gloss = 0, edgegan.py:300-301,310-311; its tape ranges below are empty)
       const size_t mre = c.tape.ops.size();
-      T r_edge = resize(c, edge, cfg.dis_size);
+      T r_edge = cfg.use_edge_dis ? resize(c, edge, cfg.edge_dis) : nullptr;
       const size_t mri = c.tape.ops.size();
-      T r_image = resize(c, image, cfg.dis_size);
+      T r_image = cfg.use_image_dis ? resize(c, image, cfg.image_dis) : nullptr;
       // The four critics are independent given the generator outputs (each writes the gradient of its OWN input tensor;
       // `image`'s gradient gets the classifier's contributions first, then -- after the join -- the resize's and the
       // concat's, the order of the single-stream sweep).  With branch lanes each runs forward and backward on the lane that
@@ -998,19 +1004,23 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
       seed_grad(c, dj);
       launch_fill(dj->g, -cfg.joint_dweight / B, B, c.stream);
       const size_t m1 = c.tape.ops.size();
-      enter(2, c.ev_branch);
-      await_group(G_DP3);
-      T de = disc_forward(c, G_DP3, r_edge, nullptr, nullptr);
-      launch_mean_neg(de->d, c.d_losses + L_EDGE_G, B, c.stream);
-      seed_grad(c, de);
-      launch_fill(de->g, -cfg.edge_dweight / B, B, c.stream);
+      if (cfg.use_edge_dis) {
+        enter(2, c.ev_branch);
+        await_group(G_DP3);
+        T de = disc_forward(c, G_DP3, r_edge, nullptr, nullptr);
+        launch_mean_neg(de->d, c.d_losses + L_EDGE_G, B, c.stream);
+        seed_grad(c, de);
+        launch_fill(de->g, -cfg.edge_dweight / B, B, c.stream);
+      }
       const size_t m2 = c.tape.ops.size();
-      enter(1, c.ev_branch);
-      await_group(G_DP2);
-      T di = disc_forward(c, G_DP2, r_image, nullptr, nullptr);
-      launch_mean_neg(di->d, c.d_losses + L_IMAGE_G, B, c.stream);
-      seed_grad(c, di);
-      launch_fill(di->g, -cfg.image_dweight / B, B, c.stream);
+      if (cfg.use_image_dis) {
+        enter(1, c.ev_branch);
+        await_group(G_DP2);
+        T di = disc_forward(c, G_DP2, r_image, nullptr, nullptr);
+        launch_mean_neg(di->d, c.d_losses + L_IMAGE_G, B, c.stream);
+        seed_grad(c, di);
+        launch_fill(di->g, -cfg.image_dweight / B, B, c.stream);
+      }
       const size_t m3 = c.tape.ops.size();
       if (cfg.multiclasses()) {
         enter(3, c.ev_cls);
@@ -1217,8 +1227,9 @@ void eval_losses(Ctx& c, const float* alpha_dev, const float* eps_dev, int bn_up
   T edge = generator_forward(c, G_G1, zin, bn_updates);
   T image = generator_forward(c, G_G2, zin, bn_updates);
   T joint = concat_w(c, edge, image);
-  T r_pic = resize(c, right_half(c, images), cfg.dis_size), r_img = resize(c, image, cfg.dis_size);
-  T r_edges = resize(c, left_half(c, images), cfg.dis_size), r_edge_out = resize(c, edge, cfg.dis_size);
+  T r_pic = nullptr, r_img = nullptr, r_edges = nullptr, r_edge_out = nullptr;
+  if (cfg.use_image_dis) r_pic = resize(c, right_half(c, images), cfg.image_dis), r_img = resize(c, image, cfg.image_dis);
+  if (cfg.use_edge_dis) r_edges = resize(c, left_half(c, images), cfg.edge_dis), r_edge_out = resize(c, edge, cfg.edge_dis);
   float* L = c.d_eval;
   struct Branch {
     int group;
@@ -1229,6 +1240,7 @@ void eval_losses(Ctx& c, const float* alpha_dev, const float* eps_dev, int bn_up
              {G_DP3, r_edges, r_edge_out, L_EDGE_D, L_EDGE_GP, L_EDGE_G}};
   for (int i = 0; i < 3; ++i) {
     const Branch& b = br[i];
+    if (!b.real) continue;   // a patch discriminator that is switched off: its losses stay 0 (edgegan.py:300-301,310-311)
     T xhat = new_tensor(c, b.real->n, b.real->h, b.real->w, b.real->c, true);
     const size_t per = xhat->numel() / B;
     launch_blend(b.real->d, b.fake->d, alpha_dev + (size_t)i * B, xhat->d, B, per, c.stream);
@@ -1264,10 +1276,10 @@ void eval_losses(Ctx& c, const float* alpha_dev, const float* eps_dev, int bn_up
   c.tape.clear();
   r->edge = edge->d;
   r->image = image->d;
-  r->resized[0] = r_pic->d;
-  r->resized[1] = r_img->d;
-  r->resized[2] = r_edges->d;
-  r->resized[3] = r_edge_out->d;
+  r->resized[0] = r_pic ? r_pic->d : nullptr;
+  r->resized[1] = r_img ? r_img->d : nullptr;
+  r->resized[2] = r_edges ? r_edges->d : nullptr;
+  r->resized[3] = r_edge_out ? r_edge_out->d : nullptr;
 }
 
 // edgegan.py:492-517,606-609: E(left half) -> z (+ one-hot) -> G1 ; second run -> G2 (own eps draw).

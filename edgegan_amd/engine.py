@@ -145,11 +145,14 @@ class EdgeGAN:
         out = {'losses12': np.zeros(12, dtype=np.float32)}
         if tensors:
             half = (B, cfg.height, cfg.width // 2, cfg.c_dim)
-            rs = half if (cfg.height, cfg.width // 2) == (cfg.dis_size, cfg.dis_size) else (B, cfg.dis_size, cfg.dis_size, cfg.c_dim)
+            def rs(size):    # (a resize to the tensor's own size is the identity)
+                return half if (cfg.height, cfg.width // 2) == (size, size) else (B, size, size, cfg.c_dim)
             out.update(d_logits=np.zeros((6, B), np.float32), edge_output=np.zeros(half, np.float32),
-                       image_output=np.zeros(half, np.float32), resized_inputs=np.zeros(rs, np.float32),
-                       resized_image_output=np.zeros(rs, np.float32), resized_edges=np.zeros(rs, np.float32),
-                       resized_edge_output=np.zeros(rs, np.float32))
+                       image_output=np.zeros(half, np.float32))
+            if cfg.use_image_discriminator:
+                out.update(resized_inputs=np.zeros(rs(cfg.image_dis), np.float32), resized_image_output=np.zeros(rs(cfg.image_dis), np.float32))
+            if cfg.use_edge_discriminator:
+                out.update(resized_edges=np.zeros(rs(cfg.edge_dis), np.float32), resized_edge_output=np.zeros(rs(cfg.edge_dis), np.float32))
         co = _CEvalOutputs(**{k: fptr(v.reshape(-1)) for k, v in out.items()})
         self._check(self._lib.eg_eval_losses(self._ctx, fptr(alpha), eps, int(bn_updates), C.byref(co)))
         d = self._compose_losses(out.pop('losses12'))

@@ -88,12 +88,5 @@ def check_supported(flags: SimpleNamespace):
         bad.append('if_resnet_g / if_resnet_d / if_resnet_e must keep their defaults (False, False, True)')
     if (flags.E_norm, flags.G_norm, flags.D_norm) != ('instance', 'instance', 'instance'):
         bad.append('E_norm / G_norm / D_norm must be "instance"')
-    if getattr(flags, 'use_image_discriminator', True) is not True or getattr(flags, 'use_edge_discriminator', True) is not True:
-        bad.append('use_image_discriminator / use_edge_discriminator must be True')
-    if flags.crop:
-        if (flags.input_height, flags.input_width) == (flags.output_height, flags.output_width):
-            pass
-    if getattr(flags, 'image_dis_size', 128) != getattr(flags, 'edge_dis_size', 128):
-        bad.append('image_dis_size and edge_dis_size must be equal')
     if bad:
         raise SystemExit('unsupported flag combination:\n  ' + '\n  '.join(bad))

@@ -41,7 +41,9 @@ def update_flags(fl):
 def engine_config(fl, device: int) -> Config:
     h, w = (fl.output_height, fl.output_width) if fl.crop else (fl.input_height, fl.input_width)
     return Config(batch_size=fl.batch_size, height=h, width=w, num_classes=fl.num_classes or 0,
-                  z_dim=getattr(fl, 'z_dim', 100), dis_size=getattr(fl, 'image_dis_size', 128),
+                  z_dim=getattr(fl, 'z_dim', 100),
+                  use_image_discriminator=bool(getattr(fl, 'use_image_discriminator', True)), image_dis_size=getattr(fl, 'image_dis_size', 128),
+                  use_edge_discriminator=bool(getattr(fl, 'use_edge_discriminator', True)), edge_dis_size=getattr(fl, 'edge_dis_size', 128),
                   lambda_gp=getattr(fl, 'lambda_gp', 10.0), zl_weight=getattr(fl, 'stage1_zl_loss', 10.0),
                   learning_rate=fl.learning_rate, joint_dweight=getattr(fl, 'joint_dweight', 1.0),
                   image_dweight=getattr(fl, 'image_dweight', 1.0), edge_dweight=getattr(fl, 'edge_dweight', 1.0),

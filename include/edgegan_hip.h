@@ -27,8 +27,12 @@ extern "C" {
 
 typedef struct eg_ctx eg_ctx;
 
-/* Flags of edgegan/train.py:14-74 that shape the graph. */
+/* Flags of edgegan/train.py:14-74 that shape the graph.
+ * struct_size makes the layout self-describing: eg_default_config() sets it to sizeof(eg_config) of the library's build,
+ * and eg_create / eg_variable_count / eg_variable_info reject any other value (code 3, "eg_config layout mismatch") -- a
+ * binding compiled against an older header fails loudly instead of reading shifted fields. */
 typedef struct eg_config {
+  unsigned int struct_size; /* sizeof(eg_config); written by eg_default_config */
   int batch_size;      /* train.py:20  (per device)                     */
   int height;          /* train.py:21-26 input/output_height            */
   int width;           /* train.py:23-28 input/output_width (edge|image)*/
@@ -36,7 +40,11 @@ typedef struct eg_config {
   int z_dim;           /* train.py:74                                   */
   int gf_dim, df_dim;  /* models/edgegan.py:47                          */
   int c_dim;           /* models/edgegan.py:48                          */
-  int dis_size;        /* train.py:64,67 image_dis_size/edge_dis_size   */
+  int use_image_discriminator; /* train.py:61-62; 0: D_patch2 is not built, d_optim_patch2 is not registered and
+                                  image_dis_dloss = image_dis_gloss = 0 (models/edgegan.py:164-168,113-114,253-263,288-301) */
+  int image_dis_size;  /* train.py:63-64                                */
+  int use_edge_discriminator;  /* train.py:65-66; the same for D_patch3 / d_optim_patch3 (models/edgegan.py:170-174,264-274,303-311) */
+  int edge_dis_size;   /* train.py:67                                   */
   float lambda_gp;     /* train.py:52                                   */
   float zl_weight;     /* train.py:41 stage1_zl_loss                    */
   float learning_rate; /* train.py:18                                   */

@@ -228,13 +228,25 @@ class Config:
     gf_dim: int = 64            # edgegan.py:47
     df_dim: int = 64
     c_dim: int = 3
-    dis_size: int = 128         # image_dis_size / edge_dis_size  train.py:64,67
+    dis_size: int = 128         # image_dis_size / edge_dis_size  train.py:64,67 (when not given separately below)
     lambda_gp: float = 10.0     # train.py:52
     zl_weight: float = 10.0     # stage1_zl_loss train.py:41
     learning_rate: float = 2e-4  # train.py:18
     joint_dweight: float = 1.0
     image_dweight: float = 1.0
     edge_dweight: float = 1.0
+    use_image_discriminator: bool = True     # train.py:61-62
+    use_edge_discriminator: bool = True      # train.py:65-66
+    image_dis_size: Optional[int] = None     # train.py:63-64
+    edge_dis_size: Optional[int] = None      # train.py:67
+
+    @property
+    def image_dis(self) -> int:
+        return self.dis_size if self.image_dis_size is None else self.image_dis_size
+
+    @property
+    def edge_dis(self) -> int:
+        return self.dis_size if self.edge_dis_size is None else self.edge_dis_size
 
     @property
     def multiclasses(self) -> bool:
@@ -584,8 +596,10 @@ def variable_specs(cfg: Config) -> List[VarSpec]:
     if cfg.multiclasses:
         v += classifier_specs(cfg)
     v += discriminator_specs('D', cfg, cfg.height, cfg.width)
-    v += discriminator_specs('D_patch2', cfg, cfg.dis_size, cfg.dis_size)
-    v += discriminator_specs('D_patch3', cfg, cfg.dis_size, cfg.dis_size)
+    if cfg.use_image_discriminator:          # edgegan.py:164-168: not constructed when switched off
+        v += discriminator_specs('D_patch2', cfg, cfg.image_dis, cfg.image_dis)
+    if cfg.use_edge_discriminator:           # edgegan.py:170-174
+        v += discriminator_specs('D_patch3', cfg, cfg.edge_dis, cfg.edge_dis)
     v += encoder_specs(cfg)
     return v
 
@@ -821,11 +835,11 @@ def forward_graph(p: P, inp: StepInputs, cfg: Config, eps_val, bn_stats=None, wa
     image = lambda: gen('G2')
     joint = lambda: once('joint', lambda: torch.cat([edge(), image()], dim=2))
     d_fake = lambda: once('d_fake', lambda: discriminator(p, 'D', joint())[1])
-    r_pic = lambda: once('r_pic', lambda: resize_bicubic(real_pic, cfg.dis_size))
-    r_img = lambda: once('r_img', lambda: resize_bicubic(image(), cfg.dis_size))
+    r_pic = lambda: once('r_pic', lambda: resize_bicubic(real_pic, cfg.image_dis))
+    r_img = lambda: once('r_img', lambda: resize_bicubic(image(), cfg.image_dis))
     di_fake = lambda: once('di_fake', lambda: discriminator(p, 'D_patch2', r_img())[1])
-    r_edges = lambda: once('r_edges', lambda: resize_bicubic(real_edge, cfg.dis_size))
-    r_edge_out = lambda: once('r_edge_out', lambda: resize_bicubic(edge(), cfg.dis_size))
+    r_edges = lambda: once('r_edges', lambda: resize_bicubic(real_edge, cfg.edge_dis))
+    r_edge_out = lambda: once('r_edge_out', lambda: resize_bicubic(edge(), cfg.edge_dis))
     de_fake = lambda: once('de_fake', lambda: discriminator(p, 'D_patch3', r_edge_out())[1])
     joint_g = lambda: once('joint_g', lambda: generator_ganloss(d_fake()))
 
@@ -833,21 +847,21 @@ def forward_graph(p: P, inp: StepInputs, cfg: Config, eps_val, bn_stats=None, wa
         _, d_real = discriminator(p, 'D', real)
         out['joint_dis_dloss'] = discriminator_ganloss(d_fake(), d_real) + gradient_penalty_term(
             p, 'D', joint(), real, inp.alpha[0], cfg.lambda_gp)
-    if 'image_dis_dloss' in want:
+    if 'image_dis_dloss' in want and cfg.use_image_discriminator:    # edgegan.py:288-301 (else: the constant 0)
         _, di_real = discriminator(p, 'D_patch2', r_pic())
         out['image_dis_dloss'] = discriminator_ganloss(di_fake(), di_real) + gradient_penalty_term(
             p, 'D_patch2', r_img(), r_pic(), inp.alpha[1], cfg.lambda_gp)
-    if 'edge_dis_dloss' in want:
+    if 'edge_dis_dloss' in want and cfg.use_edge_discriminator:      # edgegan.py:303-311
         _, de_real = discriminator(p, 'D_patch3', r_edges())
         out['edge_dis_dloss'] = discriminator_ganloss(de_fake(), de_real) + gradient_penalty_term(
             p, 'D_patch3', r_edge_out(), r_edges(), inp.alpha[2], cfg.lambda_gp)
     if 'edge_gloss' in want:
         out['joint_dis_gloss'] = joint_g()
-        out['edge_dis_gloss'] = generator_ganloss(de_fake())
+        out['edge_dis_gloss'] = generator_ganloss(de_fake()) if cfg.use_edge_discriminator else torch.zeros((), dtype=real.dtype)
         out['edge_gloss'] = cfg.joint_dweight * joint_g() + cfg.edge_dweight * out['edge_dis_gloss']
     if 'image_gloss' in want:
         out['joint_dis_gloss'] = joint_g()
-        out['image_dis_gloss'] = generator_ganloss(di_fake())
+        out['image_dis_gloss'] = generator_ganloss(di_fake()) if cfg.use_image_discriminator else torch.zeros((), dtype=real.dtype)
         out['image_gloss'] = cfg.joint_dweight * joint_g() + cfg.image_dweight * out['image_dis_gloss']
     if cfg.multiclasses and ('loss_d_ac' in want or 'image_gloss' in want):
         lr_ = classifier(p, real_pic, cfg) if 'loss_d_ac' in want else None
@@ -902,7 +916,10 @@ class OracleModel:
         return t
 
     def substep_names(self) -> List[str]:
-        return [n for n in SUBSTEPS if not (n == 'd_optim2' and not self.cfg.multiclasses)]
+        # register_optim_if (edgegan.py:109-124): d_optim_patch2 / d_optim_patch3 / d_optim2 only with their flag
+        off = {'d_optim2': not self.cfg.multiclasses, 'd_optim_patch2': not self.cfg.use_image_discriminator,
+               'd_optim_patch3': not self.cfg.use_edge_discriminator}
+        return [n for n in SUBSTEPS if not off.get(n, False)]
 
     def _leaf_params(self) -> P:
         return {n: (t.detach().clone().requires_grad_(True) if self.trainable[n] else t)

@@ -47,7 +47,9 @@ def oracle_config(cfg: ea.Config) -> O.Config:
     return O.Config(batch_size=cfg.batch_size, height=cfg.height, width=cfg.width, num_classes=cfg.num_classes,
                     z_dim=cfg.z_dim, gf_dim=cfg.gf_dim, df_dim=cfg.df_dim, c_dim=cfg.c_dim, dis_size=cfg.dis_size,
                     lambda_gp=cfg.lambda_gp, zl_weight=cfg.zl_weight, learning_rate=cfg.learning_rate,
-                    joint_dweight=cfg.joint_dweight, image_dweight=cfg.image_dweight, edge_dweight=cfg.edge_dweight)
+                    joint_dweight=cfg.joint_dweight, image_dweight=cfg.image_dweight, edge_dweight=cfg.edge_dweight,
+                    use_image_discriminator=cfg.use_image_discriminator, use_edge_discriminator=cfg.use_edge_discriminator,
+                    image_dis_size=cfg.image_dis_size, edge_dis_size=cfg.edge_dis_size)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -457,7 +459,7 @@ def _oracle_trace(cfg, values, batch, iterations, self_consistency):
     steps = []
     for it in range(iterations):
         for k, name in enumerate(O.SUBSTEPS, start=1):
-            if name == 'd_optim2' and not cfg.multiclasses:
+            if name not in om.substep_names():      # register_optim_if: d_optim2 / d_optim_patch2 / d_optim_patch3 behind their flags
                 continue
             grads, losses = om.compute_grads(name, inp, inp.eps[0])
             var_tol = {}

@@ -36,6 +36,41 @@ def test_registry_matches_oracle_restatement(built_lib, num_classes):
         assert n_train == 2 * 5249155 + 2771969 + 2 * 2788353 + 9907592 + 17151293
 
 
+@pytest.mark.parametrize('flags', [dict(use_image_discriminator=False), dict(use_edge_discriminator=False),
+                                   dict(image_dis_size=64, edge_dis_size=256)])
+def test_registry_non_default_discriminator_flags(built_lib, flags):
+    """edgegan/train.py:61-67: a patch discriminator that is switched off is never constructed (models/edgegan.py:164-174);
+    each keeps its own input size -- the d_linear_5 matrix follows it."""
+    cfg = ea.Config(batch_size=2, **flags)
+    got = [(s.name, tuple(s.shape), s.trainable) for s in ea.variable_specs(cfg)]
+    want = [(s.name, tuple(s.shape), s.trainable) for s in O.variable_specs(O.Config(batch_size=2, **flags))]
+    assert got == want
+    names = dict((n, sh) for n, sh, _ in got)
+    assert ('D_patch2/d_conv_0/conv2d/w' in names) == cfg.use_image_discriminator
+    assert ('D_patch3/d_conv_0/conv2d/w' in names) == cfg.use_edge_discriminator
+    if 'image_dis_size' in flags:
+        assert names['D_patch2/d_linear_5/Matrix'] == (4 * 4 * 512, 1) and names['D_patch3/d_linear_5/Matrix'] == (16 * 16 * 512, 1)
+
+
+def test_config_struct_is_versioned(built_lib):
+    """eg_config starts with struct_size (include/edgegan_hip.h): eg_default_config writes the library's sizeof, the Python
+    binding's ctypes layout has the same size, and a caller with another layout is refused instead of being read shifted."""
+    cc = _lib._CConfig()
+    assert built_lib.eg_default_config(ctypes.byref(cc)) == 0
+    assert cc.struct_size == ctypes.sizeof(_lib._CConfig)
+    assert (cc.batch_size, cc.height, cc.width, cc.num_classes, cc.use_image_discriminator, cc.image_dis_size,
+            cc.use_edge_discriminator, cc.edge_dis_size, cc.compute_dtype) == (64, 64, 128, 14, 1, 128, 1, 128, 0)
+    assert abs(cc.learning_rate - 2e-4) < 1e-9 and cc.lambda_gp == 10.0
+    assert built_lib.eg_variable_count(ctypes.byref(cc)) == len(ea.variable_specs(ea.Config()))
+    stale = ea.Config().to_c()
+    stale.struct_size -= 4                      # a binding built against a header with one field less
+    assert built_lib.eg_variable_count(ctypes.byref(stale)) == -1
+    ctx = ctypes.c_void_p()
+    rc = built_lib.eg_create(ctypes.byref(stale), ctypes.byref(ctx))
+    assert rc != 0 and not ctx.value
+    assert 'layout mismatch' in built_lib.eg_last_error(None).decode()
+
+
 def test_registry_high_res_config(built_lib):
     cfg = ea.Config(batch_size=2, height=256, width=512)
     names = {s.name: s.shape for s in ea.variable_specs(cfg)}

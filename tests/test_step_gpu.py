@@ -72,6 +72,39 @@ def test_substeps_single_class_batch4():
     net.close()
 
 
+@pytest.mark.parametrize('flags', [dict(use_image_discriminator=False), dict(use_edge_discriminator=False),
+                                   dict(use_image_discriminator=False, use_edge_discriminator=False, num_classes=0),
+                                   dict(image_dis_size=64, edge_dis_size=96)],
+                         ids=['no_image_dis', 'no_edge_dis', 'joint_only_single_class', 'unequal_dis_sizes'])
+def test_substeps_non_default_discriminator_flags(flags):
+    """use_image_discriminator / use_edge_discriminator = False (edgegan/train.py:61-66): the network is not built, its
+    sub-step is not registered and its loss terms are the constant 0 (models/edgegan.py:111-114,164-174,253-274,288-311);
+    image_dis_size != edge_dis_size (train.py:63-67).  Every remaining sub-step against the oracle, which applies the same
+    rules; a switched-off network has no variables on either side."""
+    cfg = ea.Config(batch_size=3, **flags)
+    names = {s.name for s in ea.variable_specs(cfg)}
+    assert any(n.startswith('D_patch2/') for n in names) == cfg.use_image_discriminator
+    assert any(n.startswith('D_patch3/') for n in names) == cfg.use_edge_discriminator
+    values = ea.init_variables(cfg, 7)
+    net = ea.EdgeGAN(cfg, values)
+    rows = parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=31))
+    ran = {r[0].split()[3] for r in rows if r[0].startswith('it0 substep')}
+    assert ('d_optim_patch2' in ran) == cfg.use_image_discriminator and ('d_optim_patch3' in ran) == cfg.use_edge_discriminator
+    _assert(rows)
+    # a whole concurrent iteration (lanes on) with the switched-off sub-steps skipped: finite, and the skipped terms read 0
+    net.set_variables(values)
+    net.train_step()
+    l = net.losses()
+    assert all(np.isfinite(v) for v in l.values()), l
+    if not cfg.use_image_discriminator:
+        assert l['image_dis_dloss'] == 0.0 and l['image_dis_gloss'] == 0.0
+    if not cfg.use_edge_discriminator:
+        assert l['edge_dis_dloss'] == 0.0 and l['edge_dis_gloss'] == 0.0
+    ev = net.evaluate(tensors=True)
+    assert ('resized_inputs' in ev) == cfg.use_image_discriminator and ('resized_edges' in ev) == cfg.use_edge_discriminator
+    net.close()
+
+
 def test_inference_matches_oracle():
     cfg = ea.Config(batch_size=2)
     values = ea.init_variables(cfg, 2)
