@@ -167,6 +167,7 @@ static float* resolve_var(Ctx& c, const std::string& name, size_t* numel, bool f
 
 int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long numel) {
   EG_API_BEGIN_CTX(ctx)
+  ctx->c.inf_warm = false;
   comm_wait_all(ctx->c);
   size_t n;
   float* d = resolve_var(ctx->c, name, &n, true);
@@ -209,12 +210,14 @@ int eg_upload_batch(eg_ctx* ctx, const float* images, const float* z, const floa
 
 int eg_substep(eg_ctx* ctx, int k, int apply) {
   EG_API_BEGIN_CTX(ctx)
+  ctx->c.inf_warm = false;
   run_substep(ctx->c, k, apply != 0);
   EG_API_END(ctx)
 }
 
 int eg_train_step(eg_ctx* ctx) {
   EG_API_BEGIN_CTX(ctx)
+  ctx->c.inf_warm = false;
   train_step(ctx->c);
   EG_API_END(ctx)
 }
@@ -227,6 +230,7 @@ int eg_train_step(eg_ctx* ctx) {
 int eg_train_batch(eg_ctx* ctx, const float* images, const float* z, const float* alpha, const float* eps) {
   EG_API_BEGIN_CTX(ctx)
   Ctx& c = ctx->c;
+  c.inf_warm = false;
   const Config& cfg = c.cfg;
   EG_CHECK(images && z && alpha && eps, "null batch pointer");
   const size_t zc = cfg.multiclasses() ? cfg.z_dim + 1 : cfg.z_dim;
@@ -332,17 +336,23 @@ static void infer_reserve(Ctx& c, int nb) {
   EG_CHECK(nb >= 1 && nb <= 4096, "nb out of range");
   const size_t in_n = (size_t)nb * cfg.H * cfg.W * cfg.c_dim, out_n = in_n / 2;
   if ((size_t)nb <= c.inf_cap) return;
+  EG_HIP(hipDeviceSynchronize());   // (runs of the previous, smaller batch may still be in flight on the other slots' lanes)
   (void)hipFree(c.inf_in);
-  (void)hipFree(c.inf_edge);
-  (void)hipFree(c.inf_image);
   (void)hipFree(c.inf_cls);
-  c.inf_in = c.inf_edge = c.inf_image = nullptr;
+  c.inf_in = nullptr;
   c.inf_cls = nullptr;
+  for (int i = 0; i < Ctx::kInferSlots; ++i) {
+    (void)hipFree(c.inf_edge[i]);
+    (void)hipFree(c.inf_image[i]);
+    c.inf_edge[i] = c.inf_image[i] = nullptr;
+  }
   c.inf_cap = 0;
   c.inf_nb = 0;   // nothing is resident any more: a failed allocation below must not leave eg_infer_run runnable
   EG_HIP(hipMalloc(&c.inf_in, in_n * 4));
-  EG_HIP(hipMalloc(&c.inf_edge, out_n * 4));
-  EG_HIP(hipMalloc(&c.inf_image, out_n * 4));
+  for (int i = 0; i < Ctx::kInferSlots; ++i) {
+    EG_HIP(hipMalloc(&c.inf_edge[i], out_n * 4));
+    EG_HIP(hipMalloc(&c.inf_image[i], out_n * 4));
+  }
   EG_HIP(hipMalloc(&c.inf_cls, (size_t)nb * 4));
   if (!c.inf_eps) EG_HIP(hipMalloc(&c.inf_eps, 8));
   c.inf_cap = nb;
@@ -356,6 +366,7 @@ int eg_infer_upload(eg_ctx* ctx, const float* images, const int* classes, int nb
   EG_CHECK(!cfg.multiclasses() || classes, "classes required");
   infer_reserve(c, nb);
   const size_t in_n = (size_t)nb * cfg.H * cfg.W * cfg.c_dim;
+  EG_HIP(hipDeviceSynchronize());   // runs still in flight on any slot read the resident batch this call replaces
   EG_HIP(hipMemcpyAsync(c.inf_in, images, in_n * 4, hipMemcpyHostToDevice, c.stream));
   EG_HIP(hipMemcpyAsync(c.inf_eps, eps2, 8, hipMemcpyHostToDevice, c.stream));
   if (classes) EG_HIP(hipMemcpyAsync(c.inf_cls, classes, (size_t)nb * 4, hipMemcpyHostToDevice, c.stream));
@@ -365,10 +376,22 @@ int eg_infer_upload(eg_ctx* ctx, const float* images, const int* classes, int nb
 }
 
 int eg_infer_run(eg_ctx* ctx) {
+  if (ctx) ctx->c.inf_entering = true;   // (api_enter: this entry point does not drain the runs already in flight)
   EG_API_BEGIN_CTX(ctx)
   Ctx& c = ctx->c;
   EG_CHECK(c.inf_nb > 0, "eg_infer_run without eg_infer_upload");
-  infer(c, c.inf_in, c.inf_cls, c.inf_nb, c.inf_eps, c.inf_edge, c.inf_image);
+  // slot of this call: its lanes and its output buffers.  The slots' calls share nothing that is written (engine.h), so up to
+  // inf_slots consecutive calls are in flight at once; a slot's next call follows its previous one in stream order.
+  const int nslots = (c.lanes_on && !c.prof_on) ? c.inf_slots : 1;
+  const int slot = (int)(c.inf_runs++ % nslots);
+  const int main_lane = nslots == 4 ? slot : 2 * slot, side_lane = nslots == 4 ? -1 : main_lane + 1;
+  c.inf_last_slot = slot;
+  infer(c, c.inf_in, c.inf_cls, c.inf_nb, c.inf_eps, c.inf_edge[slot], c.inf_image[slot], main_lane, side_lane);
+  c.inf_inflight = true;
+  if (!c.inf_warm) {   // the first run after the weights changed builds their derived copies on ITS lanes: finish it before another slot reads them
+    EG_HIP(hipDeviceSynchronize());
+    c.inf_warm = true;
+  }
   EG_API_END(ctx)
 }
 
@@ -378,8 +401,9 @@ int eg_infer_download(eg_ctx* ctx, float* edge_out, float* image_out) {
   const Config& cfg = c.cfg;
   EG_CHECK(c.inf_nb > 0 && edge_out && image_out, "eg_infer_download: nothing resident / null argument");
   const size_t out_n = (size_t)c.inf_nb * cfg.H * (cfg.W / 2) * cfg.c_dim;
-  EG_HIP(hipMemcpyAsync(edge_out, c.inf_edge, out_n * 4, hipMemcpyDeviceToHost, c.stream));
-  EG_HIP(hipMemcpyAsync(image_out, c.inf_image, out_n * 4, hipMemcpyDeviceToHost, c.stream));
+  EG_HIP(hipDeviceSynchronize());   // every slot's lanes: the latest run (and all before it) have finished
+  EG_HIP(hipMemcpyAsync(edge_out, c.inf_edge[c.inf_last_slot], out_n * 4, hipMemcpyDeviceToHost, c.stream));
+  EG_HIP(hipMemcpyAsync(image_out, c.inf_image[c.inf_last_slot], out_n * 4, hipMemcpyDeviceToHost, c.stream));
   EG_HIP(hipStreamSynchronize(c.stream));
   EG_API_END(ctx)
 }

@@ -131,9 +131,9 @@ struct Ctx {
     bool done = false;
   } pool_epi;
   bool conv_wrote_plane = false;   //   ... and reports here whether its kernel stored the output's bf16 plane
-  // inference only (set inside infer()): a residual block's 1x1 shortcut convolution runs on lane 1 beside the block's
-  // two 3x3 convolutions on lane 0 -- the encoder trunk is ONE chain of small launches otherwise
-  bool infer_lanes = false;
+  // inference only (set inside infer()): a residual block's 1x1 shortcut convolution runs on this lane beside the block's
+  // two 3x3 convolutions on the call's main lane -- the encoder trunk is ONE chain of small launches otherwise (-1: one chain)
+  int infer_side = -1;
   float* scratch = nullptr;  // persistent reduction scratch
   size_t scratch_floats = 0;
 
@@ -189,10 +189,23 @@ struct Ctx {
   hipEvent_t ev_fork = nullptr, ev_gen = nullptr, ev_g1fwd = nullptr, ev_branch = nullptr, ev_cls = nullptr;
 
   // inference staging buffers (host <-> device hand-over of eg_infer), grown on demand and kept
-  float *inf_in = nullptr, *inf_edge = nullptr, *inf_image = nullptr, *inf_eps = nullptr;
+  // Consecutive eg_infer_run calls on a resident batch are independent of one another: they rotate over kInferSlots slots
+  // (own lanes = streams + arenas, own output buffers), so several calls are in flight at once and their small launches
+  // (4x4 .. 64x64 maps: most fill a fraction of the chip) share the device (model.cpp: infer, capi.cpp: eg_infer_run)
+  static constexpr int kInferSlots = 4;
+  float *inf_in = nullptr, *inf_eps = nullptr;
+  float *inf_edge[kInferSlots] = {}, *inf_image[kInferSlots] = {};
   int* inf_cls = nullptr;
   size_t inf_cap = 0;   // images the buffers hold
   int inf_nb = 0;       // images currently resident (eg_infer_upload)
+  long long inf_runs = 0;   // eg_infer_run calls since the context was created (slot = inf_runs mod the slots in use)
+  int inf_last_slot = 0;    // slot of the latest run: what eg_infer_download returns
+  int inf_slots = 2;        // calls in flight x lanes per call: 4 = four single-chain calls, 2 = two calls of two lanes each, 1 = one call of two lanes (EG_INFER_SLOTS)
+  hipEvent_t ev_infer[kLanes] = {};   // fork event of the call whose main lane is i
+  bool inf_inflight = false;   // eg_infer_run calls may still be running on lanes other than 0: every OTHER entry point drains them first (api_enter)
+  bool inf_entering = false;   // ... set by eg_infer_run around its own api_enter
+  bool inf_warm = false;       // the weights' lazily built derived copies (transposes, bf16 planes) are all in place: set by the first
+                               // completed run, cleared whenever a variable changes -- until then a run is followed by a device sync
 
   // profiling
   bool prof_on = false;
@@ -344,7 +357,7 @@ struct EvalResult {   // device pointers valid until the next enqueueing call
 };
 void eval_losses(Ctx& c, const float* alpha_dev, const float* eps_dev, int bn_updates, EvalResult* r);
 void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const float* d_eps2, float* d_edge,
-           float* d_image);
+           float* d_image, int main_lane = 0, int side_lane = 1);
 
 // ---- data parallel (comm.cpp) -----------------------------------------------------------------
 void comm_unique_id(Ctx& c, char* out128);

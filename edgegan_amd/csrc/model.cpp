@@ -306,6 +306,11 @@ void build_context(Ctx& c) {
   EG_HIP(hipEventCreateWithFlags(&c.ev_g1fwd, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_branch, hipEventDisableTiming));
   EG_HIP(hipEventCreateWithFlags(&c.ev_cls, hipEventDisableTiming));
+  for (int i = 0; i < Ctx::kLanes; ++i) EG_HIP(hipEventCreateWithFlags(&c.ev_infer[i], hipEventDisableTiming));
+  if (const char* e = getenv("EG_INFER_SLOTS")) {   // calls in flight: 4 (one chain each), 2 (two lanes each), 1 (one call, two lanes: round 5)
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) c.inf_slots = v;
+  }
   if (const char* e = getenv("EG_LANES")) {   // 0 = one stream; bit 0 = sub-steps 1-4 concurrent, bit 1 = 6/7 concurrent, bit 2 = the critics of 5 / 7 on four lanes, bit 3 = filter / bias gradients on the lanes' leaf streams
     c.lanes_mask = atoi(e);
     c.lanes_on = c.lanes_mask != 0;
@@ -334,6 +339,12 @@ void use_lane(Ctx& c, int lane) {
 // enqueued is finished or failed), put the active lane back on its main stream, drop the queued reductions of the
 // abandoned sweep, then return to lane 0.
 void api_enter(Ctx& c) {
+  const bool from_infer_run = c.inf_entering;
+  c.inf_entering = false;
+  if (c.inf_inflight && !from_infer_run) {   // inference calls in flight on other lanes (capi.cpp: eg_infer_run): drain them
+    (void)hipDeviceSynchronize();
+    c.inf_inflight = false;
+  }
   if (c.leaf_dirty || c.stream != c.lanes[c.cur_lane].stream) {
     (void)hipDeviceSynchronize();
     (void)hipGetLastError();
@@ -342,7 +353,7 @@ void api_enter(Ctx& c) {
     c.leaf_dirty = false;
   }
   use_lane(c, 0);
-  c.infer_lanes = false;
+  c.infer_side = -1;
   c.feeds_in = FEED_NONE;
   c.prelu_plane_only = false;
   c.conv_out_into = nullptr;
@@ -413,7 +424,8 @@ T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out) {
   int cin = 64, i = 1;
   for (int n : encoder_filters(cfg)) {
     const std::string b = "E/e_resnet_" + std::to_string(n) + "_" + std::to_string(i++);
-    if (c.infer_lanes) EG_HIP(hipEventRecord(c.ev_fork, c.stream));   // the block's input is complete here
+    const int main_lane = c.cur_lane;
+    if (c.infer_side >= 0) EG_HIP(hipEventRecord(c.ev_infer[main_lane], c.stream));   // the block's input is complete here
     c.feeds_in = true;   // residual: both 3x3 convolutions are read by their InstanceNorm alone
     T o1 = conv2d(c, E, wref_param(c, P(c, b + "/res1/conv2d/w"), 9, cin, n), P(c, b + "/res1/conv2d/b"), 3, 1,
                   PAD_REFLECT);
@@ -422,16 +434,16 @@ T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out) {
     T o2 = conv2d(c, o1, wref_param(c, P(c, b + "/res2/conv2d/w"), 9, n, n), P(c, b + "/res2/conv2d/b"), 3, 1,
                   PAD_REFLECT);
     o2 = in_act(c, o2, ACT_NONE);
-    if (c.infer_lanes) {
-      use_lane(c, 1);
-      EG_HIP(hipStreamWaitEvent(c.stream, c.ev_fork, 0));
+    if (c.infer_side >= 0) {
+      use_lane(c, c.infer_side);
+      EG_HIP(hipStreamWaitEvent(c.stream, c.ev_infer[main_lane], 0));
     }
     T sc = conv2d(c, E, wref_param(c, P(c, b + "/shortcut/conv2d/w"), 1, cin, n), P(c, b + "/shortcut/conv2d/b"),
                   1, 1, PAD_REFLECT);
-    if (c.infer_lanes) {
-      EG_HIP(hipEventRecord(c.lanes[1].done, c.stream));
-      use_lane(c, 0);
-      EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[1].done, 0));
+    if (c.infer_side >= 0) {
+      EG_HIP(hipEventRecord(c.lanes[c.infer_side].done, c.stream));
+      use_lane(c, main_lane);
+      EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[c.infer_side].done, 0));
     }
     E = pool2(c, add(c, sc, o2, true));
     cin = n;
@@ -677,7 +689,13 @@ static void disc_substep(Ctx& c, int group, T real, T fake, const float* alpha_d
 // LeakyReLU stages see the row classes: in_fwd / in_bwd on the primal and real|fake rows, the linearisation (in_tangent_fwd)
 // and its reverse on the tangent rows.  The linear tape cannot express this order (per layer: every row class's norm backward,
 // then one convolution backward), so the sweep is written out here.  Same kernels, same mathematics as disc_substep; sums over
-// the batch are taken in one launch instead of three (fp32 summation order differs).  Measured per layer (f32x3, forward +
+// the batch are taken in one launch instead of three (fp32 summation order differs).
+// Round 6: the branch at the reference's cost (6F - F0 instead of 7F - 2F0, functional.py:26-29 / edgegan.py:38-42).  The
+// tangent t = J v enters the loss through <s(d), t_out>, s = 1 + sigmoid'(d), so the cotangent of the tangent at layer i is
+// J_(i->out)^T s(d) -- exactly the FIRST-ORDER gradient delta_i that phase 1 computes with the same seed (gp_head mode 0 and the
+// tangent seed of mode 1 are the same expression).  Phase 1 therefore stores its delta(out_i) in the TANGENT rows of the
+// stacked gradient tensors, and the reverse sweep's input-gradient launches run over the 3B evaluated rows only: one
+// discriminator input-gradient chain (layers 3, 2, 1 over B rows) less per sub-step.  Measured per layer (f32x3, forward +
 // both gradients): d_conv_4 of the patch discriminators 1.08 -> 0.96 ms, of the joint one 0.64 -> 0.51
 // (tools/gpu_stack_probe.py, profiles/r05g_*).
 static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float* alpha_dev, int slot_d, int slot_gp,
@@ -694,6 +712,7 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
   Param* lb = P(c, p + "/d_linear_5/bias");
   // stacked activations: X = the four inputs, pre[i] / out[i] = layer i before / after its norm + activation
   T X = new_tensor(c, R, H, W, C0, false);
+  X->g = c.arena.allocf((size_t)B * H * W * C0);   // (only the x_hat rows [0,B) ever receive a gradient: view_rows(X, 0, B))
   T pre[4], out[4], st[4];
   unsigned short* gpl[4];
   int hh = H, ww = W;
@@ -779,27 +798,38 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
   // norm + activation backward of layer i for rows [n0, n0 + n) of the evaluated points: gout -> gpre
   static const bool gpo_on = dbg_env("EG_NO_PLANE_ONLY_GRAD") == nullptr;
   const int gpo = gpo_on ? GRAD_PLANE_ONLY : 0;
-  auto norm_bwd = [&](int i, int n0, int n, int acc) {
+  // (gy0: the rows of out[i]'s GRADIENT that hold dL/d(out) of these points -- phase 1 keeps the first-order gradient of the
+  //  x_hat rows in the tangent rows, see above)
+  auto norm_bwd = [&](int i, int n0, int n, int acc, int gy0) {
     const int HW = pre[i]->h * pre[i]->w, C = ch[i + 1];
     const size_t img = (size_t)HW * C, o = (size_t)n0 * img;
     // (gpo: the fp32 gradient of pre[i] is not stored -- both gradient convolutions of layer i read the plane, Tensor::g_plane_only)
-    launch_in_bwd(pre[i]->d + o, out[i]->d + o, out[i]->g + o, st[i]->d + (size_t)n0 * 2 * C, pre[i]->g + o, acc | (gpl[i] ? gpo : 0), n, HW, C,
+    launch_in_bwd(pre[i]->d + o, out[i]->d + o, out[i]->g + (size_t)gy0 * img, st[i]->d + (size_t)n0 * 2 * C, pre[i]->g + o, acc | (gpl[i] ? gpo : 0), n, HW, C,
                   ACT_LRELU, c.stream, gpl[i] ? gpl[i] + o : nullptr);
     pre[i]->g_bf = gpl[i];            // (rows [n0, n0 + n) of the plane are current; view_rows hands them on)
     pre[i]->g_bf_stream = nullptr;
     pre[i]->g_plane_only = gpl[i] && gpo;
   };
   // ---- phase 1: x_hat, and the first-order gradient g = d/dx_hat sum_b [sigmoid(D) + D] (quirk N10) ----
+  // (data of the x_hat rows [0,B); the gradients dL/d(out_i) go to the tangent rows [3B,4B) of out[i]->g, where the reverse
+  //  sweep needs them as the cotangents of the tangent)
+  auto grad_rows = [&](T t, int data0, int grad0, int n) {   // rows [data0, data0 + n) of t whose gradient lives in rows [grad0, grad0 + n)
+    T v = rows(t, data0, n);
+    v->g = t->g + (size_t)grad0 * (t->numel() / t->n);
+    v->g_bf = nullptr;
+    v->g_plane_only = false;
+    return v;
+  };
   forward(0, B);
   {
     launch_gp_head(dval, nullptr, dgrad, nullptr, B, 0, c.stream);
-    T o3 = rows(out[3], 0, B);
+    T o3 = grad_rows(out[3], 0, 3 * B, B);
     launch_gemv_bwd_x(dgrad, lw->w, o3->g, 0, B, K, c.stream);
     o3->g_set = true;
     bool act0_done = false;
     for (int i = 3; i >= 1; --i) {
-      norm_bwd(i, 0, B, 0);
-      T yv = rows(pre[i], 0, B), xv = rows(out[i - 1], 0, B);
+      norm_bwd(i, 0, B, 0, 3 * B);
+      T yv = rows(pre[i], 0, B), xv = grad_rows(out[i - 1], 0, 3 * B, B);
       yv->g_set = true;
       if (i == 1) {   // layer 0's LeakyReLU backward rides in this launch's epilogue where the kernel that runs has one
         xv->fused_act = ACT_LRELU;
@@ -808,7 +838,7 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
       conv_backward_x(c, xv, yv, w[i], 4, 2);
       if (i == 1) act0_done = xv->g_act_done;
     }
-    T y0 = rows(pre[0], 0, B), x0 = rows(X, 0, B);
+    T y0 = grad_rows(pre[0], 0, 3 * B, B), x0 = rows(X, 0, B);
     if (!act0_done) {
       tensor_need_f32(c, y0);
       launch_act_bwd(y0->d, y0->g, y0->g, 0, y0->numel(), ACT_LRELU, c.stream);   // in place: g *= act'(out)
@@ -822,40 +852,44 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
   // ---- phase 2: real | fake | tangent in one pass ----
   forward(B, 3 * B);
   launch_mean_diff(dval + 2 * B, dval + B, c.d_losses + slot_d, B, c.stream);
-  // ---- the reverse sweep over all 4B rows ----
+  // ---- the reverse sweep: filter gradients over all 4B rows, input gradients over the 3B evaluated rows ----
   launch_gp_head(dval, dval + 3 * B, dgrad, dgrad + 3 * B, B, 1, c.stream);   // seeds of d(x_hat) and of the tangent
   launch_fill(dgrad + B, -1.f / B, B, c.stream);
   launch_fill(dgrad + 2 * B, 1.f / B, B, c.stream);
   linear1_backward_w(c, out[3]->d, dgrad, lw, lb, 3 * B, R, K);   // (the tangent rows carry no bias)
-  launch_gemv_bwd_x(dgrad, lw->w, out[3]->g, 0, R, K, c.stream);
+  launch_gemv_bwd_x(dgrad, lw->w, out[3]->g, 0, 3 * B, K, c.stream);   // (the tangent rows of out[3]->g: phase 1's s(d) x Matrix, the same product)
+  bool act0_all = false;
   for (int i = 3; i >= 1; --i) {
     const int HW = pre[i]->h * pre[i]->w, C = ch[i + 1];
     const size_t img = (size_t)HW * C, ot = (size_t)3 * B * img;
-    norm_bwd(i, B, 2 * B, 0);                                  // real | fake
-    // the tangent rows: reverse of the linearisation -- gradient w.r.t. the tangent AND w.r.t. the primal pre-norm rows [0,B)
+    norm_bwd(i, B, 2 * B, 0, B);                               // real | fake
+    // the tangent rows: reverse of the linearisation -- gradient w.r.t. the tangent (= phase 1's delta(pre_i), formed again by the
+    // same kernel that forms the term below) AND w.r.t. the primal pre-norm rows [0,B)
     launch_in_tangent_bwd(pre[i]->d, out[i]->d, st[i]->d, pre[i]->d + ot, out[i]->g + ot, pre[i]->g + ot, gpl[i] ? gpo : 0, pre[i]->g, 0, B, HW, C,
                           ACT_LRELU, c.stream, gpl[i] ? gpl[i] + ot : nullptr);
-    norm_bwd(i, 0, B, 1);                                      // the primal rows add their own first-order term
+    norm_bwd(i, 0, B, 1, 0);                                   // the primal rows add their own first-order term
     pre[i]->g_set = true;
     conv_backward_w(c, out[i - 1], pre[i], w[i], 4, 2);
-    out[i - 1]->needs_grad = true;
-    out[i - 1]->g_set = false;
-    if (i == 1) {   // layer 0's LeakyReLU backward in the epilogue: rows below 3B by their own output, the tangent rows by the primal's
-      out[0]->fused_act = ACT_LRELU;
-      out[0]->g_inplace = true;
-      out[0]->g_epi_wrap = (size_t)3 * B * (pre[0]->numel() / R);
+    // input gradient towards the evaluated rows only (the tangent rows of out[i-1]->g hold phase 1's gradient)
+    T yv = rows(pre[i], 0, 3 * B), xv = rows(out[i - 1], 0, 3 * B);
+    yv->g_set = true;
+    xv->needs_grad = true;
+    if (i == 1) {   // layer 0's LeakyReLU backward in the epilogue (every row by its own output)
+      xv->fused_act = ACT_LRELU;
+      xv->g_inplace = true;
     }
-    conv_backward_x(c, out[i - 1], pre[i], w[i], 4, 2);
+    conv_backward_x(c, xv, yv, w[i], 4, 2);
+    if (i == 1) act0_all = xv->g_act_done;
   }
-  if (!out[0]->g_act_done) {   // layer 0: LeakyReLU backward on the evaluated rows, its linearisation's reverse on the tangent rows (mask of the primal)
+  if (!act0_all) {   // layer 0: LeakyReLU backward on the evaluated rows (the tangent rows had theirs in phase 1, by the primal's mask)
     const size_t img = pre[0]->numel() / R;
     tensor_need_f32(c, pre[0]);
     launch_act_bwd(pre[0]->d, pre[0]->g, pre[0]->g, 0, (size_t)3 * B * img, ACT_LRELU, c.stream);
-    launch_act_bwd(pre[0]->d, pre[0]->g + (size_t)3 * B * img, pre[0]->g + (size_t)3 * B * img, 0, (size_t)B * img, ACT_LRELU, c.stream);
   }
   {
     pre[0]->g_set = true;
     pre[0]->g_bf = nullptr;
+    pre[0]->g_plane_only = false;
     conv_backward_w(c, X, pre[0], w[0], 4, 2);
   }
   flush_deferred(c);
@@ -1286,36 +1320,40 @@ void eval_losses(Ctx& c, const float* alpha_dev, const float* eps_dev, int bn_up
 // The reference's two sess.run calls evaluate the encoder twice on the same input; mu and log-sigma are a deterministic
 // function of that input, so the trunk is evaluated ONCE and only z = mu + eps * exp(log sigma) (encoder.py:78-79) is
 // formed per run with that run's eps -- bit-identical outputs, 1.575 of the 3.8 GFLOP per image not executed twice.
-// The two generator chains (launches of 4x4 .. 64x64 pixels, neither fills the chip) run side by side on lanes 0 and 1.
+// The two generator chains (launches of 4x4 .. 64x64 pixels, neither fills the chip) run side by side on the call's two
+// lanes (main_lane, side_lane); side_lane < 0: the whole call is ONE chain on main_lane -- what eg_infer_run uses when it
+// keeps four calls in flight (capi.cpp).  Everything a call touches is its lanes' own (arena, scratch, events) or read-only
+// (the resident inputs, the weights and their persistent derived copies), so calls on disjoint lanes do not interact.
 void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const float* d_eps2, float* d_edge,
-           float* d_image) {
+           float* d_image, int main_lane, int side_lane) {
   const Config& cfg = c.cfg;
   comm_wait_all(c);
-  use_lane(c, 0);
+  const bool two = c.lanes_on && !c.prof_on && side_lane >= 0 && side_lane != main_lane;
+  if (c.prof_on || !c.lanes_on) main_lane = 0;
+  use_lane(c, main_lane);
   reset_step(c);
   for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);
   T images = wrap_tensor(c, const_cast<float*>(d_images), NB, cfg.H, cfg.W, cfg.c_dim);
   T left = slice_w(c, images, 0, cfg.W / 2);
   T mu = nullptr, ls = nullptr;
-  const bool two = c.lanes_on && !c.prof_on;
   static const bool sc_lane = dbg_env("EG_NO_INFER_SC_LANE") == nullptr;
-  if (two && sc_lane) {   // lane 1 hosts the residual shortcuts of the trunk, then G2's chain (its arena: one reset per call)
-    use_lane(c, 1);
-    c.arena.reset();      // (lane 1's previous work is fully enqueued; stream order protects its memory)
-    use_lane(c, 0);
-    c.infer_lanes = true;
+  if (two && sc_lane) {   // the side lane hosts the residual shortcuts of the trunk, then G2's chain (its arena: one reset per call)
+    use_lane(c, side_lane);
+    c.arena.reset();      // (the side lane's previous work is fully enqueued; stream order protects its memory)
+    use_lane(c, main_lane);
+    c.infer_side = side_lane;
   }
   T z0 = encoder_forward(c, left, d_eps2, &mu, &ls);
-  c.infer_lanes = false;
+  c.infer_side = -1;
   if (two) {
-    warm_transposes(c, G_G2);   // G2's lazily built transposed filters: filled here, on lane 0, before lane 1 forks off and reads them
-    EG_HIP(hipEventRecord(c.ev_fork, c.stream));
+    warm_transposes(c, G_G2);   // G2's lazily built transposed filters: filled here, on the main lane, before the side lane forks off and reads them
+    EG_HIP(hipEventRecord(c.ev_infer[main_lane], c.stream));
   }
   for (int run = 0; run < 2; ++run) {
     if (two && run == 1) {
-      use_lane(c, 1);
-      if (!sc_lane) c.arena.reset();   // (lane 1's previous work is fully enqueued; stream order protects its memory)
-      EG_HIP(hipStreamWaitEvent(c.stream, c.ev_fork, 0));
+      use_lane(c, side_lane);
+      if (!sc_lane) c.arena.reset();   // (the side lane's previous work is fully enqueued; stream order protects its memory)
+      EG_HIP(hipStreamWaitEvent(c.stream, c.ev_infer[main_lane], 0));
     }
     T z = run == 0 ? z0 : reparam(c, mu, ls, d_eps2 + 1);
     T zin = z;
@@ -1326,11 +1364,12 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
     T out = generator_forward(c, run == 0 ? G_G1 : G_G2, zin, 0);
     launch_copy(out->d, run == 0 ? d_edge : d_image, out->numel(), c.stream);
   }
-  if (two) {   // lane 0 (the stream every read-back synchronises) continues after lane 1
-    EG_HIP(hipEventRecord(c.lanes[1].done, c.stream));
-    use_lane(c, 0);
-    EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[1].done, 0));
+  if (two) {   // the main lane continues after the side lane
+    EG_HIP(hipEventRecord(c.lanes[side_lane].done, c.stream));
+    use_lane(c, main_lane);
+    EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[side_lane].done, 0));
   }
+  use_lane(c, 0);
 }
 
 }  // namespace eg

@@ -1988,8 +1988,12 @@ Ctx::~Ctx() {
     if (loss_ready[i]) (void)hipEventDestroy(loss_ready[i]);
   }
   (void)hipFree(inf_in);
-  (void)hipFree(inf_edge);
-  (void)hipFree(inf_image);
+  for (int i = 0; i < kInferSlots; ++i) {
+    (void)hipFree(inf_edge[i]);
+    (void)hipFree(inf_image[i]);
+  }
+  for (auto e : ev_infer)
+    if (e) (void)hipEventDestroy(e);
   (void)hipFree(inf_eps);
   (void)hipFree(inf_cls);
   groups[G_G2].g = nullptr;   // lives inside G1's allocation (model.cpp: build_context)

@@ -142,6 +142,53 @@ def test_inference_shares_the_encoder_trunk_without_changing_a_bit(monkeypatch):
         assert np.array_equal(outs['15'][k][0], outs['0'][k][0]) and np.array_equal(outs['15'][k][1], outs['0'][k][1])
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_inference_calls_in_flight_return_the_same_bits(dtype, monkeypatch):
+    """eg_infer_run rotates consecutive calls over slots with their own lanes / arenas / output buffers (capi.cpp): four
+    single-chain calls in flight (EG_INFER_SLOTS=4), two calls of two lanes each (2, the default), or one (1: round 5's
+    schedule).  Whatever the schedule, and however many runs were enqueued before the download, the outputs are the bits of
+    the one-stream schedule; a new upload or a changed variable in between is honoured."""
+    cfg = ea.Config(batch_size=8, num_classes=0, compute_dtype=dtype)
+    values = ea.init_variables(cfg, 3)
+    rng = np.random.RandomState(5)
+    a = rng.uniform(-1, 1, size=(8, 64, 128, 3)).astype(np.float32)
+    b = rng.uniform(-1, 1, size=(8, 64, 128, 3)).astype(np.float32)
+    monkeypatch.setenv('EG_LANES', '0')
+    ref = ea.EdgeGAN(cfg, values)
+    want_a, want_b = ref.infer(a, None, eps2=[0.3, -0.2]), ref.infer(b, None, eps2=[0.3, -0.2])
+    w2 = dict(values)
+    w2['G1/g_dconv_4/deconv2d/b'] = values['G1/g_dconv_4/deconv2d/b'] + 0.25
+    ref.set_variable('G1/g_dconv_4/deconv2d/b', w2['G1/g_dconv_4/deconv2d/b'])
+    want_b2 = ref.infer(b, None, eps2=[0.3, -0.2])
+    ref.close()
+    monkeypatch.setenv('EG_LANES', '15')
+    for slots in ('4', '2', '1'):
+        monkeypatch.setenv('EG_INFER_SLOTS', slots)
+        net = ea.EdgeGAN(cfg, values)
+        net.infer_upload(a, None, eps2=[0.3, -0.2])
+        for runs in (1, 2, 3, 9):
+            for _ in range(runs):
+                net.infer_run()
+            e, i = net.infer_download()
+            assert np.array_equal(e, want_a[0]) and np.array_equal(i, want_a[1]), (slots, runs)
+        for _ in range(5):
+            net.infer_run()
+        net.infer_upload(b, None, eps2=[0.3, -0.2])       # replaces the batch the runs in flight read: drained first
+        for _ in range(6):
+            net.infer_run()
+        e, i = net.infer_download()
+        assert np.array_equal(e, want_b[0]) and np.array_equal(i, want_b[1]), slots
+        for _ in range(3):
+            net.infer_run()
+        net.set_variable('G1/g_dconv_4/deconv2d/b', w2['G1/g_dconv_4/deconv2d/b'])
+        for _ in range(5):
+            net.infer_run()
+        e, i = net.infer_download()
+        assert np.array_equal(e, want_b2[0]) and np.array_equal(i, want_b2[1]), slots
+        assert not np.array_equal(e, want_b[0])
+        net.close()
+
+
 def test_train_step_equals_sequential_substeps_and_is_deterministic():
     cfg = ea.Config(batch_size=2)
     values = ea.init_variables(cfg, 0)
