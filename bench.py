@@ -732,6 +732,33 @@ def main():
     # roofline of the dominant kernel: HIP events around every GEMM-shaped launch on the engine's stream.  While the
     # profiler is on, train_step runs its sub-steps one after another on one stream (a kernel is measured in isolation;
     # the timed region above overlaps independent sub-steps on several streams, which stretches individual kernels)
+    # per-collective timings of the exchange (world > 1): two more iterations with the lanes ON -- the schedule of the timed
+    # region -- and an event pair around every gradient all-reduce on the communication stream; per group the mean over the two
+    # iterations, then the MAX over the ranks: a bad scaling line names the collective that cost it
+    exchange_ms = None
+    if world > 1:
+        net.comm_timing(True)
+        for _ in range(2):
+            net.train_step()
+        net.sync()
+        recs = net.comm_timing_read()
+        net.comm_timing(False)
+        order = []
+        acc = {}
+        for i, (g, nbytes, ms) in enumerate(recs):
+            key = f'{i % max(1, len(recs) // 2)}:{g}'          # (position in the iteration: the generators exchange twice)
+            if key not in acc:
+                order.append(key)
+                acc[key] = [0.0, nbytes, 0]
+            acc[key][0] += ms
+            acc[key][2] += 1
+        means = [acc[k][0] / acc[k][2] for k in order]
+        if means:
+            mx = net.comm_reduce_scalars(means, 'max')
+            mn = net.comm_reduce_scalars(means, 'min')
+            exchange_ms = [{'collective': k, 'mbytes': round(acc[k][1] / 1e6, 2), 'ms_max_over_ranks': round(float(mx[i]), 3),
+                            'ms_min_over_ranks': round(float(mn[i]), 3),
+                            'algbw_GBps_at_max': round(acc[k][1] / 1e9 / max(float(mx[i]) * 1e-3, 1e-9), 1)} for i, k in enumerate(order)]
     roof = None
     if args.profile_steps > 0:
         # EVERY rank runs the profiled iterations: under data parallelism a training iteration issues the groups'
@@ -778,7 +805,7 @@ def main():
                                                'what': 'eg_mfma_probe: one 8-wave block per CU, 4 independent 32x32x16 bf16 MFMA chains per wave, no memory traffic'}
     net.comm_barrier()
     ci = net.comm_info()
-    iters_run = args.warmup + args.steps + (args.profile_steps if args.profile_steps > 0 else 0)
+    iters_run = args.warmup + args.steps + (args.profile_steps if args.profile_steps > 0 else 0) + (2 if world > 1 else 0)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -812,6 +839,12 @@ def main():
             'exchange': {'nranks': ci['nranks'], 'rccl_version': ci['rccl_version'], 'rccl_library': ci['rccl_library'],
                          'allreduce_calls_per_step': round(ci['allreduce_calls'] / iters_run, 2) if world > 1 else 0,
                          'allreduce_mbytes_per_step': round(ci['allreduce_bytes'] / iters_run / 1e6, 2) if world > 1 else 0.0,
+                         'per_collective': exchange_ms,
+                         'per_collective_what': 'issue order within an iteration; ms between the communication stream reaching the '
+                                                'all-reduce (this rank\'s gradients final) and its completion (includes the wait for the slowest '
+                                                'rank), mean of two iterations with the lanes on, max / min over the ranks',
+                         'env': {k: os.environ[k] for k in ('EG_COMM_CHANNELS', 'EG_COMM_CUS', 'EG_COMPUTE_AVOID_COMM_CUS', 'NCCL_MAX_NCHANNELS',
+                                                            'NCCL_MIN_NCHANNELS', 'EG_LANES') if k in os.environ},
                          'what': 'one RCCL all-reduce (sum, fp32, in place) of the flat gradient buffer per optimised network '
                                  'group and sub-step (G1+G2 in one call), on a side stream, averaged inside RMSProp'},
             'losses_finite': bool(finite), 'memory': net.memory_stats(),

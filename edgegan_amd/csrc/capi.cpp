@@ -451,6 +451,19 @@ int eg_comm_reduce_scalars(eg_ctx* ctx, float* inout, int n, int op) {
   EG_API_END(ctx)
 }
 
+int eg_comm_timing(eg_ctx* ctx, int enable) {
+  EG_API_BEGIN
+  EG_CHECK(ctx, "null context");
+  ctx->c.comm_timing = enable != 0;
+  EG_API_END(ctx)
+}
+int eg_comm_timing_read(eg_ctx* ctx, float* ms, int* group, long long* bytes, int cap, int* n) {
+  EG_API_BEGIN
+  EG_CHECK(ctx && ms && group && bytes && n && cap >= 0, "null argument");
+  *n = comm_timing_read(ctx->c, ms, group, bytes, cap);
+  EG_API_END(ctx)
+}
+
 int eg_profile_begin(eg_ctx* ctx) {
   EG_API_BEGIN
   Ctx& c = ctx->c;

@@ -55,29 +55,115 @@ void comm_unique_id(Ctx& c, char* out128) {
   memcpy(out128, id.internal, 128);
 }
 
+// The exchange's footprint on the compute units.  RCCL's all-reduce kernels run one workgroup per channel, concurrently with
+// the engine's matrix kernels, which take a whole CU each (150 KB of LDS, __launch_bounds__(512, 1)): every CU a channel
+// lands on is a CU whose resident compute block is slowed, and RCCL picks its channel count for bandwidth, not for that.
+//   EG_COMM_CHANNELS=n  caps the channels (exported as NCCL_MAX_NCHANNELS before the communicator is created, unless the
+//                       caller already set that variable; NCCL_MIN_NCHANNELS and RCCL's other variables pass through untouched:
+//                       RCCL reads the process environment)
+//   EG_COMM_CUS=n       creates the communication stream with a CU mask of n compute units (a multiple of 8: n / 8 per XCD, the
+//                       highest-numbered ones; mask bit i = XCD i % 8, CU i / 8 -- the interleaved layout of multi-XCD parts), so the
+//                       exchange cannot spread beyond them;  EG_COMPUTE_AVOID_COMM_CUS=1 (model.cpp: build_context) additionally
+//                       creates the compute lanes with the complement, which fences the two off completely at the price of n CUs
+// Both are measured knobs, not defaults: the reference is single-GPU (edgegan/train.py:77) and nothing beyond one device could
+// be measured by the builder.
+void comm_cu_mask(int ncu, bool complement, uint32_t out[8]) {
+  for (int w = 0; w < 8; ++w) out[w] = 0;
+  for (int i = 256 - ncu; i < 256; ++i) out[i >> 5] |= 1u << (i & 31);
+  if (complement)
+    for (int w = 0; w < 8; ++w) out[w] = ~out[w];
+}
+int comm_reserved_cus() {
+  const char* e = getenv("EG_COMM_CUS");
+  if (!e) return 0;
+  const int n = atoi(e);
+  EG_CHECK(n >= 8 && n <= 128 && n % 8 == 0, "EG_COMM_CUS: a multiple of 8 in 8..128, got %s", e);
+  return n;
+}
+
 void comm_init(Ctx& c, const char* id128, int rank, int nranks) {
   EG_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank/nranks");
   NcclUniqueId id;
   memcpy(id.internal, id128, 128);
   EG_HIP(hipSetDevice(c.cfg.device));
+  if (const char* ch = getenv("EG_COMM_CHANNELS")) {
+    EG_CHECK(atoi(ch) >= 1 && atoi(ch) <= 128, "EG_COMM_CHANNELS: 1..128, got %s", ch);
+    setenv("NCCL_MAX_NCHANNELS", ch, 0);
+  }
   check(c, sym<fn_init_rank>(c, "ncclCommInitRank")(&c.nccl_comm, nranks, id, rank), "ncclCommInitRank");
   c.rank = rank;
   c.nranks = nranks;
   if (!c.comm_stream) {
-    EG_HIP(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
+    if (const int ncu = comm_reserved_cus()) {
+      uint32_t mask[8];
+      comm_cu_mask(ncu, false, mask);
+      EG_HIP(hipExtStreamCreateWithCUMask(&c.comm_stream, 8, mask));
+      c.comm_cus = ncu;
+    } else {
+      EG_HIP(hipStreamCreateWithFlags(&c.comm_stream, hipStreamNonBlocking));
+    }
     for (int g = 0; g < G_COUNT; ++g) {
       EG_HIP(hipEventCreateWithFlags(&c.ev_ready[g], hipEventDisableTiming));
       EG_HIP(hipEventCreateWithFlags(&c.ev_applied[g], hipEventDisableTiming));
     }
   }
+  // Every rank must issue the same collectives in the same order, and the order of an iteration's seven all-reduces is a
+  // function of the lane schedule (EG_LANES) and of the graph (classes, switched-off discriminators): ranks that disagree
+  // would pair different groups' buffers -- or hang.  Checked here, once, instead of discovered at step one.
+  if (nranks > 1) {
+    const float key[6] = {(float)c.lanes_mask, (float)c.cfg.num_classes, (float)c.cfg.B, (float)(c.cfg.H * 4096 + c.cfg.W),
+                          (float)((c.cfg.use_image_dis ? 1 : 0) | (c.cfg.use_edge_dis ? 2 : 0)), (float)((c.cfg.bf16 ? 1 : 0) | (c.cfg.x3 ? 2 : 0))};
+    float lo[6], hi[6];
+    for (int i = 0; i < 6; ++i) lo[i] = hi[i] = key[i];
+    comm_reduce_scalars(c, lo, 6, 3);
+    comm_reduce_scalars(c, hi, 6, 2);
+    for (int i = 0; i < 6; ++i)
+      if (lo[i] != hi[i])
+        fail(3, "data-parallel ranks disagree on %s (this rank %g, over the ranks %g .. %g): every rank must run the same lane schedule "
+                "and graph, or their collectives do not pair", i == 0 ? "EG_LANES" : i == 1 ? "num_classes" : i == 2 ? "the per-GPU batch size"
+                : i == 3 ? "the image size" : i == 4 ? "use_image_discriminator / use_edge_discriminator" : "compute_dtype", key[i], lo[i], hi[i]);
+  }
 }
 
-void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream) {
+void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream, int group) {
   EG_CHECK(c.nccl_comm, "comm_allreduce without comm_init");
   ++c.comm_calls;
   c.comm_bytes += (long long)n * 4;
+  Ctx::CommRec* rec = nullptr;
+  if (c.comm_timing && c.comm_recs.size() < 4096) {   // event pair around the collective, on the stream it runs on (eg_comm_timing)
+    c.comm_recs.emplace_back();
+    rec = &c.comm_recs.back();
+    rec->group = group;
+    rec->bytes = (long long)n * 4;
+    EG_HIP(hipEventCreate(&rec->a));
+    EG_HIP(hipEventCreate(&rec->b));
+    EG_HIP(hipEventRecord(rec->a, stream));
+  }
   // ncclFloat32 = 7, ncclSum = 0
   check(c, sym<fn_allreduce>(c, "ncclAllReduce")(buf, buf, n, 7, 0, c.nccl_comm, stream), "ncclAllReduce");
+  if (rec) EG_HIP(hipEventRecord(rec->b, stream));
+}
+
+// The collectives recorded since comm_timing was switched on, in issue order: group id (engine.h: GroupId; G_G1 stands for the
+// generators' joint exchange), payload bytes, milliseconds between the two events (start = the stream reaches the collective,
+// i.e. this rank's gradients are final; end = the reduced buffer is complete: the wait for the slowest rank is inside).
+int comm_timing_read(Ctx& c, float* ms, int* group, long long* bytes, int cap) {
+  if (c.comm_stream) EG_HIP(hipStreamSynchronize(c.comm_stream));
+  int n = 0;
+  for (auto& r : c.comm_recs) {
+    if (n < cap) {
+      float t = 0.f;
+      EG_HIP(hipEventElapsedTime(&t, r.a, r.b));
+      ms[n] = t;
+      group[n] = r.group;
+      bytes[n] = r.bytes;
+      ++n;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  c.comm_recs.clear();
+  return n;
 }
 
 // Every lane's stream waits (not only the active one): pending[g] is cleared for the whole context, so a lane that
@@ -126,6 +212,11 @@ void comm_info(Ctx& c, int* version, char* libpath, int cap, long long* calls, l
 void comm_destroy(Ctx& c) {
   if (c.comm_stream) {
     (void)hipStreamSynchronize(c.comm_stream);
+    for (auto& r : c.comm_recs) {
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    c.comm_recs.clear();
     for (int g = 0; g < G_COUNT; ++g) {
       (void)hipEventDestroy(c.ev_ready[g]);
       (void)hipEventDestroy(c.ev_applied[g]);

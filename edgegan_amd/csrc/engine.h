@@ -200,7 +200,7 @@ struct Ctx {
   int inf_nb = 0;       // images currently resident (eg_infer_upload)
   long long inf_runs = 0;   // eg_infer_run calls since the context was created (slot = inf_runs mod the slots in use)
   int inf_last_slot = 0;    // slot of the latest run: what eg_infer_download returns
-  int inf_slots = 2;        // calls in flight x lanes per call: 4 = four single-chain calls, 2 = two calls of two lanes each, 1 = one call of two lanes (EG_INFER_SLOTS)
+  int inf_slots = 4;        // calls in flight x lanes per call: 4 = four single-chain calls, 2 = two calls of two lanes each, 1 = one call of two lanes (EG_INFER_SLOTS)
   hipEvent_t ev_infer[kLanes] = {};   // fork event of the call whose main lane is i
   bool inf_inflight = false;   // eg_infer_run calls may still be running on lanes other than 0: every OTHER entry point drains them first (api_enter)
   bool inf_entering = false;   // ... set by eg_infer_run around its own api_enter
@@ -224,6 +224,14 @@ struct Ctx {
   bool pending[G_COUNT] = {};
   float* comm_scal = nullptr;   // device staging of comm_reduce_scalars
   long long comm_calls = 0, comm_bytes = 0;   // gradient all-reduces enqueued / their payload (comm_info)
+  int comm_cus = 0;             // EG_COMM_CUS: compute units the communication stream is confined to (0: no mask)
+  bool comm_timing = false;     // eg_comm_timing: event pairs around every gradient all-reduce
+  struct CommRec {
+    int group = 0;
+    long long bytes = 0;
+    hipEvent_t a = nullptr, b = nullptr;
+  };
+  std::deque<CommRec> comm_recs;
 
   ~Ctx();
 };
@@ -263,7 +271,9 @@ enum PadMode { PAD_SAME = 0, PAD_REFLECT = 1 };
 T conv2d(Ctx& c, T x, WRef* w, Param* bias, int k, int stride, int pad, T accumulate_into = nullptr,
          int fused_act = 0 /* ACT_RELU / ACT_LRELU applied by the conv where its kernel can (else by act()) */,
          Param* post_prelu = nullptr);
-T deconv2d(Ctx& c, T x, WRef* w /*[25][Cout][Cin]*/, Param* bias, int cout);
+// fused_act == ACT_TANH: the caller applies tanh to the result next; a forward-only 3-channel layer (the generators' last) then
+// stores tanh(y) itself where its kernel can (returned tensor: fused_act == ACT_TANH).  y_into: the result is written there
+T deconv2d(Ctx& c, T x, WRef* w /*[25][Cout][Cin]*/, Param* bias, int cout, int fused_act = 0, float* y_into = nullptr);
 T linear(Ctx& c, T x, WRef* w /*[1][in][out]*/, Param* bias);
 T linear1(Ctx& c, T x, Param* w /*[K][1]*/, Param* bias /*nullable*/);
 T reshape(Ctx& c, T src, int n, int h, int w, int ch);
@@ -290,6 +300,7 @@ T act_tangent(Ctx& c, T tx, T out_prim, int a);
 T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times, T* stats_out = nullptr);
 T add(Ctx& c, T a, T b, bool relu);
 T pool2(Ctx& c, T x);
+T add_relu_pool2(Ctx& c, T a, T b);   // pool2(relu(a + b)): one pass in forward-only graphs
 // pool2(a + b) in one pass (the MRU unit's `mean_pool(proj + h_new)`, conv.py:239-243); a and b must have no other
 // consumer: their gradients are then ONE shared buffer (both equal the up-sampled output gradient / 4)
 T add_pool2(Ctx& c, T a, T b);
@@ -326,9 +337,12 @@ struct DiscSave {
   T out[4] = {nullptr, nullptr, nullptr, nullptr};
   T stats[4] = {nullptr, nullptr, nullptr, nullptr};
 };
-T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out = nullptr);
+// out_into: the network's output is written there (inference: the caller's output buffer, no copy behind the network)
+T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out = nullptr, float* out_into = nullptr);
 T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_of);
-T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out = nullptr, T* ls_out = nullptr);
+// z1_out: a forward-only graph may also return z for a SECOND eps draw, eps_dev[1] (inference: the E -> G2 run), from the same
+// launch; null where the head ran as separate ops
+T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out = nullptr, T* ls_out = nullptr, T* z1_out = nullptr);
 T classifier_forward(Ctx& c, T x);
 
 enum LossSlot {
@@ -362,7 +376,10 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
 // ---- data parallel (comm.cpp) -----------------------------------------------------------------
 void comm_unique_id(Ctx& c, char* out128);
 void comm_init(Ctx& c, const char* id128, int rank, int nranks);
-void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream);
+void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream, int group);
+int comm_timing_read(Ctx& c, float* ms, int* group, long long* bytes, int cap);
+void comm_cu_mask(int ncu, bool complement, uint32_t out[8]);   // EG_COMM_CUS / EG_COMPUTE_AVOID_COMM_CUS (comm.cpp)
+int comm_reserved_cus();
 void comm_reduce_scalars(Ctx& c, float* inout, int n, int op);
 void use_lane(Ctx& c, int lane);                // model.cpp
 void comm_wait_groups(Ctx& c, unsigned mask);   // main stream waits for the pending updates of these groups

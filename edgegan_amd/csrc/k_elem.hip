@@ -306,6 +306,43 @@ __global__ void pool2_bwd_v_kernel(const SlabSrc dy, float* __restrict__ dx, int
     }
   }
 }
+// y = pool2(relu(a + b)) (+ its bf16 plane): the tail of a residual block (conv.py:80-85 + encoder.py:63-66) of a forward-only
+// graph in one pass -- add_kernel's sum and ReLU, pool2_fwd_v_kernel's summation order, cvt_bf16's rounding: the same bits as the
+// three launches it replaces
+__global__ void add_relu_pool2_fwd_v_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                            unsigned short* __restrict__ y_bf, int H, int W, int C4, unsigned n4) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+    const unsigned c = i % C4;
+    unsigned t = i / C4;
+    const unsigned ox = t % Wo;
+    t /= Wo;
+    const unsigned oy = t % Ho, nb = t / Ho;
+    const size_t base = ((size_t)(nb * H + 2 * oy) * W + 2 * ox) * C4 + c;
+    const float4* pa = reinterpret_cast<const float4*>(a) + base;
+    const float4* pb = reinterpret_cast<const float4*>(b) + base;
+    const size_t o1 = (size_t)W * C4, o2 = C4, o3 = (size_t)W * C4 + C4;
+    const float4 a0 = pa[0], a1 = pa[o1], a2 = pa[o2], a3 = pa[o3];
+    const float4 b0 = pb[0], b1 = pb[o1], b2 = pb[o2], b3 = pb[o3];
+    auto rl = [](float u, float v) {
+      const float w = u + v;
+      return w < 0.f ? 0.f : w;
+    };
+    float4 r;
+    r.x = (rl(a0.x, b0.x) + rl(a1.x, b1.x) + rl(a2.x, b2.x) + rl(a3.x, b3.x)) * 0.25f;
+    r.y = (rl(a0.y, b0.y) + rl(a1.y, b1.y) + rl(a2.y, b2.y) + rl(a3.y, b3.y)) * 0.25f;
+    r.z = (rl(a0.z, b0.z) + rl(a1.z, b1.z) + rl(a2.z, b2.z) + rl(a3.z, b3.z)) * 0.25f;
+    r.w = (rl(a0.w, b0.w) + rl(a1.w, b1.w) + rl(a2.w, b2.w) + rl(a3.w, b3.w)) * 0.25f;
+    reinterpret_cast<float4*>(y)[i] = r;
+    if (y_bf) st_bf4(y_bf, i, r);
+  }
+}
+bool launch_add_relu_pool2_fwd(const float* a, const float* b, float* y, unsigned short* y_bf, int NB, int H, int W, int C, hipStream_t s) {
+  const size_t n = (size_t)NB * (H / 2) * (W / 2) * C;
+  if (C % 4 != 0 || n >= (1ull << 31) || ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) != 0) return false;
+  hipLaunchKernelGGL(add_relu_pool2_fwd_v_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, a, b, y, y_bf, H, W, C / 4, (unsigned)(n / 4));
+  return true;
+}
 // y = pool2(a + b): the element-wise sum first (as the reference does), then pooling.py's add_n order
 __global__ void add_pool2_fwd_v_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
                                        int H, int W, int C4, unsigned n4) {
@@ -602,7 +639,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_v_kernel(const float* __restric
   if (colpart) flat_colpart_store(cs, redc, colpart, C4);
 }
 __global__ void prelu_fwd_v_kernel(const SlabSrc x, const float* __restrict__ leak_p, float leak_c,
-                                   float* __restrict__ y, size_t n4, unsigned short* __restrict__ y_bf, float* __restrict__ xsum) {
+                                   float* __restrict__ y, size_t n4, unsigned short* __restrict__ y_bf, float* xsum) {   // (xsum may alias the slabs' base)
   const float lk = leak_p ? *leak_p : leak_c;
   GRID_STRIDE(i, n4) {
     const float4 v = slab_ld4_flat(x, i);
@@ -741,7 +778,8 @@ __global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* __restrict
 // the base): the first pass sums them and stores the sum to xsum, which the second pass (the same thread re-reads its own
 // stores) and the backward read
 template <int CQ>
-__global__ __launch_bounds__(256) void minmax_fwd_v(const SlabSrc xs, float* __restrict__ xsum, float* __restrict__ y,
+// (xsum carries no __restrict__: with the FEED_MINMAX hand-over it IS SlabSrc::base, the tensor the slabs are added to)
+__global__ __launch_bounds__(256) void minmax_fwd_v(const SlabSrc xs, float* xsum, float* __restrict__ y,
                                                     float* __restrict__ mm, int HW, int C, float lk) {
   constexpr int PL = 256 / CQ;
   __shared__ float4 red[2 * 4 * CQ];
@@ -1367,6 +1405,63 @@ __global__ void l1_kernel(const float* __restrict__ target, int t_stride, const 
 void launch_l1(const float* target, int t_stride, const float* recon, float* loss, float* drecon, int B, int Z,
                float weight, hipStream_t s) {
   hipLaunchKernelGGL(l1_kernel, dim3(1), dim3(256), 0, s, target, t_stride, recon, loss, drecon, B, Z, weight);
+}
+
+// The encoder's head in a forward-only graph, ONE launch per batch instead of eight (encoder.py:69-79, linear.py:79-92):
+//   feat = mean over the map of relu(x) (gmean_fwd_kernel's order);  mu = feat Wmu + bmu,  log sigma = feat Wls + bls;
+//   z_r = mu + eps_r exp(log sigma) for the call's one or two scalar draws (reparam_fwd_kernel's expression).
+// One block per image.  round_bf16 (compute_dtype bf16: a linear with 512 contracted and 100 produced channels qualifies for
+// rounded operands) rounds feat and the weights to bf16 before the fp32 multiply-add; products of bf16 numbers are exact in fp32,
+// so what differs from the MFMA path is the order of the 512-term sum only.
+__global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__ x, const float* __restrict__ wmu, const float* __restrict__ bmu,
+                                                       const float* __restrict__ wls, const float* __restrict__ bls,
+                                                       const float* __restrict__ eps, float* __restrict__ mu, float* __restrict__ ls,
+                                                       float* __restrict__ z0, float* __restrict__ z1, int HW, int C, int Z, int round_bf16) {
+  extern __shared__ float sm[];   // feat[C] | res[2 Z]
+  float* feat = sm;
+  float* res = sm + C;
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      float v = x[((size_t)n * HW + p) * C + c];
+      if (v < 0.f) v = 0.f;
+      s += v;
+    }
+    float f = s / HW;
+    if (round_bf16) f = (float)(__bf16)f;
+    feat[c] = f;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * Z; o += 256) {
+    const bool second = o >= Z;
+    const int col = second ? o - Z : o;
+    const float* w = (second ? wls : wmu) + col;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < C; ++k) {
+      float wv = w[(size_t)k * Z];
+      if (round_bf16) wv = (float)(__bf16)wv;
+      acc = fmaf(feat[k], wv, acc);
+    }
+    res[o] = acc + (second ? bls : bmu)[col];
+  }
+  __syncthreads();
+  const float e0 = eps[0], e1 = z1 ? eps[1] : 0.f;
+  for (int j = threadIdx.x; j < Z; j += 256) {
+    const float m = res[j], l = res[Z + j];
+    const size_t i = (size_t)n * Z + j;
+    mu[i] = m;
+    ls[i] = l;
+    const float ex = expf(l);
+    z0[i] = m + e0 * ex;
+    if (z1) z1[i] = m + e1 * ex;
+  }
+}
+void launch_enc_head(const float* x, const float* wmu, const float* bmu, const float* wls, const float* bls, const float* eps, float* mu,
+                     float* ls, float* z0, float* z1, int NB, int HW, int C, int Z, int round_bf16, hipStream_t s) {
+  hipLaunchKernelGGL(enc_head_kernel, dim3(NB), dim3(256), (size_t)(C + 2 * Z) * sizeof(float), s, x, wmu, bmu, wls, bls, eps, mu, ls, z0,
+                     z1, HW, C, Z, round_bf16);
 }
 
 // z = mu + eps*exp(log_sigma) with ONE scalar eps (encoder.py:78-79, quirk N3)

@@ -545,7 +545,9 @@ double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name)
     if (a.ksplit <= 1 && a.epi_act) caps |= CONV_CAP_EPI_ACT;
 #endif
   } else if (conv_scatter_eligible(a)) {
+    if (a.act == ACT_TANH && !(a.shuf && !a.accumulate)) a.act = 0;
     nm = launch_conv_scatter(a, s);
+    if (a.act == ACT_TANH) caps |= CONV_CAP_TANH;
   } else if (conv_smallc_eligible(a)) {
     nm = launch_conv_smallc(a, s);
   } else if (a.N <= 16) {

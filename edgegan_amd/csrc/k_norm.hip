@@ -793,7 +793,8 @@ __global__ void bn_moving_kernel(float* mm, float* mv, const float* stats, int C
 // float4 variants (C % 32 == 0): 8 channel quads x 32 row lanes per block
 __global__ __launch_bounds__(256) void bn_relu_fwd_v(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ out,
-                                                     float* __restrict__ stats, int R, int C, float eps) {
+                                                     float* __restrict__ stats, int R, int C, float eps,
+                                                     unsigned short* __restrict__ out_bf) {
   __shared__ float4 red[4 * 8];
   const int cq = threadIdx.x % 8, pl = threadIdx.x / 8;
   const int c = (blockIdx.x * 8 + cq) * 4;
@@ -817,9 +818,10 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_v(const float* __restrict__ x
                                 g.w / sqrtf(var.w + eps));
   for (int p = pl; p < R; p += 32) {
     const float4 v = ld4(x + (size_t)p * C + c);
-    st4(out + (size_t)p * C + c,
-        make_float4(fmaxf((v.x - mean.x) * sc.x + b.x, 0.f), fmaxf((v.y - mean.y) * sc.y + b.y, 0.f),
-                    fmaxf((v.z - mean.z) * sc.z + b.z, 0.f), fmaxf((v.w - mean.w) * sc.w + b.w, 0.f)));
+    const float4 y = make_float4(fmaxf((v.x - mean.x) * sc.x + b.x, 0.f), fmaxf((v.y - mean.y) * sc.y + b.y, 0.f),
+                                 fmaxf((v.z - mean.z) * sc.z + b.z, 0.f), fmaxf((v.w - mean.w) * sc.w + b.w, 0.f));
+    st4(out + (size_t)p * C + c, y);
+    if (out_bf) st_bf4n(out_bf, (size_t)p * C + c, y);   // (bf16 mode: the plane g_dconv_1 reads, in the same pass)
   }
   if (pl == 0) {
     st4(stats + c, mean);
@@ -833,7 +835,8 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_v(const float* __restrict__ x
 template <int NI>
 __global__ __launch_bounds__(256) void bn_relu_fwd_vr(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ out,
-                                                      float* __restrict__ stats, int R, int C, float eps) {
+                                                      float* __restrict__ stats, int R, int C, float eps,
+                                                      unsigned short* __restrict__ out_bf) {
   __shared__ float4 red[4 * 8];
   const int cq = threadIdx.x % 8, pl = threadIdx.x / 8;
   const int c = (blockIdx.x * 8 + cq) * 4;
@@ -864,10 +867,12 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_vr(const float* __restrict__ 
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int p = pl + 32 * i;
-    if (p < R)
-      st4(out + (size_t)p * C + c,
-          make_float4(fmaxf((v[i].x - mean.x) * sc.x + b.x, 0.f), fmaxf((v[i].y - mean.y) * sc.y + b.y, 0.f),
-                      fmaxf((v[i].z - mean.z) * sc.z + b.z, 0.f), fmaxf((v[i].w - mean.w) * sc.w + b.w, 0.f)));
+    if (p < R) {
+      const float4 y = make_float4(fmaxf((v[i].x - mean.x) * sc.x + b.x, 0.f), fmaxf((v[i].y - mean.y) * sc.y + b.y, 0.f),
+                                   fmaxf((v[i].z - mean.z) * sc.z + b.z, 0.f), fmaxf((v[i].w - mean.w) * sc.w + b.w, 0.f));
+      st4(out + (size_t)p * C + c, y);
+      if (out_bf) st_bf4n(out_bf, (size_t)p * C + c, y);
+    }
   }
   if (pl == 0) {
     st4(stats + c, mean);
@@ -953,18 +958,19 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_v(const float* __restrict__ x
   }
 }
 
-void launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats, int R,
-                        int C, float eps, hipStream_t s) {
+bool launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats, int R,
+                        int C, float eps, hipStream_t s, unsigned short* out_bf) {
   if (C % 32 == 0) {
     if (R <= 32 * 4)
-      hipLaunchKernelGGL(bn_relu_fwd_vr<4>, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
+      hipLaunchKernelGGL(bn_relu_fwd_vr<4>, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps, out_bf);
     else if (R <= 32 * 32)
-      hipLaunchKernelGGL(bn_relu_fwd_vr<32>, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
+      hipLaunchKernelGGL(bn_relu_fwd_vr<32>, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps, out_bf);
     else
-      hipLaunchKernelGGL(bn_relu_fwd_v, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
-    return;
+      hipLaunchKernelGGL(bn_relu_fwd_v, dim3(C / 32), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps, out_bf);
+    return out_bf != nullptr;
   }
   hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
+  return false;
 }
 void launch_bn_relu_bwd(const float* x, const float* out, const float* dout, const float* gamma,
                         const float* stats, float* dx, int acc_dx, float* dgamma, int acc_dg, float* dbeta,

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
               float r = v[j];
               if (a.bias) r += a.bias[ch];
               if (a.accumulate) r += *qy;
+              if (a.act == ACT_TANH) r = tanhf(r);   // (generator.py:70-74: the generator's output activation, forward-only graphs; act_fwd_kernel's expression)
               *qy = r;
             }
           } else {

@@ -112,7 +112,8 @@ struct ConvArgs {
 // prelu_bwd, minmax_bwd -- their float4 forms): compute, store the plane, do NOT store the fp32 gradient (bf16 mode: both
 // gradient kernels of the convolution behind it read the plane; ops.cpp: Tensor::g_plane_only)
 enum { GRAD_ACCUMULATE = 1, GRAD_PLANE_ONLY = 2 };
-enum ConvCaps { CONV_CAP_EPI_ACT = 1, CONV_CAP_Y2 = 2, CONV_CAP_POOL = 4 };
+enum ConvCaps { CONV_CAP_EPI_ACT = 1, CONV_CAP_Y2 = 2, CONV_CAP_POOL = 4,
+                CONV_CAP_TANH = 8 /* ConvArgs::act == ACT_TANH applied to the stored value (the phase-merged scatter kernel) */ };
 
 // A tensor that may still be the K-split slabs of the convolution that produced it (ConvArgs::keep_slabs): its value is
 // bias[c] + slab 0 + slab 1 + ... (+ base), conv_split_reduce's order, formed by the CONSUMER's load instead of a
@@ -386,8 +387,9 @@ void launch_act_bwd(const float* out, const float* dout, float* dx, int accumula
 
 // BatchNorm (training statistics) + ReLU over [R][C] rows: y = relu(gamma*(x-mean)/sqrt(var+eps)+beta)
 // stats = {mean[C], var[C]}
-void launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats,
-                        int R, int C, float eps, hipStream_t s);
+// out_bf: also the output's bf16 plane (bf16 mode: what g_dconv_1 reads); returns whether the kernel that ran stored it
+bool launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats,
+                        int R, int C, float eps, hipStream_t s, unsigned short* out_bf = nullptr);
 void launch_bn_relu_bwd(const float* x, const float* out, const float* dout, const float* gamma,
                         const float* stats, float* dx, int acc_dx, float* dgamma, int acc_dg, float* dbeta,
                         int acc_db, int R, int C, float eps, hipStream_t s);
@@ -419,6 +421,11 @@ size_t col_sum_scratch_floats(size_t R, int C);
 void launch_col_sum(const float* dy, float* db, int accumulate, size_t R, int C, float* scratch, hipStream_t s);
 // 2x2 mean pool NHWC fwd / bwd
 void launch_pool2_fwd(const float* x, float* y, int NB, int H, int W, int C, hipStream_t s);
+// y = pool2(relu(a + b)) (+ y's bf16 plane) in one pass; false: the shape has no float4 form (the caller runs the separate ops)
+// forward-only encoder head: relu + global mean, the two FC8 linears, z_r = mu + eps_r exp(log sigma) (z1 may be null)
+void launch_enc_head(const float* x, const float* wmu, const float* bmu, const float* wls, const float* bls, const float* eps, float* mu,
+                     float* ls, float* z0, float* z1, int NB, int HW, int C, int Z, int round_bf16, hipStream_t s);
+bool launch_add_relu_pool2_fwd(const float* a, const float* b, float* y, unsigned short* y_bf, int NB, int H, int W, int C, hipStream_t s);
 void launch_pool2_bwd(const float* dy, float* dx, int accumulate, int NB, int H, int W, int C, hipStream_t s,
                       unsigned short* dx_bf = nullptr,   // dx_bf: also store the bf16 plane of dx (k_elem.hip: st_bf4)
                       const SlabSrc* dy_slabs = nullptr);   // float4 form only (ops.cpp: flat_slab_ok)

@@ -139,7 +139,15 @@ void build_context(Ctx& c) {
   EG_CHECK((!cfg.use_image_dis || (cfg.image_dis >= 16 && cfg.image_dis <= 1024)) && (!cfg.use_edge_dis || (cfg.edge_dis >= 16 && cfg.edge_dis <= 1024)),
            "image_dis_size / edge_dis_size out of range (16..1024)");
   EG_HIP(hipSetDevice(cfg.device));
-  EG_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  // EG_COMPUTE_AVOID_COMM_CUS=1 with EG_COMM_CUS=n (comm.cpp): the compute lanes never use the n compute units the exchange runs on
+  uint32_t avoid[8];
+  const bool fenced = getenv("EG_COMPUTE_AVOID_COMM_CUS") && atoi(getenv("EG_COMPUTE_AVOID_COMM_CUS")) != 0 && comm_reserved_cus() > 0;
+  if (fenced) comm_cu_mask(comm_reserved_cus(), true, avoid);
+  auto new_stream = [&](hipStream_t* s) {
+    if (fenced) EG_HIP(hipExtStreamCreateWithCUMask(s, 8, avoid));
+    else EG_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+  };
+  new_stream(&c.stream);
   for (int g = 0; g < G_COUNT; ++g) c.groups[g].prefix = kGroupPrefix[g];
   for (const VarInfo& vi : enumerate_variables(cfg)) {
     auto p = std::make_unique<Param>();
@@ -290,7 +298,8 @@ void build_context(Ctx& c) {
       else if (*q >= 'A' && *q <= 'D') slot = &c.lanes[*q - 'A'].leaf;
       else if (*q == 'x') slot = &dummy;
       EG_CHECK(slot && !*slot, "EG_STREAM_PLAN: bad or repeated token '%c'", *q);
-      EG_HIP(hipStreamCreateWithFlags(slot, hipStreamNonBlocking));
+      if (slot == &dummy) EG_HIP(hipStreamCreateWithFlags(slot, hipStreamNonBlocking));
+      else new_stream(slot);
       if (slot == &dummy) c.placeholder_streams.push_back(dummy);
     }
     for (int i = 0; i < Ctx::kLanes; ++i) EG_CHECK(c.lanes[i].stream && c.lanes[i].leaf, "EG_STREAM_PLAN misses a stream");
@@ -364,7 +373,7 @@ void api_enter(Ctx& c) {
 // networks
 // ---------------------------------------------------------------------------------------------
 // generator.py:35-74 (_convnet): linear -> reshape -> BatchNorm(!) -> ReLU -> 3x[deconv,IN,ReLU] -> deconv -> tanh
-T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out) {
+T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out, float* out_into) {
   const Config& cfg = c.cfg;
   const std::string p = kGroupPrefix[group];
   const int gf = cfg.gf, h16 = cfg.H / 16, w16 = cfg.W / 2 / 16;
@@ -378,10 +387,17 @@ T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out) {
   for (int i = 1; i <= 4; ++i) {
     const std::string b = p + "/g_dconv_" + std::to_string(i) + "/deconv2d/";
     c.feeds_in = i < 4;   // deconv_block: the InstanceNorm is the transposed convolution's only reader
-    x = deconv2d(c, x, wref_param(c, P(c, b + "w"), 25, ch[i], ch[i - 1]), P(c, b + "b"), ch[i]);
+    x = deconv2d(c, x, wref_param(c, P(c, b + "w"), 25, ch[i], ch[i - 1]), P(c, b + "b"), ch[i], i == 4 ? ACT_TANH : 0,
+                 i == 4 ? out_into : nullptr);
     if (i < 4) x = in_act(c, x, ACT_RELU);
   }
-  return act(c, x, ACT_TANH);
+  if (x->fused_act == ACT_TANH) {   // (forward-only graph: the last layer's store applied it)
+    x->fused_act = 0;
+    return x;
+  }
+  T out = act(c, x, ACT_TANH);
+  if (out_into && out->d != out_into) launch_copy(out->d, out_into, out->numel(), c.stream);
+  return out;
 }
 
 // discriminator.py:58-81 (_convnet).  With tangent_of != null this evaluates the forward-mode
@@ -417,7 +433,7 @@ T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_o
 }
 
 // encoder.py:54-84 (_resnet) with conv.py:70-85 (residual, REFLECT pad, bias=True)
-T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out) {
+T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out, T* z1_out) {
   const Config& cfg = c.cfg;
   T E = conv2d(c, x, wref_param(c, P(c, "E/e_resnet_64_0/conv2d/w"), 16, cfg.c_dim, 64),
                P(c, "E/e_resnet_64_0/conv2d/b"), 4, 2, PAD_SAME, nullptr, ACT_RELU);
@@ -445,10 +461,30 @@ T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out) {
       use_lane(c, main_lane);
       EG_HIP(hipStreamWaitEvent(c.stream, c.lanes[c.infer_side].done, 0));
     }
-    E = pool2(c, add(c, sc, o2, true));
+    E = add_relu_pool2(c, sc, o2);
     cin = n;
   }
   EG_CHECK(E->h <= 8 && E->w <= 8, "encoder tail expects <= 8x8 before the 8x8 SAME average pool");
+  if (z1_out) *z1_out = nullptr;
+  {
+    // forward-only graph (inference, the post-update evaluation): relu + mean, both FC8 linears and the reparametrisation of the
+    // call's one or two eps draws in one launch (k_elem.hip: enc_head_kernel)
+    static const bool head_on = dbg_env("EG_NO_ENC_HEAD") == nullptr;
+    Param *wm = P(c, "E/FC8_mu/w"), *bm = P(c, "E/FC8_mu/b"), *ws = P(c, "E/FC8_sigma/w"), *bs = P(c, "E/FC8_sigma/b");
+    if (head_on && !E->needs_grad && !wm->want_grad && !ws->want_grad && !bm->want_grad && !bs->want_grad) {
+      const int Z = cfg.z_dim;
+      T mu = new_tensor(c, E->n, 1, 1, Z, false), ls = new_tensor(c, E->n, 1, 1, Z, false), z0 = new_tensor(c, E->n, 1, 1, Z, false);
+      T z1 = z1_out ? new_tensor(c, E->n, 1, 1, Z, false) : nullptr;
+      // (the linear's bf16 rule, ops.cpp attach_bf16 / oracle.bf16_conv_rule: contracted channels % 32 == 0, > 16 produced, % 4 == 0)
+      const int round = (cfg.bf16 && cin % 32 == 0 && Z > 16 && Z % 4 == 0) ? 1 : 0;
+      launch_enc_head(E->d, wm->w, bm->w, ws->w, bs->w, eps_dev, mu->d, ls->d, z0->d, z1 ? z1->d : nullptr, E->n, E->h * E->w, cin, Z, round,
+                      c.stream);
+      if (mu_out) *mu_out = mu;
+      if (ls_out) *ls_out = ls;
+      if (z1_out) *z1_out = z1;
+      return z0;
+    }
+  }
   T feat = gmean(c, E, true);  // relu + avg_pool(8x8, SAME) == mean of the valid elements
   T mu = linear(c, feat, wref_param(c, P(c, "E/FC8_mu/w"), 1, cin, cfg.z_dim), P(c, "E/FC8_mu/b"));
   T ls = linear(c, feat, wref_param(c, P(c, "E/FC8_sigma/w"), 1, cin, cfg.z_dim), P(c, "E/FC8_sigma/b"));
@@ -596,7 +632,7 @@ static void apply_group(Ctx& c, int group) {
   if (c.nccl_comm) {
     EG_HIP(hipEventRecord(c.ev_ready[group], c.stream));
     EG_HIP(hipStreamWaitEvent(c.comm_stream, c.ev_ready[group], 0));
-    comm_allreduce(c, g.g, g.n_live, c.comm_stream);
+    comm_allreduce(c, g.g, g.n_live, c.comm_stream, group);
     launch_rmsprop(g.w, g.g, g.ms, g.mom, g.n_live, c.cfg.lr, 1.f / c.nranks, c.comm_stream);
     EG_HIP(hipEventRecord(c.ev_applied[group], c.comm_stream));
     c.pending[group] = true;
@@ -624,7 +660,7 @@ static void apply_generators(Ctx& c) {
   EG_CHECK(g2.g == g1.g + g1.n_train, "generator gradient buffers are not adjacent");
   EG_HIP(hipEventRecord(c.ev_ready[G_G1], c.stream));
   EG_HIP(hipStreamWaitEvent(c.comm_stream, c.ev_ready[G_G1], 0));
-  comm_allreduce(c, g1.g, g1.n_train + g2.n_live, c.comm_stream);
+  comm_allreduce(c, g1.g, g1.n_train + g2.n_live, c.comm_stream, G_G1);
   launch_rmsprop(g1.w, g1.g, g1.ms, g1.mom, g1.n_live, c.cfg.lr, 1.f / c.nranks, c.comm_stream);
   launch_rmsprop(g2.w, g2.g, g2.ms, g2.mom, g2.n_live, c.cfg.lr, 1.f / c.nranks, c.comm_stream);
   EG_HIP(hipEventRecord(c.ev_applied[G_G1], c.comm_stream));
@@ -897,7 +933,9 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
   set_want_grad(c, group, false);
 }
 
-// EG_D_TAPE=1 (experiments build): the tape-driven form, for A/B runs and as the reference the stacked form is tested against
+// EG_D_TAPE=1 (experiments build only -- dbg_env is compiled out of the shipped library, where this always takes the stacked
+// form): the tape-driven form at 7F - 2F0, kept for in-box A/B runs.  The stacked form's coverage is the oracle: every
+// discriminator sub-step test of tests/test_step_gpu.py / test_tight_gpu.py / test_x3_gpu.py / test_bf16_gpu.py runs it.
 static void d_substep(Ctx& c, int group, T real, T fake, const float* alpha_dev, int slot_d, int slot_gp, bool apply) {
   static const bool tape_form = dbg_env("EG_D_TAPE") != nullptr;
   if (tape_form) disc_substep(c, group, real, fake, alpha_dev, slot_d, slot_gp, apply);
@@ -920,8 +958,8 @@ static T generator_output_nograd(Ctx& c, int group, T zin, int bn_t) {
     return wrap_tensor(c, c.d_gen_cache[i], cfg.B, cfg.H, cfg.W / 2, cfg.c_dim);
   }
   T st = nullptr;
-  T out = generator_forward(c, group, zin, bn_t, &st);
-  launch_copy(out->d, c.d_gen_cache[i], out->numel(), c.stream);
+  T out = generator_forward(c, group, zin, bn_t, &st, c.d_gen_cache[i]);   // (forward-only: the last layer stores tanh(y) straight into the cache)
+  if (out->d != c.d_gen_cache[i]) launch_copy(out->d, c.d_gen_cache[i], out->numel(), c.stream);
   launch_copy(st->d, c.d_gen_bn[i], (size_t)2 * C, c.stream);
   c.gen_cache_valid[i] = true;
   return out;
@@ -1343,7 +1381,8 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
     use_lane(c, main_lane);
     c.infer_side = side_lane;
   }
-  T z0 = encoder_forward(c, left, d_eps2, &mu, &ls);
+  T z1f = nullptr;
+  T z0 = encoder_forward(c, left, d_eps2, &mu, &ls, &z1f);
   c.infer_side = -1;
   if (two) {
     warm_transposes(c, G_G2);   // G2's lazily built transposed filters: filled here, on the main lane, before the side lane forks off and reads them
@@ -1355,14 +1394,13 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
       if (!sc_lane) c.arena.reset();   // (the side lane's previous work is fully enqueued; stream order protects its memory)
       EG_HIP(hipStreamWaitEvent(c.stream, c.ev_infer[main_lane], 0));
     }
-    T z = run == 0 ? z0 : reparam(c, mu, ls, d_eps2 + 1);
+    T z = run == 0 ? z0 : (z1f ? z1f : reparam(c, mu, ls, d_eps2 + 1));
     T zin = z;
     if (cfg.multiclasses()) {
       zin = new_tensor(c, NB, 1, 1, cfg.g_in(), false);
       launch_class_onehot(z->d, d_classes, zin->d, NB, cfg.z_dim, cfg.num_classes, c.stream);
     }
-    T out = generator_forward(c, run == 0 ? G_G1 : G_G2, zin, 0);
-    launch_copy(out->d, run == 0 ? d_edge : d_image, out->numel(), c.stream);
+    generator_forward(c, run == 0 ? G_G1 : G_G2, zin, 0, nullptr, run == 0 ? d_edge : d_image);
   }
   if (two) {   // the main lane continues after the side lane
     EG_HIP(hipEventRecord(c.lanes[side_lane].done, c.stream));

@@ -362,9 +362,11 @@ static const float* merged_filter(Ctx& c, WRef* w, int k, int C) {
 // [NB][IH][IW][C] producing 12 channels that the epilogue scatters to the 2x2 output pixels ([NB][2IH][2IW][3]).
 // Against 4 phase launches with a 3 -> 16 padded tile this reads the coarse operand 9 instead of 16 times and issues
 // 9 x 16 instead of 16 x 16 padded MACs per coarse pixel and channel.
-static void run_merged_phases(Ctx& c, const float* x, int NB, int IH, int IW, int C, const float* wm, const float* bias,
-                              float* y, int accumulate) {
+// act == ACT_TANH: the output activation rides in the store where the kernel that runs has that form; returns whether it did
+static bool run_merged_phases(Ctx& c, const float* x, int NB, int IH, int IW, int C, const float* wm, const float* bias,
+                              float* y, int accumulate, int act = 0) {
   ConvArgs a{};
+  a.act = accumulate ? 0 : act;
   a.x = x;
   a.wgt = wm;
   a.bias = bias;
@@ -390,6 +392,7 @@ static void run_merged_phases(Ctx& c, const float* x, int NB, int IH, int IW, in
   a.nphase = 1;
   a.ph[0] = ConvPhase{IH, IW, 0, 0, 3, 3, 0, 0, -1, -1};
   run_conv(c, a);
+  return a.act == ACT_TANH && (a.caps & CONV_CAP_TANH);
 }
 
 // compute_dtype bf16: hand the conv a bf16 copy of the filter with the contracted index contiguous.  `transposed`
@@ -482,6 +485,21 @@ static unsigned short* limb_planes(Ctx& c, WRef* w, bool transposed, int nplanes
   return tmp;
 }
 
+// the filter rounded to bf16 with the contracted index contiguous, for the 64 x 64 bf16 kernel (k_gemm_bf16.hip): per sub-step
+static void bf16_filter_copy(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
+  unsigned short*& slot = transposed ? w->wbT : w->wb;
+  if (!slot) {
+    const size_t n = (size_t)w->T * w->R * w->Cc;
+    slot = reinterpret_cast<unsigned short*>(c.arena.allocf((n + 1) / 2));
+    if (transposed) launch_tap_transpose_bf16(w->w, slot, w->T, w->R, w->Cc, c.stream);
+    else launch_cvt_bf16(w->w, slot, n, c.stream);
+    if (dbg_env("EG_TRACE_CVT")) fprintf(stderr, "[cvt] weight n=%zu transposed=%d lane=%d\n", n, (int)transposed, c.cur_lane);
+  }
+  a.wgt_bf = slot;
+  a.wbf_ts = (long long)a.C * a.N;
+  a.ldwbf = a.C;
+}
+
 static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
   c.alt_w = nullptr;   // (a hand-over to run_conv that an earlier caller never consumed must not reach this launch)
   if (c.cfg.x3) {   // three limb planes instead of one rounded copy (k_gemm_x3.hip)
@@ -514,20 +532,16 @@ static void attach_bf16(Ctx& c, ConvArgs& a, WRef* w, bool transposed) {
   // 64 .. 127 output channels: the plane-fed kernel (k_conv_bf16p.hip) has a 64-channel form; whether it takes the launch is
   // only known in run_conv (K split, tile geometry) -- remember the filter so that run_conv can ask for its K-step-major plane
   if (a.N >= 64) {
+    // (the rounded copy below is made in run_conv, and only if the plane-fed kernel does not take the launch: it used to be
+    //  made here and then left unread -- one cvt_bf16 launch per use of g_dconv_3's filter)
     c.alt_w = w;
     c.alt_transposed = transposed;
+    a.wgt_bf = reinterpret_cast<const unsigned short*>(uintptr_t(16));   // (placeholder until run_conv: the K-split model looks at non-null only)
+    a.wbf_ts = (long long)a.C * a.N;
+    a.ldwbf = a.C;
+    return;
   }
-  unsigned short*& slot = transposed ? w->wbT : w->wb;
-  if (!slot) {
-    const size_t n = (size_t)w->T * w->R * w->Cc;
-    slot = reinterpret_cast<unsigned short*>(c.arena.allocf((n + 1) / 2));
-    if (transposed) launch_tap_transpose_bf16(w->w, slot, w->T, w->R, w->Cc, c.stream);
-    else launch_cvt_bf16(w->w, slot, n, c.stream);
-    if (dbg_env("EG_TRACE_CVT")) fprintf(stderr, "[cvt] weight n=%zu transposed=%d lane=%d\n", n, (int)transposed, c.cur_lane);
-  }
-  a.wgt_bf = slot;
-  a.wbf_ts = (long long)a.C * a.N;
-  a.ldwbf = a.C;
+  bf16_filter_copy(c, a, w, transposed);
 }
 
 // bf16 plane of a tensor's data / gradient (bf16 mode; common.h: Tensor::d_bf).  A plane its producer wrote is visible
@@ -556,7 +570,17 @@ static const unsigned short* tensor_plane(Ctx& c, T t, bool grad) {
 // (exact; every reader of such a tensor is a dense contraction that would round to bf16 itself)
 static void need_f32(Ctx& c, T t) {
   if (!t->d_plane_only) return;
-  launch_cvt_from_bf16(t->d_bf, t->d, t->numel(), c.stream);
+  Ctx::Lane& l = c.lanes[c.cur_lane];
+  if (c.stream == l.leaf && l.leaf != l.stream) {
+    // inside a LeafScope (a filter gradient that gathers fp32): the widening runs on the lane's MAIN stream and the leaf stream
+    // waits for it -- clearing d_plane_only below tells every later main-stream reader that d is valid, which is only true on
+    // the stream that wrote it
+    launch_cvt_from_bf16(t->d_bf, t->d, t->numel(), l.stream);
+    EG_HIP(hipEventRecord(l.leaf_in, l.stream));
+    EG_HIP(hipStreamWaitEvent(l.leaf, l.leaf_in, 0));
+  } else {
+    launch_cvt_from_bf16(t->d_bf, t->d, t->numel(), c.stream);
+  }
   if (dbg_env("EG_TRACE_CVT")) fprintf(stderr, "[widen] data n=%d h=%d w=%d c=%d lane=%d label=%s\n", t->n, t->h, t->w, t->c, c.cur_lane, c.cur_label.c_str());
   t->d_plane_only = false;
 }
@@ -631,6 +655,7 @@ static void run_conv(Ctx& c, ConvArgs& a, T xsrc, bool xgrad, float* x_full) {
       a.ksplit = 1;
     }
   }
+  if (c.cfg.bf16 && a.limbs == 0 && alt_w && a.wgt_bf == reinterpret_cast<const unsigned short*>(uintptr_t(16))) bf16_filter_copy(c, a, alt_w, c.alt_transposed);   // (not taken: the 64 x 64 bf16 kernel's copy)
   if (c.cfg.bf16 && a.limbs == 1 && xsrc && a.x == (xgrad ? xsrc->g : xsrc->d) && a.x_ps == xsrc->c) {
     const size_t pb = xsrc->numel() * sizeof(unsigned short);
     a.x_bf = reinterpret_cast<const unsigned short*>(uintptr_t(16));   // (placeholder: eligibility looks at alignment only)
@@ -1197,15 +1222,20 @@ void conv_backward_x(Ctx& c, T x, T y, WRef* w, int k, int stride) {
 // deconv2d -- conv.py:39-58: tf.nn.conv2d_transpose SAME, 5x5 stride 2, filter [kh,kw,Cout,Cin],
 // + bias; y[o] += x[i] w[k] with o = 2i + k - 1 (Appendix B.2), run as 4 sub-pixel phases.
 // ---------------------------------------------------------------------------------------------
-T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout) {
+T deconv2d(Ctx& c, T x, WRef* w, Param* bias, int cout, int fused_act, float* y_into) {
   const int k = 5, pt = 1, Cin = x->c;
   EG_CHECK(w->T == 25 && w->R == cout && w->Cc == Cin, "deconv2d weight shape");
   const int OH = x->h * 2, OW = x->w * 2;
-  T y = new_tensor(c, x->n, OH, OW, cout, false);
+  T y = y_into ? wrap_tensor(c, y_into, x->n, OH, OW, cout) : new_tensor(c, x->n, OH, OW, cout, false);
   const bool merged = cout == 3 && Cin % 16 == 0;   // g_dconv_4: all 4 phases in one 3x3 launch over the coarse grid
   if (merged) {
     if (c.prof_on) c.cur_label = w->name + " fwd";
-    run_merged_phases(c, x->d, x->n, x->h, x->w, Cin, merged_filter(c, w, 5, Cin), bias ? bias->w : nullptr, y->d, 0);
+    // forward-only graphs (inference, the generator outputs of the discriminator sub-steps): the output tanh in the store
+    const bool fwd_only = !(x->needs_grad || w->want_grad || (bias && bias->want_grad));
+    static const bool tanh_on = dbg_env("EG_NO_EPI_TANH") == nullptr;
+    const bool done = run_merged_phases(c, x->d, x->n, x->h, x->w, Cin, merged_filter(c, w, 5, Cin), bias ? bias->w : nullptr, y->d, 0,
+                                        (fwd_only && tanh_on && fused_act == ACT_TANH) ? ACT_TANH : 0);
+    y->fused_act = done ? ACT_TANH : 0;
   }
   const float* wT = merged ? nullptr : wref_transposed(c, w);  // [25][Cin][Cout]
   ConvArgs a{};
@@ -1445,7 +1475,9 @@ T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int upda
   const int C = x->c, R = (int)x->pixels();
   T out = new_tensor(c, x->n, x->h, x->w, C, true);
   T st = new_tensor(c, 1, 1, 1, 2 * C, false);
-  launch_bn_relu_fwd(x->d, gamma->w, beta->w, out->d, st->d, R, C, 1e-5f, c.stream);
+  // (bf16 mode: the plane the first transposed convolution stages, from the same pass -- no cvt_bf16 launch behind it)
+  unsigned short* plane = C % 32 == 0 ? producer_plane(c, out, false) : nullptr;
+  if (!launch_bn_relu_fwd(x->d, gamma->w, beta->w, out->d, st->d, R, C, 1e-5f, c.stream, plane)) out->d_bf = nullptr;
   if (stats_out) *stats_out = st;
   if (update_times > 0) launch_bn_moving_update(mm->w, mv->w, st->d, C, R, 0.9f, update_times, c.stream);
   const bool need = x->needs_grad || gamma->want_grad;
@@ -1521,6 +1553,20 @@ T pool2(Ctx& c, T x) {
     });
   }
   return out;
+}
+
+// pool2(relu(a + b)) -- a residual block's tail (conv.py:80-85, encoder.py:63-66).  Forward-only graphs (inference, the
+// post-update evaluation) run it as ONE pass that also stores the bf16 plane the next block's convolutions read; a graph that
+// differentiates keeps add() and pool2()
+T add_relu_pool2(Ctx& c, T a, T b) {
+  static const bool on = dbg_env("EG_NO_RES_TAIL") == nullptr;
+  if (on && !a->needs_grad && !b->needs_grad && a->h % 2 == 0 && a->w % 2 == 0) {
+    T out = new_tensor(c, a->n, a->h / 2, a->w / 2, a->c, false);
+    unsigned short* plane = producer_plane(c, out, false);
+    if (launch_add_relu_pool2_fwd(a->d, b->d, out->d, plane, a->n, a->h, a->w, a->c, c.stream)) return out;
+    out->d_bf = nullptr;
+  }
+  return pool2(c, add(c, a, b, true));
 }
 
 T add_pool2(Ctx& c, T a, T b) {
@@ -1806,6 +1852,9 @@ static T prelu_tail(Ctx& c, T x, T out, Param* leak, float leak_const) {
       Ctx& c = *cp;
       if (!out->g_set) return;
       if (out->g_act_done) {   // the convolution that wrote out's gradient applied this backward: the buffer holds d(x)
+        // (conv_dgrad took the epilogue only because x had no gradient and no other writer yet; a consumer of x recorded between
+        //  this op and that convolution would have written x->g since -- refuse loudly, as grad_acc does, instead of dropping it)
+        EG_CHECK(!x->g_set && (x->g == nullptr || x->g == out->g), "prelu backward in the epilogue: the PReLU's input already holds a gradient");
         x->g = out->g;
         x->g_set = true;
         x->g_bf = out->g_bf;

@@ -272,6 +272,21 @@ class EdgeGAN:
         return {'nranks': nr.value, 'rccl_version': vs, 'rccl_library': path.value.decode() or None,
                 'allreduce_calls': calls.value, 'allreduce_bytes': nbytes.value}
 
+    GROUP_NAMES = {0: 'G1+G2', 1: 'G2', 2: 'D2', 3: 'D', 4: 'D_patch2', 5: 'D_patch3', 6: 'E'}
+
+    def comm_timing(self, enable: bool = True):
+        """Event pairs around every gradient all-reduce from now on (include/edgegan_hip.h: eg_comm_timing)."""
+        self._check(self._lib.eg_comm_timing(self._ctx, 1 if enable else 0))
+
+    def comm_timing_read(self, cap: int = 4096):
+        """[(group name, payload bytes, milliseconds)] of the collectives since the last read, in issue order."""
+        ms = np.zeros(cap, np.float32)
+        grp = np.zeros(cap, np.int32)
+        nb = (C.c_longlong * cap)()
+        n = C.c_int()
+        self._check(self._lib.eg_comm_timing_read(self._ctx, fptr(ms), iptr(grp), nb, cap, C.byref(n)))
+        return [(self.GROUP_NAMES.get(int(grp[i]), str(int(grp[i]))), int(nb[i]), float(ms[i])) for i in range(n.value)]
+
     def comm_barrier(self):
         if self.nranks > 1:
             self.comm_reduce_scalars([0.0])

@@ -156,6 +156,17 @@ int eg_comm_reduce_scalars(eg_ctx* ctx, float* inout, int n, int op);
 int eg_comm_info(eg_ctx* ctx, int* nranks, int* rccl_version, char* libpath, int libpath_cap, long long* allreduce_calls,
                  long long* allreduce_bytes);
 
+/* per-collective timing of the gradient exchange (no reference counterpart).  eg_comm_timing(ctx, 1) brackets every gradient
+ * all-reduce enqueued from now on with a HIP event pair on the communication stream; eg_comm_timing_read waits for that stream and
+ * returns, in issue order, for up to `cap` collectives since the last read: the network group (0 G1+G2 joint exchange, 2 D2, 3 D,
+ * 4 D_patch2, 5 D_patch3, 6 E), the payload in bytes and the milliseconds between the stream reaching the collective and its
+ * result being complete (the wait for the slowest rank is inside) -- bench.py prints the per-group mean, max over the ranks.
+ * Environment (read at eg_create / eg_comm_init, documented in csrc/comm.cpp): EG_COMM_CHANNELS=n caps RCCL's channels (=
+ * workgroups = compute units taken from the matrix kernels), EG_COMM_CUS=n confines the communication stream to n compute units by
+ * a CU mask, EG_COMPUTE_AVOID_COMM_CUS=1 keeps the compute lanes off those; RCCL's own NCCL_* / RCCL_* variables pass through. */
+int eg_comm_timing(eg_ctx* ctx, int enable);
+int eg_comm_timing_read(eg_ctx* ctx, float* ms, int* group, long long* bytes, int cap, int* n);
+
 /* ---- measurement -------------------------------------------------------------------------------
  * Between begin/end every GEMM-shaped launch is bracketed by HIP events on the engine's stream;
  * end writes a JSON object {"kernels":[{"name","launches","ms","flops"}...]} into buf. */

@@ -109,6 +109,37 @@ def test_two_rank_iterations_lanes_equal_one_stream_and_replicas_stay_identical(
     assert len(moved) > 100, len(moved)
 
 
+def test_collectives_are_issued_in_one_order_on_every_rank_under_every_lane_schedule(shim, tmp_path):
+    """Seven gradient all-reduces per iteration (D, D_patch2, D_patch3, D2, G1+G2, E, G1+G2: one per optimised group and sub-step,
+    edgegan/models/edgegan.py:109-124), issued on the communication stream in the order the host enqueues the sub-steps.  That
+    order depends on the lane schedule (EG_LANES: the classifier's sub-step is enqueued first when sub-steps 1-4 run
+    concurrently, sub-step 7 before the end of 6) -- and on nothing else: for every mask both ranks record the same sequence of
+    (group, payload), it holds each group's exchanges exactly as often as the reference optimises that group, and the payloads
+    are the groups' live gradient sizes."""
+    want = sorted(['D', 'D_patch2', 'D_patch3', 'D2', 'G1+G2', 'E', 'G1+G2'])
+    seen = {}
+    for mask in ('0', '1', '2', '4', '8', '7', '15'):
+        ranks = _run_ranks(shim, tmp_path, 'order', 'order' + mask, EG_LANES=mask)
+        g0, g1 = list(ranks[0]['groups']), list(ranks[1]['groups'])
+        assert g0 == g1 and list(ranks[0]['nbytes']) == list(ranks[1]['nbytes']), (mask, g0, g1)
+        assert len(g0) == 14 and g0[:7] == g0[7:], (mask, g0)            # two iterations, the same order in each
+        assert sorted(g0[:7]) == want, (mask, g0)
+        assert g0.index('G1+G2') > max(g0[:7].index(d) for d in ('D', 'D_patch2', 'D_patch3', 'D2')), (mask, g0)
+        seen[mask] = tuple(g0[:7])
+        sizes = dict(zip(g0, (int(b) for b in ranks[0]['nbytes'])))
+        assert sizes['D2'] > sizes['G1+G2'] > sizes['E'] > sizes['D_patch2'] == sizes['D_patch3'] > sizes['D'] > 0, sizes
+    assert seen['0'] == ('D', 'D_patch2', 'D_patch3', 'D2', 'G1+G2', 'E', 'G1+G2')      # one stream: the reference's registration order
+    assert len(set(seen.values())) >= 2, seen                                           # (the schedules do differ: the check above is not vacuous)
+
+
+def test_ranks_that_disagree_on_the_lane_schedule_are_refused_at_bring_up(shim, tmp_path):
+    """EG_LANES decides the order of an iteration's collectives (the test above): two ranks with different values would pair
+    different groups' buffers.  eg_comm_init compares the schedule and the graph-shaping flags over the ranks and fails on all
+    of them (csrc/comm.cpp: comm_init)."""
+    ranks = _run_ranks(shim, tmp_path, 'lanes_disagree', 'lanesdis')
+    assert all(int(r['reported'][0]) == 1 for r in ranks)
+
+
 def test_stand_in_reports_a_collective_the_ranks_disagree_on(shim, tmp_path):
     """What makes the two-rank tests above meaningful as a guard for bench.py / train.py: a collective that the ranks do
     not enqueue alike (round 2's bench bug: profiled iterations on rank 0 only) is an error on every rank, not a hang."""
