@@ -298,6 +298,8 @@ T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int act);
 T act(Ctx& c, T x, int a);
 T act_tangent(Ctx& c, T tx, T out_prim, int a);
 T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times, T* stats_out = nullptr);
+T gen_head(Ctx& c, T zin, Param* wlin, Param* blin, Param* gamma, Param* beta, Param* mm, Param* mv, int h, int w, int C, int update_times,
+           T* stats_out);   // forward-only generator head in one launch, or null (ops.cpp)
 T add(Ctx& c, T a, T b, bool relu);
 T pool2(Ctx& c, T x);
 T add_relu_pool2(Ctx& c, T a, T b);   // pool2(relu(a + b)): one pass in forward-only graphs

@@ -1417,9 +1417,10 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
                                                        const float* __restrict__ wls, const float* __restrict__ bls,
                                                        const float* __restrict__ eps, float* __restrict__ mu, float* __restrict__ ls,
                                                        float* __restrict__ z0, float* __restrict__ z1, int HW, int C, int Z, int round_bf16) {
-  extern __shared__ float sm[];   // feat[C] | res[2 Z]
+  extern __shared__ float sm[];   // feat[C] | part[KS][2 Z]
+  constexpr int KS = 4;           // K slices: 4 x (2 Z / 4) column quads = 200 of the 256 threads busy at Z = 100, 128 dependent FMAs each
   float* feat = sm;
-  float* res = sm + C;
+  float* part = sm + C;
   const int n = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
@@ -1433,23 +1434,35 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
     feat[c] = f;
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < 2 * Z; o += 256) {
-    const bool second = o >= Z;
-    const int col = second ? o - Z : o;
+  // thread = (K slice, column quad of [mu | log sigma]); each slice's partial sum in ascending k, the slices summed in order below
+  const int Zq = Z / 4, nq = 2 * Zq;
+  for (int t = threadIdx.x; t < KS * nq; t += 256) {
+    const int ks = t / nq, q = t - ks * nq;
+    const bool second = q >= Zq;
+    const int col = (second ? q - Zq : q) * 4;
     const float* w = (second ? wls : wmu) + col;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < C; ++k) {
-      float wv = w[(size_t)k * Z];
-      if (round_bf16) wv = (float)(__bf16)wv;
-      acc = fmaf(feat[k], wv, acc);
+    const int per = (C + KS - 1) / KS, k0 = ks * per, k1 = min(C, k0 + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 16
+    for (int k = k0; k < k1; ++k) {
+      float4 wv = *reinterpret_cast<const float4*>(w + (size_t)k * Z);
+      if (round_bf16) wv = make_float4((float)(__bf16)wv.x, (float)(__bf16)wv.y, (float)(__bf16)wv.z, (float)(__bf16)wv.w);
+      const float f = feat[k];
+      acc.x = fmaf(f, wv.x, acc.x); acc.y = fmaf(f, wv.y, acc.y); acc.z = fmaf(f, wv.z, acc.z); acc.w = fmaf(f, wv.w, acc.w);
     }
-    res[o] = acc + (second ? bls : bmu)[col];
+    *reinterpret_cast<float4*>(part + (size_t)ks * 2 * Z + (second ? Z : 0) + col) = acc;
   }
   __syncthreads();
   const float e0 = eps[0], e1 = z1 ? eps[1] : 0.f;
   for (int j = threadIdx.x; j < Z; j += 256) {
-    const float m = res[j], l = res[Z + j];
+    float m = 0.f, l = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      m += part[ks * 2 * Z + j];
+      l += part[ks * 2 * Z + Z + j];
+    }
+    m += bmu[j];
+    l += bls[j];
     const size_t i = (size_t)n * Z + j;
     mu[i] = m;
     ls[i] = l;
@@ -1460,7 +1473,7 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
 }
 void launch_enc_head(const float* x, const float* wmu, const float* bmu, const float* wls, const float* bls, const float* eps, float* mu,
                      float* ls, float* z0, float* z1, int NB, int HW, int C, int Z, int round_bf16, hipStream_t s) {
-  hipLaunchKernelGGL(enc_head_kernel, dim3(NB), dim3(256), (size_t)(C + 2 * Z) * sizeof(float), s, x, wmu, bmu, wls, bls, eps, mu, ls, z0,
+  hipLaunchKernelGGL(enc_head_kernel, dim3(NB), dim3(256), (size_t)(C + 4 * 2 * Z) * sizeof(float), s, x, wmu, bmu, wls, bls, eps, mu, ls, z0,
                      z1, HW, C, Z, round_bf16);
 }
 

@@ -378,18 +378,23 @@ T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out, flo
   const std::string p = kGroupPrefix[group];
   const int gf = cfg.gf, h16 = cfg.H / 16, w16 = cfg.W / 2 / 16;
   const int feat = gf * 8 * h16 * w16;
-  T z_ = linear(c, zin, wref_param(c, P(c, p + "/g_lin_0/Matrix"), 1, zin->c, feat), P(c, p + "/g_lin_0/bias"));
-  T x = reshape(c, z_, zin->n, h16, w16, gf * 8);
-  x = bn_relu(c, x, P(c, p + "/batch_norm/BatchNorm/gamma"), P(c, p + "/batch_norm/BatchNorm/beta"),
-              P(c, p + "/batch_norm/BatchNorm/moving_mean"), P(c, p + "/batch_norm/BatchNorm/moving_variance"),
-              bn_times, bn_stats_out);
+  Param *gam = P(c, p + "/batch_norm/BatchNorm/gamma"), *bet = P(c, p + "/batch_norm/BatchNorm/beta");
+  Param *mm = P(c, p + "/batch_norm/BatchNorm/moving_mean"), *mv = P(c, p + "/batch_norm/BatchNorm/moving_variance");
+  T x = gen_head(c, zin, P(c, p + "/g_lin_0/Matrix"), P(c, p + "/g_lin_0/bias"), gam, bet, mm, mv, h16, w16, gf * 8, bn_times, bn_stats_out);
+  if (!x) {
+    T z_ = linear(c, zin, wref_param(c, P(c, p + "/g_lin_0/Matrix"), 1, zin->c, feat), P(c, p + "/g_lin_0/bias"));
+    x = reshape(c, z_, zin->n, h16, w16, gf * 8);
+    x = bn_relu(c, x, gam, bet, mm, mv, bn_times, bn_stats_out);
+  }
   const int ch[5] = {gf * 8, gf * 4, gf * 2, gf, cfg.c_dim};
   for (int i = 1; i <= 4; ++i) {
     const std::string b = p + "/g_dconv_" + std::to_string(i) + "/deconv2d/";
     c.feeds_in = i < 4;   // deconv_block: the InstanceNorm is the transposed convolution's only reader
     x = deconv2d(c, x, wref_param(c, P(c, b + "w"), 25, ch[i], ch[i - 1]), P(c, b + "b"), ch[i], i == 4 ? ACT_TANH : 0,
                  i == 4 ? out_into : nullptr);
-    if (i < 4) x = in_act(c, x, ACT_RELU);
+    // (bf16 mode, forward-only graph: the next transposed convolution stages the bf16 plane -- the fp32 copy is not written;
+    //  g_dconv_4 gathers fp32, so layer 3's output keeps both)
+    if (i < 4) x = in_act(c, x, ACT_RELU, nullptr, /*plane_only=*/cfg.bf16 && !x->needs_grad && i < 3);
   }
   if (x->fused_act == ACT_TANH) {   // (forward-only graph: the last layer's store applied it)
     x->fused_act = 0;
@@ -445,7 +450,7 @@ T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out, T* z1
     c.feeds_in = true;   // residual: both 3x3 convolutions are read by their InstanceNorm alone
     T o1 = conv2d(c, E, wref_param(c, P(c, b + "/res1/conv2d/w"), 9, cin, n), P(c, b + "/res1/conv2d/b"), 3, 1,
                   PAD_REFLECT);
-    o1 = in_act(c, o1, ACT_RELU);
+    o1 = in_act(c, o1, ACT_RELU, nullptr, /*plane_only=*/cfg.bf16 && !o1->needs_grad);   // (forward-only graph: res2 stages the plane)
     c.feeds_in = true;
     T o2 = conv2d(c, o1, wref_param(c, P(c, b + "/res2/conv2d/w"), 9, n, n), P(c, b + "/res2/conv2d/b"), 3, 1,
                   PAD_REFLECT);
@@ -471,7 +476,7 @@ T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out, T* z1
     // call's one or two eps draws in one launch (k_elem.hip: enc_head_kernel)
     static const bool head_on = dbg_env("EG_NO_ENC_HEAD") == nullptr;
     Param *wm = P(c, "E/FC8_mu/w"), *bm = P(c, "E/FC8_mu/b"), *ws = P(c, "E/FC8_sigma/w"), *bs = P(c, "E/FC8_sigma/b");
-    if (head_on && !E->needs_grad && !wm->want_grad && !ws->want_grad && !bm->want_grad && !bs->want_grad) {
+    if (head_on && cfg.z_dim % 4 == 0 && !E->needs_grad && !wm->want_grad && !ws->want_grad && !bm->want_grad && !bs->want_grad) {
       const int Z = cfg.z_dim;
       T mu = new_tensor(c, E->n, 1, 1, Z, false), ls = new_tensor(c, E->n, 1, 1, Z, false), z0 = new_tensor(c, E->n, 1, 1, Z, false);
       T z1 = z1_out ? new_tensor(c, E->n, 1, 1, Z, false) : nullptr;

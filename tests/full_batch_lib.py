@@ -29,7 +29,7 @@ CASES = [(f'b64/{n}', n, dict(batch_size=64), 0, 1234, False)
          for n in ('d_optim', 'd_optim_patch2', 'd_optim_patch3', 'd_optim2', 'g_optim_u', 'e_optim')] + \
         [('b64/g_optim_b', 'g_optim_b', dict(batch_size=64), 1, 1, False)] + \
         [(f'bf16_b16/{n}', n, dict(batch_size=16), 5, 21, True) for n in ('d_optim', 'd_optim2', 'g_optim_u', 'd_optim_patch3')] + \
-        [('bf16_256x512_b2/d_optim2', 'd_optim2', dict(batch_size=2, height=256, width=512), 5, 21, True)] + \
+        [(f'bf16_256x512_b2/{n}', n, dict(batch_size=2, height=256, width=512), 5, 21, True) for n in ('d_optim2', 'd_optim', 'g_optim_u')] + \
         [('bf16_b64/d_optim2', 'd_optim2', dict(batch_size=64), 5, 21, True)]      # configs[3]'s per-GPU batch
 CASE = {c[0]: c for c in CASES}
 

@@ -91,8 +91,10 @@ def test_bf16_substeps_14_classes():
 
 
 @pytest.mark.parametrize('name,B,H,W', [('d_optim', 16, 64, 128), ('d_optim2', 16, 64, 128), ('g_optim_u', 16, 64, 128),
-                                        ('d_optim2', 2, 256, 512), ('d_optim_patch3', 16, 64, 128), ('d_optim2', 64, 64, 128)],
-                         ids=['d_optim-b16', 'd_optim2-b16', 'g_optim_u-b16', 'd_optim2-256x512-b2', 'd_optim_patch3-b16', 'd_optim2-b64'])
+                                        ('d_optim2', 2, 256, 512), ('d_optim_patch3', 16, 64, 128), ('d_optim2', 64, 64, 128),
+                                        ('d_optim', 2, 256, 512), ('g_optim_u', 2, 256, 512)],
+                         ids=['d_optim-b16', 'd_optim2-b16', 'g_optim_u-b16', 'd_optim2-256x512-b2', 'd_optim_patch3-b16', 'd_optim2-b64',
+                              'd_optim-256x512-b2', 'g_optim_u-256x512-b2'])
 def test_bf16_substep_at_batch16_against_the_emulating_oracle(name, B, H, W):
     """the bf16 mode against the EMULATING oracle (operands of every qualifying contraction rounded to
     bf16 exactly as the engine rounds them, everything else fp64: edgegan/models/edgegan.py:109-116 evaluated under
@@ -109,10 +111,15 @@ def test_bf16_substep_at_batch16_against_the_emulating_oracle(name, B, H, W):
     transposed convolutions' phases) and the classifier's sub-step at configs[4]'s geometry (256x512, batch 2: 128x128 ...
     16x16 maps, 2^2 more pixels per image than any 64x128 test) against the same emulating oracle; later in round 5 the edge
     discriminator's sub-step (bicubic resize in front of the stacked passes) at batch 16 and the classifier's sub-step at configs[3]'s
-    full per-GPU batch of 64.  (The encoder's sub-step is not in this list on purpose: at random init the emulating oracle's OWN
+    full per-GPU batch of 64.  Round 6: the joint discriminator's and the generators' sub-steps at configs[4]'s
+    geometry (256x512, batch 2) -- an oracle comparison where the full-size test below only has the f32x3 engine to compare with.
+    (The encoder's sub-step is not in this list on purpose: at random init the emulating oracle's OWN
     fp32-vs-fp64 deviation on it is 0.2 ... 0.3 for most filters -- bf16 rounding moves the signs inside its L1 loss and the ReLU
     decisions of its 4 ... 16-pixel InstanceNorm layers -- so a tolerance derived from it proves nothing; measured engine error 0.21
-    median.  Its bf16 coverage is the batch-2 test above and the property tests below.)"""
+    median.  Round 6 looked for a better-conditioned state: after 10 / 25 / 50 / 100 training iterations of the fp32 oracle the
+    emulated e_optim's self-deviation stays at a median 0.07 ... 0.08 and a maximum 0.3 while the un-emulated fp32 one falls to 1e-4
+    (tools/cpu_eoptim_conditioning.py, profiles/r06_eoptim_conditioning.txt): the sensitivity is to the bf16 rounding boundaries of
+    the operands, which training does not move away from.  Its bf16 coverage is the batch-2 test above and the property tests below.)"""
     import full_batch_lib as FB
     import test_tight_gpu as TT
     key = (f'bf16_b{B}/' if (H, W) == (64, 128) else f'bf16_{H}x{W}_b{B}/') + name
