@@ -891,7 +891,7 @@ def main():
                     ea, np, local, SimpleNamespace(batch=16, classes=14, height=256, width=512, dtype='bf16'), 5, 2, 1,
                     'configs[4]: 14-class 256x512 bf16 full training iteration, batch 16 per GPU (its per-GPU workload)', deadline, live)
                 out['config1_infer_b64'] = infer_leg(
-                    ea, np, 0, 1, local, SimpleNamespace(batch=64, classes=0, height=64, width=128, dtype='bf16'), 50, 5, 3, deadline, live)
+                    ea, np, 0, 1, local, SimpleNamespace(batch=64, classes=0, height=64, width=128, dtype='bf16'), 400, 20, 3, deadline, live)
             except Exception as e:   # a side leg must never hide the headline
                 out['side_legs_error'] = repr(e)
             out['bench_seconds'] = round(time.time() - t_start, 1)

@@ -340,7 +340,11 @@ struct DiscSave {
   T stats[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 // out_into: the network's output is written there (inference: the caller's output buffer, no copy behind the network)
-T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out = nullptr, float* out_into = nullptr);
+// fused_head: a forward-only evaluation may run linear + BatchNorm + ReLU as one launch (ops.cpp: gen_head).  Its batch
+// statistics are the same numbers in another summation order, so a caller whose statistics must be the BITS of a differentiated
+// evaluation of the same forward (sub-step 6 beside sub-step 7: train_step applies both moving-average updates from one of them)
+// passes false
+T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out = nullptr, float* out_into = nullptr, bool fused_head = true);
 T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_of);
 // z1_out: a forward-only graph may also return z for a SECOND eps draw, eps_dev[1] (inference: the E -> G2 run), from the same
 // launch; null where the head ran as separate ops

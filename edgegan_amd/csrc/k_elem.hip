@@ -1413,24 +1413,27 @@ void launch_l1(const float* target, int t_stride, const float* recon, float* los
 // One block per image.  round_bf16 (compute_dtype bf16: a linear with 512 contracted and 100 produced channels qualifies for
 // rounded operands) rounds feat and the weights to bf16 before the fp32 multiply-add; products of bf16 numbers are exact in fp32,
 // so what differs from the MFMA path is the order of the 512-term sum only.
+template <bool ROUND>
 __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__ x, const float* __restrict__ wmu, const float* __restrict__ bmu,
                                                        const float* __restrict__ wls, const float* __restrict__ bls,
                                                        const float* __restrict__ eps, float* __restrict__ mu, float* __restrict__ ls,
-                                                       float* __restrict__ z0, float* __restrict__ z1, int HW, int C, int Z, int round_bf16) {
+                                                       float* __restrict__ z0, float* __restrict__ z1, int HW, int C, int Z) {
   extern __shared__ float sm[];   // feat[C] | part[KS][2 Z]
-  constexpr int KS = 4;           // K slices: 4 x (2 Z / 4) column quads = 200 of the 256 threads busy at Z = 100, 128 dependent FMAs each
+  constexpr int KS = 4;           // K slices: 4 x (2 Z / 4) column quads = 200 of the 256 threads busy at Z = 100, C / 4 dependent FMAs each
+  constexpr int U = 16;           // filter rows in flight per thread (the loop is latency-bound: one block per image, 64 blocks)
   float* feat = sm;
   float* part = sm + C;
   const int n = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
+#pragma unroll 4
     for (int p = 0; p < HW; ++p) {
       float v = x[((size_t)n * HW + p) * C + c];
       if (v < 0.f) v = 0.f;
       s += v;
     }
     float f = s / HW;
-    if (round_bf16) f = (float)(__bf16)f;
+    if (ROUND) f = (float)(__bf16)f;
     feat[c] = f;
   }
   __syncthreads();
@@ -1443,12 +1446,19 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
     const float* w = (second ? wls : wmu) + col;
     const int per = (C + KS - 1) / KS, k0 = ks * per, k1 = min(C, k0 + per);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 16
-    for (int k = k0; k < k1; ++k) {
-      float4 wv = *reinterpret_cast<const float4*>(w + (size_t)k * Z);
-      if (round_bf16) wv = make_float4((float)(__bf16)wv.x, (float)(__bf16)wv.y, (float)(__bf16)wv.z, (float)(__bf16)wv.w);
-      const float f = feat[k];
-      acc.x = fmaf(f, wv.x, acc.x); acc.y = fmaf(f, wv.y, acc.y); acc.z = fmaf(f, wv.z, acc.z); acc.w = fmaf(f, wv.w, acc.w);
+    for (int kb = k0; kb < k1; kb += U) {
+      float4 wv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) wv[u] = *reinterpret_cast<const float4*>(w + (size_t)min(kb + u, k1 - 1) * Z);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (kb + u < k1) {
+          float4 v = wv[u];
+          if (ROUND) v = make_float4((float)(__bf16)v.x, (float)(__bf16)v.y, (float)(__bf16)v.z, (float)(__bf16)v.w);
+          const float f = feat[kb + u];
+          acc.x = fmaf(f, v.x, acc.x); acc.y = fmaf(f, v.y, acc.y); acc.z = fmaf(f, v.z, acc.z); acc.w = fmaf(f, v.w, acc.w);
+        }
+      }
     }
     *reinterpret_cast<float4*>(part + (size_t)ks * 2 * Z + (second ? Z : 0) + col) = acc;
   }
@@ -1473,8 +1483,11 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
 }
 void launch_enc_head(const float* x, const float* wmu, const float* bmu, const float* wls, const float* bls, const float* eps, float* mu,
                      float* ls, float* z0, float* z1, int NB, int HW, int C, int Z, int round_bf16, hipStream_t s) {
-  hipLaunchKernelGGL(enc_head_kernel, dim3(NB), dim3(256), (size_t)(C + 4 * 2 * Z) * sizeof(float), s, x, wmu, bmu, wls, bls, eps, mu, ls, z0,
-                     z1, HW, C, Z, round_bf16);
+  const size_t lds = (size_t)(C + 4 * 2 * Z) * sizeof(float);
+  if (round_bf16)
+    hipLaunchKernelGGL(enc_head_kernel<true>, dim3(NB), dim3(256), lds, s, x, wmu, bmu, wls, bls, eps, mu, ls, z0, z1, HW, C, Z);
+  else
+    hipLaunchKernelGGL(enc_head_kernel<false>, dim3(NB), dim3(256), lds, s, x, wmu, bmu, wls, bls, eps, mu, ls, z0, z1, HW, C, Z);
 }
 
 // z = mu + eps*exp(log_sigma) with ONE scalar eps (encoder.py:78-79, quirk N3)

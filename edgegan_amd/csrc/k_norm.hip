@@ -978,8 +978,8 @@ bool launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, f
 //     y[b][p][c] = bias[p C + c] + sum_k z[b][k] W[k][p C + c]          (B <= 64 rows, P <= 16 positions, K <= 128)
 //     out = relu((y - mean_c) gamma_c / sqrt(var_c + eps) + beta_c),  mean / var over the B P values of channel c
 // A block owns 8 channels (all P positions, all rows: every value its statistics need); thread (q, rr) = (tid % 16, tid / 16)
-// holds position q of rows rr, rr + 16, rr + 32, rr + 48 -- 32 accumulators.  W's 8-channel column groups and z are staged in
-// LDS once; sums in ascending k with fp32 fma (the three-launch form contracts K = 100 / 114 on the exact-fp32 MFMA in every
+// holds position q of rows rr, rr + 16, rr + 32, rr + 48 -- 32 accumulators.  z is staged in LDS once, the thread's 8 filter
+// columns come straight from global memory, ten rows in flight; sums in ascending k with fp32 fma (the three-launch form contracts K = 100 / 114 on the exact-fp32 MFMA in every
 // compute mode: same arithmetic class, another summation order); statistics: per-thread partials, then a fixed-order sum over
 // the 256 threads.  bn_relu_fwd_vr's formulas for mean, variance, scale and the output.
 __global__ __launch_bounds__(256) void gen_head_kernel(const float* __restrict__ zin, const float* __restrict__ W, const float* __restrict__ bias,
@@ -987,18 +987,28 @@ __global__ __launch_bounds__(256) void gen_head_kernel(const float* __restrict__
                                                        unsigned short* __restrict__ out_bf, float* __restrict__ stats, int B, int K, int P, int C,
                                                        float eps) {
   extern __shared__ float gsm[];
-  const int NC = P * 8;
-  float* Ws = gsm;                      // [K][P][8]
-  float* zs = Ws + (size_t)K * NC;      // [B][K]
-  float* red = zs + (size_t)B * K;      // [256][8]
+  float* zs = gsm;                      // [64][K] (rows >= B: zeros)
+  float* red = zs + (size_t)64 * K;     // [256][8]
   float* bc = red + 256 * 8;            // [8] broadcast slot
   const int tid = threadIdx.x, c0 = blockIdx.x * 8;
   const size_t F = (size_t)P * C;
-  for (int i = tid; i < K * P * 2; i += 256) {
-    const int k = i / (P * 2), j = i - k * (P * 2), p = j >> 1, h = j & 1;
-    *reinterpret_cast<float4*>(Ws + (size_t)k * NC + p * 8 + 4 * h) = ld4(W + (size_t)k * F + (size_t)p * C + c0 + 4 * h);
+  {  // z: 64 K floats, every thread's loads issued before its stores (the kernel is one short latency-bound chain)
+    constexpr int ZU = 8;
+    const int total = 64 * K;
+    for (int base = 0; base < total; base += 256 * ZU) {
+      float v[ZU];
+#pragma unroll
+      for (int u = 0; u < ZU; ++u) {
+        const int i = base + u * 256 + tid;
+        v[u] = (i < B * K) ? zin[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < ZU; ++u) {
+        const int i = base + u * 256 + tid;
+        if (i < total) zs[i] = v[u];
+      }
+    }
   }
-  for (int i = tid; i < B * K; i += 256) zs[i] = zin[i];
   __syncthreads();
   const int q = tid & 15, rr = tid >> 4;
   const bool qv = q < P;
@@ -1008,15 +1018,29 @@ __global__ __launch_bounds__(256) void gen_head_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
   if (qv) {
-    for (int k = 0; k < K; ++k) {
-      const float4 w0 = *reinterpret_cast<const float4*>(Ws + (size_t)k * NC + q * 8), w1 = *reinterpret_cast<const float4*>(Ws + (size_t)k * NC + q * 8 + 4);
-      const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    // the thread's 8 filter columns straight from global memory (32 bytes per k; the 16 threads of a position share them through
+    // the cache), KU rows in flight
+    constexpr int KU = 10;
+    const float* wq = W + (size_t)q * C + c0;
+    for (int kb = 0; kb < K; kb += KU) {
+      float4 w0[KU], w1[KU];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = rr + 16 * i;
-        const float a = r < B ? zs[(size_t)r * K + k] : 0.f;
+      for (int u = 0; u < KU; ++u) {
+        const float* wp = wq + (size_t)min(kb + u, K - 1) * F;
+        w0[u] = ld4(wp);
+        w1[u] = ld4(wp + 4);
+      }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(a, w[j], acc[i][j]);
+      for (int u = 0; u < KU; ++u) {
+        if (kb + u < K) {
+          const float w[8] = {w0[u].x, w0[u].y, w0[u].z, w0[u].w, w1[u].x, w1[u].y, w1[u].z, w1[u].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float a = zs[(size_t)(rr + 16 * i) * K + kb + u];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(a, w[j], acc[i][j]);
+          }
+        }
       }
     }
     const float4 b0 = ld4(bias + (size_t)q * C + c0), b1 = ld4(bias + (size_t)q * C + c0 + 4);
@@ -1028,6 +1052,7 @@ __global__ __launch_bounds__(256) void gen_head_kernel(const float* __restrict__
   }
   const float R = (float)(B * P);
   float mean[8], var[8];
+#pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     float part[8];
 #pragma unroll
@@ -1042,17 +1067,31 @@ __global__ __launch_bounds__(256) void gen_head_kernel(const float* __restrict__
       part[j] = t;
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = part[j];
+    *reinterpret_cast<float4*>(red + tid * 8) = make_float4(part[0], part[1], part[2], part[3]);
+    *reinterpret_cast<float4*>(red + tid * 8 + 4) = make_float4(part[4], part[5], part[6], part[7]);
     __syncthreads();
-    if (tid < 8) {
+    // fixed-order sum over the 256 threads' partials: 32 threads per channel sum 8 partials each (ascending), then a 32-term sum
+    {
+      const int ch = tid & 7, g = tid >> 3;     // g: 0..31
       float t = 0.f;
-      for (int u = 0; u < 256; ++u) t += red[u * 8 + tid];
-      bc[tid] = t / R;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += red[(g * 8 + u) * 8 + ch];
+      __syncthreads();
+      red[g * 8 + ch] = t;
+      __syncthreads();
+      if (tid < 8) {
+        float tt = 0.f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) tt += red[u * 8 + tid];
+        bc[tid] = tt / R;
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) (pass == 0 ? mean[j] : var[j]) = bc[j];
+    for (int j = 0; j < 8; ++j) {
+      if (pass == 0) mean[j] = bc[j];
+      else var[j] = bc[j];
+    }
   }
   if (tid < 8) {
     stats[c0 + tid] = mean[tid];
@@ -1084,7 +1123,7 @@ __global__ __launch_bounds__(256) void gen_head_kernel(const float* __restrict__
 bool gen_head_eligible(int B, int K, int P, int C) { return B >= 1 && B <= 64 && K >= 1 && K <= 128 && P >= 1 && P <= 16 && C % 8 == 0; }
 void launch_gen_head(const float* zin, const float* W, const float* bias, const float* gamma, const float* beta, float* out,
                      unsigned short* out_bf, float* stats, int B, int K, int P, int C, float eps, hipStream_t s) {
-  const size_t lds = ((size_t)K * P * 8 + (size_t)B * K + 256 * 8 + 8) * sizeof(float);
+  const size_t lds = ((size_t)64 * K + 256 * 8 + 8) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -414,7 +414,7 @@ def test_train_and_test_command_lines_end_to_end(tmp_path, monkeypatch):
                 Image.fromarray(rng.randint(0, 256, size=(64, 128, 3)).astype(np.uint8)).save(
                     root / 'class14' / phase / str(c) / f'{i}.png')
     monkeypatch.chdir(tmp_path)
-    args = ['--name=t1', f'--dataroot={root}', '--batch_size=2', '--epoch=1', '--save_checkpoint_frequency=3']
+    args = ['--name=t1', f'--dataroot={root}', '--batch_size=2', '--epoch=1', '--save_checkpoint_frequency=3', '--noreference_evaluation']
     TR.main(args)
     out = tmp_path / 'outputs' / 't1'
     assert (out / 'flags.json').exists() and (out / 'logs').is_dir()
@@ -425,7 +425,8 @@ def test_train_and_test_command_lines_end_to_end(tmp_path, monkeypatch):
     ev = summary.read_events(str(next((out / 'logs').glob('events.out.tfevents.*'))))
     assert len(ev) == 1 + 2 and set(ev[1][1]) == set(summary.SCALAR_TAGS) and ev[1][0] == 1 and ev[2][0] == 2
     # the reference's own read-back semantics: post-update evaluation + histogram / image summaries (edgegan.py:344-411)
-    TR.main(['--name=t2', f'--dataroot={root}', '--batch_size=2', '--epoch=1', '--reference_evaluation'])
+    # (the DEFAULT since round 6: a user of the reference sees the reference's numbers)
+    TR.main(['--name=t2', f'--dataroot={root}', '--batch_size=2', '--epoch=1'])
     tags = summary.read_event_tags(str(next((tmp_path / 'outputs' / 't2' / 'logs').glob('events.out.tfevents.*'))))
     kinds = {}
     for _, t in tags:

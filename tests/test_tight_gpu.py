@@ -163,8 +163,9 @@ FULL_BATCH_EXACT_FP32 = ['d_optim', 'd_optim2']
 _FULL_BATCH_ORACLE = {}     # name -> (g64, l64, self_dev): the f32x3 re-run of these tests (test_x3_gpu.py) reuses the oracle's work
 
 
-def _full_batch_oracle(name, cfg, values, b):
-    if name not in _FULL_BATCH_ORACLE:
+def _full_batch_oracle(name, cfg, values, b, key=None):
+    key = key or name
+    if key not in _FULL_BATCH_ORACLE:
         om = O.OracleModel(parity.oracle_config(cfg), values, dtype=torch.float64)
         inp = O.StepInputs(parity.t64(b['images']), parity.t64(b['z']), parity.t64(b['alpha']), parity.t64(b['eps']))
         om32 = O.OracleModel(parity.oracle_config(cfg), values, dtype=torch.float32)
@@ -188,9 +189,9 @@ def _full_batch_oracle(name, cfg, values, b):
             if vn in g64:
                 kappa = l1 / max(abs(float(g64[vn])), 1e-300)
                 self_dev[vn] = max(self_dev[vn], SLOPE_KAPPA_TOL * kappa / SELF_DEV_FACTOR)
-        _FULL_BATCH_ORACLE[name] = ({k: v.detach() for k, v in g64.items()}, {k: float(v) for k, v in l64.items()}, self_dev, near_kink)
-        _FULL_BATCH_NEAR[name] = sorted(rec.near, key=lambda r: r[2])
-    return _FULL_BATCH_ORACLE[name]
+        _FULL_BATCH_ORACLE[key] = ({k: v.detach() for k, v in g64.items()}, {k: float(v) for k, v in l64.items()}, self_dev, near_kink)
+        _FULL_BATCH_NEAR[key] = sorted(rec.near, key=lambda r: r[2])
+    return _FULL_BATCH_ORACLE[key]
 
 
 # The flip tolerance, proven where it is used: when a flip-exposed variable misses its TIGHT tolerance, the deviation
@@ -209,7 +210,7 @@ FLIP_MAX_CANDIDATES = 6
 _FULL_BATCH_NEAR = {}
 
 
-def _flip_proof(name, cfg, values, b, g64, need, tight, gmax):
+def _flip_proof(name, cfg, values, b, g64, need, tight, gmax, key=None):
     """need: {failing flip-exposed variable: its gradient from the engine}; tight: {variable: tolerance}.  Returns (flipped
     candidates, {variable: error against the flipped oracle}, all candidates)."""
     import itertools
@@ -220,7 +221,7 @@ def _flip_proof(name, cfg, values, b, g64, need, tight, gmax):
             continue
         per_n = np.sqrt(((h - g) ** 2).reshape(-1, g.shape[-1]).sum(0))
         chans.setdefault(g.shape[-1], set()).update(int(n) for n in np.argsort(-per_n)[:2])
-    cand = [r for r in _FULL_BATCH_NEAR.get(name, []) if len(r[4]) == 4 and r[4][-1] in chans and int(r[1] % r[4][-1]) in chans[r[4][-1]]]
+    cand = [r for r in _FULL_BATCH_NEAR.get(key or name, []) if len(r[4]) == 4 and r[4][-1] in chans and int(r[1] % r[4][-1]) in chans[r[4][-1]]]
     cand = cand[:FLIP_MAX_CANDIDATES]
     om = O.OracleModel(parity.oracle_config(cfg), values, dtype=torch.float64)
     inp = O.StepInputs(parity.t64(b['images']), parity.t64(b['z']), parity.t64(b['alpha']), parity.t64(b['eps']))
@@ -240,6 +241,32 @@ def _flip_proof(name, cfg, values, b, g64, need, tight, gmax):
             if best is None or score < best[0]:
                 best = (score, sub, errs)
     return [cand[i] for i in best[1]], best[2], cand
+
+
+def _rows_with_flip_proof(net, name, cfg, values, b, g64, l64, var_tol, tight_tol, tag, exposed, key=None):
+    """Every optimised variable of sub-step `name` against the fp64 gradients g64 at its tight tolerance; a flip-exposed variable
+    (exposed(vn)) that misses it must be explained by mirrored near-kink inputs of the oracle (_flip_proof): its row is then REPLACED
+    by one at the same tolerance against the oracle with those elements flipped -- or stays failing."""
+    rows = _grad_rows(net, None, None, name, 1e-3, tag, var_tol=var_tol, precomputed=(g64, l64))
+    gmax = max(float(g.abs().max()) for g in g64.values())
+    need = {}
+    for vn in var_tol:
+        if exposed(vn) and vn in g64 and float(g64[vn].abs().max()) >= 1e-9 * gmax:
+            h = net.get_variable(vn + '/grad').astype(np.float64)
+            if parity.rel_l2(h, g64[vn].numpy(), 1e-5 * gmax) > tight_tol[vn]:
+                need[vn] = h
+    if need:
+        flipped, errs, cand = _flip_proof(name, cfg, values, b, g64, need, tight_tol, gmax, key=key)
+        what = ', '.join(f'{c[3]} {c[4]} element {c[1]} at {c[2]:.1e} rms' for c in flipped) or 'none'
+        if os.environ.get('EG_FLIP_REPORT'):
+            print(tag, name, 'flip proof:', len(cand), 'candidates; flipped:', what,
+                  {vn: ('%.1e' % parity.rel_l2(need[vn], g64[vn].numpy(), 1e-5 * gmax), '%.1e' % errs[vn], '%.1e' % tight_tol[vn]) for vn in need})
+        # the proof row REPLACES the failing row: tight tolerance, against the oracle with the listed elements mirrored
+        rows = [r for r in rows if not any(f' grad {vn} [' in r[0] for vn in need)]
+        for vn in need:
+            rows.append((f'{tag} {name} grad {vn} against the oracle with {len(flipped)} of {len(cand)} near-kink candidates flipped ({what}) [L2]',
+                         errs[vn], tight_tol[vn]))
+    return rows
 
 
 @pytest.mark.parametrize('name', FULL_BATCH_EXACT_FP32)
@@ -279,26 +306,8 @@ def test_full_batch_fp32_substep_against_fp64_oracle(name):
     var_tol = {vn: SELF_DEV_OUTLIERS.get(vn, SELF_DEV_FACTOR) * d for vn, d in self_dev.items()}
     tight_tol = {vn: max(1e-3, t) for vn, t in var_tol.items()}
     if live:
-        rows = _grad_rows(net, None, None, name, 1e-3, 'B=64', var_tol=var_tol, precomputed=(g64, l64))
-        # flip-exposed rows that miss the tight tolerance: prove that flips of recorded near-kink elements explain them (_flip_proof)
-        gmax = max(float(g.abs().max()) for g in g64.values())
-        need = {}
-        for vn in var_tol:
-            if (FLIP_EXPOSED.match(vn) or FLIP_EXPOSED_D.match(vn)) and vn in g64 and float(g64[vn].abs().max()) >= 1e-9 * gmax:
-                h = net.get_variable(vn + '/grad').astype(np.float64)
-                if parity.rel_l2(h, g64[vn].numpy(), 1e-5 * gmax) > tight_tol[vn]:
-                    need[vn] = h
-        if need:
-            flipped, errs, cand = _flip_proof(name, cfg, values, b, g64, need, tight_tol, gmax)
-            what = ', '.join(f'{c[3]} {c[4]} element {c[1]} at {c[2]:.1e} rms' for c in flipped) or 'none'
-            if os.environ.get('EG_FLIP_REPORT'):
-                print(name, 'flip proof:', len(cand), 'candidates; flipped:', what,
-                      {vn: ('%.1e' % parity.rel_l2(need[vn], g64[vn].numpy(), 1e-5 * gmax), '%.1e' % errs[vn], '%.1e' % tight_tol[vn]) for vn in need})
-            # the proof row REPLACES the failing row: tight tolerance, against the oracle with the listed elements mirrored
-            rows = [r for r in rows if not any(f' grad {vn} [' in r[0] for vn in need)]
-            for vn in need:
-                rows.append((f'B=64 {name} grad {vn} against the oracle with {len(flipped)} of {len(cand)} near-kink candidates flipped ({what}) [L2]',
-                             errs[vn], tight_tol[vn]))
+        rows = _rows_with_flip_proof(net, name, cfg, values, b, g64, l64, var_tol, tight_tol, 'B=64',
+                                     lambda vn: bool(FLIP_EXPOSED.match(vn) or FLIP_EXPOSED_D.match(vn)))
     else:
         rows = _grad_rows_digest(net, name, fb, 1e-3, 'B=64', var_tol=var_tol)
     net.close()
