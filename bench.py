@@ -411,37 +411,28 @@ def attach_live_traffic(roof, spec, mode, deadline):
                                   'KiB units' % lt['launches_sampled'])
 
 
-def train_leg(ea, np, local, spec, steps, warmup, profile_steps, workload, deadline, live):
-    """One more BASELINE configuration measured in the same process, after the headline: the same 7-sub-step iteration on a
-    synthetic batch resident in HBM, timed over `steps` iterations (lanes on), then `profile_steps` serialised iterations for
-    the roofline of ITS dominant kernel, then (separate child runs) that kernel's HBM traffic."""
-    cfg = ea.Config(batch_size=spec.batch, num_classes=spec.classes, device=local, compute_dtype=spec.dtype, height=spec.height,
-                    width=spec.width)
-    net = ea.EdgeGAN(cfg, ea.init_variables(cfg, 0))
-    b = ea.synthetic_batch(cfg, seed=1234)
-    net.upload_batch(b['images'], b['z'], b['alpha'], b['eps'])
-    for _ in range(warmup):
-        net.train_step()
-    net.sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        net.train_step()
-    net.sync()
-    dt = time.perf_counter() - t0
-    finite = all(np.isfinite(v) for v in net.losses().values())
-    roof = None
-    if profile_steps > 0:
-        net.profile_begin()
-        for _ in range(profile_steps):
-            net.train_step()
-        roof = roofline_of(net.profile_end()['kernels'], profile_steps, spec.batch)
-    mem = net.memory_stats()
-    net.close()
-    if live:
-        attach_live_traffic(roof, spec, 'train', deadline)
-    return {'value': round(spec.batch * steps / dt, 2), 'unit': 'images/s', 'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps,
-            'warmup': warmup, 'dtype': spec.dtype, 'config': {'workload': workload, 'per_gpu_batch': spec.batch},
-            'losses_finite': bool(finite), 'memory': mem, 'roofline': roof}
+def side_leg(extra_args, workload, deadline, live, timeout=150):
+    """One more BASELINE configuration in the default run's line: this same bench in a FRESH process (own HIP context, no torch
+    threads of the CPU baseline around, the same state a stand-alone `python bench.py <extra_args>` has -- in-process legs
+    measured 4 ... 25 % below their stand-alone runs), its one JSON line reduced to what the leg reports."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + extra_args + ['--no-cpu-baseline', '--no-alt', '--no-side-legs']
+    if not live or time.time() > deadline:
+        cmd.append('--no-live-traffic')
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ))
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+        d = json.loads(line)
+    except Exception as e:      # a side leg must never hide the headline
+        return {'value': None, 'error': repr(e)}
+    keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'losses_finite', 'outputs_finite', 'memory', 'host_enqueue_ms_per_step',
+            'algorithmic_tflops_per_gpu', 'roofline')
+    leg = {k: d[k] for k in keep if k in d}
+    leg['config'] = {'workload': workload, 'per_gpu_batch': d.get('config', {}).get('per_gpu_batch')}
+    leg['command'] = 'python bench.py ' + ' '.join(extra_args)
+    if '--no-live-traffic' in cmd and live and leg.get('roofline'):
+        leg['roofline']['traffic_source'] = 'not measured: the run had used its time budget before this leg\'s PMC passes'
+    return leg
 
 
 def infer_leg(ea, np, rank, world, local, spec, steps, warmup, profile_steps, deadline, live):
@@ -853,6 +844,27 @@ def main():
         }
         if world == 1 and args.dtype == 'f32x3' and not args.no_alt:
             out['exact_fp32_mfma_mode'] = alt_mode(ea, dict(cfg_kwargs, compute_dtype='f32'), values, batch, args)
+        if world == 1 and net is not None:
+            net.close()         # (the side legs and the PMC child runs own contexts of their own)
+            net = None
+        if (world == 1 and not args.no_side_legs and args.dtype == 'f32x3'
+                and (args.height, args.width, args.batch, args.classes) == (64, 128, 64, 14)):
+            # the other BASELINE configurations, in the driver's one line: each leg = this bench in a fresh
+            # process -- its own timed region (barrier + device sync on both sides), its own roofline object with the dominant
+            # kernel's HBM traffic measured in ITS run.  PMC passes of a leg are skipped once the whole run is past its budget.
+            deadline = t_start + 100
+            live = not args.no_live_traffic
+            out['bf16_mode'] = side_leg(
+                ['--dtype', 'bf16', '--steps', '10', '--warmup', '3'],
+                'configs[3] arithmetic (bf16 MFMA operands, fp32 accumulate / storage): 14-class 64x128 full training iteration '
+                '(7 RMSProp sub-steps), batch 64 per GPU (the per-GPU workload of the 8-GPU DP configuration)', deadline, live)
+            out['config4_256x512_b16_bf16'] = side_leg(
+                ['--dtype', 'bf16', '--height', '256', '--width', '512', '--batch', '16', '--steps', '5', '--warmup', '2', '--profile-steps', '1'],
+                'configs[4]: 14-class 256x512 bf16 full training iteration, batch 16 per GPU (its per-GPU workload)', deadline, live)
+            out['config1_infer_b64'] = side_leg(
+                ['--mode', 'infer', '--steps', '400', '--warmup', '20', '--profile-steps', '3'],
+                'configs[1]: single-class 64x128 bf16 generator-only inference (edgegan.test path: E -> G1, E -> G2), batch 64, inputs '
+                'resident in HBM, up to four calls in flight', deadline, live)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(dict(num_classes=args.classes, height=args.height, width=args.width),
@@ -860,10 +872,7 @@ def main():
             except Exception as e:  # the baseline must never hide the GPU number
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
         if world == 1 and roof and not args.no_live_traffic:
-            # roofline.traffic measured HERE (the committed table meant the driver never observed traffic): the engine
-            # is closed first, the PMC child runs own a context of their own
-            net.close()
-            net = None
+            # roofline.traffic measured HERE (the committed table meant the driver never observed traffic)
             lt = live_traffic(roof['kernel'], args)
             if lt:
                 roof['traffic'] = round(lt['bytes'], 1)
@@ -872,29 +881,7 @@ def main():
                 roof['traffic_source'] = ('measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each) over a '
                                           '2-iteration child run with the sub-steps serialised, averaged over %d launches of this kernel; '
                                           'read side x 2 (gfx950), KiB units' % lt['launches_sampled'])
-        if (world == 1 and not args.no_side_legs and args.dtype == 'f32x3'
-                and (args.height, args.width, args.batch, args.classes) == (64, 128, 64, 14)):
-            # the other BASELINE configurations, in the driver's one line: each leg = its own engine, its
-            # own timed region, its own roofline object.  PMC child runs of a leg are skipped once the run is past its budget.
-            from types import SimpleNamespace
-            if net is not None:
-                net.close()
-                net = None
-            deadline = t_start + 105
-            live = not args.no_live_traffic
-            try:
-                out['bf16_mode'] = train_leg(
-                    ea, np, local, SimpleNamespace(batch=64, classes=14, height=64, width=128, dtype='bf16'), 10, 3, 2,
-                    'configs[3] arithmetic (bf16 MFMA operands, fp32 accumulate / storage): 14-class 64x128 full training iteration '
-                    '(7 RMSProp sub-steps), batch 64 per GPU (the per-GPU workload of the 8-GPU DP configuration)', deadline, live)
-                out['config4_256x512_b16_bf16'] = train_leg(
-                    ea, np, local, SimpleNamespace(batch=16, classes=14, height=256, width=512, dtype='bf16'), 5, 2, 1,
-                    'configs[4]: 14-class 256x512 bf16 full training iteration, batch 16 per GPU (its per-GPU workload)', deadline, live)
-                out['config1_infer_b64'] = infer_leg(
-                    ea, np, 0, 1, local, SimpleNamespace(batch=64, classes=0, height=64, width=128, dtype='bf16'), 400, 20, 3, deadline, live)
-            except Exception as e:   # a side leg must never hide the headline
-                out['side_legs_error'] = repr(e)
-            out['bench_seconds'] = round(time.time() - t_start, 1)
+        out['bench_seconds'] = round(time.time() - t_start, 1)
         print(json.dumps(out))
     if net is not None:
         net.close()

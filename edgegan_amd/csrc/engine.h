@@ -298,8 +298,6 @@ T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int act);
 T act(Ctx& c, T x, int a);
 T act_tangent(Ctx& c, T tx, T out_prim, int a);
 T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times, T* stats_out = nullptr);
-T gen_head(Ctx& c, T zin, Param* wlin, Param* blin, Param* gamma, Param* beta, Param* mm, Param* mv, int h, int w, int C, int update_times,
-           T* stats_out);   // forward-only generator head in one launch, or null (ops.cpp)
 T add(Ctx& c, T a, T b, bool relu);
 T pool2(Ctx& c, T x);
 T add_relu_pool2(Ctx& c, T a, T b);   // pool2(relu(a + b)): one pass in forward-only graphs
@@ -340,11 +338,7 @@ struct DiscSave {
   T stats[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 // out_into: the network's output is written there (inference: the caller's output buffer, no copy behind the network)
-// fused_head: a forward-only evaluation may run linear + BatchNorm + ReLU as one launch (ops.cpp: gen_head).  Its batch
-// statistics are the same numbers in another summation order, so a caller whose statistics must be the BITS of a differentiated
-// evaluation of the same forward (sub-step 6 beside sub-step 7: train_step applies both moving-average updates from one of them)
-// passes false
-T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out = nullptr, float* out_into = nullptr, bool fused_head = true);
+T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out = nullptr, float* out_into = nullptr);
 T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_of);
 // z1_out: a forward-only graph may also return z for a SECOND eps draw, eps_dev[1] (inference: the E -> G2 run), from the same
 // launch; null where the head ran as separate ops

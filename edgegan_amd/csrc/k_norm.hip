@@ -972,166 +972,6 @@ bool launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, f
   hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, gamma, beta, out, stats, R, C, eps);
   return false;
 }
-// ---------------------------------------------------------------------------------------------------------------------
-// The generator's head in a forward-only graph, ONE launch instead of three (generator.py:44-53: linear -> reshape ->
-// BatchNorm with batch statistics (quirk N1) -> ReLU; + the bf16 plane g_dconv_1 stages in the bf16 mode):
-//     y[b][p][c] = bias[p C + c] + sum_k z[b][k] W[k][p C + c]          (B <= 64 rows, P <= 16 positions, K <= 128)
-//     out = relu((y - mean_c) gamma_c / sqrt(var_c + eps) + beta_c),  mean / var over the B P values of channel c
-// A block owns 8 channels (all P positions, all rows: every value its statistics need); thread (q, rr) = (tid % 16, tid / 16)
-// holds position q of rows rr, rr + 16, rr + 32, rr + 48 -- 32 accumulators.  z is staged in LDS once, the thread's 8 filter
-// columns come straight from global memory, ten rows in flight; sums in ascending k with fp32 fma (the three-launch form contracts K = 100 / 114 on the exact-fp32 MFMA in every
-// compute mode: same arithmetic class, another summation order); statistics: per-thread partials, then a fixed-order sum over
-// the 256 threads.  bn_relu_fwd_vr's formulas for mean, variance, scale and the output.
-__global__ __launch_bounds__(256) void gen_head_kernel(const float* __restrict__ zin, const float* __restrict__ W, const float* __restrict__ bias,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,
-                                                       unsigned short* __restrict__ out_bf, float* __restrict__ stats, int B, int K, int P, int C,
-                                                       float eps) {
-  extern __shared__ float gsm[];
-  float* zs = gsm;                      // [64][K] (rows >= B: zeros)
-  float* red = zs + (size_t)64 * K;     // [256][8]
-  float* bc = red + 256 * 8;            // [8] broadcast slot
-  const int tid = threadIdx.x, c0 = blockIdx.x * 8;
-  const size_t F = (size_t)P * C;
-  {  // z: 64 K floats, every thread's loads issued before its stores (the kernel is one short latency-bound chain)
-    constexpr int ZU = 8;
-    const int total = 64 * K;
-    for (int base = 0; base < total; base += 256 * ZU) {
-      float v[ZU];
-#pragma unroll
-      for (int u = 0; u < ZU; ++u) {
-        const int i = base + u * 256 + tid;
-        v[u] = (i < B * K) ? zin[i] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < ZU; ++u) {
-        const int i = base + u * 256 + tid;
-        if (i < total) zs[i] = v[u];
-      }
-    }
-  }
-  __syncthreads();
-  const int q = tid & 15, rr = tid >> 4;
-  const bool qv = q < P;
-  float acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-  if (qv) {
-    // the thread's 8 filter columns straight from global memory (32 bytes per k; the 16 threads of a position share them through
-    // the cache), KU rows in flight
-    constexpr int KU = 10;
-    const float* wq = W + (size_t)q * C + c0;
-    for (int kb = 0; kb < K; kb += KU) {
-      float4 w0[KU], w1[KU];
-#pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        const float* wp = wq + (size_t)min(kb + u, K - 1) * F;
-        w0[u] = ld4(wp);
-        w1[u] = ld4(wp + 4);
-      }
-#pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        if (kb + u < K) {
-          const float w[8] = {w0[u].x, w0[u].y, w0[u].z, w0[u].w, w1[u].x, w1[u].y, w1[u].z, w1[u].w};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float a = zs[(size_t)(rr + 16 * i) * K + kb + u];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(a, w[j], acc[i][j]);
-          }
-        }
-      }
-    }
-    const float4 b0 = ld4(bias + (size_t)q * C + c0), b1 = ld4(bias + (size_t)q * C + c0 + 4);
-    const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] += b[j];
-  }
-  const float R = (float)(B * P);
-  float mean[8], var[8];
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    float part[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float t = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (qv && rr + 16 * i < B) {
-          const float d = pass == 0 ? acc[i][j] : acc[i][j] - mean[j];
-          t += pass == 0 ? d : d * d;
-        }
-      part[j] = t;
-    }
-    __syncthreads();
-    *reinterpret_cast<float4*>(red + tid * 8) = make_float4(part[0], part[1], part[2], part[3]);
-    *reinterpret_cast<float4*>(red + tid * 8 + 4) = make_float4(part[4], part[5], part[6], part[7]);
-    __syncthreads();
-    // fixed-order sum over the 256 threads' partials: 32 threads per channel sum 8 partials each (ascending), then a 32-term sum
-    {
-      const int ch = tid & 7, g = tid >> 3;     // g: 0..31
-      float t = 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t += red[(g * 8 + u) * 8 + ch];
-      __syncthreads();
-      red[g * 8 + ch] = t;
-      __syncthreads();
-      if (tid < 8) {
-        float tt = 0.f;
-#pragma unroll
-        for (int u = 0; u < 32; ++u) tt += red[u * 8 + tid];
-        bc[tid] = tt / R;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (pass == 0) mean[j] = bc[j];
-      else var[j] = bc[j];
-    }
-  }
-  if (tid < 8) {
-    stats[c0 + tid] = mean[tid];
-    stats[C + c0 + tid] = var[tid];
-  }
-  if (!qv) return;
-  const float4 g0 = ld4(gamma + c0), g1 = ld4(gamma + c0 + 4), e0 = ld4(beta + c0), e1 = ld4(beta + c0 + 4);
-  const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-  float sc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) sc[j] = g[j] / sqrtf(var[j] + eps);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = rr + 16 * i;
-    if (r >= B) continue;
-    float y[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) y[j] = fmaxf((acc[i][j] - mean[j]) * sc[j] + be[j], 0.f);
-    const size_t o = ((size_t)r * P + q) * C + c0;
-    const float4 y0 = make_float4(y[0], y[1], y[2], y[3]), y1 = make_float4(y[4], y[5], y[6], y[7]);
-    st4(out + o, y0);
-    st4(out + o + 4, y1);
-    if (out_bf) {
-      st_bf4n(out_bf, o, y0);
-      st_bf4n(out_bf, o + 4, y1);
-    }
-  }
-}
-bool gen_head_eligible(int B, int K, int P, int C) { return B >= 1 && B <= 64 && K >= 1 && K <= 128 && P >= 1 && P <= 16 && C % 8 == 0; }
-void launch_gen_head(const float* zin, const float* W, const float* bias, const float* gamma, const float* beta, float* out,
-                     unsigned short* out_bf, float* stats, int B, int K, int P, int C, float eps, hipStream_t s) {
-  const size_t lds = ((size_t)64 * K + 256 * 8 + 8) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gen_head_kernel, dim3(C / 8), dim3(256), lds, s, zin, W, bias, gamma, beta, out, out_bf, stats, B, K, P, C, eps);
-}
-
 void launch_bn_relu_bwd(const float* x, const float* out, const float* dout, const float* gamma,
                         const float* stats, float* dx, int acc_dx, float* dgamma, int acc_dg, float* dbeta,
                         int acc_db, int R, int C, float eps, hipStream_t s) {

@@ -390,10 +390,6 @@ void launch_act_bwd(const float* out, const float* dout, float* dx, int accumula
 // out_bf: also the output's bf16 plane (bf16 mode: what g_dconv_1 reads); returns whether the kernel that ran stored it
 bool launch_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats,
                         int R, int C, float eps, hipStream_t s, unsigned short* out_bf = nullptr);
-// forward-only generator head: linear + BatchNorm (batch statistics) + ReLU (+ the output's bf16 plane) in one launch
-bool gen_head_eligible(int B, int K, int P, int C);
-void launch_gen_head(const float* zin, const float* W, const float* bias, const float* gamma, const float* beta, float* out,
-                     unsigned short* out_bf, float* stats, int B, int K, int P, int C, float eps, hipStream_t s);
 void launch_bn_relu_bwd(const float* x, const float* out, const float* dout, const float* gamma,
                         const float* stats, float* dx, int acc_dx, float* dgamma, int acc_dg, float* dbeta,
                         int acc_db, int R, int C, float eps, hipStream_t s);

@@ -373,20 +373,20 @@ void api_enter(Ctx& c) {
 // networks
 // ---------------------------------------------------------------------------------------------
 // generator.py:35-74 (_convnet): linear -> reshape -> BatchNorm(!) -> ReLU -> 3x[deconv,IN,ReLU] -> deconv -> tanh
-T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out, float* out_into, bool fused_head) {
+T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out, float* out_into) {
   const Config& cfg = c.cfg;
   const std::string p = kGroupPrefix[group];
   const int gf = cfg.gf, h16 = cfg.H / 16, w16 = cfg.W / 2 / 16;
   const int feat = gf * 8 * h16 * w16;
-  Param *gam = P(c, p + "/batch_norm/BatchNorm/gamma"), *bet = P(c, p + "/batch_norm/BatchNorm/beta");
-  Param *mm = P(c, p + "/batch_norm/BatchNorm/moving_mean"), *mv = P(c, p + "/batch_norm/BatchNorm/moving_variance");
-  T x = fused_head ? gen_head(c, zin, P(c, p + "/g_lin_0/Matrix"), P(c, p + "/g_lin_0/bias"), gam, bet, mm, mv, h16, w16, gf * 8, bn_times, bn_stats_out)
-                   : nullptr;
-  if (!x) {
-    T z_ = linear(c, zin, wref_param(c, P(c, p + "/g_lin_0/Matrix"), 1, zin->c, feat), P(c, p + "/g_lin_0/bias"));
-    x = reshape(c, z_, zin->n, h16, w16, gf * 8);
-    x = bn_relu(c, x, gam, bet, mm, mv, bn_times, bn_stats_out);
-  }
+  T z_ = linear(c, zin, wref_param(c, P(c, p + "/g_lin_0/Matrix"), 1, zin->c, feat), P(c, p + "/g_lin_0/bias"));
+  T x = reshape(c, z_, zin->n, h16, w16, gf * 8);
+  // (a one-launch form of linear + BatchNorm + ReLU for forward-only graphs was built and measured in round 6: 43 us against
+  //  18 + 12 for the two launches it replaced -- 64 blocks of a latency-bound gather of 32-byte filter pieces -- and its batch
+  //  statistics, the same numbers in another summation order, broke the bit-equality of sub-step 6's forward with sub-step 7's:
+  //  removed, docs/experiments.md)
+  x = bn_relu(c, x, P(c, p + "/batch_norm/BatchNorm/gamma"), P(c, p + "/batch_norm/BatchNorm/beta"),
+              P(c, p + "/batch_norm/BatchNorm/moving_mean"), P(c, p + "/batch_norm/BatchNorm/moving_variance"),
+              bn_times, bn_stats_out);
   const int ch[5] = {gf * 8, gf * 4, gf * 2, gf, cfg.c_dim};
   for (int i = 1; i <= 4; ++i) {
     const std::string b = p + "/g_dconv_" + std::to_string(i) + "/deconv2d/";
@@ -1149,9 +1149,7 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
     case 6: {  // e_optim: L1 latent reconstruction through G1 (edgegan.py:275,337-342)
       set_want_grad(c, G_E, true);
       T zin = make_zin(c);
-      // (the head as three launches: the BatchNorm statistics of this forward-only evaluation must be the bits of sub-step 7's
-      //  differentiated one -- the concurrent schedule applies both sub-steps' moving-average updates from sub-step 7's)
-      T edge = generator_forward(c, G_G1, zin, bn1, nullptr, nullptr, /*fused_head=*/false);
+      T edge = generator_forward(c, G_G1, zin, bn1);
       if (opts && opts->record_after_g1_fwd) EG_HIP(hipEventRecord(opts->record_after_g1_fwd, c.stream));
       T zr = encoder_forward(c, edge, c.d_eps);
       seed_grad(c, zr);

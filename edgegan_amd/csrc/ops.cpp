@@ -1499,24 +1499,6 @@ T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int upda
   return out;
 }
 
-// generator.py:44-53 for a forward-only graph: linear -> [B, h, w, C] -> BatchNorm (batch statistics) -> ReLU in one launch
-// (k_norm.hip: gen_head_kernel); null where the shape has no such form or something in the chain needs a gradient
-T gen_head(Ctx& c, T zin, Param* wlin, Param* blin, Param* gamma, Param* beta, Param* mm, Param* mv, int h, int w, int C, int update_times,
-           T* stats_out) {
-  static const bool on = dbg_env("EG_NO_GEN_HEAD") == nullptr;
-  const int B = zin->n, K = zin->c, Pn = h * w;
-  if (!on || zin->needs_grad || wlin->want_grad || blin->want_grad || gamma->want_grad || beta->want_grad) return nullptr;
-  if (!gen_head_eligible(B, K, Pn, C) || wlin->numel != (size_t)K * Pn * C) return nullptr;
-  if ((c.cfg.bf16 || c.cfg.x3) && K % 32 == 0) return nullptr;   // (the linear would then run on rounded / limb operands: keep that path)
-  T out = new_tensor(c, B, h, w, C, false);
-  T st = new_tensor(c, 1, 1, 1, 2 * C, false);
-  unsigned short* plane = C % 32 == 0 ? producer_plane(c, out, false) : nullptr;
-  launch_gen_head(zin->d, wlin->w, blin->w, gamma->w, beta->w, out->d, plane, st->d, B, K, Pn, C, 1e-5f, c.stream);
-  if (stats_out) *stats_out = st;
-  if (update_times > 0) launch_bn_moving_update(mm->w, mv->w, st->d, C, B * Pn, 0.9f, update_times, c.stream);
-  return out;
-}
-
 T add(Ctx& c, T a, T b, bool relu) {
   T out = new_tensor(c, a->n, a->h, a->w, a->c, a->needs_grad || b->needs_grad);
   launch_add(a->d, b->d, out->d, relu ? 1 : 0, a->numel(), c.stream);
