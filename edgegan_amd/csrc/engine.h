@@ -176,7 +176,8 @@ struct Ctx {
     hipStream_t leaf = nullptr;
     hipEvent_t leaf_in = nullptr, leaf_out = nullptr;
   };
-  static constexpr int kLanes = 4;
+  static constexpr int kTrainLanes = 4;   // the lanes train_step schedules on: created in build_context, in the order the hardware-queue placement assumes
+  static constexpr int kLanes = 8;        // + the extra inference slots' lanes (main stream, arena, scratch; no leaf stream), created at first use
   Lane lanes[kLanes];
   int cur_lane = 0;
   bool lanes_on = true;
@@ -192,7 +193,7 @@ struct Ctx {
   // Consecutive eg_infer_run calls on a resident batch are independent of one another: they rotate over kInferSlots slots
   // (own lanes = streams + arenas, own output buffers), so several calls are in flight at once and their small launches
   // (4x4 .. 64x64 maps: most fill a fraction of the chip) share the device (model.cpp: infer, capi.cpp: eg_infer_run)
-  static constexpr int kInferSlots = 4;
+  static constexpr int kInferSlots = 8;
   float *inf_in = nullptr, *inf_eps = nullptr;
   float *inf_edge[kInferSlots] = {}, *inf_image[kInferSlots] = {};
   int* inf_cls = nullptr;
@@ -200,12 +201,24 @@ struct Ctx {
   int inf_nb = 0;       // images currently resident (eg_infer_upload)
   long long inf_runs = 0;   // eg_infer_run calls since the context was created (slot = inf_runs mod the slots in use)
   int inf_last_slot = 0;    // slot of the latest run: what eg_infer_download returns
-  int inf_slots = 4;        // calls in flight x lanes per call: 4 = four single-chain calls, 2 = two calls of two lanes each, 1 = one call of two lanes (EG_INFER_SLOTS)
+  int inf_slots = 4;        // calls in flight x lanes per call: 8 / 4 = eight / four single-chain calls, 2 = two calls of two lanes each, 1 = one call of two lanes (EG_INFER_SLOTS)
   hipEvent_t ev_infer[kLanes] = {};   // fork event of the call whose main lane is i
   bool inf_inflight = false;   // eg_infer_run calls may still be running on lanes other than 0: every OTHER entry point drains them first (api_enter)
   bool inf_entering = false;   // ... set by eg_infer_run around its own api_enter
   bool inf_warm = false;       // the weights' lazily built derived copies (transposes, bf16 planes) are all in place: set by the first
                                // completed run, cleared whenever a variable changes -- until then a run is followed by a device sync
+
+  // One training iteration as a HIP graph (model.cpp: train_step_graphed; EG_GRAPH=1, or automatically at small batch where the
+  // iteration is bound by the host's ~1,050 kernel launches): captured from the lanes' streams once the launch sequence is
+  // stable, replayed with one hipGraphLaunch per iteration; any entry point that changes the schedule drops it (api_enter)
+  int graph_mode = -1;          // -1 auto (by batch size), 0 off, 1 on
+  hipGraphExec_t graph_exec = nullptr;
+  bool graph_valid = false;
+  int graph_warm = 0;           // plain iterations run since the schedule last changed
+  bool graph_keep = false;      // set by the entry points that leave the captured schedule intact, around their api_enter
+  long long graph_launches = 0;
+  bool capturing = false;       // inside the stream capture of train_step_graphed
+  long long capture_epoch = 0;  // counts captures (LimbCache::built_epoch)
 
   // profiling
   bool prof_on = false;
@@ -366,6 +379,7 @@ struct SubOpts {
 };
 void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts = nullptr);
 void train_step(Ctx& c);
+void train_step_graphed(Ctx& c);   // train_step, replayed from a captured HIP graph where that is enabled and possible
 struct EvalResult {   // device pointers valid until the next enqueueing call
   const float *edge = nullptr, *image = nullptr, *resized[4] = {nullptr, nullptr, nullptr, nullptr};
 };
