@@ -96,7 +96,7 @@ EXPORTS = ['eg_default_config', 'eg_variable_count', 'eg_variable_info', 'eg_cre
            'eg_last_error', 'eg_set_variable', 'eg_get_variable', 'eg_upload_batch', 'eg_substep',
            'eg_train_step', 'eg_train_batch', 'eg_losses_wait', 'eg_read_losses', 'eg_eval_losses', 'eg_infer', 'eg_infer_upload', 'eg_infer_run', 'eg_infer_download', 'eg_sync', 'eg_comm_unique_id', 'eg_comm_init',
            'eg_comm_reduce_scalars', 'eg_comm_info', 'eg_comm_timing', 'eg_comm_timing_read',
-           'eg_profile_begin', 'eg_profile_end', 'eg_profile_layers', 'eg_memory_stats', 'eg_graph_info', 'eg_mfma_probe', 'eg_test_op', 'eg_net_forward', 'eg_crc32c']
+           'eg_profile_begin', 'eg_profile_end', 'eg_profile_layers', 'eg_memory_stats', 'eg_mfma_probe', 'eg_test_op', 'eg_net_forward', 'eg_crc32c']
 
 _lib = None
 
@@ -142,7 +142,6 @@ def load_library() -> C.CDLL:
     lib.eg_profile_end.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.eg_profile_layers.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
     lib.eg_memory_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
-    lib.eg_graph_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     lib.eg_mfma_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.eg_test_op.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(fp), C.POINTER(C.c_longlong), C.c_int, ip,
                                C.c_int, C.POINTER(fp), C.POINTER(C.c_longlong)]

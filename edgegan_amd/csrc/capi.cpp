@@ -49,9 +49,6 @@ static Config to_config(const eg_config* k) {
 // entry points that enqueue work: always start on lane 0 (the context's own stream; train_step ends there too, and
 // an error in the middle of a concurrent iteration may have left another lane active)
 #define EG_API_BEGIN_CTX(ctxp) try { api_enter((ctxp)->c);
-// ... and the ones among them that leave a captured iteration's schedule intact (engine.h: Ctx::graph_keep): the iteration
-// itself, its feed, read-backs and synchronisation
-#define EG_API_BEGIN_CTX_KEEP(ctxp) try { (ctxp)->c.graph_keep = true; api_enter((ctxp)->c);
 #define EG_API_END(ctxp)                                  \
   }                                                       \
   catch (const eg::Error& e) {                            \
@@ -184,7 +181,7 @@ int eg_set_variable(eg_ctx* ctx, const char* name, const float* host, long long 
 }
 
 int eg_get_variable(eg_ctx* ctx, const char* name, float* host, long long numel) {
-  EG_API_BEGIN_CTX_KEEP(ctx)
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   size_t n;
   float* d = resolve_var(ctx->c, name, &n, false);
@@ -195,7 +192,7 @@ int eg_get_variable(eg_ctx* ctx, const char* name, float* host, long long numel)
 }
 
 int eg_upload_batch(eg_ctx* ctx, const float* images, const float* z, const float* alpha, const float* eps) {
-  EG_API_BEGIN_CTX_KEEP(ctx)
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   Ctx& c = ctx->c;
   const Config& cfg = c.cfg;
@@ -219,9 +216,9 @@ int eg_substep(eg_ctx* ctx, int k, int apply) {
 }
 
 int eg_train_step(eg_ctx* ctx) {
-  EG_API_BEGIN_CTX_KEEP(ctx)
+  EG_API_BEGIN_CTX(ctx)
   ctx->c.inf_warm = false;
-  train_step_graphed(ctx->c);
+  train_step(ctx->c);
   EG_API_END(ctx)
 }
 
@@ -231,7 +228,7 @@ int eg_train_step(eg_ctx* ctx) {
 // iteration's losses are copied to a pinned slot behind it.  eg_losses_wait(back) blocks only until THAT iteration has
 // finished, so a loop that reads iteration k-1's losses after enqueueing iteration k never lets the GPU run dry.
 int eg_train_batch(eg_ctx* ctx, const float* images, const float* z, const float* alpha, const float* eps) {
-  EG_API_BEGIN_CTX_KEEP(ctx)
+  EG_API_BEGIN_CTX(ctx)
   Ctx& c = ctx->c;
   c.inf_warm = false;
   const Config& cfg = c.cfg;
@@ -273,7 +270,7 @@ int eg_train_batch(eg_ctx* ctx, const float* images, const float* z, const float
   EG_HIP(hipMemcpyAsync(c.d_eps, h + n_img + n_z + n_a, 4, hipMemcpyHostToDevice, c.stream));
   EG_HIP(hipEventRecord(c.feed_copied[slot], c.stream));
   c.gen_cache_valid[0] = c.gen_cache_valid[1] = false;
-  train_step_graphed(c);
+  train_step(c);
   use_lane(c, 0);
   EG_HIP(hipMemcpyAsync(c.loss_host[slot], c.d_losses, L_COUNT * 4, hipMemcpyDeviceToHost, c.stream));
   EG_HIP(hipEventRecord(c.loss_ready[slot], c.stream));
@@ -293,7 +290,7 @@ int eg_losses_wait(eg_ctx* ctx, int back, float* out12) {
 }
 
 int eg_read_losses(eg_ctx* ctx, float* out12) {
-  EG_API_BEGIN_CTX_KEEP(ctx)
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   EG_HIP(hipMemcpyAsync(out12, ctx->c.d_losses, L_COUNT * 4, hipMemcpyDeviceToHost, ctx->c.stream));
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
@@ -420,7 +417,7 @@ int eg_infer(eg_ctx* ctx, const float* images, const int* classes, int nb, const
 }
 
 int eg_sync(eg_ctx* ctx) {
-  EG_API_BEGIN_CTX_KEEP(ctx)
+  EG_API_BEGIN_CTX(ctx)
   comm_wait_all(ctx->c);
   EG_HIP(hipStreamSynchronize(ctx->c.stream));
   EG_HIP(hipDeviceSynchronize());   // every lane, leaf and exchange stream of this device: the host-side "everything is done"
@@ -564,14 +561,6 @@ int eg_mfma_probe(eg_ctx* ctx, int iters, int random_operands, double* tflops) {
   (void)hipEventDestroy(e1);
   EG_HIP(hipFree(scratch));
   *tflops = 2.0 * 32 * 32 * 16 * 16.0 * iters * 8 * cus / (ms * 1e9);
-  EG_API_END(ctx)
-}
-
-int eg_graph_info(eg_ctx* ctx, int* mode, long long* launches) {
-  EG_API_BEGIN
-  EG_CHECK(ctx && mode && launches, "null argument");
-  *mode = ctx->c.graph_mode;
-  *launches = ctx->c.graph_launches;
   EG_API_END(ctx)
 }
 

@@ -191,7 +191,6 @@ struct LimbCache {
   hipEvent_t ready = nullptr;
   hipStream_t built_on = nullptr;
   unsigned waited = 0;   // bit per stream (ops.cpp: stream_bit) that has already ordered itself behind `ready`
-  long long built_epoch = -1;   // Ctx::capture_epoch when `ready` was recorded (a captured iteration must not wait for an event of an earlier, un-captured one)
   // what the planes are built from (set at the first build): the batched rebuild (ops.cpp: limb_planes) refreshes every
   // stale cache of the same domain (network group / the spectral-norm weights) in one launch
   const float* src = nullptr;

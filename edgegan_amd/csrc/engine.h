@@ -208,18 +208,6 @@ struct Ctx {
   bool inf_warm = false;       // the weights' lazily built derived copies (transposes, bf16 planes) are all in place: set by the first
                                // completed run, cleared whenever a variable changes -- until then a run is followed by a device sync
 
-  // One training iteration as a HIP graph (model.cpp: train_step_graphed; EG_GRAPH=1, or automatically at small batch where the
-  // iteration is bound by the host's ~1,050 kernel launches): captured from the lanes' streams once the launch sequence is
-  // stable, replayed with one hipGraphLaunch per iteration; any entry point that changes the schedule drops it (api_enter)
-  int graph_mode = -1;          // -1 auto (by batch size), 0 off, 1 on
-  hipGraphExec_t graph_exec = nullptr;
-  bool graph_valid = false;
-  int graph_warm = 0;           // plain iterations run since the schedule last changed
-  bool graph_keep = false;      // set by the entry points that leave the captured schedule intact, around their api_enter
-  long long graph_launches = 0;
-  bool capturing = false;       // inside the stream capture of train_step_graphed
-  long long capture_epoch = 0;  // counts captures (LimbCache::built_epoch)
-
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -379,7 +367,6 @@ struct SubOpts {
 };
 void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts = nullptr);
 void train_step(Ctx& c);
-void train_step_graphed(Ctx& c);   // train_step, replayed from a captured HIP graph where that is enabled and possible
 struct EvalResult {   // device pointers valid until the next enqueueing call
   const float *edge = nullptr, *image = nullptr, *resized[4] = {nullptr, nullptr, nullptr, nullptr};
 };

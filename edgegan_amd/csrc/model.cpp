@@ -361,13 +361,6 @@ void use_lane(Ctx& c, int lane) {
 void api_enter(Ctx& c) {
   const bool from_infer_run = c.inf_entering;
   c.inf_entering = false;
-  // a captured iteration (train_step_graphed) replays a fixed launch sequence on fixed addresses: whatever may change either --
-  // a variable written, another graph evaluated on the lanes' arenas, derived copies built or dropped -- drops it
-  if (!c.graph_keep) {
-    c.graph_valid = false;
-    c.graph_warm = 0;
-  }
-  c.graph_keep = false;
   if (c.inf_inflight && !from_infer_run) {   // inference calls in flight on other lanes (capi.cpp: eg_infer_run): drain them
     (void)hipDeviceSynchronize();
     c.inf_inflight = false;
@@ -1022,8 +1015,8 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
   const int bn2 = (opts && opts->bn_times_g2 >= 0) ? opts->bn_times_g2 : bn_t;
   auto await_group = [&](int g) {   // see SubOpts::wait_for_group
     if (!(opts && opts->wait_for_group)) return;
-    // (a lane does not wait for its OWN event -- stream order already is that dependency, and a stream capture, model.cpp:
-    //  train_step_graphed, does not survive a stream waiting for an event recorded on itself: hipStreamEndCapture crashes)
+    // (a lane does not wait for its OWN event: stream order already is that dependency -- and a stream capture of the iteration
+    //  does not survive one: hipStreamEndCapture crashes, docs/experiments.md "the iteration as a HIP graph")
     if (opts->wait_for_group[g] && opts->wait_for_group[g] != c.lanes[c.cur_lane].done)
       EG_HIP(hipStreamWaitEvent(c.stream, opts->wait_for_group[g], 0));
     comm_wait_groups(c, 1u << g);
@@ -1307,117 +1300,6 @@ void train_step(Ctx& c) {
   EG_HIP(hipEventRecord(c.lanes[l6].done, c.lanes[l6].stream));
   EG_HIP(hipStreamWaitEvent(c.lanes[0].stream, c.lanes[l6].done, 0));
   ++c.step_count;
-}
-
-// The iteration as a HIP graph.  train_step is ~1,050 kernel launches plus ~300 event operations on nine streams: 5.3 ms of host
-// time, which bounds the iteration at small batch (configs[0], batch 4: the GPU needs less than that) and is one CPU core per
-// rank under data parallelism.  After the first iterations the sequence is replay-stable by construction (DESIGN.md section 2:
-// bump arenas reset per sub-step, no allocation on the path, every derived copy rebuilt at the same place of every iteration),
-// so it is captured ONCE -- stream capture on lane 0; the other lanes and the leaf streams join the capture through the fork
-// events they wait for and are joined back before the iteration ends -- and replayed with one hipGraphLaunch.  The graph's nodes
-// are the same kernels with the same arguments in the same dependency order: bitwise the results of train_step.  Not under data
-// parallelism (the exchange stays outside any capture), not while profiling; a capture that fails disables the mechanism, drops
-// every derived copy the abandoned pass claimed to have built and runs the iteration plainly.
-void train_step_graphed(Ctx& c) {
-  if (c.graph_mode < 0) {
-    const char* e = getenv("EG_GRAPH");
-    c.graph_mode = e ? (atoi(e) != 0 ? 1 : 0) : (c.cfg.B * c.cfg.H * c.cfg.W <= 16 * 64 * 128 ? 1 : 0);
-  }
-  if (c.graph_mode != 1 || c.nccl_comm || c.prof_on) {
-    train_step(c);
-    return;
-  }
-  if (c.graph_valid && c.graph_exec) {
-    use_lane(c, 0);
-    EG_HIP(hipGraphLaunch(c.graph_exec, c.lanes[0].stream));
-    ++c.step_count;
-    ++c.graph_launches;
-    return;
-  }
-  if (c.graph_warm < 2) {   // (arenas grown, lazily created events and function attributes in place, caches in their steady rhythm)
-    train_step(c);
-    ++c.graph_warm;
-    return;
-  }
-  if (c.graph_exec) {
-    (void)hipGraphExecDestroy(c.graph_exec);
-    c.graph_exec = nullptr;
-  }
-  use_lane(c, 0);
-  hipStream_t s0 = c.lanes[0].stream;
-  auto abandon = [&]() {   // nothing of the captured pass ran on the device: forget what the host believes it built
-    (void)hipGetLastError();
-    c.graph_mode = 0;
-    for (auto& p : c.params) p->invalidate_derived();
-    for (auto& sw : c.sn) {
-      sw.wT_valid = false;
-      sw.wL[0].valid = sw.wL[1].valid = false;
-      for (int i = 0; i < 2; ++i) {
-        sw.partT_valid[i] = false;
-        sw.partL[i][0].valid = sw.partL[i][1].valid = false;
-      }
-    }
-    c.sn_valid = false;
-    c.gen_cache_valid[0] = c.gen_cache_valid[1] = false;
-  };
-  const bool dbg = getenv("EG_GRAPH_DEBUG") != nullptr;
-  // everything enqueued so far is finished before the capture starts: the captured iteration -- and every replay, which lane 0
-  // orders behind the previous one -- may then take all earlier work for granted (ops.cpp: limb_planes)
-  EG_HIP(hipDeviceSynchronize());
-  if (hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed) != hipSuccess) {
-    abandon();
-    train_step(c);
-    return;
-  }
-  if (dbg) fprintf(stderr, "[graph] capture begun\n");
-  const long long steps_before = c.step_count;
-  hipGraph_t g = nullptr;
-  c.capturing = true;
-  ++c.capture_epoch;
-  try {
-    train_step(c);
-    if (dbg) fprintf(stderr, "[graph] iteration recorded\n");
-    // every stream the capture pulled in must be joined back into lane 0 before it ends (a lane that was forked but got no
-    // work -- lane 3 without a classifier -- is not joined by train_step itself)
-    use_lane(c, 0);
-    for (int i = 0; i < Ctx::kTrainLanes; ++i)
-      for (hipStream_t st : {i > 0 ? c.lanes[i].stream : (hipStream_t) nullptr, c.lanes[i].leaf}) {
-        if (!st) continue;
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        EG_HIP(hipStreamIsCapturing(st, &cs));
-        if (cs != hipStreamCaptureStatusActive) continue;
-        EG_HIP(hipEventRecord(c.lanes[i].leaf_out, st));
-        EG_HIP(hipStreamWaitEvent(s0, c.lanes[i].leaf_out, 0));
-        if (dbg) fprintf(stderr, "[graph] joined lane %d %s stream\n", i, st == c.lanes[i].leaf ? "leaf" : "main");
-      }
-  } catch (...) {
-    c.capturing = false;
-    (void)hipStreamEndCapture(s0, &g);
-    if (g) (void)hipGraphDestroy(g);
-    abandon();
-    throw;
-  }
-  c.capturing = false;
-  use_lane(c, 0);
-  hipError_t e = hipStreamEndCapture(s0, &g);
-  if (dbg) {
-    size_t nn = 0;
-    if (g) (void)hipGraphGetNodes(g, nullptr, &nn);
-    fprintf(stderr, "[graph] end capture: %d (%s), %zu nodes\n", (int)e, hipGetErrorString(e), nn);
-  }
-  if (e == hipSuccess && g) e = hipGraphInstantiate(&c.graph_exec, g, nullptr, nullptr, 0);
-  if (dbg) fprintf(stderr, "[graph] instantiate: %d (%s)\n", (int)e, hipGetErrorString(e));
-  if (g) (void)hipGraphDestroy(g);
-  if (e != hipSuccess || !c.graph_exec) {
-    c.graph_exec = nullptr;
-    c.step_count = steps_before;
-    abandon();
-    train_step(c);
-    return;
-  }
-  c.graph_valid = true;
-  EG_HIP(hipGraphLaunch(c.graph_exec, s0));   // (the captured pass itself: capture records, it does not run)
-  ++c.graph_launches;
 }
 
 // Forward-only evaluation of every loss with the CURRENT weights -- what the reference's observe-only runs compute

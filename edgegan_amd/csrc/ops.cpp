@@ -469,18 +469,11 @@ static unsigned short* limb_planes(Ctx& c, WRef* w, bool transposed, int nplanes
         if (b.count == kSplitMax) flush();
       }
       flush();
-      for (LimbCache* q : built) {
-        EG_HIP(hipEventRecord(q->ready, c.stream));
-        q->built_epoch = c.capturing ? c.capture_epoch : -1;
-      }
+      for (LimbCache* q : built) EG_HIP(hipEventRecord(q->ready, c.stream));
     } else if (lc->built_on != c.stream && !(lc->waited & stream_bit(c))) {
-      // built on another stream: this stream's reads go behind the build (later reads on it follow in stream order).  Inside a
-      // captured iteration a build of an EARLIER iteration is not waited for: a captured stream may not depend on un-captured
-      // work, and it need not -- the graph is launched behind everything the context enqueued before (model.cpp)
-      if (!c.capturing || lc->built_epoch == c.capture_epoch) {
-        EG_HIP(hipStreamWaitEvent(c.stream, lc->ready, 0));
-        lc->waited |= stream_bit(c);
-      }
+      // built on another stream: this stream's reads go behind the build (later reads on it follow in stream order)
+      EG_HIP(hipStreamWaitEvent(c.stream, lc->ready, 0));
+      lc->waited |= stream_bit(c);
     }
     return lc->buf;
   }
@@ -2050,7 +2043,6 @@ Ctx::~Ctx() {
   }
   for (auto e : ev_infer)
     if (e) (void)hipEventDestroy(e);
-  if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
   (void)hipFree(inf_eps);
   (void)hipFree(inf_cls);
   groups[G_G2].g = nullptr;   // lives inside G1's allocation (model.cpp: build_context)

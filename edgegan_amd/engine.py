@@ -311,12 +311,6 @@ class EdgeGAN:
         self._check(self._lib.eg_memory_stats(self._ctx, C.byref(a), C.byref(b)))
         return {'arena_peak_bytes': a.value, 'arena_reserved_bytes': b.value}
 
-    def graph_info(self) -> dict:
-        """Whether train_step replays a captured HIP graph (include/edgegan_hip.h: eg_graph_info) and how often it has."""
-        m, n = C.c_int(), C.c_longlong()
-        self._check(self._lib.eg_graph_info(self._ctx, C.byref(m), C.byref(n)))
-        return {'mode': m.value, 'graph_launches': n.value}
-
     def mfma_probe(self, iters: int = 20000, random_operands: bool = True) -> float:
         """TFLOP/s of a memory-free bf16 MFMA loop on this device (include/edgegan_hip.h: eg_mfma_probe)."""
         t = C.c_double()

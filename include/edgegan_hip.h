@@ -176,12 +176,6 @@ int eg_profile_end(eg_ctx* ctx, char* buf, int cap);
  * the per-layer roofline table of profiles/ (tools/layer_table.py) */
 int eg_profile_layers(eg_ctx* ctx, char* buf, long long cap);
 int eg_memory_stats(eg_ctx* ctx, long long* arena_peak_bytes, long long* arena_reserved_bytes);
-/* eg_train_step / eg_train_batch replay the iteration from a captured HIP graph (one hipGraphLaunch instead of ~1,050 kernel
- * launches and ~300 event operations of host work) when EG_GRAPH=1, or by default when the batch is small enough for the host to
- * be the bound (batch x height x width <= 16 x 64 x 128); never under data parallelism or while profiling.  mode: 1 on, 0 off
- * (or abandoned after a failed capture), -1 not decided yet; launches: iterations replayed from the graph so far (no reference
- * counterpart: the reference's sess.run is TensorFlow's own executor) */
-int eg_graph_info(eg_ctx* ctx, int* mode, long long* launches);
 /* TFLOP/s the matrix pipe of this device sustains on a memory-free v_mfma_f32_32x32x16_bf16 loop (one 8-wave block per
  * CU, iters x 16 MFMAs per wave), with constant (random_operands = 0) or pseudo-random bf16 operands: the data toggling
  * sets the pipe's power and with it its clock.  bench.py prints both next to roofline.peak (no reference counterpart). */
