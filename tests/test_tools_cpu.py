@@ -143,3 +143,36 @@ def test_trace_overlap_on_a_synthetic_trace(tmp_path, capsys):
     assert 'block-slot fill' in out and '68.' in out                # 150 ns full + 20 ns x 16 / (256 x 8 x 4) of 220
     a = [l for l in out.splitlines() if l.startswith('A ')][0].split()
     assert abs(float(a[-1]) - 1.25) < 1e-6                          # A: 100 concurrent vs 80 serialised
+
+
+def test_bench_roofline_object_and_side_leg_reduction(tmp_path, monkeypatch):
+    """bench.py's pure host logic (no GPU): the `roofline` object built from the engine's per-kernel event records -- dominant
+    kernel = the bucket with the most time, limb kernels priced at 6 executed bf16 MFMA flops per fp32 flop against the dense bf16
+    peak -- and a side leg's reduction of a child run's JSON line (a failing child must never hide the headline)."""
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ks = [{'name': 'conv_gemm_x3h<256,128>', 'launches': 90, 'ms': 19.4, 'flops': 90 * 49.6e9},
+          {'name': 'wgrad_x3r<3x3,2x64,128>', 'launches': 20, 'ms': 5.2, 'flops': 20 * 53e9},
+          {'name': 'conv_pk<c3,k3>', 'launches': 48, 'ms': 1.0, 'flops': 48 * 0.23e9}]
+    r = bench.roofline_of(ks, profile_steps=2, batch=64)
+    assert r['kernel'] == 'conv_gemm_x3h<256,128>' and r['launches_per_step'] == 45 and r['peak'] == 2500.0
+    alg = 90 * 49.6e9 / 19.4e-3 / 1e12
+    assert abs(r['achieved'] - 6 * alg) < 0.01 and abs(r['frac'] - 6 * alg / 2500.0) < 1e-4
+    assert abs(r['all_gemm_kernels']['ms_per_step'] - 12.8) < 1e-9 and r['traffic'] is None
+    r2 = bench.roofline_of([{'name': 'conv_gemm<128,128,vec>', 'launches': 10, 'ms': 1.0, 'flops': 1e12}], 1, 64)
+    assert r2['peak'] == 157.3 and abs(r2['achieved'] - 1000.0) < 1e-6            # exact-fp32 MFMA kernels: algorithmic flops, fp32 peak
+    assert bench.roofline_of([], 1, 64) is None
+    # side_leg: a child that prints one contract line ...
+    child = tmp_path / 'child.py'
+    child.write_text('import json,sys\nprint("noise")\nprint(json.dumps({"value": 3400.5, "unit": "images/s", "ms_per_step": 18.8, "steps": 10, "warmup": 3,'
+                     ' "dtype": "bf16", "losses_finite": True, "config": {"per_gpu_batch": 64, "workload": "child text"},'
+                     ' "roofline": {"kernel": "conv_bf16p<128,128>", "frac": 0.2, "traffic": 6.4e7}, "metric": "not kept"}))\n')
+    monkeypatch.setattr(bench, '__file__', str(child))
+    leg = bench.side_leg(['--dtype', 'bf16'], 'workload text', deadline=1e18, live=True)
+    assert leg['value'] == 3400.5 and leg['roofline']['traffic'] == 6.4e7 and leg['config'] == {'workload': 'workload text', 'per_gpu_batch': 64}
+    assert 'metric' not in leg and leg['command'] == 'python bench.py --dtype bf16'
+    # ... and one that dies
+    child.write_text('import sys\nsys.exit(3)\n')
+    bad = bench.side_leg(['--dtype', 'bf16'], 'w', deadline=1e18, live=True)
+    assert bad['value'] is None and 'error' in bad
