@@ -836,7 +836,7 @@ def main():
                          'per_collective_what': 'issue order within an iteration; ms between the communication stream reaching the '
                                                 'all-reduce (this rank\'s gradients final) and its completion (includes the wait for the slowest '
                                                 'rank), mean of two iterations with the lanes on, max / min over the ranks',
-                         'env': {k: os.environ[k] for k in ('EG_COMM_CHANNELS', 'EG_COMM_CUS', 'EG_COMPUTE_AVOID_COMM_CUS', 'NCCL_MAX_NCHANNELS',
+                         'env': {k: os.environ[k] for k in ('EG_COMM_CHANNELS', 'EG_COMM_CUS', 'NCCL_MAX_NCHANNELS',
                                                             'NCCL_MIN_NCHANNELS', 'EG_LANES') if k in os.environ},
                          'what': 'one RCCL all-reduce (sum, fp32, in place) of the flat gradient buffer per optimised network '
                                  'group and sub-step (G1+G2 in one call), on a side stream, averaged inside RMSProp'},

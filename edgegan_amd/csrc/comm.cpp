@@ -63,15 +63,13 @@ void comm_unique_id(Ctx& c, char* out128) {
 //                       RCCL reads the process environment)
 //   EG_COMM_CUS=n       creates the communication stream with a CU mask of n compute units (a multiple of 8: n / 8 per XCD, the
 //                       highest-numbered ones; mask bit i = XCD i % 8, CU i / 8 -- the interleaved layout of multi-XCD parts), so the
-//                       exchange cannot spread beyond them;  EG_COMPUTE_AVOID_COMM_CUS=1 (model.cpp: build_context) additionally
-//                       creates the compute lanes with the complement, which fences the two off completely at the price of n CUs
+//                       exchange cannot spread beyond them.  (The complementary mask on the COMPUTE lanes was measured and removed:
+//                       a CU-masked stream costs the matrix kernels 29 % whatever its size, profiles/r06j_cu_mask_cost.txt.)
 // Both are measured knobs, not defaults: the reference is single-GPU (edgegan/train.py:77) and nothing beyond one device could
 // be measured by the builder.
-void comm_cu_mask(int ncu, bool complement, uint32_t out[8]) {
+void comm_cu_mask(int ncu, uint32_t out[8]) {
   for (int w = 0; w < 8; ++w) out[w] = 0;
   for (int i = 256 - ncu; i < 256; ++i) out[i >> 5] |= 1u << (i & 31);
-  if (complement)
-    for (int w = 0; w < 8; ++w) out[w] = ~out[w];
 }
 int comm_reserved_cus() {
   const char* e = getenv("EG_COMM_CUS");
@@ -96,7 +94,7 @@ void comm_init(Ctx& c, const char* id128, int rank, int nranks) {
   if (!c.comm_stream) {
     if (const int ncu = comm_reserved_cus()) {
       uint32_t mask[8];
-      comm_cu_mask(ncu, false, mask);
+      comm_cu_mask(ncu, mask);
       EG_HIP(hipExtStreamCreateWithCUMask(&c.comm_stream, 8, mask));
       c.comm_cus = ncu;
     } else {
@@ -224,6 +222,11 @@ void comm_destroy(Ctx& c) {
     }
     (void)hipStreamDestroy(c.comm_stream);
     c.comm_stream = nullptr;
+    if (c.apply_stream) {
+      (void)hipStreamSynchronize(c.apply_stream);
+      (void)hipStreamDestroy(c.apply_stream);
+    }
+    c.apply_stream = nullptr;
     (void)hipFree(c.comm_scal);
     c.comm_scal = nullptr;
   }

@@ -226,6 +226,7 @@ struct Ctx {
   float* comm_scal = nullptr;   // device staging of comm_reduce_scalars
   long long comm_calls = 0, comm_bytes = 0;   // gradient all-reduces enqueued / their payload (comm_info)
   int comm_cus = 0;             // EG_COMM_CUS: compute units the communication stream is confined to (0: no mask)
+  hipStream_t apply_stream = nullptr;   // ... then the optimizer behind an exchange runs here, unmasked (model.cpp: comm_apply_stream)
   bool comm_timing = false;     // eg_comm_timing: event pairs around every gradient all-reduce
   struct CommRec {
     int group = 0;
@@ -379,7 +380,7 @@ void comm_unique_id(Ctx& c, char* out128);
 void comm_init(Ctx& c, const char* id128, int rank, int nranks);
 void comm_allreduce(Ctx& c, float* buf, size_t n, hipStream_t stream, int group);
 int comm_timing_read(Ctx& c, float* ms, int* group, long long* bytes, int cap);
-void comm_cu_mask(int ncu, bool complement, uint32_t out[8]);   // EG_COMM_CUS / EG_COMPUTE_AVOID_COMM_CUS (comm.cpp)
+void comm_cu_mask(int ncu, uint32_t out[8]);   // EG_COMM_CUS (comm.cpp)
 int comm_reserved_cus();
 void comm_reduce_scalars(Ctx& c, float* inout, int n, int op);
 void use_lane(Ctx& c, int lane);                // model.cpp

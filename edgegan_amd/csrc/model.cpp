@@ -139,14 +139,10 @@ void build_context(Ctx& c) {
   EG_CHECK((!cfg.use_image_dis || (cfg.image_dis >= 16 && cfg.image_dis <= 1024)) && (!cfg.use_edge_dis || (cfg.edge_dis >= 16 && cfg.edge_dis <= 1024)),
            "image_dis_size / edge_dis_size out of range (16..1024)");
   EG_HIP(hipSetDevice(cfg.device));
-  // EG_COMPUTE_AVOID_COMM_CUS=1 with EG_COMM_CUS=n (comm.cpp): the compute lanes never use the n compute units the exchange runs on
-  uint32_t avoid[8];
-  const bool fenced = getenv("EG_COMPUTE_AVOID_COMM_CUS") && atoi(getenv("EG_COMPUTE_AVOID_COMM_CUS")) != 0 && comm_reserved_cus() > 0;
-  if (fenced) comm_cu_mask(comm_reserved_cus(), true, avoid);
-  auto new_stream = [&](hipStream_t* s) {
-    if (fenced) EG_HIP(hipExtStreamCreateWithCUMask(s, 8, avoid));
-    else EG_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-  };
+  // (the compute lanes are ordinary streams: creating them with the complement of the exchange's CU mask, EG_COMM_CUS in comm.cpp, was
+  //  measured in round 6 -- 1,744 -> 1,246 / 1,236 / 1,242 images/s for 8 / 16 / 32 excluded compute units: a CU-masked stream costs
+  //  the matrix kernels 29 % whatever the mask's size, profiles/r06j_cu_mask_cost.txt -- and removed)
+  auto new_stream = [&](hipStream_t* s) { EG_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); };
   new_stream(&c.stream);
   for (int g = 0; g < G_COUNT; ++g) c.groups[g].prefix = kGroupPrefix[g];
   for (const VarInfo& vi : enumerate_variables(cfg)) {
@@ -639,6 +635,17 @@ static T make_zin(Ctx& c) {
 // the side stream behind an event, so the exchange of sub-step k overlaps the compute of sub-step k+1 whenever
 // that one does not read this group's weights (sub-steps 1-4 touch disjoint groups and G is frozen until 5;
 // E's update overlaps sub-step 7) -- run_substep() waits for exactly the groups it reads.
+// The stream a group's averaging RMSProp runs on behind its all-reduce: the communication stream itself -- or, when that stream
+// carries a CU mask (EG_COMM_CUS), an unmasked side stream ordered behind the collective by an event: the optimizer is an
+// HBM-bound pass over up to 17 M parameters that must not be confined to the exchange's few compute units
+static hipStream_t comm_apply_stream(Ctx& c, int group) {
+  if (!c.comm_cus) return c.comm_stream;
+  if (!c.apply_stream) EG_HIP(hipStreamCreateWithFlags(&c.apply_stream, hipStreamNonBlocking));
+  EG_HIP(hipEventRecord(c.ev_ready[group], c.comm_stream));     // (ev_ready[group] has done its first job: the exchange is enqueued behind it)
+  EG_HIP(hipStreamWaitEvent(c.apply_stream, c.ev_ready[group], 0));
+  return c.apply_stream;
+}
+
 static void apply_group(Ctx& c, int group) {
   NetGroup& g = c.groups[group];
   if (group == G_G1) c.gen_cache_valid[0] = false;
@@ -650,8 +657,9 @@ static void apply_group(Ctx& c, int group) {
     EG_HIP(hipEventRecord(c.ev_ready[group], c.stream));
     EG_HIP(hipStreamWaitEvent(c.comm_stream, c.ev_ready[group], 0));
     comm_allreduce(c, g.g, g.n_live, c.comm_stream, group);
-    launch_rmsprop(g.w, g.g, g.ms, g.mom, g.n_live, c.cfg.lr, 1.f / c.nranks, c.comm_stream);
-    EG_HIP(hipEventRecord(c.ev_applied[group], c.comm_stream));
+    hipStream_t as = comm_apply_stream(c, group);   // (the optimizer does not run under the exchange's CU mask)
+    launch_rmsprop(g.w, g.g, g.ms, g.mom, g.n_live, c.cfg.lr, 1.f / c.nranks, as);
+    EG_HIP(hipEventRecord(c.ev_applied[group], as));
     c.pending[group] = true;
     return;
   }
@@ -678,10 +686,11 @@ static void apply_generators(Ctx& c) {
   EG_HIP(hipEventRecord(c.ev_ready[G_G1], c.stream));
   EG_HIP(hipStreamWaitEvent(c.comm_stream, c.ev_ready[G_G1], 0));
   comm_allreduce(c, g1.g, g1.n_train + g2.n_live, c.comm_stream, G_G1);
-  launch_rmsprop(g1.w, g1.g, g1.ms, g1.mom, g1.n_live, c.cfg.lr, 1.f / c.nranks, c.comm_stream);
-  launch_rmsprop(g2.w, g2.g, g2.ms, g2.mom, g2.n_live, c.cfg.lr, 1.f / c.nranks, c.comm_stream);
-  EG_HIP(hipEventRecord(c.ev_applied[G_G1], c.comm_stream));
-  EG_HIP(hipEventRecord(c.ev_applied[G_G2], c.comm_stream));
+  hipStream_t as = comm_apply_stream(c, G_G1);
+  launch_rmsprop(g1.w, g1.g, g1.ms, g1.mom, g1.n_live, c.cfg.lr, 1.f / c.nranks, as);
+  launch_rmsprop(g2.w, g2.g, g2.ms, g2.mom, g2.n_live, c.cfg.lr, 1.f / c.nranks, as);
+  EG_HIP(hipEventRecord(c.ev_applied[G_G1], as));
+  EG_HIP(hipEventRecord(c.ev_applied[G_G2], as));
   c.pending[G_G1] = c.pending[G_G2] = true;
 }
 

@@ -163,7 +163,7 @@ int eg_comm_info(eg_ctx* ctx, int* nranks, int* rccl_version, char* libpath, int
  * result being complete (the wait for the slowest rank is inside) -- bench.py prints the per-group mean, max over the ranks.
  * Environment (read at eg_create / eg_comm_init, documented in csrc/comm.cpp): EG_COMM_CHANNELS=n caps RCCL's channels (=
  * workgroups = compute units taken from the matrix kernels), EG_COMM_CUS=n confines the communication stream to n compute units by
- * a CU mask, EG_COMPUTE_AVOID_COMM_CUS=1 keeps the compute lanes off those; RCCL's own NCCL_* / RCCL_* variables pass through. */
+ * a CU mask; RCCL's own NCCL_* / RCCL_* variables pass through. */
 int eg_comm_timing(eg_ctx* ctx, int enable);
 int eg_comm_timing_read(eg_ctx* ctx, float* ms, int* group, long long* bytes, int cap, int* n);
 

@@ -376,6 +376,42 @@ def test_rccl_single_rank_allreduce_and_overlap_path():
     assert outs[0][1] == outs[1][1]
 
 
+def test_exchange_footprint_knobs_do_not_change_a_bit(monkeypatch):
+    """EG_COMM_CUS (the communication stream confined to n compute units by a CU mask) and EG_COMM_CHANNELS (RCCL's channel cap,
+    exported as NCCL_MAX_NCHANNELS) are placement knobs (csrc/comm.cpp): with both set, a one-rank data-parallel run on the real
+    RCCL -- masked communication stream, all-reduce + averaging RMSProp on it, per-collective timing on -- reproduces the plain run
+    bit for bit, and the seven collectives of an iteration are recorded.  (What the knobs do to an 8-device exchange cannot be
+    measured on this pool; a complementary mask on the compute lanes was measured to cost 29 % and removed.)"""
+    cfg = ea.Config(batch_size=2)
+    values = ea.init_variables(cfg, 0)
+    batch = ea.synthetic_batch(cfg)
+    ref = ea.EdgeGAN(cfg, values)
+    ref.upload_batch(**batch)
+    ref.train_step()
+    want = ref.get_variables(slots=True)
+    ref.close()
+    for k, v in (('EG_COMM_CUS', '16'), ('EG_COMM_CHANNELS', '4')):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv('NCCL_MAX_NCHANNELS', raising=False)
+    net = ea.EdgeGAN(cfg, values)
+    net.comm_init(net.comm_unique_id(), 0, 1)
+    import ctypes
+    getenv = ctypes.CDLL(None).getenv          # (the library's setenv is not visible through os.environ's snapshot)
+    getenv.restype = ctypes.c_char_p
+    assert getenv(b'NCCL_MAX_NCHANNELS') == b'4'
+    net.comm_timing(True)
+    net.upload_batch(**batch)
+    net.train_step()
+    net.sync()
+    recs = net.comm_timing_read()
+    got = net.get_variables(slots=True)
+    net.close()
+    assert len(recs) == 7 and sorted(g for g, _, _ in recs) == sorted(['D', 'D_patch2', 'D_patch3', 'D2', 'G1+G2', 'E', 'G1+G2'])
+    assert all(ms >= 0.0 and nbytes > 0 for _, nbytes, ms in recs)
+    for k in want:
+        assert np.array_equal(want[k], got[k]), k
+
+
 def test_checkpoint_round_trip_on_device(tmp_path):
     """save -> fresh engine -> load: every variable and RMSProp slot identical; resume counter from the name."""
     from edgegan_amd import checkpoint, tf_bundle
