@@ -777,7 +777,7 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
     d.t = c.arena.allocf(K);
     d.dv = c.arena.allocf(K);
     d.sv = c.arena.allocf(sn_sv_floats(Co));
-    d.scal = c.arena.allocf(80);
+    d.scal = c.arena.allocf(SN_SCAL_FLOATS);
     d.dW = c.arena.allocf((size_t)K * Co);
     d.dWbar = io.has(2) ? io.up(2) : nullptr;
     d.K = K;

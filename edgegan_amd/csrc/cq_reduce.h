@@ -88,4 +88,72 @@ __device__ __forceinline__ void cq_reduce_minmax(float4& mn, float4& mx, float4*
                    fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)), fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w)));
 }
 
+// the same two reductions for blocks of NW waves (red: [NV][NW][CQ] / [2][NW][CQ]); NW = 4 is the form above, other block
+// sizes sum the waves' partials in wave order (fixed)
+template <int NV, int CQ, int NW>
+__device__ __forceinline__ void cq_reduce_w(float4 (&v)[NV], float4* red) {
+  if constexpr (NW == 4) {
+    cq_reduce<NV, CQ>(v, red);
+  } else {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+#pragma unroll
+      for (int o = CQ; o < 64; o <<= 1) {
+        v[k].x += __shfl_xor(v[k].x, o, 64);
+        v[k].y += __shfl_xor(v[k].y, o, 64);
+        v[k].z += __shfl_xor(v[k].z, o, 64);
+        v[k].w += __shfl_xor(v[k].w, o, 64);
+      }
+    }
+    __syncthreads();
+    if (lane < CQ) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) red[(k * NW + wave) * CQ + lane] = v[k];
+    }
+    __syncthreads();
+    const int cq = threadIdx.x % CQ;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float4 t = red[(k * NW) * CQ + cq];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const float4 a = red[(k * NW + w) * CQ + cq];
+        t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+      }
+      v[k] = t;
+    }
+  }
+}
+template <int CQ, int NW>
+__device__ __forceinline__ void cq_reduce_minmax_w(float4& mn, float4& mx, float4* red) {
+  if constexpr (NW == 4) {
+    cq_reduce_minmax<CQ>(mn, mx, red);
+  } else {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = CQ; o < 64; o <<= 1) {
+      mn.x = fminf(mn.x, __shfl_xor(mn.x, o, 64)); mn.y = fminf(mn.y, __shfl_xor(mn.y, o, 64));
+      mn.z = fminf(mn.z, __shfl_xor(mn.z, o, 64)); mn.w = fminf(mn.w, __shfl_xor(mn.w, o, 64));
+      mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o, 64));
+      mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o, 64));
+    }
+    __syncthreads();
+    if (lane < CQ) {
+      red[wave * CQ + lane] = mn;
+      red[(NW + wave) * CQ + lane] = mx;
+    }
+    __syncthreads();
+    const int cq = threadIdx.x % CQ;
+    mn = red[cq];
+    mx = red[NW * CQ + cq];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const float4 a = red[w * CQ + cq], b = red[(NW + w) * CQ + cq];
+      mn = make_float4(fminf(mn.x, a.x), fminf(mn.y, a.y), fminf(mn.z, a.z), fminf(mn.w, a.w));
+      mx = make_float4(fmaxf(mx.x, b.x), fmaxf(mx.y, b.y), fmaxf(mx.z, b.z), fmaxf(mx.w, b.w));
+    }
+  }
+}
+
 }  // namespace eg

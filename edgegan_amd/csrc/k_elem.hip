@@ -540,13 +540,74 @@ __global__ void resize3_kernel(const float* __restrict__ x, float* __restrict__ 
     o[2] = s2;
   }
 }
+// the same sums with the column taps in registers and no branch in the tap loops (round 6): the table loads of a pixel are
+// tyn + TN index / weight pairs instead of tyn (1 + txn), and the 3 TN pixel loads of a row are issued back to back (the looped
+// form above branched on every zero weight: one dependent load chain per tap, 29 us for 1 M output pixels).  A tap of weight 0
+// (table padding; its index is a valid pixel) contributes nothing through a select, in the order of the looped form: same bits.
+template <int TN>
+__global__ __launch_bounds__(256) void resize3_taps_kernel(const float* __restrict__ x, float* __restrict__ y, int acc, int IH, int IW,
+                                                           int OH, int OW, const int* __restrict__ ty_i, const float* __restrict__ ty_w,
+                                                           int tyn, const int* __restrict__ tx_i, const float* __restrict__ tx_w, int txn,
+                                                           size_t npix) {
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < npix; i += gridDim.x * 256u) {
+    const int ox = (int)(i % (unsigned)OW);
+    unsigned t = i / (unsigned)OW;
+    const int oy = (int)(t % (unsigned)OH);
+    const size_t nb = t / (unsigned)OH;
+    float wx[TN];
+    int ix[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const bool vb = b < txn;
+      wx[b] = vb ? tx_w[ox * txn + b] : 0.f;
+      ix[b] = vb ? tx_i[ox * txn + b] * 3 : 0;
+    }
+    const float* img = x + nb * IH * IW * 3;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int a = 0; a < tyn; ++a) {
+      const float wy = ty_w[oy * tyn + a];
+      if (wy == 0.f) continue;   // (a wave's pixels share their row: uniform in practice)
+      const float* row = img + (size_t)ty_i[oy * tyn + a] * IW * 3;
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const float* px = row + ix[b];
+        const float p0 = px[0], p1 = px[1], p2 = px[2];
+        const bool on = wx[b] != 0.f;
+        r0 = on ? r0 + wx[b] * p0 : r0;
+        r1 = on ? r1 + wx[b] * p1 : r1;
+        r2 = on ? r2 + wx[b] * p2 : r2;
+      }
+      s0 += wy * r0;
+      s1 += wy * r1;
+      s2 += wy * r2;
+    }
+    float* o = y + (size_t)i * 3;
+    if (acc) {
+      s0 += o[0];
+      s1 += o[1];
+      s2 += o[2];
+    }
+    o[0] = s0;
+    o[1] = s1;
+    o[2] = s2;
+  }
+}
 void launch_resize(const float* x, float* y, int accumulate, int NB, int IH, int IW, int OH, int OW, int C,
                    const int* ty_i, const float* ty_w, int tyn, const int* tx_i, const float* tx_w, int txn,
                    hipStream_t s) {
   if (C == 3 && (size_t)NB * OH * OW < (1ull << 31)) {
     const size_t npix = (size_t)NB * OH * OW;
-    hipLaunchKernelGGL(resize3_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, y, accumulate, IH, IW, OH, OW, ty_i,
-                       ty_w, tyn, tx_i, tx_w, txn, npix);
+#define EG_RESIZE3(TN)                                                                                                        \
+  hipLaunchKernelGGL(resize3_taps_kernel<TN>, dim3(ew_blocks(npix)), dim3(256), 0, s, x, y, accumulate, IH, IW, OH, OW, ty_i, ty_w, \
+                     tyn, tx_i, tx_w, txn, npix)
+    if (txn <= 4) EG_RESIZE3(4);
+    else if (txn <= 8) EG_RESIZE3(8);
+    else if (txn <= 12) EG_RESIZE3(12);
+    else
+      hipLaunchKernelGGL(resize3_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, y, accumulate, IH, IW, OH, OW, ty_i,
+                         ty_w, tyn, tx_i, tx_w, txn, npix);
+#undef EG_RESIZE3
     return;
   }
   const size_t n = (size_t)NB * OH * OW * C;
@@ -777,12 +838,14 @@ __global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* __restrict
 // xs.n > 1: x is still the K-split slabs of the gate's hidden-state convolution (+ the image-row convolution's output as
 // the base): the first pass sums them and stores the sum to xsum, which the second pass (the same thread re-reads its own
 // stores) and the backward read
-template <int CQ>
+// NW waves per block: 4 where the channel groups alone fill the chip (CQ = 8), 16 for the 8-channel gate of the classifier's
+// first unit (64 blocks of 4,096 pixels: at 256 threads each thread walked 32 dependent iterations per pass -- 23 / 45 us)
+template <int CQ, int NW>
 // (xsum carries no __restrict__: with the FEED_MINMAX hand-over it IS SlabSrc::base, the tensor the slabs are added to)
-__global__ __launch_bounds__(256) void minmax_fwd_v(const SlabSrc xs, float* xsum, float* __restrict__ y,
-                                                    float* __restrict__ mm, int HW, int C, float lk) {
-  constexpr int PL = 256 / CQ;
-  __shared__ float4 red[2 * 4 * CQ];
+__global__ __launch_bounds__(64 * NW) void minmax_fwd_v(const SlabSrc xs, float* xsum, float* __restrict__ y,
+                                                        float* __restrict__ mm, int HW, int C, float lk) {
+  constexpr int PL = 64 * NW / CQ;
+  __shared__ float4 red[2 * NW * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
   const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
   const size_t base = (size_t)n * HW * C + c;
@@ -800,7 +863,7 @@ __global__ __launch_bounds__(256) void minmax_fwd_v(const SlabSrc xs, float* xsu
     mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
     mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
   }
-  cq_reduce_minmax<CQ>(mn, mx, red);
+  cq_reduce_minmax_w<CQ, NW>(mn, mx, red);
   const float4 inv = make_float4(1.f / (mx.x - mn.x), 1.f / (mx.y - mn.y), 1.f / (mx.z - mn.z), 1.f / (mx.w - mn.w));
   for (int p = pl; p < HW; p += PL) {
     const size_t i = base + (size_t)p * C;
@@ -813,13 +876,13 @@ __global__ __launch_bounds__(256) void minmax_fwd_v(const SlabSrc xs, float* xsu
   }
 }
 
-template <int CQ>
-__global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x, const float* __restrict__ mm,
-                                                    const float* __restrict__ dy, float* __restrict__ dx, int acc,
-                                                    int HW, int C, float lk, unsigned short* __restrict__ dx_bf,
-                                                    float* __restrict__ colpart) {
-  constexpr int PL = 256 / CQ;
-  __shared__ float4 red[4 * 4 * CQ];
+template <int CQ, int NW>
+__global__ __launch_bounds__(64 * NW) void minmax_bwd_v(const float* __restrict__ x, const float* __restrict__ mm,
+                                                        const float* __restrict__ dy, float* __restrict__ dx, int acc,
+                                                        int HW, int C, float lk, unsigned short* __restrict__ dx_bf,
+                                                        float* __restrict__ colpart) {
+  constexpr int PL = 64 * NW / CQ;
+  __shared__ float4 red[4 * NW * CQ];
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
   const int n = blockIdx.x, c = (blockIdx.y * CQ + cq) * 4;
   const size_t base = (size_t)n * HW * C + c;
@@ -834,7 +897,7 @@ __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x,
     s[2].x += v.x == mn[0] ? 1.f : 0.f; s[2].y += v.y == mn[1] ? 1.f : 0.f; s[2].z += v.z == mn[2] ? 1.f : 0.f; s[2].w += v.w == mn[3] ? 1.f : 0.f;
     s[3].x += v.x == mx[0] ? 1.f : 0.f; s[3].y += v.y == mx[1] ? 1.f : 0.f; s[3].z += v.z == mx[2] ? 1.f : 0.f; s[3].w += v.w == mx[3] ? 1.f : 0.f;
   }
-  cq_reduce<4, CQ>(s, red);
+  cq_reduce_w<4, CQ, NW>(s, red);
   const float S1[4] = {s[0].x, s[0].y, s[0].z, s[0].w}, S2[4] = {s[1].x, s[1].y, s[1].z, s[1].w},
               Cn[4] = {s[2].x, s[2].y, s[2].z, s[2].w}, Cx[4] = {s[3].x, s[3].y, s[3].z, s[3].w};
   float d[4], dmn[4], dmx[4];
@@ -864,7 +927,7 @@ __global__ __launch_bounds__(256) void minmax_bwd_v(const float* __restrict__ x,
     cs[0].x += o.x; cs[0].y += o.y; cs[0].z += o.z; cs[0].w += o.w;
   }
   if (colpart) {   // row n of the gate bias gradient's first stage (kernels.h: colpart)
-    cq_reduce<1, CQ>(cs, red);
+    cq_reduce_w<1, CQ, NW>(cs, red);
     if (pl == 0) st4(colpart + (size_t)n * C + c, cs[0]);
   }
 }
@@ -874,11 +937,11 @@ void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int 
   const SlabSrc xs = x_slabs ? *x_slabs : plain_src(x);
   EG_CHECK(xs.n <= 1 || (C % 8 == 0 && xsum), "minmax_fwd: a slab input needs C %% 8 == 0 and a destination for the sum");
   if (C % 32 == 0) {
-    hipLaunchKernelGGL(minmax_fwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, xs, xsum, y, mm, HW, C, pre_leak);
+    hipLaunchKernelGGL((minmax_fwd_v<8, 4>), dim3(NB, C / 32), dim3(256), 0, s, xs, xsum, y, mm, HW, C, pre_leak);
     return;
   }
   if (C % 8 == 0) {
-    hipLaunchKernelGGL(minmax_fwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, xs, xsum, y, mm, HW, C, pre_leak);
+    hipLaunchKernelGGL((minmax_fwd_v<2, 16>), dim3(NB, C / 8), dim3(1024), 0, s, xs, xsum, y, mm, HW, C, pre_leak);
     return;
   }
   hipLaunchKernelGGL(minmax_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, y, mm, HW, C, pre_leak);
@@ -889,12 +952,12 @@ void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* 
   EG_CHECK(!colpart || C % 8 == 0, "minmax_bwd: column partials need C %% 8 == 0");
   EG_CHECK(!(accumulate & GRAD_PLANE_ONLY) || dx_bf, "minmax_bwd: GRAD_PLANE_ONLY without a plane");
   if (C % 32 == 0) {
-    hipLaunchKernelGGL(minmax_bwd_v<8>, dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, dx_bf, colpart);
+    hipLaunchKernelGGL((minmax_bwd_v<8, 4>), dim3(NB, C / 32), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, dx_bf, colpart);
     return;
   }
   EG_CHECK(!dx_bf, "minmax_bwd: a bf16 plane was requested with C %% 32 != 0");
   if (C % 8 == 0) {
-    hipLaunchKernelGGL(minmax_bwd_v<2>, dim3(NB, C / 8), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, nullptr, colpart);
+    hipLaunchKernelGGL((minmax_bwd_v<2, 16>), dim3(NB, C / 8), dim3(1024), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak, nullptr, colpart);
     return;
   }
   hipLaunchKernelGGL(minmax_bwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, mm, dy, dx, accumulate, HW, C, pre_leak);
@@ -1223,22 +1286,47 @@ void launch_sn_fwd(const SNDesc* tab, int count, int maxK, int maxCo, hipStream_
   hipLaunchKernelGGL(sn_scale_kernel, dim3(256, count), dim3(256), 0, s, tab);
 }
 // backward ------------------------------------------------------------------------------------
-// stage 1: partial dots of dWbar.W into dv[0..63] (dv is scratch here, >= 64 floats since K >= 64? no: use scal[8..71])
+// stage 1: partial dots of dWbar.W into scal[8 .. 8 + SN_DOT_PARTS) -- one partial per block, summed in block order by stage 2.
+// Round 6: 16-byte loads, four quads of each operand in flight per thread, 256 parts per weight (the 64-part scalar form
+// walked the 5.3 M elements of the classifier's last unit one dependent load at a time: 145 us for 137 MB)
+#define SN_DOT_PARTS (SN_SCAL_FLOATS - 8)
 __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const SNDesc* __restrict__ tab) {
   __shared__ float sm[4];
   const SNDesc d = tab[blockIdx.y];
   const size_t n = (size_t)d.K * d.Co;
   float s = 0.f;
-  GRID_STRIDE(i, n) s += d.dWbar[i] * d.W[i];
+  if ((n & 3) == 0 && ((((uintptr_t)d.dWbar) | ((uintptr_t)d.W)) & 15) == 0) {
+    const float4* __restrict__ a4 = reinterpret_cast<const float4*>(d.dWbar);
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(d.W);
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 256;
+    size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+      const float4 a0 = a4[i], a1 = a4[i + stride], a2 = a4[i + 2 * stride], a3 = a4[i + 3 * stride];
+      const float4 b0 = w4[i], b1 = w4[i + stride], b2 = w4[i + 2 * stride], b3 = w4[i + 3 * stride];
+      s0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+      s1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+      s2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
+      s3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
+    }
+    for (; i < n4; i += stride) {
+      const float4 a0 = a4[i], b0 = w4[i];
+      s0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+    }
+    s = (s0 + s1) + (s2 + s3);
+  } else {
+    GRID_STRIDE(i, n) s += d.dWbar[i] * d.W[i];
+  }
   const float tot = block_sum(s, sm);
   if (threadIdx.x == 0) d.scal[8 + blockIdx.x] = tot;
 }
 // stage 2: dot, dsigma, coefficient for ds = coef * sv
 __global__ void sn_bwd_coef_kernel(const SNDesc* __restrict__ tab, int nparts) {
   const SNDesc d = tab[blockIdx.x];
+  float dot = 0.f;   // one wave: lane l sums parts l, l + 64, ...; then the fixed-order wave sum
+  for (int i = threadIdx.x; i < nparts; i += 64) dot += d.scal[8 + i];
+  dot = wave_sum(dot);
   if (threadIdx.x != 0) return;
-  float dot = 0.f;
-  for (int i = 0; i < nparts; ++i) dot += d.scal[8 + i];
   const float sigma = d.scal[2], ns = d.scal[1];
   const float dsigma = -dot / (sigma * sigma);
   const float q = ns + SN_EPS;
@@ -1261,6 +1349,30 @@ __global__ void sn_bwd_final_kernel(const SNDesc* __restrict__ tab) {
   const float inv_sigma = 1.f / d.scal[2], nt = d.scal[0], P = d.scal[4], coef = d.scal[5];
   const float invq = 1.f / (nt + SN_EPS);
   const size_t n = (size_t)d.K * d.Co;
+  if ((d.Co & 3) == 0 && ((((uintptr_t)d.dWbar) | ((uintptr_t)d.dW) | ((uintptr_t)d.sv) | ((uintptr_t)d.u)) & 15) == 0) {
+    // a quad = four consecutive columns of one row k (the same expressions per element as the scalar form below)
+    const unsigned co4 = (unsigned)d.Co >> 2;
+    const size_t n4 = n >> 2;
+    GRID_STRIDE(q, n4) {
+      const unsigned k = (unsigned)(q / co4), c4 = (unsigned)(q - (size_t)k * co4);
+      const float v = d.t[k];
+      const float dt = d.dv[k] * invq - P * v / nt;
+      const float4 a = reinterpret_cast<const float4*>(d.dWbar)[q];
+      const float4 sv = reinterpret_cast<const float4*>(d.sv)[c4], u = reinterpret_cast<const float4*>(d.u)[c4];
+      float4 g;
+      g.x = a.x * inv_sigma + v * coef * sv.x + dt * u.x;
+      g.y = a.y * inv_sigma + v * coef * sv.y + dt * u.y;
+      g.z = a.z * inv_sigma + v * coef * sv.z + dt * u.z;
+      g.w = a.w * inv_sigma + v * coef * sv.w + dt * u.w;
+      float4* o = reinterpret_cast<float4*>(d.dW) + q;
+      if (d.acc_dW) {
+        const float4 p = *o;
+        g.x += p.x; g.y += p.y; g.z += p.z; g.w += p.w;
+      }
+      *o = g;
+    }
+    return;
+  }
   GRID_STRIDE(i, n) {
     const int k = (int)(i / d.Co), c = (int)(i % d.Co);
     const float v = d.t[k];
@@ -1270,7 +1382,7 @@ __global__ void sn_bwd_final_kernel(const SNDesc* __restrict__ tab) {
   }
 }
 void launch_sn_bwd(const SNDesc* tab, int count, int maxK, int maxCo, hipStream_t s) {
-  const int nparts = 64;
+  const int nparts = SN_DOT_PARTS;
   hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nparts, count), dim3(256), 0, s, tab);
   hipLaunchKernelGGL(sn_bwd_coef_kernel, dim3(count), dim3(64), 0, s, tab, nparts);
   hipLaunchKernelGGL(sn_rowdot_kernel, dim3((maxK + 3) / 4, count), dim3(256), 0, s, tab, 1);
@@ -1301,14 +1413,41 @@ void launch_mean_neg(const float* x, float* out, int B, hipStream_t s) {
 }
 
 // gradient penalty (functional.py:26-29, lambda from train.py:52)
-__global__ __launch_bounds__(256) void gp_norm_kernel(const float* __restrict__ g, float* __restrict__ norms,
-                                                      size_t per) {
-  __shared__ float sm[4];
+// one 1024-thread block per sample: 16-byte loads, three quads in flight per thread, fixed-order sum (round 6; the
+// 256-thread scalar form took 39 us for the 12.6 MB of a batch of 64)
+__global__ __launch_bounds__(1024) void gp_norm_kernel(const float* __restrict__ g, float* __restrict__ norms,
+                                                       size_t per) {
+  __shared__ float sm[16];
   const float* p = g + (size_t)blockIdx.x * per;
   float s = 0.f;
-  for (size_t i = threadIdx.x; i < per; i += 256) s += p[i] * p[i];
-  const float t = block_sum(s, sm);
-  if (threadIdx.x == 0) norms[blockIdx.x] = sqrtf(t);
+  if ((per & 3) == 0 && (((uintptr_t)g) & 15) == 0) {
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+    const size_t n4 = per >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    size_t i = threadIdx.x;
+    for (; i + 2048 < n4; i += 3072) {
+      const float4 a = p4[i], b = p4[i + 1024], c = p4[i + 2048];
+      s0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+      s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+      s2 += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+    }
+    for (; i < n4; i += 1024) {
+      const float4 a = p4[i];
+      s0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    }
+    s = s0 + s1 + s2;
+  } else {
+    for (size_t i = threadIdx.x; i < per; i += 1024) s += p[i] * p[i];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sm[w];
+    norms[blockIdx.x] = sqrtf(t);
+  }
 }
 __global__ void gp_v_kernel(const float* __restrict__ g, const float* __restrict__ norms, float* __restrict__ v,
                             size_t per, int B, float lambda, size_t n) {
@@ -1326,7 +1465,7 @@ __global__ void gp_loss_kernel(const float* norms, float* gp, int B, float lambd
 }
 void launch_gp_v(const float* g, float* v, float* norms, float* gp, int B, size_t per, float lambda,
                  hipStream_t s) {
-  hipLaunchKernelGGL(gp_norm_kernel, dim3(B), dim3(256), 0, s, g, norms, per);
+  hipLaunchKernelGGL(gp_norm_kernel, dim3(B), dim3(1024), 0, s, g, norms, per);
   const size_t n = (size_t)B * per;
   if (v) hipLaunchKernelGGL(gp_v_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, g, norms, v, per, B, lambda, n);
   hipLaunchKernelGGL(gp_loss_kernel, dim3(1), dim3(256), 0, s, norms, gp, B, lambda);

@@ -502,6 +502,88 @@ static void conv_fix_ksplit(ConvArgs& a) {
       a.y_total / 4 >= (1ull << 32))
     a.ksplit = 1;
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// rows_linear_kernel (round 6): y[m][n] (+)= b[n] + sum_k x[m][k] w[k][n] for a HANDFUL of rows (m <= 64: the batch) with a
+// short contraction (k <= 128) and many columns -- the generators' first linear z -> 8,192 (generator.py:45-52), the input
+// gradients of FC8_mu / FC8_sigma and of the classifier's class head (linear.py:10-31,34-76).  The 64 x 64-tile gather kernel
+// spends 15 - 22 us on them: 2 K steps of a pipeline built for thousands, one M tile.  Here a block owns 32 rows x 64 columns;
+// x's tile sits in LDS transposed ([k][row], read as broadcast quads), a thread owns one column and the k = kq (mod 4) quarter
+// of the contraction for all 32 rows (32 fp32 FMA chains, the filter row loads four deep in flight), and the four quarters
+// are summed in LDS in the order kq = 0 .. 3.  fp32 FMAs: exact products, one rounding per step -- the fp32 MFMA path's
+// arithmetic in another order (parity: the op tests' linear shapes, tests/parity.py).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kRowsLinC = 128, kRowsLinPitch = 36;
+__global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restrict__ x, int x_ps, const float* __restrict__ w, int ldw,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int y_ps, int M, int C,
+                                                          int N, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float xs[kRowsLinC * kRowsLinPitch];
+  __shared__ float red[4 * 32 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 32;
+  for (int i = tid; i < 32 * C; i += 256) {
+    const int r = i / C, k = i - r * C;
+    xs[k * kRowsLinPitch + r] = (m0 + r < M) ? x[(size_t)(m0 + r) * x_ps + k] : 0.f;
+  }
+  __syncthreads();
+  const int col = n0 + lane;
+  const bool cv = col < N;
+  const float* wc = w + (cv ? col : 0);
+  float acc[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) acc[r] = 0.f;
+  int k = kq;
+  for (; k + 12 < C; k += 16) {
+    const float w0 = wc[(size_t)k * ldw], w1 = wc[(size_t)(k + 4) * ldw], w2 = wc[(size_t)(k + 8) * ldw], w3 = wc[(size_t)(k + 12) * ldw];
+    const float wv[4] = {w0, w1, w2, w3};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4* xr = reinterpret_cast<const float4*>(xs + (k + 4 * u) * kRowsLinPitch);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 v = xr[q];
+        acc[4 * q] += v.x * wv[u]; acc[4 * q + 1] += v.y * wv[u]; acc[4 * q + 2] += v.z * wv[u]; acc[4 * q + 3] += v.w * wv[u];
+      }
+    }
+  }
+  for (; k < C; k += 4) {
+    const float wv = wc[(size_t)k * ldw];
+    const float4* xr = reinterpret_cast<const float4*>(xs + k * kRowsLinPitch);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 v = xr[q];
+      acc[4 * q] += v.x * wv; acc[4 * q + 1] += v.y * wv; acc[4 * q + 2] += v.z * wv; acc[4 * q + 3] += v.w * wv;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 32; ++r) red[(kq * 32 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  for (int o = tid; o < 32 * 64; o += 256) {
+    const int r = o >> 6, c = o & 63;
+    if (m0 + r < M && n0 + c < N) {
+      float v = ((red[r * 64 + c] + red[(32 + r) * 64 + c]) + red[(64 + r) * 64 + c]) + red[(96 + r) * 64 + c];
+      if (bias) v += bias[n0 + c];
+      float* yp = y + (size_t)(m0 + r) * y_ps + n0 + c;
+      *yp = accumulate ? *yp + v : v;
+    }
+  }
+}
+static bool rows_linear_eligible(const ConvArgs& a, int maxM) {
+  static const bool off = dbg_env("EG_NO_ROWS_LINEAR") != nullptr;
+  if (off || !a.wgt || a.nphase != 1 || maxM > 64 || a.C > kRowsLinC || a.N < 256) return false;
+  const ConvPhase& p = a.ph[0];
+  if (p.Ty != 1 || p.Tx != 1 || a.S != 1 || a.os != 1 || a.reflect || a.shuf || a.x_up || a.ksplit > 1) return false;
+  if (a.IH != 1 || a.IW != 1 || a.OHf != 1 || a.OWf != 1 || p.OHp != 1 || p.OWp != 1 || p.offy || p.offx || p.ophy || p.ophx) return false;
+  if (a.epi_act || a.y2_leak || a.pool_y || a.y_bf || a.epi_bf) return false;
+  return true;
+}
+static const char* launch_rows_linear(const ConvArgs& a, hipStream_t s) {
+  const ConvPhase& p = a.ph[0];
+  const float* w = a.wgt + (long long)(p.kh0 * a.KW + p.kw0) * a.w_ts;
+  hipLaunchKernelGGL(rows_linear_kernel, dim3((a.N + 63) / 64, (a.NB + 31) / 32), dim3(256), 0, s, a.x, a.x_ps, w, a.ldw, a.bias, a.y,
+                     a.y_ps, a.NB, a.C, a.N, a.accumulate);
+  return "rows_linear<32,64>";
+}
+
 // ConvArgs::x_up is honoured by the plane-fed kernel and the halo kernel (their stride-1 forms): would launch_conv_gemm run one
 // of them for these arguments?  (the same tests in the same order as the dispatch below)
 bool conv_up_kernel(const ConvArgs& a_in) {
@@ -568,6 +650,8 @@ double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name)
     }
     else if (conv_bf16_eligible(a))
       nm = launch_conv_gemm_bf16(a, maxM, big, s);
+    else if (rows_linear_eligible(a, maxM))
+      nm = launch_rows_linear(a, s);
     else if (big)
       nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s,
                                            a.ksplit > 1 ? "conv_gemm<128,128,vec,splitk>" : "conv_gemm<128,128,vec>",

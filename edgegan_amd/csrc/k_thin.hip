@@ -244,7 +244,10 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
     return (unsigned)((((nb * H + row) * W + col) * a.x_ps + 8 * g) * 4);
   };
   // flat sequence of this wave's work items (round, tile, K step); the operand loads run PD items ahead
-  constexpr int PD = 4;
+#ifndef EG_SCATTER_PD
+#define EG_SCATTER_PD 4
+#endif
+  constexpr int PD = EG_SCATTER_PD;   // (even: the filter fragments are double buffered by item parity)
   f32x4 ra[PD][2];
   const int items = rounds * tpw * KS;
   int ld_k = 0, ld_j = 0, ld_ks = 0;

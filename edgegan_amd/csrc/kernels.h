@@ -485,13 +485,14 @@ void launch_gemv_bwd_w(const float* x, const float* dy, float* dw, int acc_w, fl
                        int K, hipStream_t s);
 
 // ---- spectral norm (normalization.py:38-76), batched over a table of weights -----------------
+constexpr int SN_SCAL_FLOATS = 8 + 256;
 struct SNDesc {
   const float* W;   // [K][Co]
   const float* u;   // [Co]
   float* Wbar;      // [K][Co] = W/sigma
   float* t;         // [K]  scratch: W u^T  (then v)
   float* sv;        // [sn_sv_floats(Co)]: v W in the first Co floats, then the K-split partials
-  float* scal;      // [80]: 0 nt, 1 ns, 2 sigma, 3 dot(dWbar,W), 4 P=dot(dv,v), 5 ds coefficient, 8.. partials
+  float* scal;      // [SN_SCAL_FLOATS]: 0 nt, 1 ns, 2 sigma, 3 dot(dWbar,W), 4 P=dot(dv,v), 5 ds coefficient, 8.. the 256 partials of dot(dWbar,W)
   const float* dWbar;  // backward input
   float* dW;        // backward output
   float* dv;        // [K] scratch

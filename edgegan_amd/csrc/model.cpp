@@ -232,7 +232,7 @@ void build_context(Ctx& c) {
       EG_HIP(hipMalloc(&s.t, (size_t)s.K * 4));
       EG_HIP(hipMalloc(&s.dv, (size_t)s.K * 4));
       EG_HIP(hipMalloc(&s.sv, (size_t)sn_sv_floats(s.Co) * 4));
-      EG_HIP(hipMalloc(&s.scal, 80 * 4));
+      EG_HIP(hipMalloc(&s.scal, SN_SCAL_FLOATS * 4));
       if (scope.size() > 12 && scope.compare(scope.size() - 12, 12, "/update_gate") == 0) {   // [3,3,hidden+3,hidden]
         s.split_rows = p->shape[2] - 3;
         const size_t nh = (size_t)s.T * s.split_rows * s.Co, nx = (size_t)s.T * 3 * s.Co;
