@@ -520,38 +520,47 @@ __global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restric
   __shared__ float red[4 * 32 * 64];
   const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
   const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 32;
-  for (int i = tid; i < 32 * C; i += 256) {
-    const int r = i / C, k = i - r * C;
-    xs[k * kRowsLinPitch + r] = (m0 + r < M) ? x[(size_t)(m0 + r) * x_ps + k] : 0.f;
-  }
-  __syncthreads();
   const int col = n0 + lane;
   const bool cv = col < N;
   const float* wc = w + (cv ? col : 0);
+  // every global load of the block is issued before the first use: the thread's <= 32 filter elements (k = kq, kq + 4, ...)
+  // and its 16 elements of x's tile -- two memory latencies in the whole kernel instead of one per K step
+  float wv[kRowsLinC / 4];
+#pragma unroll
+  for (int j = 0; j < kRowsLinC / 4; ++j) {
+    const int k = kq + 4 * j;
+    wv[j] = (k < C && cv) ? wc[(size_t)k * ldw] : 0.f;
+  }
+  {
+    const int r = tid >> 3, k8 = tid & 7;
+    const float* xr = x + (size_t)(m0 + r) * x_ps;
+    const bool rv = m0 + r < M;
+    float xv[kRowsLinC / 8];
+#pragma unroll
+    for (int j = 0; j < kRowsLinC / 8; ++j) {
+      const int k = k8 + 8 * j;
+      xv[j] = (rv && k < C) ? xr[k] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < kRowsLinC / 8; ++j) {
+      const int k = k8 + 8 * j;
+      if (k < C) xs[k * kRowsLinPitch + r] = xv[j];
+    }
+  }
+  __syncthreads();
   float acc[32];
 #pragma unroll
   for (int r = 0; r < 32; ++r) acc[r] = 0.f;
-  int k = kq;
-  for (; k + 12 < C; k += 16) {
-    const float w0 = wc[(size_t)k * ldw], w1 = wc[(size_t)(k + 4) * ldw], w2 = wc[(size_t)(k + 8) * ldw], w3 = wc[(size_t)(k + 12) * ldw];
-    const float wv[4] = {w0, w1, w2, w3};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float4* xr = reinterpret_cast<const float4*>(xs + (k + 4 * u) * kRowsLinPitch);
+  for (int j = 0; j < kRowsLinC / 4; ++j) {
+    const int k = kq + 4 * j;
+    if (k < C) {   // (uniform over the wave)
+      const float4* xr = reinterpret_cast<const float4*>(xs + k * kRowsLinPitch);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const float4 v = xr[q];
-        acc[4 * q] += v.x * wv[u]; acc[4 * q + 1] += v.y * wv[u]; acc[4 * q + 2] += v.z * wv[u]; acc[4 * q + 3] += v.w * wv[u];
+        acc[4 * q] += v.x * wv[j]; acc[4 * q + 1] += v.y * wv[j]; acc[4 * q + 2] += v.z * wv[j]; acc[4 * q + 3] += v.w * wv[j];
       }
-    }
-  }
-  for (; k < C; k += 4) {
-    const float wv = wc[(size_t)k * ldw];
-    const float4* xr = reinterpret_cast<const float4*>(xs + k * kRowsLinPitch);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 v = xr[q];
-      acc[4 * q] += v.x * wv; acc[4 * q + 1] += v.y * wv; acc[4 * q + 2] += v.z * wv; acc[4 * q + 3] += v.w * wv;
     }
   }
 #pragma unroll

@@ -32,6 +32,12 @@ def main():
             continue
         x = rng.normal(size=(NB, H, W, C)).astype(np.float32)
         w = (rng.normal(size=(k, k, C, N)) * 0.05).astype(np.float32)
+        if os.environ.get('OPERANDS') == 'zero':       # power probe: the same launches on all-zero operands (no toggling in the
+            x[...] = 0                                 # matrix pipe's data paths): a kernel that speeds up is power-limited
+            w[...] = 0
+        elif os.environ.get('OPERANDS') == 'const':
+            x[...] = 1.5
+            w[...] = 0.75
         OH, OW = (H + s - 1) // s, (W + s - 1) // s
         dy = rng.normal(size=(NB, OH, OW, N)).astype(np.float32)
         shapes = [(NB, OH, OW, N), x.shape, w.shape, None]

@@ -88,6 +88,27 @@ def main():
     print('launches that fill < 50 %% of the slots, by total time:')
     for n, (tot, c) in sorted(small.items(), key=lambda kv: -kv[1][0])[:15]:
         print('   %-100s %6d launches %8.2f ms' % (n[:100], c, tot / 1e6))
+    # solo time: how long each kernel ran with NOTHING beside it -- the part of the span that only a shorter chain (fewer or
+    # faster dependent launches) can shrink, whatever the other lanes do
+    bounds = sorted(set([t for t, _ in ev]))
+    import bisect
+    starts = sorted((s, e, n) for n, s, e in conc)
+    solo = defaultdict(lambda: [0.0, 0])
+    active = []
+    j = 0
+    for a, b in zip(bounds, bounds[1:]):
+        while j < len(starts) and starts[j][0] <= a:
+            active.append(starts[j])
+            j += 1
+        active = [k for k in active if k[1] > a]
+        if len(active) == 1:
+            solo[active[0][2]][0] += b - a
+    for n, s, e in conc:
+        solo[n][1] += 1
+    tot_solo = sum(v[0] for v in solo.values())
+    print('solo time (exactly one kernel in flight): %.2f ms = %.1f %% of the span; by kernel:' % (tot_solo / 1e6, 100.0 * tot_solo / span))
+    for n, (tt, c) in sorted(solo.items(), key=lambda kv: -kv[1][0])[:top]:
+        print('   %-100s %6d launches %8.2f ms solo' % (n[:100], c, tt / 1e6))
     sd = defaultdict(lambda: [0, 0])
     for n, s, e in ser:
         sd[n][0] += e - s
