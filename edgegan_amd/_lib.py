@@ -26,7 +26,8 @@ class _CConfig(C.Structure):
                 ('use_edge_discriminator', C.c_int), ('edge_dis_size', C.c_int),
                 ('lambda_gp', C.c_float), ('zl_weight', C.c_float),
                 ('learning_rate', C.c_float), ('joint_dweight', C.c_float), ('image_dweight', C.c_float),
-                ('edge_dweight', C.c_float), ('device', C.c_int), ('compute_dtype', C.c_int)]
+                ('edge_dweight', C.c_float), ('device', C.c_int), ('compute_dtype', C.c_int),
+                ('e_norm', C.c_int), ('g_norm', C.c_int), ('d_norm', C.c_int)]
 
 
 @dataclass
@@ -53,6 +54,9 @@ class Config:
     use_edge_discriminator: bool = True    # train.py:65-66
     image_dis_size: Optional[int] = None   # train.py:63-64 (None: dis_size)
     edge_dis_size: Optional[int] = None    # train.py:67    (None: dis_size)
+    E_norm: str = 'instance'   # train.py:54-59: 'instance' | 'batch' (nn/modules/normalization.py:10-29)
+    G_norm: str = 'instance'
+    D_norm: str = 'instance'
 
     @property
     def image_dis(self) -> int:
@@ -75,7 +79,11 @@ class Config:
                         self.df_dim, self.c_dim, int(self.use_image_discriminator), self.image_dis,
                         int(self.use_edge_discriminator), self.edge_dis, self.lambda_gp, self.zl_weight,
                         self.learning_rate, self.joint_dweight, self.image_dweight, self.edge_dweight, self.device,
-                        {'f32': 0, 'bf16': 1, 'f32x3': 2}[_dtype_override(self.compute_dtype)])
+                        {'f32': 0, 'bf16': 1, 'f32x3': 2}[_dtype_override(self.compute_dtype)],
+                        _NORMS[self.E_norm], _NORMS[self.G_norm], _NORMS[self.D_norm])
+
+
+_NORMS = {'instance': 0, 'batch': 1}
 
 
 def _dtype_override(dtype: str) -> str:

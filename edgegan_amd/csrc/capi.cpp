@@ -42,6 +42,10 @@ static Config to_config(const eg_config* k) {
   c.device = k->device;
   c.bf16 = k->compute_dtype == 1;
   c.x3 = k->compute_dtype == 2;
+  EG_CHECK((unsigned)k->e_norm <= 1u && (unsigned)k->g_norm <= 1u && (unsigned)k->d_norm <= 1u, "e_norm / g_norm / d_norm: 0 = instance, 1 = batch");
+  c.e_bn = k->e_norm == 1;
+  c.g_bn = k->g_norm == 1;
+  c.d_bn = k->d_norm == 1;
   return c;
 }
 
@@ -67,7 +71,7 @@ extern "C" {
 
 int eg_default_config(eg_config* k) {
   if (!k) return 1;
-  *k = eg_config{(unsigned)sizeof(eg_config), 64, 64, 128, 14, 100, 64, 64, 3, 1, 128, 1, 128, 10.f, 10.f, 2e-4f, 1.f, 1.f, 1.f, 0, 0};
+  *k = eg_config{(unsigned)sizeof(eg_config), 64, 64, 128, 14, 100, 64, 64, 3, 1, 128, 1, 128, 10.f, 10.f, 2e-4f, 1.f, 1.f, 1.f, 0, 0, /* e_norm, g_norm, d_norm = instance */ 0, 0, 0};
   return 0;
 }
 
@@ -712,6 +716,38 @@ int eg_test_op(eg_ctx* ctx, const char* op_, int n_in, const float* const* input
       io.down_grad(1, x);
       io.down_pgrad(2, g);
       io.down_pgrad(3, b);
+    }
+  } else if (op == "bn_act") {  // ip: NB,H,W,C,act ; in: x,gamma,beta,dy? ; out: y,dx,dgamma,dbeta
+    need_ip(5);
+    T x = io.tensor(0, ip[0], ip[1], ip[2], ip[3], io.has(3));
+    Param* g = io.param(1, io.has(3));
+    Param* b = io.param(2, io.has(3));
+    T y = bn_act(c, x, g, b, nullptr, nullptr, ip[4], 0);
+    io.down(0, y->d, y->numel());
+    if (io.has(3)) {
+      io.seed(y, 3);
+      c.tape.backward();
+      io.down_grad(1, x);
+      io.down_pgrad(2, g);
+      io.down_pgrad(3, b);
+    }
+  } else if (op == "bn_tangent") {  // ip: NB,H,W,C,act ; in: x,gamma,beta,tx,dty ; out: y,ty,dtx,dx,dgamma
+    need_ip(5);
+    T x = io.tensor(0, ip[0], ip[1], ip[2], ip[3], true);
+    Param* g = io.param(1, true);
+    Param* b = io.param(2, true);
+    T tx = io.tensor(3, ip[0], ip[1], ip[2], ip[3], true);
+    T st;
+    T y = bn_act(c, x, g, b, nullptr, nullptr, ip[4], 0, &st);
+    T ty = bn_act_tangent(c, tx, x, y, st, g, ip[4]);
+    io.down(0, y->d, y->numel());
+    io.down(1, ty->d, ty->numel());
+    if (io.has(4)) {
+      io.seed(ty, 4);
+      c.tape.backward();
+      io.down_grad(2, tx);
+      io.down_grad(3, x);
+      io.down_pgrad(4, g);
     }
   } else if (op == "resize" || op == "pool2" || op == "gmean" || op == "minmax") {
     need_ip(5);  // ip: NB,H,W,C,(size | pre_relu | unused) ; in: x,dy? ; out: y,dx

@@ -18,6 +18,7 @@ struct Config {
   int device = 0;
   bool bf16 = false;  // dense contractions on the bf16 MFMA (operands rounded, fp32 accumulate / storage)
   bool x3 = false;    // fp32 contractions as three-limb bf16 splits on the bf16 MFMA (exact limb products, fp32 accumulate)
+  bool e_bn = false, g_bn = false, d_bn = false;   // E_norm / G_norm / D_norm == 'batch' (train.py:54-59; default 'instance')
   bool multiclasses() const { return num_classes > 0; }
   int g_in() const { return z_dim + (multiclasses() ? num_classes : 0); }
 };
@@ -161,6 +162,12 @@ struct Ctx {
   float* d_gen_cache[2] = {nullptr, nullptr};
   float* d_gen_bn[2] = {nullptr, nullptr};   // batch statistics of that forward, for the moving-average updates
   bool gen_cache_valid[2] = {false, false};
+  // E_norm / G_norm / D_norm = 'batch': statistics of the generators' block norms of the cached forward (moving-average updates of
+  // the evaluations that reuse it), the last generator forward's block statistics, and how often a block norm evaluated now
+  // advances its moving statistics (the encoder's and the discriminators': once per evaluation of an applied sub-step)
+  float* d_gen_bn_blk[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  T gen_blk_stats[3] = {nullptr, nullptr, nullptr};
+  int bn_times_block = 0;
 
   // Lanes: sub-steps without data dependencies run on separate streams (own arena and reduction scratch each) so
   // that the HBM-bound kernels of one overlap the MFMA-bound kernels of another; `stream` / `arena` / `scratch`
@@ -300,6 +307,8 @@ T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int act);
 T act(Ctx& c, T x, int a);
 T act_tangent(Ctx& c, T tx, T out_prim, int a);
 T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times, T* stats_out = nullptr);
+T bn_act(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int act, int update_times, T* stats_out = nullptr);
+T bn_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, Param* gamma, int act);
 T add(Ctx& c, T a, T b, bool relu);
 T pool2(Ctx& c, T x);
 T add_relu_pool2(Ctx& c, T a, T b);   // pool2(relu(a + b)): one pass in forward-only graphs

@@ -10,6 +10,8 @@
 //
 // Block = 256 threads = 64 channels x 4 pixel lanes, one block per (sample, 64-channel group):
 // a wave reads 256-byte channel rows (coalesced), reductions over the 4 pixel lanes go through LDS.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 #include "cq_reduce.h"
@@ -986,6 +988,278 @@ void launch_bn_relu_bwd(const float* x, const float* out, const float* dout, con
 void launch_bn_moving_update(float* mm, float* mv, const float* stats, int C, int R, float decay, int times,
                              hipStream_t s) {
   hipLaunchKernelGGL(bn_moving_kernel, dim3((C + 255) / 256), dim3(256), 0, s, mm, mv, stats, C, R, decay, times);
+}
+
+// =============================================================================================
+// BatchNorm as the `norm` of a conv_block / deconv_block / residual (normalization.py:19-25 with E_norm / G_norm / D_norm =
+// 'batch', train.py:54-59; round 6): tf.contrib.layers.batch_norm(center, scale, is_training=True) over ALL rows of one
+// evaluation -- y = act(gamma (x - mean) s + beta), s = (var + eps)^-1/2, biased var -- followed by the block's activation.
+// The rows [R][C] of a feature map are far more than one block can walk (R = N H W up to 2^18), so every reduction is two-stage:
+// row chunks of BN_RPC rows x 64 channels per block write partials, one small kernel combines them in chunk order (fixed
+// order, no atomics), an element-wise kernel applies.  Statistics: per-chunk mean and centred second moment, merged with
+// the pairwise update (Chan et al.) -- no E[x^2] - E[x]^2 cancellation.
+//   J = a (I - 11^T/m) - (b/m) xc xc^T,  a = gamma s,  b = gamma s^3   (symmetric: backward and forward tangent share bn_japply)
+// and the reverse of the tangent (the gradient-penalty term, functional.py:26-29 differentiated once more) follows from
+//   da/dx_i = -gamma s^3 xc_i/m,  db/dx_i = -3 gamma s^5 xc_i/m.
+// =============================================================================================
+constexpr int BN_RPC = 256;
+// partials of a chunk: NV sums over its rows of f(row, channel); block = 64 channels x 4 row lanes
+__global__ __launch_bounds__(256) void bn_chunk_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int R, int C) {
+  __shared__ float red[1 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cx;
+  const bool cv = c < C;
+  const int r0 = blockIdx.x * BN_RPC, r1 = min(R, r0 + BN_RPC);
+  float s[1] = {0.f};
+  if (cv)
+    for (int p = r0 + py; p < r1; p += 4) s[0] += x[(size_t)p * C + c];
+  lane4_reduce<1>(s, red, cx, py);
+  const float mean = s[0] / (float)(r1 - r0);
+  float q[1] = {0.f};
+  if (cv)
+    for (int p = r0 + py; p < r1; p += 4) {
+      const float d = x[(size_t)p * C + c] - mean;
+      q[0] += d * d;
+    }
+  lane4_reduce<1>(q, red, cx, py);
+  if (cv && py == 0) {
+    part[((size_t)blockIdx.x * C + c) * 2] = mean;
+    part[((size_t)blockIdx.x * C + c) * 2 + 1] = q[0];
+  }
+}
+// stats[c] = mean, stats[C + c] = biased variance; the moving statistics advance `times` times (unbiased variance: fused batch norm)
+__global__ void bn_finalize_stats_kernel(const float* __restrict__ part, int nchunks, int R, int C, float* __restrict__ stats,
+                                         float* mm, float* mv, float decay, int times) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    const float nk = (float)min(BN_RPC, R - k * BN_RPC);
+    const float mk = part[((size_t)k * C + c) * 2], qk = part[((size_t)k * C + c) * 2 + 1];
+    const float d = mk - mean, nt = n + nk;
+    mean += d * (nk / nt);
+    m2 += qk + d * d * (n * nk / nt);
+    n = nt;
+  }
+  const float var = m2 / (float)R;
+  stats[c] = mean;
+  stats[C + c] = var;
+  if (times > 0 && mm && mv) {
+    const float uv = var * ((float)R / (float)(R > 1 ? R - 1 : 1));
+    float a = mm[c], b = mv[c];
+    for (int t = 0; t < times; ++t) {
+      a = a * decay + (1.f - decay) * mean;
+      b = b * decay + (1.f - decay) * uv;
+    }
+    mm[c] = a;
+    mv[c] = b;
+  }
+}
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ out, size_t n, int C, float eps, int act) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C);
+    const float rs = 1.f / sqrtf(stats[C + c] + eps);
+    out[i] = act_apply((x[i] - stats[c]) * rs * gamma[c] + beta[c], act);
+  }
+}
+// MODE 0 (backward): e = v act'(out); MODE 1 (forward tangent): e = v.  Chunk partials of sum e and sum e xh, xh = (x - mean) s
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_chunk_j_kernel(const float* __restrict__ x, const float* __restrict__ out,
+                                                         const float* __restrict__ v, const float* __restrict__ stats,
+                                                         float* __restrict__ part, int R, int C, float eps, int act) {
+  __shared__ float red[2 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cx;
+  const bool cv = c < C;
+  const int r0 = blockIdx.x * BN_RPC, r1 = min(R, r0 + BN_RPC);
+  const float mean = cv ? stats[c] : 0.f, rs = cv ? 1.f / sqrtf(stats[C + c] + eps) : 1.f;
+  float s[2] = {0.f, 0.f};
+  if (cv)
+    for (int p = r0 + py; p < r1; p += 4) {
+      const size_t i = (size_t)p * C + c;
+      float e = v[i];
+      if (MODE == 0) e *= act_grad_from_out(out[i], act);
+      s[0] += e;
+      s[1] += e * ((x[i] - mean) * rs);
+    }
+  lane4_reduce<2>(s, red, cx, py);
+  if (cv && py == 0) {
+    part[((size_t)blockIdx.x * C + c) * 2] = s[0];
+    part[((size_t)blockIdx.x * C + c) * 2 + 1] = s[1];
+  }
+}
+// sums[c] = sum e, sums[C + c] = sum e xh (chunk order); backward: dgamma (+)= sum e xh, dbeta (+)= sum e
+__global__ void bn_finalize_j_kernel(const float* __restrict__ part, int nchunks, int C, float* __restrict__ sums,
+                                     float* dgamma, int acc_dg, float* dbeta, int acc_db) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    a += part[((size_t)k * C + c) * 2];
+    b += part[((size_t)k * C + c) * 2 + 1];
+  }
+  sums[c] = a;
+  sums[C + c] = b;
+  if (dgamma) dgamma[c] = acc_dg ? dgamma[c] + b : b;
+  if (dbeta) dbeta[c] = acc_db ? dbeta[c] + a : a;
+}
+// res = gamma s (e - mean(e) - xh mean(e xh));  MODE 0: dx (+)= res;  MODE 1: tout = act'(out) res
+template <int MODE>
+__global__ void bn_japply_kernel(const float* __restrict__ x, const float* __restrict__ out, const float* __restrict__ v,
+                                 const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ sums,
+                                 float* __restrict__ dst, int accumulate, size_t n, int R, int C, float eps, int act) {
+  const float inv_m = 1.f / (float)R;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C);
+    const float rs = 1.f / sqrtf(stats[C + c] + eps);
+    const float xh = (x[i] - stats[c]) * rs;
+    const float o = out[i];
+    float e = v[i];
+    if (MODE == 0) e *= act_grad_from_out(o, act);
+    float res = gamma[c] * rs * (e - sums[c] * inv_m - xh * (sums[C + c] * inv_m));
+    if (MODE == 1) res *= act_grad_from_out(o, act);
+    dst[i] = accumulate ? dst[i] + res : res;
+  }
+}
+// reverse of the forward tangent, stage A: chunk partials of sum e (e = dtout act'(out)) and sum t
+__global__ __launch_bounds__(256) void bn_chunk_tb_means_kernel(const float* __restrict__ out, const float* __restrict__ tx,
+                                                                const float* __restrict__ dtout, float* __restrict__ part, int R,
+                                                                int C, int act) {
+  __shared__ float red[2 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cx;
+  const bool cv = c < C;
+  const int r0 = blockIdx.x * BN_RPC, r1 = min(R, r0 + BN_RPC);
+  float s[2] = {0.f, 0.f};
+  if (cv)
+    for (int p = r0 + py; p < r1; p += 4) {
+      const size_t i = (size_t)p * C + c;
+      s[0] += dtout[i] * act_grad_from_out(out[i], act);
+      s[1] += tx[i];
+    }
+  lane4_reduce<2>(s, red, cx, py);
+  if (cv && py == 0) {
+    part[((size_t)blockIdx.x * C + c) * 2] = s[0];
+    part[((size_t)blockIdx.x * C + c) * 2 + 1] = s[1];
+  }
+}
+// stage B: with the means, chunk partials of A = sum (e - eb)(t - tb), S_xt = sum xc t, S_ex = sum e xc
+__global__ __launch_bounds__(256) void bn_chunk_tb_moments_kernel(const float* __restrict__ x, const float* __restrict__ out,
+                                                                  const float* __restrict__ tx, const float* __restrict__ dtout,
+                                                                  const float* __restrict__ stats, const float* __restrict__ means,
+                                                                  float* __restrict__ part, int R, int C, int act) {
+  __shared__ float red[3 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cx;
+  const bool cv = c < C;
+  const int r0 = blockIdx.x * BN_RPC, r1 = min(R, r0 + BN_RPC);
+  const float mean = cv ? stats[c] : 0.f;
+  const float eb = cv ? means[c] / (float)R : 0.f, tb = cv ? means[C + c] / (float)R : 0.f;
+  float s[3] = {0.f, 0.f, 0.f};
+  if (cv)
+    for (int p = r0 + py; p < r1; p += 4) {
+      const size_t i = (size_t)p * C + c;
+      const float e = dtout[i] * act_grad_from_out(out[i], act), t = tx[i], xc = x[i] - mean;
+      s[0] += (e - eb) * (t - tb);
+      s[1] += xc * t;
+      s[2] += e * xc;
+    }
+  lane4_reduce<3>(s, red, cx, py);
+  if (cv && py == 0) {
+    part[((size_t)blockIdx.x * C + c) * 3] = s[0];
+    part[((size_t)blockIdx.x * C + c) * 3 + 1] = s[1];
+    part[((size_t)blockIdx.x * C + c) * 3 + 2] = s[2];
+  }
+}
+// moments[c], [C + c], [2C + c] = A, S_xt, S_ex;  dgamma (+)= s A - (s^3/m) S_ex S_xt
+__global__ void bn_finalize_tb_kernel(const float* __restrict__ part, int nchunks, int R, int C, const float* __restrict__ stats,
+                                      float eps, float* __restrict__ moments, float* dgamma, int acc_dg) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f, d = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    a += part[((size_t)k * C + c) * 3];
+    b += part[((size_t)k * C + c) * 3 + 1];
+    d += part[((size_t)k * C + c) * 3 + 2];
+  }
+  moments[c] = a;
+  moments[C + c] = b;
+  moments[2 * C + c] = d;
+  if (dgamma) {
+    const float s = 1.f / sqrtf(stats[C + c] + eps);
+    const float g = s * a - s * s * s * d * b / (float)R;
+    dgamma[c] = acc_dg ? dgamma[c] + g : g;
+  }
+}
+// stage C:  dtx (+)= J e;   dx (+)= c1 xc - (b/m) [ (e - eb) S_xt + (t - tb) S_ex ],  c1 = (-gamma s^3 A + 3 gamma s^5 S_ex S_xt / m) / m
+__global__ void bn_tb_apply_kernel(const float* __restrict__ x, const float* __restrict__ out, const float* __restrict__ tx,
+                                   const float* __restrict__ dtout, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ means, const float* __restrict__ moments, float* __restrict__ dtx,
+                                   int acc_dtx, float* __restrict__ dx, int acc_dx, size_t n, int R, int C, float eps, int act) {
+  const float m = (float)R;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C);
+    const float s = 1.f / sqrtf(stats[C + c] + eps), g = gamma[c];
+    const float s3 = s * s * s;
+    const float A = moments[c], S_xt = moments[C + c], S_ex = moments[2 * C + c];
+    const float eb = means[c] / m, tb = means[C + c] / m;
+    const float e = dtout[i] * act_grad_from_out(out[i], act), t = tx[i], xc = x[i] - stats[c];
+    const float gt = g * s * (e - eb) - g * s3 * S_ex / m * xc;
+    const float c1 = (-g * s3 * A + 3.f * g * s3 * s * s * S_ex * S_xt / m) / m;
+    const float gx = c1 * xc - g * s3 / m * ((e - eb) * S_xt + (t - tb) * S_ex);
+    dtx[i] = acc_dtx ? dtx[i] + gt : gt;
+    dx[i] = acc_dx ? dx[i] + gx : gx;
+  }
+}
+
+static inline int bn_chunks(int R) { return (R + BN_RPC - 1) / BN_RPC; }
+size_t bn_scratch_floats(int R, int C) { return (size_t)bn_chunks(R) * C * 3 + (size_t)5 * C; }
+static inline int bn_ew_blocks(size_t n) { return (int)std::min<size_t>(4096, (n + 255) / 256); }
+void launch_bn_act_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats, float* scratch, float* mm,
+                       float* mv, int times, int R, int C, float eps, int act, hipStream_t s) {
+  const int nch = bn_chunks(R);
+  hipLaunchKernelGGL(bn_chunk_stats_kernel, dim3(nch, (C + 63) / 64), dim3(256), 0, s, x, scratch, R, C);
+  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, nch, R, C, stats, mm, mv, 0.9f, times);
+  const size_t n = (size_t)R * C;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_ew_blocks(n)), dim3(256), 0, s, x, stats, gamma, beta, out, n, C, eps, act);
+}
+void launch_bn_act_bwd(const float* x, const float* out, const float* dout, const float* gamma, const float* stats, float* scratch,
+                       float* dx, int acc_dx, float* dgamma, int acc_dg, float* dbeta, int acc_db, int R, int C, float eps, int act,
+                       hipStream_t s) {
+  const int nch = bn_chunks(R);
+  float* sums = scratch + (size_t)nch * C * 3;
+  hipLaunchKernelGGL(bn_chunk_j_kernel<0>, dim3(nch, (C + 63) / 64), dim3(256), 0, s, x, out, dout, stats, scratch, R, C, eps, act);
+  hipLaunchKernelGGL(bn_finalize_j_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, nch, C, sums, dgamma, acc_dg, dbeta, acc_db);
+  const size_t n = (size_t)R * C;
+  if (dx)
+    hipLaunchKernelGGL(bn_japply_kernel<0>, dim3(bn_ew_blocks(n)), dim3(256), 0, s, x, out, dout, stats, gamma, sums, dx, acc_dx, n, R,
+                       C, eps, act);
+}
+void launch_bn_act_tangent_fwd(const float* x, const float* out, const float* gamma, const float* stats, const float* tx, float* tout,
+                               float* scratch, int R, int C, float eps, int act, hipStream_t s) {
+  const int nch = bn_chunks(R);
+  float* sums = scratch + (size_t)nch * C * 3;
+  hipLaunchKernelGGL(bn_chunk_j_kernel<1>, dim3(nch, (C + 63) / 64), dim3(256), 0, s, x, out, tx, stats, scratch, R, C, eps, act);
+  hipLaunchKernelGGL(bn_finalize_j_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, nch, C, sums, nullptr, 0, nullptr, 0);
+  const size_t n = (size_t)R * C;
+  hipLaunchKernelGGL(bn_japply_kernel<1>, dim3(bn_ew_blocks(n)), dim3(256), 0, s, x, out, tx, stats, gamma, sums, tout, 0, n, R, C, eps,
+                     act);
+}
+void launch_bn_act_tangent_bwd(const float* x, const float* out, const float* gamma, const float* stats, const float* tx,
+                               const float* dtout, float* scratch, float* dtx, int acc_dtx, float* dx, int acc_dx, float* dgamma,
+                               int acc_dg, int R, int C, float eps, int act, hipStream_t s) {
+  const int nch = bn_chunks(R);
+  float* means = scratch + (size_t)nch * C * 3;
+  float* moments = means + 2 * C;
+  hipLaunchKernelGGL(bn_chunk_tb_means_kernel, dim3(nch, (C + 63) / 64), dim3(256), 0, s, out, tx, dtout, scratch, R, C, act);
+  hipLaunchKernelGGL(bn_finalize_j_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, nch, C, means, nullptr, 0, nullptr, 0);
+  hipLaunchKernelGGL(bn_chunk_tb_moments_kernel, dim3(nch, (C + 63) / 64), dim3(256), 0, s, x, out, tx, dtout, stats, means, scratch, R,
+                     C, act);
+  hipLaunchKernelGGL(bn_finalize_tb_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, nch, R, C, stats, eps, moments, dgamma, acc_dg);
+  const size_t n = (size_t)R * C;
+  hipLaunchKernelGGL(bn_tb_apply_kernel, dim3(bn_ew_blocks(n)), dim3(256), 0, s, x, out, tx, dtout, stats, gamma, means, moments, dtx,
+                     acc_dtx, dx, acc_dx, n, R, C, eps, act);
 }
 
 }  // namespace eg

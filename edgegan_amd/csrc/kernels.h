@@ -394,6 +394,20 @@ void launch_bn_relu_bwd(const float* x, const float* out, const float* dout, con
                         const float* stats, float* dx, int acc_dx, float* dgamma, int acc_dg, float* dbeta,
                         int acc_db, int R, int C, float eps, hipStream_t s);
 // moving statistics update: mm = d*mm + (1-d)*mean, mv = d*mv + (1-d)*var*R/(R-1), applied `times` times
+// BatchNorm (batch statistics, learned scale / shift) + activation as the `norm` of a block (normalization.py:19-25 with
+// E_norm / G_norm / D_norm = 'batch'): two-stage over row chunks; scratch = bn_scratch_floats(R, C) floats per call in flight.
+// stats = [mean | biased var] (2 C floats).  The tangent pair serves the gradient penalty through a BatchNorm discriminator.
+size_t bn_scratch_floats(int R, int C);
+void launch_bn_act_fwd(const float* x, const float* gamma, const float* beta, float* out, float* stats, float* scratch, float* mm,
+                       float* mv, int times, int R, int C, float eps, int act, hipStream_t s);
+void launch_bn_act_bwd(const float* x, const float* out, const float* dout, const float* gamma, const float* stats, float* scratch,
+                       float* dx, int acc_dx, float* dgamma, int acc_dg, float* dbeta, int acc_db, int R, int C, float eps, int act,
+                       hipStream_t s);
+void launch_bn_act_tangent_fwd(const float* x, const float* out, const float* gamma, const float* stats, const float* tx, float* tout,
+                               float* scratch, int R, int C, float eps, int act, hipStream_t s);
+void launch_bn_act_tangent_bwd(const float* x, const float* out, const float* gamma, const float* stats, const float* tx,
+                               const float* dtout, float* scratch, float* dtx, int acc_dtx, float* dx, int acc_dx, float* dgamma,
+                               int acc_dg, int R, int C, float eps, int act, hipStream_t s);
 void launch_bn_moving_update(float* mm, float* mv, const float* stats, int C, int R, float decay, int times,
                              hipStream_t s);
 

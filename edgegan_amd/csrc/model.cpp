@@ -14,6 +14,14 @@ static inline int ceil_half(int n) { return (n + 1) / 2; }
 // registry: names / shapes / initialisers, creation order of
 // edgegan.py:202-275: G1, G2, D2, D, D_patch2, D_patch3, E
 // ---------------------------------------------------------------------------------------------
+// the variables contrib batch_norm creates under <scope>/batch_norm (normalization.py:20-25; creation order beta, gamma, moving_*)
+static void bn_vars(std::vector<VarInfo>& v, const std::string& scope, int C, int group) {
+  v.push_back({scope + "/batch_norm/BatchNorm/beta", {C}, true, false, 0, 0.f, group});
+  v.push_back({scope + "/batch_norm/BatchNorm/gamma", {C}, true, false, 0, 1.f, group});
+  v.push_back({scope + "/batch_norm/BatchNorm/moving_mean", {C}, false, false, 0, 0.f, group});
+  v.push_back({scope + "/batch_norm/BatchNorm/moving_variance", {C}, false, false, 0, 1.f, group});
+}
+
 static void gen_vars(std::vector<VarInfo>& v, const Config& cfg, int group) {
   const std::string p = kGroupPrefix[group];
   int h = cfg.H, w = cfg.W / 2;
@@ -33,6 +41,7 @@ static void gen_vars(std::vector<VarInfo>& v, const Config& cfg, int group) {
     const std::string b = p + "/g_dconv_" + std::to_string(i) + "/deconv2d/";
     v.push_back({b + "w", {5, 5, ch[i], ch[i - 1]}, true, false, 1, 0.02f, group});
     v.push_back({b + "b", {ch[i]}, true, false, 0, 0.f, group});
+    if (cfg.g_bn && i < 4) bn_vars(v, p + "/g_dconv_" + std::to_string(i), ch[i], group);   // deconv_block (conv.py:124-130), G_norm = 'batch'
   }
 }
 
@@ -45,6 +54,7 @@ static void disc_vars(std::vector<VarInfo>& v, const Config& cfg, int group, int
   int h = in_h, w = in_w;
   for (int i = 0; i < 4; ++i) {
     v.push_back({p + "/" + kDiscNames[i] + "/conv2d/w", {4, 4, ch[i], ch[i + 1]}, true, false, 2, 0.02f, group});
+    if (cfg.d_bn && i > 0) bn_vars(v, p + "/" + kDiscNames[i], ch[i + 1], group);   // conv_block (conv.py:61-67), D_norm = 'batch'
     h = ceil_half(h);
     w = ceil_half(w);
   }
@@ -66,8 +76,10 @@ static void enc_vars(std::vector<VarInfo>& v, const Config& cfg) {
     const std::string b = "E/e_resnet_" + std::to_string(n) + "_" + std::to_string(i++);
     v.push_back({b + "/res1/conv2d/w", {3, 3, cin, n}, true, false, 2, 0.02f, G_E});
     v.push_back({b + "/res1/conv2d/b", {n}, true, false, 0, 0.f, G_E});
+    if (cfg.e_bn) bn_vars(v, b + "/res1", n, G_E);   // residual (conv.py:70-85), E_norm = 'batch'
     v.push_back({b + "/res2/conv2d/w", {3, 3, n, n}, true, false, 2, 0.02f, G_E});
     v.push_back({b + "/res2/conv2d/b", {n}, true, false, 0, 0.f, G_E});
+    if (cfg.e_bn) bn_vars(v, b + "/res2", n, G_E);
     v.push_back({b + "/shortcut/conv2d/w", {1, 1, cin, n}, true, false, 2, 0.02f, G_E});
     v.push_back({b + "/shortcut/conv2d/b", {n}, true, false, 0, 0.f, G_E});
     cin = n;
@@ -268,6 +280,7 @@ void build_context(Ctx& c) {
   for (int i = 0; i < 2; ++i) {
     EG_HIP(hipMalloc(&c.d_gen_cache[i], img / 2 * 4));
     EG_HIP(hipMalloc(&c.d_gen_bn[i], (size_t)2 * cfg.gf * 8 * 4));
+    for (int j = 0; cfg.g_bn && j < 3; ++j) EG_HIP(hipMalloc(&c.d_gen_bn_blk[i][j], (size_t)2 * (cfg.gf * 4 >> j) * 4));
   }
   EG_HIP(hipMemsetAsync(c.d_losses, 0, 64 * 4, c.stream));
   EG_HIP(hipMemsetAsync(c.d_eps, 0, 16 * 4, c.stream));
@@ -380,6 +393,13 @@ void api_enter(Ctx& c) {
 // networks
 // ---------------------------------------------------------------------------------------------
 // generator.py:35-74 (_convnet): linear -> reshape -> BatchNorm(!) -> ReLU -> 3x[deconv,IN,ReLU] -> deconv -> tanh
+// the block norm with E_norm / G_norm / D_norm = 'batch' (normalization.py:19-25): BatchNorm over this evaluation's rows + the
+// block's activation.  The moving statistics advance `times` times; they never enter a result (is_training=True, line 24).
+static T block_bn(Ctx& c, T x, const std::string& scope, int a, int times, T* stats_out = nullptr) {
+  const std::string b = scope + "/batch_norm/BatchNorm/";
+  return bn_act(c, x, P(c, b + "gamma"), P(c, b + "beta"), P(c, b + "moving_mean"), P(c, b + "moving_variance"), a, times, stats_out);
+}
+
 T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out, float* out_into) {
   const Config& cfg = c.cfg;
   const std::string p = kGroupPrefix[group];
@@ -397,12 +417,17 @@ T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out, flo
   const int ch[5] = {gf * 8, gf * 4, gf * 2, gf, cfg.c_dim};
   for (int i = 1; i <= 4; ++i) {
     const std::string b = p + "/g_dconv_" + std::to_string(i) + "/deconv2d/";
-    c.feeds_in = i < 4;   // deconv_block: the InstanceNorm is the transposed convolution's only reader
+    c.feeds_in = i < 4 && !cfg.g_bn;   // deconv_block: the InstanceNorm is the transposed convolution's only reader
     x = deconv2d(c, x, wref_param(c, P(c, b + "w"), 25, ch[i], ch[i - 1]), P(c, b + "b"), ch[i], i == 4 ? ACT_TANH : 0,
                  i == 4 ? out_into : nullptr);
     // (bf16 mode, forward-only graph: the next transposed convolution stages the bf16 plane -- the fp32 copy is not written;
     //  g_dconv_4 gathers fp32, so layer 3's output keeps both)
-    if (i < 4) x = in_act(c, x, ACT_RELU, nullptr, /*plane_only=*/cfg.bf16 && !x->needs_grad && i < 3);
+    if (i < 4 && cfg.g_bn) {   // G_norm = 'batch' (generator.py:54-68 through conv.py:124-130)
+      T bst = nullptr;
+      x = block_bn(c, x, p + "/g_dconv_" + std::to_string(i), ACT_RELU, bn_times, &bst);
+      c.gen_blk_stats[i - 1] = bst;
+    } else if (i < 4)
+      x = in_act(c, x, ACT_RELU, nullptr, /*plane_only=*/cfg.bf16 && !x->needs_grad && i < 3);
   }
   if (x->fused_act == ACT_TANH) {   // (forward-only graph: the last layer's store applied it)
     x->fused_act = 0;
@@ -425,11 +450,21 @@ T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_o
     WRef* w = wref_param(c, P(c, p + "/" + kDiscNames[i] + "/conv2d/w"), 16, ch[i], ch[i + 1]);
     // (first block: conv + LeakyReLU, fused where the small-C kernel runs the conv; `pre` is then the activated output,
     //  which is all the tangent pass and the backward need of it)
-    c.feeds_in = i > 0 && !tangent_of;   // conv_block: the InstanceNorm is the convolution's only forward reader
+    c.feeds_in = i > 0 && !tangent_of && !cfg.d_bn;   // conv_block: the InstanceNorm is the convolution's only forward reader
     c.conv_plane_only_next = cfg.bf16 && i == 0 && !tangent_of && !save;   // (no tangent pass will read this output's values)
     T pre = conv2d(c, x, w, nullptr, 4, 2, PAD_SAME, nullptr, (i == 0 && !tangent_of) ? ACT_LRELU : 0);
     T out, st = nullptr;
-    if (!tangent_of) {
+    if (cfg.d_bn && i > 0) {   // D_norm = 'batch' (discriminator.py:63-72 through conv.py:61-67)
+      const std::string scope = p + "/" + kDiscNames[i];
+      out = !tangent_of ? block_bn(c, pre, scope, ACT_LRELU, c.bn_times_block, &st)
+                        : bn_act_tangent(c, pre, tangent_of->pre[i], tangent_of->out[i], tangent_of->stats[i],
+                                         P(c, scope + "/batch_norm/BatchNorm/gamma"), ACT_LRELU);
+      if (save && !tangent_of) {
+        save->pre[i] = pre;
+        save->out[i] = out;
+        save->stats[i] = st;
+      }
+    } else if (!tangent_of) {
       out = (i == 0) ? pre : in_act(c, pre, ACT_LRELU, &st, /*plane_only=*/cfg.bf16 && i < 3);   // (layer 3 feeds the linear head)
       if (save) {
         save->pre[i] = pre;
@@ -455,14 +490,16 @@ T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out, T* z1
     const std::string b = "E/e_resnet_" + std::to_string(n) + "_" + std::to_string(i++);
     const int main_lane = c.cur_lane;
     if (c.infer_side >= 0) EG_HIP(hipEventRecord(c.ev_infer[main_lane], c.stream));   // the block's input is complete here
-    c.feeds_in = true;   // residual: both 3x3 convolutions are read by their InstanceNorm alone
+    c.feeds_in = !cfg.e_bn;   // residual: both 3x3 convolutions are read by their InstanceNorm alone
     T o1 = conv2d(c, E, wref_param(c, P(c, b + "/res1/conv2d/w"), 9, cin, n), P(c, b + "/res1/conv2d/b"), 3, 1,
                   PAD_REFLECT);
-    o1 = in_act(c, o1, ACT_RELU, nullptr, /*plane_only=*/cfg.bf16 && !o1->needs_grad);   // (forward-only graph: res2 stages the plane)
-    c.feeds_in = true;
+    // E_norm = 'batch' (encoder.py:67 through conv.py:70-85): BatchNorm in both halves of the block
+    o1 = cfg.e_bn ? block_bn(c, o1, b + "/res1", ACT_RELU, c.bn_times_block)
+                  : in_act(c, o1, ACT_RELU, nullptr, /*plane_only=*/cfg.bf16 && !o1->needs_grad);   // (forward-only graph: res2 stages the plane)
+    c.feeds_in = !cfg.e_bn;
     T o2 = conv2d(c, o1, wref_param(c, P(c, b + "/res2/conv2d/w"), 9, n, n), P(c, b + "/res2/conv2d/b"), 3, 1,
                   PAD_REFLECT);
-    o2 = in_act(c, o2, ACT_NONE);
+    o2 = cfg.e_bn ? block_bn(c, o2, b + "/res2", ACT_NONE, c.bn_times_block) : in_act(c, o2, ACT_NONE);
     if (c.infer_side >= 0) {
       use_lane(c, c.infer_side);
       EG_HIP(hipStreamWaitEvent(c.stream, c.ev_infer[main_lane], 0));
@@ -722,19 +759,34 @@ static void disc_substep(Ctx& c, int group, T real, T fake, const float* alpha_d
   float* v = c.arena.allocf(xhat->numel());
   float* norms = c.arena.allocf(B);
   launch_gp_v(g, v, norms, c.d_losses + slot_gp, B, per, cfg.lambda_gp, c.stream);
-  // --- real / fake pass (stacked 2B) ---
-  T rf = new_tensor(c, 2 * B, real->h, real->w, real->c, false);
-  launch_copy(real->d, rf->d, real->numel(), c.stream);
-  launch_copy(fake->d, rf->d + real->numel(), fake->numel(), c.stream);
-  T d_rf = disc_forward(c, group, rf, nullptr, nullptr);
-  launch_mean_diff(d_rf->d + B, d_rf->d, c.d_losses + slot_d, B, c.stream);
+  // --- real / fake pass (stacked 2B; D_norm = 'batch': two evaluations of B rows -- the reference calls the discriminator on
+  //     each input separately, edgegan.py:236-262, and BatchNorm's statistics are per call) ---
+  T d_rf = nullptr, d_real = nullptr, d_fake = nullptr;
+  if (cfg.d_bn) {
+    d_real = disc_forward(c, group, real, nullptr, nullptr);
+    d_fake = disc_forward(c, group, fake, nullptr, nullptr);
+    launch_mean_diff(d_fake->d, d_real->d, c.d_losses + slot_d, B, c.stream);
+  } else {
+    T rf = new_tensor(c, 2 * B, real->h, real->w, real->c, false);
+    launch_copy(real->d, rf->d, real->numel(), c.stream);
+    launch_copy(fake->d, rf->d + real->numel(), fake->numel(), c.stream);
+    d_rf = disc_forward(c, group, rf, nullptr, nullptr);
+    launch_mean_diff(d_rf->d + B, d_rf->d, c.d_losses + slot_d, B, c.stream);
+  }
   // --- tangent pass along v ---
   T tv = wrap_tensor(c, v, B, real->h, real->w, real->c);
   T td = disc_forward(c, group, tv, nullptr, &sv);
   // --- seeds and the single reverse sweep ---
-  seed_grad(c, d_rf);
-  launch_fill(d_rf->g, -1.f / B, B, c.stream);
-  launch_fill(d_rf->g + B, 1.f / B, B, c.stream);
+  if (cfg.d_bn) {
+    seed_grad(c, d_real);
+    launch_fill(d_real->g, -1.f / B, B, c.stream);
+    seed_grad(c, d_fake);
+    launch_fill(d_fake->g, 1.f / B, B, c.stream);
+  } else {
+    seed_grad(c, d_rf);
+    launch_fill(d_rf->g, -1.f / B, B, c.stream);
+    launch_fill(d_rf->g + B, 1.f / B, B, c.stream);
+  }
   seed_grad(c, d_hat);
   seed_grad(c, td);
   launch_gp_head(d_hat->d, td->d, d_hat->g, td->g, B, 1, c.stream);
@@ -964,7 +1016,8 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
 // discriminator sub-step test of tests/test_step_gpu.py / test_tight_gpu.py / test_x3_gpu.py / test_bf16_gpu.py runs it.
 static void d_substep(Ctx& c, int group, T real, T fake, const float* alpha_dev, int slot_d, int slot_gp, bool apply) {
   static const bool tape_form = dbg_env("EG_D_TAPE") != nullptr;
-  if (tape_form) disc_substep(c, group, real, fake, alpha_dev, slot_d, slot_gp, apply);
+  // (D_norm = 'batch': the tape form -- the stacked sweep's row classes are InstanceNorm's, and BatchNorm couples the rows of a call)
+  if (tape_form || c.cfg.d_bn) disc_substep(c, group, real, fake, alpha_dev, slot_d, slot_gp, apply);
   else disc_substep_stacked(c, group, real, fake, alpha_dev, slot_d, slot_gp, apply);
 }
 
@@ -976,17 +1029,25 @@ static T generator_output_nograd(Ctx& c, int group, T zin, int bn_t) {
   const int i = group == G_G1 ? 0 : 1;
   const std::string p = kGroupPrefix[group];
   const int C = cfg.gf * 8, R = cfg.B * (cfg.H / 16) * (cfg.W / 2 / 16);
+  const int bch[3] = {cfg.gf * 4, cfg.gf * 2, cfg.gf};   // G_norm = 'batch': the block norms of g_dconv_1 .. 3
   if (c.gen_cache_valid[i]) {
-    if (bn_t > 0)
+    if (bn_t > 0) {
       launch_bn_moving_update(P(c, p + "/batch_norm/BatchNorm/moving_mean")->w,
                               P(c, p + "/batch_norm/BatchNorm/moving_variance")->w, c.d_gen_bn[i], C, R, 0.9f, bn_t,
                               c.stream);
+      for (int j = 0; cfg.g_bn && j < 3; ++j) {
+        const std::string b = p + "/g_dconv_" + std::to_string(j + 1) + "/batch_norm/BatchNorm/";
+        launch_bn_moving_update(P(c, b + "moving_mean")->w, P(c, b + "moving_variance")->w, c.d_gen_bn_blk[i][j], bch[j],
+                                R << (2 * (j + 1)), 0.9f, bn_t, c.stream);
+      }
+    }
     return wrap_tensor(c, c.d_gen_cache[i], cfg.B, cfg.H, cfg.W / 2, cfg.c_dim);
   }
   T st = nullptr;
   T out = generator_forward(c, group, zin, bn_t, &st, c.d_gen_cache[i]);   // (forward-only: the last layer stores tanh(y) straight into the cache)
   if (out->d != c.d_gen_cache[i]) launch_copy(out->d, c.d_gen_cache[i], out->numel(), c.stream);
   launch_copy(st->d, c.d_gen_bn[i], (size_t)2 * C, c.stream);
+  for (int j = 0; cfg.g_bn && j < 3; ++j) launch_copy(c.gen_blk_stats[j]->d, c.d_gen_bn_blk[i][j], (size_t)2 * bch[j], c.stream);
   c.gen_cache_valid[i] = true;
   return out;
 }
@@ -1020,6 +1081,7 @@ void run_substep(Ctx& c, int k, bool apply, const SubOpts* opts) {
   // contrib batch_norm updates its moving statistics whenever a generator forward is evaluated in a
   // training run (updates_collections=None); gradient-only probes (apply=false) leave them alone.
   const int bn_t = apply ? 1 : 0;
+  c.bn_times_block = bn_t;   // (E_norm / D_norm = 'batch': a block norm advances its moving statistics once per evaluation)
   const int bn1 = (opts && opts->bn_times_g1 >= 0) ? opts->bn_times_g1 : bn_t;   // G1 / G2 moving-statistics updates
   const int bn2 = (opts && opts->bn_times_g2 >= 0) ? opts->bn_times_g2 : bn_t;
   auto await_group = [&](int g) {   // see SubOpts::wait_for_group
@@ -1325,6 +1387,7 @@ void eval_losses(Ctx& c, const float* alpha_dev, const float* eps_dev, int bn_up
   for (int g = 0; g < G_COUNT; ++g) set_want_grad(c, g, false);
   T images = wrap_tensor(c, c.d_images, B, cfg.H, cfg.W, cfg.c_dim);
   T zin = make_zin(c);
+  c.bn_times_block = bn_updates;
   T edge = generator_forward(c, G_G1, zin, bn_updates);
   T image = generator_forward(c, G_G2, zin, bn_updates);
   T joint = concat_w(c, edge, image);
@@ -1357,6 +1420,14 @@ void eval_losses(Ctx& c, const float* alpha_dev, const float* eps_dev, int bn_up
     launch_gp_v(xhat->g, v, norms, L + b.slot_gp, B, per, cfg.lambda_gp, c.stream);
     c.tape.ops.resize(mark);
     reset_grads(c);
+    if (cfg.d_bn) {   // (BatchNorm statistics are per call: real and fake are two evaluations)
+      T d_real = disc_forward(c, b.group, b.real, nullptr, nullptr), d_fake = disc_forward(c, b.group, b.fake, nullptr, nullptr);
+      launch_mean_diff(d_fake->d, d_real->d, L + b.slot_d, B, c.stream);
+      launch_mean_neg(d_fake->d, L + b.slot_g, B, c.stream);
+      launch_copy(d_real->d, c.d_eval + 16 + (size_t)i * 2 * B, (size_t)B, c.stream);   // logits: real [B] | fake [B]
+      launch_copy(d_fake->d, c.d_eval + 16 + (size_t)i * 2 * B + B, (size_t)B, c.stream);
+      continue;
+    }
     T rf = new_tensor(c, 2 * B, b.real->h, b.real->w, b.real->c, false);
     launch_copy(b.real->d, rf->d, b.real->numel(), c.stream);
     launch_copy(b.fake->d, rf->d + b.real->numel(), b.fake->numel(), c.stream);
@@ -1395,6 +1466,7 @@ void infer(Ctx& c, const float* d_images, const int* d_classes, int NB, const fl
            float* d_image, int main_lane, int side_lane) {
   const Config& cfg = c.cfg;
   comm_wait_all(c);
+  c.bn_times_block = 0;   // (the test graph's moving-average updates are never saved: edgegan.py:492-517)
   const bool two = c.lanes_on && !c.prof_on && side_lane >= 0 && side_lane != main_lane;
   if (c.prof_on || !c.lanes_on) main_lane = 0;
   ensure_lane(c, main_lane);

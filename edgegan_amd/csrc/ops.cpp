@@ -1499,6 +1499,58 @@ T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int upda
   return out;
 }
 
+// normalization.py:19-25 as the norm of a conv_block / deconv_block / residual (E_norm / G_norm / D_norm = 'batch'): contrib
+// batch_norm over all rows of this evaluation, learned scale / shift, then the block's activation.  fp32 in every mode (a
+// plane-fed consumer converts for itself: tensor_plane).  stats_out: [mean | var] for the tangent pass.
+T bn_act(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int a, int update_times, T* stats_out) {
+  const int C = x->c, R = (int)x->pixels();
+  need_f32(c, x);
+  T out = new_tensor(c, x->n, x->h, x->w, C, true);
+  T st = new_tensor(c, 1, 1, 1, 2 * C, false);
+  launch_bn_act_fwd(x->d, gamma->w, beta->w, out->d, st->d, c.arena.allocf(bn_scratch_floats(R, C)), mm ? mm->w : nullptr,
+                    mv ? mv->w : nullptr, update_times, R, C, 1e-5f, a, c.stream);
+  if (stats_out) *stats_out = st;
+  const bool need = x->needs_grad || gamma->want_grad;
+  out->needs_grad = need;
+  if (need) {
+    Ctx* cp = &c;
+    c.tape.push([=]() {
+      Ctx& c = *cp;
+      if (!out->g_set) return;
+      float* dx = nullptr;
+      int acc = 0;
+      if (x->needs_grad) dx = grad_acc(c, x, &acc);
+      const bool pg = c.param_grad_enabled && gamma->want_grad;
+      launch_bn_act_bwd(x->d, out->d, out->g, gamma->w, st->d, c.arena.allocf(bn_scratch_floats(R, C)), dx, acc, pg ? gamma->g : nullptr,
+                        gamma->g_set ? 1 : 0, pg ? beta->g : nullptr, beta->g_set ? 1 : 0, R, C, 1e-5f, a, c.stream);
+      if (pg) gamma->g_set = beta->g_set = true;
+    });
+  }
+  return out;
+}
+
+// forward-mode tangent of bn_act at the primal (x_prim, out_prim, stats_prim); its reverse yields the gradients w.r.t. the
+// tangent, the primal input and gamma (the gradient penalty through a BatchNorm discriminator)
+T bn_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, Param* gamma, int a) {
+  const int C = tx->c, R = (int)tx->pixels();
+  T tout = new_tensor(c, tx->n, tx->h, tx->w, C, true);
+  launch_bn_act_tangent_fwd(x_prim->d, out_prim->d, gamma->w, stats_prim->d, tx->d, tout->d, c.arena.allocf(bn_scratch_floats(R, C)), R, C,
+                            1e-5f, a, c.stream);
+  Ctx* cp = &c;
+  c.tape.push([=]() {
+    Ctx& c = *cp;
+    if (!tout->g_set) return;
+    int acc_t, acc_x;
+    float* dtx = grad_acc(c, tx, &acc_t);
+    float* dx = grad_acc(c, x_prim, &acc_x);
+    const bool pg = c.param_grad_enabled && gamma->want_grad;
+    launch_bn_act_tangent_bwd(x_prim->d, out_prim->d, gamma->w, stats_prim->d, tx->d, tout->g, c.arena.allocf(bn_scratch_floats(R, C)), dtx,
+                              acc_t, dx, acc_x, pg ? gamma->g : nullptr, gamma->g_set ? 1 : 0, R, C, 1e-5f, a, c.stream);
+    if (pg) gamma->g_set = true;
+  });
+  return tout;
+}
+
 T add(Ctx& c, T a, T b, bool relu) {
   T out = new_tensor(c, a->n, a->h, a->w, a->c, a->needs_grad || b->needs_grad);
   launch_add(a->d, b->d, out->d, relu ? 1 : 0, a->numel(), c.stream);
@@ -2079,6 +2131,7 @@ Ctx::~Ctx() {
   for (int i = 0; i < 2; ++i) {
     (void)hipFree(d_gen_cache[i]);
     (void)hipFree(d_gen_bn[i]);
+    for (int j = 0; j < 3; ++j) (void)hipFree(d_gen_bn_blk[i][j]);
   }
   // the context's own stream / scratch are lane 0's; make them the active ones again before freeing
   if (lanes[0].stream) stream = lanes[0].stream;

@@ -3,7 +3,7 @@
 Accepted syntax is absl's: ``--name=value``, ``--name value``, booleans as ``--flag`` / ``--noflag`` /
 ``--flag=true|false``.  Flags the reference defines but never reads (test.py's ``type``, ``optim``, ``model``) are
 accepted for command-line compatibility; flags selecting graph variants outside the hot path
-(``if_resnet_g/d``, ``if_resnet_e=False``, non-instance norms) are rejected loudly."""
+(``if_resnet_g/d``, ``if_resnet_e=False``) are rejected loudly; E_norm / G_norm / D_norm take 'instance' or 'batch'."""
 from __future__ import annotations
 
 import math
@@ -87,7 +87,8 @@ def check_supported(flags: SimpleNamespace):
     bad = []
     if flags.if_resnet_g or flags.if_resnet_d or not flags.if_resnet_e:
         bad.append('if_resnet_g / if_resnet_d / if_resnet_e must keep their defaults (False, False, True)')
-    if (flags.E_norm, flags.G_norm, flags.D_norm) != ('instance', 'instance', 'instance'):
-        bad.append('E_norm / G_norm / D_norm must be "instance"')
+    for nm in ('E_norm', 'G_norm', 'D_norm'):   # normalization.py:12: 'instance' | 'batch' (None is not reachable from a string flag)
+        if getattr(flags, nm) not in ('instance', 'batch'):
+            bad.append(f'{nm} must be "instance" or "batch"')
     if bad:
         raise SystemExit('unsupported flag combination:\n  ' + '\n  '.join(bad))

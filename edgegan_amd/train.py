@@ -47,7 +47,8 @@ def engine_config(fl, device: int) -> Config:
                   lambda_gp=getattr(fl, 'lambda_gp', 10.0), zl_weight=getattr(fl, 'stage1_zl_loss', 10.0),
                   learning_rate=fl.learning_rate, joint_dweight=getattr(fl, 'joint_dweight', 1.0),
                   image_dweight=getattr(fl, 'image_dweight', 1.0), edge_dweight=getattr(fl, 'edge_dweight', 1.0),
-                  device=device)
+                  device=device, E_norm=getattr(fl, 'E_norm', 'instance'), G_norm=getattr(fl, 'G_norm', 'instance'),
+                  D_norm=getattr(fl, 'D_norm', 'instance'))
 
 
 def epoch_permutation(n: int, seed: int, epoch: int) -> np.ndarray:

@@ -239,6 +239,9 @@ class Config:
     use_edge_discriminator: bool = True      # train.py:65-66
     image_dis_size: Optional[int] = None     # train.py:63-64
     edge_dis_size: Optional[int] = None      # train.py:67
+    E_norm: str = 'instance'                 # train.py:54-59: 'instance' | 'batch' (normalization.py:10-29)
+    G_norm: str = 'instance'
+    D_norm: str = 'instance'
 
     @property
     def image_dis(self) -> int:
@@ -349,6 +352,24 @@ def norm(x: Tensor, kind: Optional[str]) -> Tensor:
         return instance_norm(x)
     assert kind is None
     return x
+
+
+def _bn_specs(scope: str, c: int):
+    """The variables contrib batch_norm creates under `<scope>/batch_norm` (normalization.py:20-25)."""
+    return [VarSpec(f'{scope}/batch_norm/BatchNorm/beta', (c,), True, 'const:0'),
+            VarSpec(f'{scope}/batch_norm/BatchNorm/gamma', (c,), True, 'const:1'),
+            VarSpec(f'{scope}/batch_norm/BatchNorm/moving_mean', (c,), False, 'const:0'),
+            VarSpec(f'{scope}/batch_norm/BatchNorm/moving_variance', (c,), False, 'const:1')]
+
+
+def block_norm(p, scope: str, x: Tensor, kind: Optional[str]) -> Tensor:
+    """`_norm(out, is_train, norm)` inside conv_block / deconv_block / residual (conv.py:65,75,80,128): 'instance', or 'batch'
+    = contrib batch_norm over ALL rows of this call with the block's own beta / gamma (normalization.py:19-25; the moving
+    statistics never enter a result: is_training=True)."""
+    if kind == 'batch':
+        y, _, _ = batch_norm_train(x, p[f'{scope}/batch_norm/BatchNorm/gamma'], p[f'{scope}/batch_norm/BatchNorm/beta'])
+        return y
+    return norm(x, kind)
 
 
 # Test instrumentation (tests/test_tight_gpu.py): when a dict, every PReLU records sum_i |t_i| of the per-element terms
@@ -506,6 +527,8 @@ def generator_specs(prefix: str, cfg: Config) -> List[VarSpec]:
     for i in range(1, 5):
         v.append(VarSpec(f'{prefix}/g_dconv_{i}/deconv2d/w', (5, 5, chans[i], chans[i - 1]), True, 'normal:0.02'))
         v.append(VarSpec(f'{prefix}/g_dconv_{i}/deconv2d/b', (chans[i],), True, 'const:0'))
+        if cfg.G_norm == 'batch' and i < 4:
+            v += _bn_specs(f'{prefix}/g_dconv_{i}', chans[i])
     return v
 
 
@@ -518,6 +541,8 @@ def discriminator_specs(prefix: str, cfg: Config, in_h: int, in_w: int) -> List[
     h, w = in_h, in_w
     for i, n in enumerate(names):
         v.append(VarSpec(f'{prefix}/{n}/conv2d/w', (4, 4, chans[i], chans[i + 1]), True, 'trunc:0.02'))
+        if cfg.D_norm == 'batch' and i > 0:
+            v += _bn_specs(f'{prefix}/{n}', chans[i + 1])
         h, w = _ceil_half(h), _ceil_half(w)
     v.append(VarSpec(f'{prefix}/d_linear_5/Matrix', (h * w * chans[-1], 1), True, 'normal:0.02'))
     v.append(VarSpec(f'{prefix}/d_linear_5/bias', (1,), True, 'const:0'))
@@ -538,10 +563,11 @@ def encoder_specs(cfg: Config) -> List[VarSpec]:
     cin = 64
     for i, n in enumerate(encoder_filters(cfg)):
         base = f'E/e_resnet_{n}_{i + 1}'
+        bn = cfg.E_norm == 'batch'
         v += [VarSpec(f'{base}/res1/conv2d/w', (3, 3, cin, n), True, 'trunc:0.02'),
-              VarSpec(f'{base}/res1/conv2d/b', (n,), True, 'const:0'),
+              VarSpec(f'{base}/res1/conv2d/b', (n,), True, 'const:0')] + (_bn_specs(f'{base}/res1', n) if bn else []) + [
               VarSpec(f'{base}/res2/conv2d/w', (3, 3, n, n), True, 'trunc:0.02'),
-              VarSpec(f'{base}/res2/conv2d/b', (n,), True, 'const:0'),
+              VarSpec(f'{base}/res2/conv2d/b', (n,), True, 'const:0')] + (_bn_specs(f'{base}/res2', n) if bn else []) + [
               VarSpec(f'{base}/shortcut/conv2d/w', (1, 1, cin, n), True, 'trunc:0.02'),
               VarSpec(f'{base}/shortcut/conv2d/b', (n,), True, 'const:0')]
         cin = n
@@ -629,29 +655,29 @@ def generator(p: P, prefix: str, z: Tensor, cfg: Config, bn_stats: Optional[list
         x = deconv2d(x, p[f'{prefix}/g_dconv_{i}/deconv2d/w'], p[f'{prefix}/g_dconv_{i}/deconv2d/b'],
                      sizes[4 - i])
         if i < 4:
-            x = relu(instance_norm(x))
+            x = relu(block_norm(p, f'{prefix}/g_dconv_{i}', x, cfg.G_norm))
     return torch.tanh(x)
 
 
-def discriminator(p: P, prefix: str, x: Tensor) -> Tuple[Tensor, Tensor]:
-    """edgegan/models/discriminator.py:58-81: returns (sigmoid(D), D)."""
+def discriminator(p: P, prefix: str, x: Tensor, norm_kind: str = 'instance') -> Tuple[Tensor, Tensor]:
+    """edgegan/models/discriminator.py:58-81: returns (sigmoid(D), D).  norm_kind = D_norm (train.py:58-59)."""
     names = ['d_conv_0', 'd_conv_1', 'd_conv_3', 'd_conv_4']
     for i, n in enumerate(names):
         x = conv2d(x, p[f'{prefix}/{n}/conv2d/w'], 2, 'SAME')
         if i > 0:
-            x = instance_norm(x)
+            x = block_norm(p, f'{prefix}/{n}', x, norm_kind)
         x = activation(x, 'lrelu')
     x = x.reshape(x.shape[0], -1)
     d = linear(x, p[f'{prefix}/d_linear_5/Matrix'], p[f'{prefix}/d_linear_5/bias'])
     return torch.sigmoid(d), d
 
 
-def residual(p: P, base: str, x: Tensor) -> Tensor:
-    """edgegan/nn/modules/conv.py:70-85 with norm='instance', pad='REFLECT', bias=True."""
+def residual(p: P, base: str, x: Tensor, norm_kind: str = 'instance') -> Tensor:
+    """edgegan/nn/modules/conv.py:70-85 with norm = E_norm ('instance' by default), pad='REFLECT', bias=True."""
     out = conv2d(x, p[f'{base}/res1/conv2d/w'], 1, 'REFLECT', p[f'{base}/res1/conv2d/b'])
-    out = relu(instance_norm(out))
+    out = relu(block_norm(p, f'{base}/res1', out, norm_kind))
     out = conv2d(out, p[f'{base}/res2/conv2d/w'], 1, 'REFLECT', p[f'{base}/res2/conv2d/b'])
-    out = instance_norm(out)
+    out = block_norm(p, f'{base}/res2', out, norm_kind)
     sc = conv2d(x, p[f'{base}/shortcut/conv2d/w'], 1, 'REFLECT', p[f'{base}/shortcut/conv2d/b'])
     return relu(sc + out)
 
@@ -662,7 +688,7 @@ def encoder(p: P, x: Tensor, eps, cfg: Config) -> Tuple[Tensor, Tensor, Tensor]:
     E = conv2d(x, p['E/e_resnet_64_0/conv2d/w'], 2, 'SAME', p['E/e_resnet_64_0/conv2d/b'])
     E = relu(E)
     for i, n in enumerate(encoder_filters(cfg)):
-        E = residual(p, f'E/e_resnet_{n}_{i + 1}', E)
+        E = residual(p, f'E/e_resnet_{n}_{i + 1}', E, cfg.E_norm)
         E = avg_pool2(E)
     E = relu(E)
     E = avg_pool_same(E, 8)
@@ -758,7 +784,7 @@ def acgan_loss_focal(real_logits: Tensor, labels: Tensor, fake_logits: Tensor,
 
 
 def gradient_penalty_term(p: P, prefix: str, synthesized: Tensor, real: Tensor, alpha: Tensor,
-                          weight: float) -> Tensor:
+                          weight: float, norm_kind: str = 'instance') -> Tensor:
     """edgegan/models/edgegan.py:32-42 (`random_blend`, `penalty`) + functional.py:26-29.
 
     Quirk N10 (found while restating; not in SURVEY): `penalty` passes the discriminator's whole
@@ -769,7 +795,7 @@ def gradient_penalty_term(p: P, prefix: str, synthesized: Tensor, real: Tensor, 
     inter = real + a * (synthesized - real)                         # b + alpha*(a-b), edgegan.py:35
     if not inter.requires_grad:
         inter = inter.detach().requires_grad_(True)
-    sig, logit = discriminator(p, prefix, inter)
+    sig, logit = discriminator(p, prefix, inter, norm_kind)
     g, = torch.autograd.grad(sig.sum() + logit.sum(), inter, create_graph=True)
     grad_l2 = torch.sqrt(torch.sum(g ** 2, dim=(1, 2, 3)))
     return weight * torch.mean((grad_l2 - 1) ** 2)
@@ -834,27 +860,27 @@ def forward_graph(p: P, inp: StepInputs, cfg: Config, eps_val, bn_stats=None, wa
     edge = lambda: gen('G1')
     image = lambda: gen('G2')
     joint = lambda: once('joint', lambda: torch.cat([edge(), image()], dim=2))
-    d_fake = lambda: once('d_fake', lambda: discriminator(p, 'D', joint())[1])
+    d_fake = lambda: once('d_fake', lambda: discriminator(p, 'D', joint(), cfg.D_norm)[1])
     r_pic = lambda: once('r_pic', lambda: resize_bicubic(real_pic, cfg.image_dis))
     r_img = lambda: once('r_img', lambda: resize_bicubic(image(), cfg.image_dis))
-    di_fake = lambda: once('di_fake', lambda: discriminator(p, 'D_patch2', r_img())[1])
+    di_fake = lambda: once('di_fake', lambda: discriminator(p, 'D_patch2', r_img(), cfg.D_norm)[1])
     r_edges = lambda: once('r_edges', lambda: resize_bicubic(real_edge, cfg.edge_dis))
     r_edge_out = lambda: once('r_edge_out', lambda: resize_bicubic(edge(), cfg.edge_dis))
-    de_fake = lambda: once('de_fake', lambda: discriminator(p, 'D_patch3', r_edge_out())[1])
+    de_fake = lambda: once('de_fake', lambda: discriminator(p, 'D_patch3', r_edge_out(), cfg.D_norm)[1])
     joint_g = lambda: once('joint_g', lambda: generator_ganloss(d_fake()))
 
     if 'joint_dis_dloss' in want:
-        _, d_real = discriminator(p, 'D', real)
+        _, d_real = discriminator(p, 'D', real, cfg.D_norm)
         out['joint_dis_dloss'] = discriminator_ganloss(d_fake(), d_real) + gradient_penalty_term(
-            p, 'D', joint(), real, inp.alpha[0], cfg.lambda_gp)
+            p, 'D', joint(), real, inp.alpha[0], cfg.lambda_gp, cfg.D_norm)
     if 'image_dis_dloss' in want and cfg.use_image_discriminator:    # edgegan.py:288-301 (else: the constant 0)
-        _, di_real = discriminator(p, 'D_patch2', r_pic())
+        _, di_real = discriminator(p, 'D_patch2', r_pic(), cfg.D_norm)
         out['image_dis_dloss'] = discriminator_ganloss(di_fake(), di_real) + gradient_penalty_term(
-            p, 'D_patch2', r_img(), r_pic(), inp.alpha[1], cfg.lambda_gp)
+            p, 'D_patch2', r_img(), r_pic(), inp.alpha[1], cfg.lambda_gp, cfg.D_norm)
     if 'edge_dis_dloss' in want and cfg.use_edge_discriminator:      # edgegan.py:303-311
-        _, de_real = discriminator(p, 'D_patch3', r_edges())
+        _, de_real = discriminator(p, 'D_patch3', r_edges(), cfg.D_norm)
         out['edge_dis_dloss'] = discriminator_ganloss(de_fake(), de_real) + gradient_penalty_term(
-            p, 'D_patch3', r_edge_out(), r_edges(), inp.alpha[2], cfg.lambda_gp)
+            p, 'D_patch3', r_edge_out(), r_edges(), inp.alpha[2], cfg.lambda_gp, cfg.D_norm)
     if 'edge_gloss' in want:
         out['joint_dis_gloss'] = joint_g()
         out['edge_dis_gloss'] = generator_ganloss(de_fake()) if cfg.use_edge_discriminator else torch.zeros((), dtype=real.dtype)

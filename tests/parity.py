@@ -49,7 +49,8 @@ def oracle_config(cfg: ea.Config) -> O.Config:
                     lambda_gp=cfg.lambda_gp, zl_weight=cfg.zl_weight, learning_rate=cfg.learning_rate,
                     joint_dweight=cfg.joint_dweight, image_dweight=cfg.image_dweight, edge_dweight=cfg.edge_dweight,
                     use_image_discriminator=cfg.use_image_discriminator, use_edge_discriminator=cfg.use_edge_discriminator,
-                    image_dis_size=cfg.image_dis_size, edge_dis_size=cfg.edge_dis_size)
+                    image_dis_size=cfg.image_dis_size, edge_dis_size=cfg.edge_dis_size,
+                    E_norm=cfg.E_norm, G_norm=cfg.G_norm, D_norm=cfg.D_norm)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -219,6 +220,47 @@ def check_in_tangent(net, act=2, shape=(2, 8, 8, 64), seed=3):
             (f'in_tangent[{ACTS[act]} {shape}] dx_primal', relerr(dx, gx.numpy()), BWD_TOL)]
 
 
+def _bn_block(x, g, b, act):
+    return O.activation(O.batch_norm_train(x, g, b)[0], ACTS[act])
+
+
+def check_bn_act(net, act=2, shape=(3, 8, 8, 64), seed=6):
+    """The block norm of E_norm / G_norm / D_norm = 'batch' (normalization.py:19-25) + activation: forward, dx, dgamma, dbeta.
+    The shapes cross the kernels' 256-row chunks (R = 192 .. 4,608 rows) and leave partial 64-channel groups."""
+    rng = np.random.RandomState(seed)
+    x = (rng.normal(size=shape) * 1.3 + 0.4).astype(np.float32)
+    g = (1.0 + 0.3 * rng.normal(size=shape[-1])).astype(np.float32)
+    b = (0.2 * rng.normal(size=shape[-1])).astype(np.float32)
+    dy = rng.normal(size=shape).astype(np.float32)
+    xt, gt, bt = t64(x, True), t64(g, True), t64(b, True)
+    yr = _bn_block(xt, gt, bt, act)
+    gr = torch.autograd.grad((yr * t64(dy)).sum(), [xt, gt, bt])
+    y, dx, dg, db = net.test_op('bn_act', [x, g, b, dy], list(shape) + [act], [shape, shape, g.shape, b.shape])
+    tag = f'bn_act[{ACTS[act]} {shape}]'
+    return [(f'{tag} y', relerr(y, yr.detach().numpy()), FWD_TOL), (f'{tag} dx', relerr(dx, gr[0].numpy()), BWD_TOL),
+            (f'{tag} dgamma', relerr(dg, gr[1].numpy()), BWD_TOL), (f'{tag} dbeta', relerr(db, gr[2].numpy()), BWD_TOL)]
+
+
+def check_bn_tangent(net, act=2, shape=(3, 8, 8, 64), seed=7):
+    """Forward-mode tangent of BatchNorm + activation and its reverse (the gradient penalty through a D_norm = 'batch'
+    discriminator): ty, and the gradients of <dty, ty> w.r.t. the tangent, the primal input and gamma against autograd's
+    double backward of the same formula."""
+    rng = np.random.RandomState(seed)
+    x = (rng.normal(size=shape) * 1.3 + 0.4).astype(np.float32)
+    g = (1.0 + 0.3 * rng.normal(size=shape[-1])).astype(np.float32)
+    b = (0.2 * rng.normal(size=shape[-1])).astype(np.float32)
+    tx = rng.normal(size=shape).astype(np.float32)
+    dty = rng.normal(size=shape).astype(np.float32)
+    xt, gt, bt, txt = t64(x, True), t64(g, True), t64(b, True), t64(tx, True)
+    yr, tyr = torch.autograd.functional.jvp(lambda u: _bn_block(u, gt, bt, act), (xt,), (txt,), create_graph=True)
+    gx, gtx, gg = torch.autograd.grad((tyr * t64(dty)).sum(), [xt, txt, gt])
+    y, ty, dtx, dx, dg = net.test_op('bn_tangent', [x, g, b, tx, dty], list(shape) + [act], [shape] * 4 + [g.shape])
+    tag = f'bn_tangent[{ACTS[act]} {shape}]'
+    return [(f'{tag} y', relerr(y, yr.detach().numpy()), FWD_TOL), (f'{tag} ty', relerr(ty, tyr.detach().numpy()), FWD_TOL),
+            (f'{tag} dtx', relerr(dtx, gtx.numpy()), BWD_TOL), (f'{tag} dx_primal', relerr(dx, gx.numpy()), BWD_TOL),
+            (f'{tag} dgamma', relerr(dg, gg.numpy()), BWD_TOL)]
+
+
 def check_simple(net, op, shape, extra, ref_fn, seed=4, positive=False):
     rng = np.random.RandomState(seed)
     x = rng.normal(size=shape).astype(np.float32)
@@ -359,6 +401,10 @@ def all_op_checks(net):
         return (t - mn) / (mx - mn)
     rows += check_simple(net, 'minmax', (2, 8, 8, 40), 0, mm)
     rows += check_bn(net)
+    for act, shape in ((1, (3, 8, 8, 64)), (2, (2, 16, 32, 128)), (0, (3, 24, 16, 96)), (2, (64, 4, 8, 512)), (1, (2, 3, 32, 40))):
+        rows += check_bn_act(net, act, shape)
+    for act, shape in ((2, (3, 8, 8, 64)), (2, (2, 16, 32, 128)), (2, (5, 16, 16, 256)), (1, (2, 3, 32, 40))):
+        rows += check_bn_tangent(net, act, shape)
     rows += check_prelu(net)
     rows += check_gate(net)
     rows += check_linear1(net)

@@ -52,6 +52,29 @@ def test_registry_non_default_discriminator_flags(built_lib, flags):
         assert names['D_patch2/d_linear_5/Matrix'] == (4 * 4 * 512, 1) and names['D_patch3/d_linear_5/Matrix'] == (16 * 16 * 512, 1)
 
 
+@pytest.mark.parametrize('flags', [dict(G_norm='batch'), dict(E_norm='batch'), dict(D_norm='batch'),
+                                   dict(E_norm='batch', G_norm='batch', D_norm='batch', num_classes=0)])
+def test_registry_batch_norm_flags(built_lib, flags):
+    """edgegan/train.py:54-59 E_norm / G_norm / D_norm = 'batch' (nn/modules/normalization.py:19-25): every normalised block
+    gains contrib batch_norm's four variables under <block>/batch_norm/BatchNorm -- the generators' g_dconv_1..3
+    (generator.py:54-68), the discriminators' d_conv_1, d_conv_3, d_conv_4 (discriminator.py:63-72; d_conv_0 has norm=None),
+    both halves of every residual block of the encoder (encoder.py:67, conv.py:73-80); beta / gamma trainable."""
+    cfg = ea.Config(batch_size=2, **flags)
+    got = [(s.name, tuple(s.shape), s.trainable) for s in ea.variable_specs(cfg)]
+    want = [(s.name, tuple(s.shape), s.trainable) for s in O.variable_specs(O.Config(batch_size=2, **flags))]
+    assert got == want
+    names = {n: (sh, tr) for n, sh, tr in got}
+    assert ('G1/g_dconv_2/batch_norm/BatchNorm/gamma' in names) == (cfg.G_norm == 'batch')
+    assert ('D_patch2/d_conv_3/batch_norm/BatchNorm/beta' in names) == (cfg.D_norm == 'batch')
+    assert 'D/d_conv_0/batch_norm/BatchNorm/beta' not in names and 'G1/g_dconv_4/batch_norm/BatchNorm/beta' not in names
+    assert ('E/e_resnet_256_2/res2/batch_norm/BatchNorm/moving_variance' in names) == (cfg.E_norm == 'batch')
+    if cfg.G_norm == 'batch':
+        assert names['G2/g_dconv_1/batch_norm/BatchNorm/gamma'] == ((256,), True)
+        assert names['G2/g_dconv_1/batch_norm/BatchNorm/moving_mean'] == ((256,), False)
+    with pytest.raises(KeyError):
+        ea.Config(G_norm='layer').to_c()
+
+
 def test_config_struct_is_versioned(built_lib):
     """eg_config starts with struct_size (include/edgegan_hip.h): eg_default_config writes the library's sizeof, the Python
     binding's ctypes layout has the same size, and a caller with another layout is refused instead of being read shifted."""

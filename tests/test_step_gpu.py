@@ -105,6 +105,51 @@ def test_substeps_non_default_discriminator_flags(flags):
     net.close()
 
 
+@pytest.mark.parametrize('flags', [dict(G_norm='batch'), dict(E_norm='batch'), dict(D_norm='batch'),
+                                   dict(E_norm='batch', G_norm='batch', D_norm='batch', num_classes=0)],
+                         ids=['G_batch', 'E_batch', 'D_batch', 'all_batch_single_class'])
+def test_substeps_batch_norm_flags(flags):
+    """E_norm / G_norm / D_norm = 'batch' (edgegan/train.py:54-59, nn/modules/normalization.py:19-25): contrib batch_norm with
+    learned scale / shift in the encoder's residual blocks, the generators' transposed-convolution blocks and blocks 2 - 4 of
+    the three discriminators -- there including its forward tangent and the reverse of that tangent, which the gradient
+    penalty's second derivative runs through (functional.py:26-29).  Every sub-step against the fp64 oracle (autograd's
+    double backward through torch's own arithmetic of the same formula), gradients of beta / gamma included; then a whole
+    concurrent iteration and the post-update evaluation."""
+    cfg = ea.Config(batch_size=3, **flags)
+    names = {s.name for s in ea.variable_specs(cfg)}
+    assert ('G1/g_dconv_1/batch_norm/BatchNorm/gamma' in names) == (cfg.G_norm == 'batch')
+    values = ea.init_variables(cfg, 11)
+    rng = np.random.RandomState(5)
+    for n in values:      # (beta = 0, gamma = 1 at initialisation: move them so that a wrong scale / shift gradient shows)
+        if n.endswith('BatchNorm/gamma'):
+            values[n] = (1.0 + 0.2 * rng.standard_normal(values[n].shape)).astype(np.float32)
+        elif n.endswith('BatchNorm/beta'):
+            values[n] = (0.1 * rng.standard_normal(values[n].shape)).astype(np.float32)
+    net = ea.EdgeGAN(cfg, values)
+    # (self_consistency: per-variable tolerance max(1e-2, 3 x the oracle's own fp32-vs-fp64 deviation) -- e_optim's L1 / ReLU kinks
+    #  at a random initialisation, parity.substep_checks)
+    rows = parity.substep_checks(net, values, ea.synthetic_batch(cfg, seed=37), self_consistency=True)
+    checked = {r[0] for r in rows}
+    if cfg.D_norm == 'batch':
+        assert any('D/d_conv_3/batch_norm/BatchNorm/gamma' in r for r in checked), sorted(checked)[:20]
+    _assert(rows)
+    net.set_variables(values)
+    net.train_step()
+    l = net.losses()
+    assert all(np.isfinite(v) for v in l.values()), l
+    ev = net.evaluate()
+    assert all(np.isfinite(v) for v in ev.values() if np.isscalar(v)), ev
+    net.close()
+    if len(flags) > 1:      # the three-norm case once more in the two other arithmetic modes (the block norms stay fp32 kernels)
+        for dtype in ('f32x3', 'bf16'):
+            cfg2 = ea.Config(batch_size=3, compute_dtype=dtype, **flags)
+            net = ea.EdgeGAN(cfg2, values)
+            bf = dtype == 'bf16'       # (bf16 mode: the tolerances of tests/test_bf16_gpu.py against the operand-rounding oracle)
+            _assert(parity.substep_checks(net, values, ea.synthetic_batch(cfg2, seed=37), bf16=bf, self_consistency=True,
+                                          grad_tol=0.1 if bf else 1e-2, loss_tol=1e-2 if bf else 1e-4))
+            net.close()
+
+
 def test_inference_matches_oracle():
     cfg = ea.Config(batch_size=2)
     values = ea.init_variables(cfg, 2)
