@@ -28,6 +28,14 @@ def test_flag_syntax_matches_absl():
     cfg = TR.engine_config(F.parse(['--batch_size=4', '--nomulticlasses'], F.TRAIN_FLAGS) if False else
                            TR.update_flags(F.parse(['--batch_size=4', '--nomulticlasses'], F.TRAIN_FLAGS)), 0)
     assert (cfg.batch_size, cfg.num_classes, cfg.height, cfg.width) == (4, 0, 64, 128)
+    # train.py:54-59: E_norm / G_norm / D_norm take 'instance' or 'batch' (normalization.py:12) and reach the engine's config
+    fb = TR.update_flags(F.parse(['--G_norm=batch', '--D_norm', 'batch'], F.TRAIN_FLAGS))
+    F.check_supported(fb)
+    cb = TR.engine_config(fb, 0)
+    assert (cb.E_norm, cb.G_norm, cb.D_norm) == ('instance', 'batch', 'batch')
+    assert (cb.to_c().e_norm, cb.to_c().g_norm, cb.to_c().d_norm) == (0, 1, 1)
+    with pytest.raises(SystemExit):
+        F.check_supported(F.parse(['--E_norm=layer'], F.TRAIN_FLAGS))
 
 
 def test_bytescale_is_a_min_max_stretch_for_floats():

@@ -234,8 +234,11 @@ def test_inference_calls_in_flight_return_the_same_bits(dtype, monkeypatch):
         net.close()
 
 
-def test_train_step_equals_sequential_substeps_and_is_deterministic():
-    cfg = ea.Config(batch_size=2)
+@pytest.mark.parametrize('flags', [dict(), dict(E_norm='batch', G_norm='batch', D_norm='batch')], ids=['default', 'batch_norms'])
+def test_train_step_equals_sequential_substeps_and_is_deterministic(flags):
+    """(batch_norms: every variable includes the block norms' beta / gamma, their RMSProp slots and all moving statistics --
+    the concurrent schedule advances them exactly as the seven sequential sub-steps do)"""
+    cfg = ea.Config(batch_size=2, **flags)
     values = ea.init_variables(cfg, 0)
     batch = ea.synthetic_batch(cfg)
     outs = []
