@@ -71,6 +71,11 @@ CONV_CASES = [
     ('cls Conv_3 1x1 C128->256', 2, 8, 8, 128, 256, 1, 1, 0, True),
     ('g_lin_0-like linear 114->256', 4, 1, 1, 114, 256, 1, 1, 0, True),
     ('FC8-like linear 512->100', 4, 1, 1, 512, 100, 1, 1, 0, True),
+    # batch-row linears on the rows_linear kernel (k_gemm.hip; <= 64 rows, <= 128 contracted, >= 256 columns): two row blocks with
+    # a partial one, a partial 64-column block, the smallest contraction
+    ('g_lin_0 linear 114->8192 nb 37 (rows_linear)', 37, 1, 1, 114, 8192, 1, 1, 0, True),
+    ('FC8 input-gradient-like linear 100->512 nb 64 (rows_linear)', 64, 1, 1, 100, 512, 1, 1, 0, False),
+    ('class-head input-gradient-like linear 14->776 nb 5 (rows_linear)', 5, 1, 1, 14, 776, 1, 1, 0, True),
     ('fc-like linear 768->14 (flat N)', 4, 1, 1, 768, 14, 1, 1, 0, True),
     # thin layers at the extents that select the dedicated kernels (k_thin.hip): several strips per image with halo
     # rows, one-row rounds (W = 64), whole-image blocks (8x8), the 3-channel image rows of the MRU units

@@ -111,8 +111,9 @@ def test_x3_substeps_single_class_batch4():
     test_step_gpu.test_substeps_single_class_batch4()
 
 
-def test_x3_train_step_equals_sequential_substeps_and_is_deterministic():
-    test_step_gpu.test_train_step_equals_sequential_substeps_and_is_deterministic()
+@pytest.mark.parametrize('flags', [dict(), dict(E_norm='batch', G_norm='batch', D_norm='batch')], ids=['default', 'batch_norms'])
+def test_x3_train_step_equals_sequential_substeps_and_is_deterministic(flags):
+    test_step_gpu.test_train_step_equals_sequential_substeps_and_is_deterministic(flags)
 
 
 @pytest.mark.parametrize('name', list(test_tight_gpu.SF.LOSSES))
