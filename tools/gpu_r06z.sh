@@ -3,7 +3,7 @@
 # the inference timeline and fusion check, smoke, the whole GPU suite
 cd /root/repo
 export TMPDIR=/tmp
-TAG=r06z
+TAG=${1:-r06z}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 bash tools/gpu_round_profile.sh $TAG > $OUT/round_profile.log 2>&1
