@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = 93.551 - 2 * 0.3263
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (never the 2:1-sparse figure)
-PMC_SET = 'r06z'                # the profile set profiles/pmc_utilisation_latest.csv was derived from (tools/gpu_round_profile.sh)
+PMC_SET = 'r06y'                # the profile set profiles/pmc_utilisation_latest.csv was derived from (tools/gpu_round_profile.sh)
 X3_LIMB_PRODUCTS = 6            # limb products issued per fp32 product in f32x3 mode (edgegan_amd/csrc/k_gemm_x3.hip)
 
 

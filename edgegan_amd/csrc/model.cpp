@@ -1011,9 +1011,10 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
   set_want_grad(c, group, false);
 }
 
-// EG_D_TAPE=1 (experiments build only -- dbg_env is compiled out of the shipped library, where this always takes the stacked
-// form): the tape-driven form at 7F - 2F0, kept for in-box A/B runs.  The stacked form's coverage is the oracle: every
-// discriminator sub-step test of tests/test_step_gpu.py / test_tight_gpu.py / test_x3_gpu.py / test_bf16_gpu.py runs it.
+// The stacked form runs every InstanceNorm discriminator sub-step (its coverage is the oracle: every discriminator sub-step test
+// of tests/test_step_gpu.py / test_tight_gpu.py / test_x3_gpu.py / test_bf16_gpu.py).  The tape-driven form at 7F - 2F0 runs the
+// sub-steps under D_norm = 'batch' (tests/test_step_gpu.py::test_substeps_batch_norm_flags against the oracle) and, with EG_D_TAPE=1
+// in the experiments build (dbg_env is compiled out of the shipped library), the InstanceNorm ones for in-box A/B runs.
 static void d_substep(Ctx& c, int group, T real, T fake, const float* alpha_dev, int slot_d, int slot_gp, bool apply) {
   static const bool tape_form = dbg_env("EG_D_TAPE") != nullptr;
   // (D_norm = 'batch': the tape form -- the stacked sweep's row classes are InstanceNorm's, and BatchNorm couples the rows of a call)
