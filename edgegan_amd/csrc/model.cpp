@@ -1296,8 +1296,16 @@ void train_step(Ctx& c) {
   {
     // the classifier sub-step is the longest of the four and the one whose gradient exchange (69 MB under data
     // parallelism) sub-step 5 waits for: enqueue it first so its all-reduce runs under the discriminator sub-steps
+    // EG_PIPE_PROBE (experiments build; timing only, the results are wrong): the classifier sub-step on a fifth lane that nothing
+    // waits for before the end of the iteration -- what a software pipeline (the NEXT batch's classifier gradients under sub-steps
+    // 5 - 7) would overlap; docs/experiments.md
+    static const bool pipe_probe = dbg_env("EG_PIPE_PROBE") != nullptr;
     if (cls) {
-      use_lane(c, 3);
+      if (pipe_probe) {
+        ensure_lane(c, 4);
+        EG_HIP(hipStreamWaitEvent(c.lanes[4].stream, c.ev_fork, 0));
+      }
+      use_lane(c, pipe_probe ? 4 : 3);
       run_substep(c, 4, true);
       use_lane(c, 0);
     }
@@ -1371,6 +1379,10 @@ void train_step(Ctx& c) {
   use_lane(c, 0);
   EG_HIP(hipEventRecord(c.lanes[l6].done, c.lanes[l6].stream));
   EG_HIP(hipStreamWaitEvent(c.lanes[0].stream, c.lanes[l6].done, 0));
+  if (c.lanes[4].stream && dbg_env("EG_PIPE_PROBE")) {   // (probe: join the fifth lane)
+    EG_HIP(hipEventRecord(c.lanes[4].done, c.lanes[4].stream));
+    EG_HIP(hipStreamWaitEvent(c.lanes[0].stream, c.lanes[4].done, 0));
+  }
   ++c.step_count;
 }
 
