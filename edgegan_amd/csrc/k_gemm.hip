@@ -593,15 +593,35 @@ static const char* launch_rows_linear(const ConvArgs& a, hipStream_t s) {
   return "rows_linear<32,64>";
 }
 
+// The kernel family launch_conv_gemm runs for these arguments (a: after conv_fix_ksplit).  ONE function for the launcher and for
+// the predicates that must agree with it (conv_up_kernel below; ADVICE r5: the predicate used to repeat the dispatch's tests by hand).
+enum ConvFamily { CONV_PK, CONV_X3Q, CONV_SCATTER, CONV_SMALLC, CONV_NARROW, CONV_BF16P, CONV_X3, CONV_BF16, CONV_ROWS_LINEAR, CONV_GENERIC };
+static ConvFamily conv_family(const ConvArgs& a, int maxM) {
+  if (conv_pk_eligible(a)) return CONV_PK;
+#ifdef EG_EXPERIMENTS
+  if (a.x3q && a.N > 16 && conv_x3q_eligible(a)) return CONV_X3Q;
+#endif
+  if (conv_scatter_eligible(a)) return CONV_SCATTER;
+  if (conv_smallc_eligible(a)) return CONV_SMALLC;
+  if (a.N <= 16) return CONV_NARROW;
+  if (conv_bf16p_eligible(a)) return CONV_BF16P;   // bf16 mode, the operand's bf16 plane is there: staged by LDS-DMA (k_conv_bf16p.hip)
+  if (conv_x3_eligible(a)) return CONV_X3;
+  if (conv_bf16_eligible(a)) return CONV_BF16;
+  if (rows_linear_eligible(a, maxM)) return CONV_ROWS_LINEAR;
+  return CONV_GENERIC;
+}
 // ConvArgs::x_up is honoured by the plane-fed kernel and the halo kernel (their stride-1 forms): would launch_conv_gemm run one
-// of them for these arguments?  (the same tests in the same order as the dispatch below)
+// of them for these arguments?
 bool conv_up_kernel(const ConvArgs& a_in) {
   ConvArgs a = a_in;
   conv_fix_ksplit(a);
-  if (a.S != 1 || a.nphase != 1 || a.x3q || (a.IH & 1) || (a.IW & 1)) return false;
-  if (conv_pk_eligible(a) || conv_scatter_eligible(a) || conv_smallc_eligible(a) || a.N <= 16) return false;
-  if (conv_bf16p_eligible(a)) return true;
-  return conv_x3_eligible(a) && conv_x3_takes_halo(a, a.x3_tile ? a.x3_tile == 1 : conv_big_tile(a, conv_max_m(a)));
+  if (a.S != 1 || a.nphase != 1 || (a.IH & 1) || (a.IW & 1)) return false;
+  const int maxM = conv_max_m(a);
+  switch (conv_family(a, maxM)) {
+    case CONV_BF16P: return true;
+    case CONV_X3: return conv_x3_takes_halo(a, a.x3_tile ? a.x3_tile == 1 : conv_big_tile(a, maxM));
+    default: return false;
+  }
 }
 
 double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name) {
@@ -623,52 +643,61 @@ double launch_conv_gemm(ConvArgs& a_in, hipStream_t s, const char** kernel_name)
            "conv launch without an fp32 filter that no limb / bf16 kernel accepts (N=%d C=%d)", a.N, a.C);
   // (ops.cpp: conv2d asked for the output's bf16 plane, which only conv_pk writes)
   EG_CHECK(!a.y_bf || conv_pk_eligible(a), "output plane requested for a launch the packed-K kernel does not take (N=%d C=%d)", a.N, a.C);
-  if (conv_pk_eligible(a)) {
-    a.y2_leak = nullptr;
-    nm = launch_conv_pk(a, s);
-    // (ConvArgs::y2 is NOT taken here although the float4 epilogue could store it: this kernel is bound by its 32-byte
-    //  partial-line output writes, and a second output stream of the same shape cost 97 us on the classifier's 8 -> 128
-    //  layer at 64 x 64 where the separate PReLU pass costs 49 -- profiles/r05b_*)
+  switch (conv_family(a, maxM)) {
+    case CONV_PK:
+      a.y2_leak = nullptr;
+      nm = launch_conv_pk(a, s);
+      // (ConvArgs::y2 is NOT taken here although the float4 epilogue could store it: this kernel is bound by its 32-byte
+      //  partial-line output writes, and a second output stream of the same shape cost 97 us on the classifier's 8 -> 128
+      //  layer at 64 x 64 where the separate PReLU pass costs 49 -- profiles/r05b_*)
+      break;
 #ifdef EG_EXPERIMENTS
-  } else if (a.x3q && a.N > 16 && conv_x3q_eligible(a)) {
-    if (a.epi_act == ACT_PRELU_X) a.epi_act = 0;   // (that kernel's epilogue has the ReLU / LeakyReLU forms only)
-    nm = launch_conv_x3q(a, s);
-    if (a.ksplit <= 1 && a.epi_act) caps |= CONV_CAP_EPI_ACT;
+    case CONV_X3Q:
+      if (a.epi_act == ACT_PRELU_X) a.epi_act = 0;   // (that kernel's epilogue has the ReLU / LeakyReLU forms only)
+      nm = launch_conv_x3q(a, s);
+      if (a.ksplit <= 1 && a.epi_act) caps |= CONV_CAP_EPI_ACT;
+      break;
 #endif
-  } else if (conv_scatter_eligible(a)) {
-    if (a.act == ACT_TANH && !(a.shuf && !a.accumulate)) a.act = 0;
-    nm = launch_conv_scatter(a, s);
-    if (a.act == ACT_TANH) caps |= CONV_CAP_TANH;
-  } else if (conv_smallc_eligible(a)) {
-    nm = launch_conv_smallc(a, s);
-  } else if (a.N <= 16) {
-    if ((long long)((maxM + 255) / 256) * a.nphase >= 256)
-      nm = conv_dispatch<256, 16, 64, 16>(a, maxM, avec, bvec, s, "conv_gemm<256,16,vec>", "conv_gemm<256,16,avec>",
-                                          "conv_gemm<256,16,flat>");
-    else
-      nm = conv_dispatch<64, 16, 16, 16>(a, maxM, avec, bvec, s, "conv_gemm<64,16,vec>", "conv_gemm<64,16,avec>",
-                                         "conv_gemm<64,16,flat>");
-  } else {
-    const bool big = conv_big_tile(a, maxM);   // (tile by CU load balance, above)
-    if (conv_bf16p_eligible(a)) {   // bf16 mode, the operand's bf16 plane is there: staged by LDS-DMA (k_conv_bf16p.hip)
+    case CONV_SCATTER:
+      if (a.act == ACT_TANH && !(a.shuf && !a.accumulate)) a.act = 0;
+      nm = launch_conv_scatter(a, s);
+      if (a.act == ACT_TANH) caps |= CONV_CAP_TANH;
+      break;
+    case CONV_SMALLC:
+      nm = launch_conv_smallc(a, s);
+      break;
+    case CONV_NARROW:
+      if ((long long)((maxM + 255) / 256) * a.nphase >= 256)
+        nm = conv_dispatch<256, 16, 64, 16>(a, maxM, avec, bvec, s, "conv_gemm<256,16,vec>", "conv_gemm<256,16,avec>",
+                                            "conv_gemm<256,16,flat>");
+      else
+        nm = conv_dispatch<64, 16, 16, 16>(a, maxM, avec, bvec, s, "conv_gemm<64,16,vec>", "conv_gemm<64,16,avec>",
+                                           "conv_gemm<64,16,flat>");
+      break;
+    case CONV_BF16P:
       nm = launch_conv_bf16p(a, s);
       if (a.ksplit <= 1) caps |= CONV_CAP_EPI_ACT | CONV_CAP_Y2;
       if (conv_bf16p_pool_ok(a)) caps |= CONV_CAP_POOL;
-    } else if (conv_x3_eligible(a)) {
-      nm = launch_conv_gemm_x3(a, maxM, a.x3_tile ? a.x3_tile == 1 : big, s, &caps);
-    }
-    else if (conv_bf16_eligible(a))
-      nm = launch_conv_gemm_bf16(a, maxM, big, s);
-    else if (rows_linear_eligible(a, maxM))
+      break;
+    case CONV_X3:
+      nm = launch_conv_gemm_x3(a, maxM, a.x3_tile ? a.x3_tile == 1 : conv_big_tile(a, maxM), s, &caps);
+      break;
+    case CONV_BF16:
+      nm = launch_conv_gemm_bf16(a, maxM, conv_big_tile(a, maxM), s);
+      break;
+    case CONV_ROWS_LINEAR:
       nm = launch_rows_linear(a, s);
-    else if (big)
-      nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s,
-                                           a.ksplit > 1 ? "conv_gemm<128,128,vec,splitk>" : "conv_gemm<128,128,vec>",
-                                           "conv_gemm<128,128,avec>", "conv_gemm<128,128,flat>");
-    else
-      nm = conv_dispatch<64, 64, 32, 32>(a, maxM, avec, bvec, s,
-                                         a.ksplit > 1 ? "conv_gemm<64,64,vec,splitk>" : "conv_gemm<64,64,vec>",
-                                         "conv_gemm<64,64,avec>", "conv_gemm<64,64,flat>");
+      break;
+    default:
+      if (conv_big_tile(a, maxM))   // (tile by CU load balance, above)
+        nm = conv_dispatch<128, 128, 64, 64>(a, maxM, avec, bvec, s,
+                                             a.ksplit > 1 ? "conv_gemm<128,128,vec,splitk>" : "conv_gemm<128,128,vec>",
+                                             "conv_gemm<128,128,avec>", "conv_gemm<128,128,flat>");
+      else
+        nm = conv_dispatch<64, 64, 32, 32>(a, maxM, avec, bvec, s,
+                                           a.ksplit > 1 ? "conv_gemm<64,64,vec,splitk>" : "conv_gemm<64,64,vec>",
+                                           "conv_gemm<64,64,avec>", "conv_gemm<64,64,flat>");
+      break;
   }
   if (a.ksplit > 1 && !a.keep_slabs) launch_conv_split_reduce(a.ws, a.y, a.bias, a.y_total, a.y_ps, a.N, a.ksplit, a.accumulate, s);
   static const bool trace = dbg_env("EG_TRACE_GEMM") != nullptr;   // shape log for offline tile/split tuning
@@ -1284,12 +1313,31 @@ static void wgrad_launch(const WgradArgs& a, float* out, int dense, hipStream_t 
     hipLaunchKernelGGL((wgrad_kernel<BM, BN, WTM, WTN, 16, false>), grid, dim3(256), 0, s, a, out, dense);
 }
 
+// The kernel family launch_wgrad runs for these arguments (`out`: where the launch writes -- dw, or the slab workspace): one
+// function for the launcher and for wgrad_up_kernel
+enum WgradFamily { WG_BF16P, WG_X3, WG_PK, WG_BF16, WG_FLATM, WG_GENERIC };
+static bool wgrad_vec(const WgradArgs& a, const float* out) {
+  return (a.C % 4 == 0) && (a.N % 4 == 0) && (a.x_ps % 4 == 0) && (a.dy_ps % 4 == 0) && (((uintptr_t)a.x & 15) == 0) &&
+         (((uintptr_t)a.dy & 15) == 0) && (a.ldw % 4 == 0) && (a.w_ts % 4 == 0) && (((uintptr_t)out & 15) == 0);
+}
+static WgradFamily wgrad_family(const WgradArgs& a, const float* out) {
+  const bool out16 = (((uintptr_t)out) & 15) == 0;
+  if (wgrad_bf16p_units(a) && out16) return WG_BF16P;
+  if (wgrad_x3(a) && out16) return WG_X3;
+  if (wgrad_pk_eligible(a) && out16) return WG_PK;
+  if (a.bf16 && wgrad_vec(a, out) && !wgrad_flatm(a)) return WG_BF16;
+  if (wgrad_flatm(a)) return WG_FLATM;
+  return WG_GENERIC;
+}
 // WgradArgs::dy_up is honoured by the plane-fed kernel and the row-halo limb kernel: would launch_wgrad run one of them?
 bool wgrad_up_kernel(const WgradArgs& a) {
   const float* out = a.nsplit == 1 ? a.dw : a.ws;
-  if ((((uintptr_t)out) & 15) != 0 || (a.OH & 1) || (a.OW & 1)) return false;
-  if (wgrad_bf16p_units(a)) return true;
-  return wgrad_x3(a) && wgrad_x3_rowhalo_units(a) > 0;
+  if ((a.OH & 1) || (a.OW & 1)) return false;
+  switch (wgrad_family(a, out)) {
+    case WG_BF16P: return true;
+    case WG_X3: return wgrad_x3_rowhalo_units(a) > 0;
+    default: return false;
+  }
 }
 
 double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name) {
@@ -1297,28 +1345,28 @@ double launch_wgrad(const WgradArgs& a, hipStream_t s, const char** kernel_name)
   float* out = direct ? a.dw : a.ws;
   const int dense = direct ? 0 : 1;
   EG_CHECK(!a.dy_up || wgrad_up_kernel(a), "wgrad launch: dy_up with a kernel that does not read the half-resolution operand (N=%d C=%d)", a.N, a.C);
-  const bool vec = (a.C % 4 == 0) && (a.N % 4 == 0) && (a.x_ps % 4 == 0) && (a.dy_ps % 4 == 0) &&
-                   (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0) && (a.ldw % 4 == 0) &&
-                   (a.w_ts % 4 == 0) && (((uintptr_t)out & 15) == 0);
+  const bool vec = wgrad_vec(a, out);
   const char* nm;
-  if (wgrad_bf16p_units(a) && (((uintptr_t)out & 15) == 0)) {
-    nm = launch_wgrad_bf16p(a, out, dense, s);
-  } else if (wgrad_x3(a) && (((uintptr_t)out & 15) == 0)) {
-    nm = launch_wgrad_x3(a, out, dense, true, s);
-  } else if (wgrad_pk_eligible(a) && (((uintptr_t)out & 15) == 0)) {
-    nm = launch_wgrad_pk(a, out, dense, s);
-  } else if (a.bf16 && vec && !wgrad_flatm(a)) {
-    nm = launch_wgrad_bf16(a, out, dense, wgrad_big(a), s);
-  } else if (wgrad_flatm(a)) {
-    dim3 grid(((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64), a.nsplit);
-    hipLaunchKernelGGL(wgrad_flatm_kernel<32>, grid, dim3(256), 0, s, a, out, dense);
-    nm = "wgrad_flatm<64,64>";
-  } else if (wgrad_big(a)) {
-    if (vec) { wgrad_launch<128, 128, 64, 64, true>(a, out, dense, s); nm = "wgrad<128,128,vec>"; }
-    else { wgrad_launch<128, 128, 64, 64, false>(a, out, dense, s); nm = "wgrad<128,128,flat>"; }
-  } else {
-    if (vec) { wgrad_launch<64, 64, 32, 32, true>(a, out, dense, s); nm = "wgrad<64,64,vec>"; }
-    else { wgrad_launch<64, 64, 32, 32, false>(a, out, dense, s); nm = "wgrad<64,64,flat>"; }
+  switch (wgrad_family(a, out)) {
+    case WG_BF16P: nm = launch_wgrad_bf16p(a, out, dense, s); break;
+    case WG_X3: nm = launch_wgrad_x3(a, out, dense, true, s); break;
+    case WG_PK: nm = launch_wgrad_pk(a, out, dense, s); break;
+    case WG_BF16: nm = launch_wgrad_bf16(a, out, dense, wgrad_big(a), s); break;
+    case WG_FLATM: {
+      dim3 grid(((a.KH * a.KW * a.C + 63) / 64) * ((a.N + 63) / 64), a.nsplit);
+      hipLaunchKernelGGL(wgrad_flatm_kernel<32>, grid, dim3(256), 0, s, a, out, dense);
+      nm = "wgrad_flatm<64,64>";
+      break;
+    }
+    default:
+      if (wgrad_big(a)) {
+        if (vec) { wgrad_launch<128, 128, 64, 64, true>(a, out, dense, s); nm = "wgrad<128,128,vec>"; }
+        else { wgrad_launch<128, 128, 64, 64, false>(a, out, dense, s); nm = "wgrad<128,128,flat>"; }
+      } else {
+        if (vec) { wgrad_launch<64, 64, 32, 32, true>(a, out, dense, s); nm = "wgrad<64,64,vec>"; }
+        else { wgrad_launch<64, 64, 32, 32, false>(a, out, dense, s); nm = "wgrad<64,64,flat>"; }
+      }
+      break;
   }
   if (!direct) {
     const size_t total = (size_t)a.KH * a.KW * a.C * a.N;
