@@ -259,26 +259,42 @@ __global__ __launch_bounds__(256) void in_fwd_vr(const float* __restrict__ x, fl
   const float* xp = x + (size_t)n * HW * C + c;
   float4 xv[NP];
   float4 s[1] = {f4_zero()};
+  if (nslab > 1) {   // an un-summed K-split convolution output: bias + slabs in conv_split_reduce's order.  Slab by slab with the
+                     // block's NP loads of a slab in flight together (the per-pixel form -- load a slab's quad, add, next slab --
+                     // was NP x nslab dependent round trips: 25 .. 60 us per block at any batch size)
+    const float4 b4 = slab_bias ? ld4(slab_bias + c) : f4_zero();
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int p = pl + i * PL;
-    if (nslab > 1) {   // an un-summed K-split convolution output: bias + slabs in conv_split_reduce's order
-      float4 v = f4_zero();
-      if (p < HW) {
-        if (slab_bias) v = ld4(slab_bias + c);
-        for (int k = 0; k < nslab; ++k) {
-          const float4 q = ld4(xp + (size_t)k * slab_stride + (size_t)p * C);
-          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        // training: the summed pre-norm tensor is what the backward (and the gradient penalty's tangent pass) reads
-        if (xsum) st4(xsum + (size_t)n * HW * C + c + (size_t)p * C, v);
+    for (int i = 0; i < NP; ++i) xv[i] = b4;
+    for (int k = 0; k < nslab; ++k) {
+      const float* sp = xp + (size_t)k * slab_stride;
+      float4 q[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int p = pl + i * PL;
+        q[i] = ld4(sp + (size_t)(p < HW ? p : 0) * C);
       }
-      xv[i] = v;
-    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) { xv[i].x += q[i].x; xv[i].y += q[i].y; xv[i].z += q[i].z; xv[i].w += q[i].w; }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = pl + i * PL;
+      if (p < HW) {
+        // training: the summed pre-norm tensor is what the backward (and the gradient penalty's tangent pass) reads
+        if (xsum) st4(xsum + (size_t)n * HW * C + c + (size_t)p * C, xv[i]);
+      } else {
+        xv[i] = f4_zero();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = pl + i * PL;
       xv[i] = p < HW ? ld4(xp + (size_t)p * C) : f4_zero();
     }
-    s[0].x += xv[i].x; s[0].y += xv[i].y; s[0].z += xv[i].z; s[0].w += xv[i].w;
   }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) { s[0].x += xv[i].x; s[0].y += xv[i].y; s[0].z += xv[i].z; s[0].w += xv[i].w; }
   cq_reduce<1, CQ>(s, red);
   const float inv = 1.f / HW;
   const float4 mean = make_float4(s[0].x * inv, s[0].y * inv, s[0].z * inv, s[0].w * inv);
@@ -343,10 +359,9 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
   const size_t base = (size_t)n * HW * C + c;
   const Stat4 st = load_stats4(stats, (size_t)n * C + c);
   float4 s[2] = {f4_zero(), f4_zero()};
-  for (int p = pl; p < HW; p += PL) {
-    const size_t i = base + (size_t)p * C;
-    float4 e = ld4(v + i);
-    const float4 xv = ld4(x + i);
+  // Both passes walk the pixels four at a time with the eight (twelve) loads of a group issued before the first use -- the one-pixel
+  // loop was a memory round trip per iteration and pass (HW / PL = 32 .. 128 of them per block); same order of every sum.
+  auto reduce1 = [&](float4 e, const float4& xv) __attribute__((always_inline)) {
     if (MODE == 0) {
       const float4 g = actg_from_x(xv, st, act);
       e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w;
@@ -354,27 +369,58 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
     s[0].x += e.x; s[0].y += e.y; s[0].z += e.z; s[0].w += e.w;
     s[1].x += e.x * (xv.x - st.mean.x); s[1].y += e.y * (xv.y - st.mean.y);
     s[1].z += e.z * (xv.z - st.mean.z); s[1].w += e.w * (xv.w - st.mean.w);
+  };
+  {
+    int p = pl;
+    for (; p + 3 * PL < HW; p += 4 * PL) {
+      float4 e[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t i = base + (size_t)(p + u * PL) * C;
+        e[u] = ld4(v + i);
+        xv[u] = ld4(x + i);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) reduce1(e[u], xv[u]);
+    }
+    for (; p < HW; p += PL) {
+      const size_t i = base + (size_t)p * C;
+      reduce1(ld4(v + i), ld4(x + i));
+    }
   }
   cq_reduce<2, CQ>(s, red);
   const float hw = (float)HW;
   const float4 eb = make_float4(s[0].x / hw, s[0].y / hw, s[0].z / hw, s[0].w / hw);
   const float4 k2 = make_float4(st.r.x * st.r.x * s[1].x / (hw * st.sigma.x), st.r.y * st.r.y * s[1].y / (hw * st.sigma.y),
                                 st.r.z * st.r.z * s[1].z / (hw * st.sigma.z), st.r.w * st.r.w * s[1].w / (hw * st.sigma.w));
-  for (int p = pl; p < HW; p += PL) {
-    const size_t i = base + (size_t)p * C;
-    const float4 xv = ld4(x + i);
+  auto apply1 = [&](size_t i, const float4& xv, float4 e, const float4& d) __attribute__((always_inline)) {
     const float4 g = actg_from_x(xv, st, act);
-    float4 e = ld4(v + i);
     if (MODE == 0) { e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w; }
     float4 res = make_float4(st.r.x * (e.x - eb.x) - k2.x * (xv.x - st.mean.x), st.r.y * (e.y - eb.y) - k2.y * (xv.y - st.mean.y),
                              st.r.z * (e.z - eb.z) - k2.z * (xv.z - st.mean.z), st.r.w * (e.w - eb.w) - k2.w * (xv.w - st.mean.w));
     if (MODE == 1) { res.x *= g.x; res.y *= g.y; res.z *= g.z; res.w *= g.w; }
-    if (accumulate & 1) {
-      const float4 d = ld4(dst + i);
-      res.x += d.x; res.y += d.y; res.z += d.z; res.w += d.w;
-    }
+    if (accumulate & 1) { res.x += d.x; res.y += d.y; res.z += d.z; res.w += d.w; }
     if (dst && !(accumulate & 2)) st4(dst + i, res);   // (plane-only: the tangent-forward output, or GRAD_PLANE_ONLY)
     if (dst_bf) st_bf4n(dst_bf, i, res);
+  };
+  {
+    int p = pl;
+    for (; p + 3 * PL < HW; p += 4 * PL) {
+      float4 e[4], xv[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t i = base + (size_t)(p + u * PL) * C;
+        xv[u] = ld4(x + i);
+        e[u] = ld4(v + i);
+        d[u] = (accumulate & 1) ? ld4(dst + i) : f4_zero();
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) apply1(base + (size_t)(p + u * PL) * C, xv[u], e[u], d[u]);
+    }
+    for (; p < HW; p += PL) {
+      const size_t i = base + (size_t)p * C;
+      apply1(i, ld4(x + i), ld4(v + i), (accumulate & 1) ? ld4(dst + i) : f4_zero());
+    }
   }
 }
 
@@ -382,7 +428,7 @@ __global__ __launch_bounds__(256) void in_japply_v(const float* __restrict__ x, 
 // pass (HW <= 32 * NP): out / dout / x are read from memory once
 // v (the output gradient) may still be the K-split slabs of the input-gradient convolution that produced it (SlabSrc)
 template <int NP, int CQ>
-__global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, const float* __restrict__ out,
+__global__ __launch_bounds__(256, (NP == 8 ? 4 : NP == 16 ? 2 : 1)) void in_bwd_vr(const float* __restrict__ x, const float* __restrict__ out,
                                                  const SlabSrc v, const float* __restrict__ stats,
                                                  float* __restrict__ dst, int accumulate, int HW, int C, int act,
                                                  unsigned short* __restrict__ dst_bf, float* __restrict__ colpart) {
@@ -394,21 +440,52 @@ __global__ __launch_bounds__(256) void in_bwd_vr(const float* __restrict__ x, co
   const Stat4 st = load_stats4(stats, (size_t)n * C + c);
   float4 ev[NP], xc[NP];
   float4 s[2] = {f4_zero(), f4_zero()};
+  // Round 6: ALL of the block's loads are issued before the first value is used.  The per-element form (load e, load x, use, next
+  // element) compiled to one s_waitcnt vmcnt(0) per element -- 16 dependent memory round trips per block, ~30 us whatever the batch
+  // (the same 31 us at batch 4 and at batch 64).  Out-of-range pixels read pixel 0 and are zeroed afterwards (no branch around a
+  // load); a slab input is summed slab by slab (bias, slab 0, slab 1, ..., base: slab_ld4's order) with NP loads in flight per slab.
+  auto off = [&](int k) __attribute__((always_inline)) {   // (recomputed at every use: 2 registers of address per element otherwise)
+    const int p = pl + k * PL;
+    return base + (size_t)(p < HW ? p : 0) * C;
+  };
+#pragma unroll
+  for (int k = 0; k < NP; ++k) xc[k] = ld4(x + off(k));
+  if (v.n <= 1) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) ev[k] = ld4(v.p + off(k));
+  } else {
+    const float4 b4 = v.bias ? ld4(v.bias + c) : f4_zero();
+#pragma unroll
+    for (int k = 0; k < NP; ++k) ev[k] = b4;
+    constexpr int NQ = NP > 4 ? NP / 2 : NP;   // loads in flight per batch of the slab sums (registers: the whole set costs a wave of occupancy)
+    for (int z = 0; z <= v.n; ++z) {       // (z == v.n: the base, last -- slab_ld4's order)
+      if (z == v.n && !v.base) break;
+      const float* src = z < v.n ? v.p + (size_t)z * v.stride : v.base;
+#pragma unroll
+      for (int h = 0; h < NP; h += NQ) {
+        float4 q[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) q[k] = ld4(src + off(h + k));
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) { ev[h + k].x += q[k].x; ev[h + k].y += q[k].y; ev[h + k].z += q[k].z; ev[h + k].w += q[k].w; }
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const int p = pl + k * PL;
-    ev[k] = f4_zero();
-    xc[k] = f4_zero();
     if (p < HW) {
-      const size_t i = base + (size_t)p * C;
-      float4 e = slab_ld4(v, i, c);
-      const float4 xv = ld4(x + i);
+      const float4 xv = xc[k];
+      float4 e = ev[k];
       const float4 g = actg_from_x(xv, st, act);
       e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w;
       ev[k] = e;
       xc[k] = make_float4(xv.x - st.mean.x, xv.y - st.mean.y, xv.z - st.mean.z, xv.w - st.mean.w);
       s[0].x += e.x; s[0].y += e.y; s[0].z += e.z; s[0].w += e.w;
       s[1].x += e.x * xc[k].x; s[1].y += e.y * xc[k].y; s[1].z += e.z * xc[k].z; s[1].w += e.w * xc[k].w;
+    } else {
+      ev[k] = f4_zero();
+      xc[k] = f4_zero();
     }
   }
   cq_reduce<2, CQ>(s, red);
@@ -583,6 +660,8 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_vr(const float* __restrict
   const Stat4 st = load_stats4(stats, (size_t)n * C + c);
   float4 ev[NP], xc[NP], tv[NP];
   float4 m[2] = {f4_zero(), f4_zero()};
+  // (issuing the 3 NP loads before the first use, as in_bwd_vr does, measured SLOWER here at batch 64 -- 51 -> 57 us -- and equal at
+  //  batch 4: 290 registers either way, one block per CU; docs/experiments.md)
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const int p = pl + k * PL;
