@@ -851,24 +851,46 @@ __global__ __launch_bounds__(64 * NW) void minmax_fwd_v(const SlabSrc xs, float*
   const size_t base = (size_t)n * HW * C + c;
   const float* x = xs.n > 1 ? xsum : xs.p;
   float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-  for (int p = pl; p < HW; p += PL) {
-    float4 raw;
-    if (xs.n > 1) {
-      raw = slab_ld4(xs, base + (size_t)p * C, c);
-      st4(xsum + base + (size_t)p * C, raw);
-    } else {
-      raw = ld4(x + base + (size_t)p * C);
-    }
+  // (round 6: the pixel loops take four pixels per step with their loads issued together -- one memory round trip per FOUR
+  //  iterations instead of one per iteration; min / max and the stores are order-independent)
+  auto upd = [&](const float4& raw) __attribute__((always_inline)) {
     const float4 v = mm_pre4(raw, lk);
     mn.x = fminf(mn.x, v.x); mn.y = fminf(mn.y, v.y); mn.z = fminf(mn.z, v.z); mn.w = fminf(mn.w, v.w);
     mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+  };
+  if (xs.n > 1) {
+    for (int p = pl; p < HW; p += PL) {
+      const float4 raw = slab_ld4(xs, base + (size_t)p * C, c);
+      st4(xsum + base + (size_t)p * C, raw);
+      upd(raw);
+    }
+  } else {
+    int p = pl;
+    for (; p + 3 * PL < HW; p += 4 * PL) {
+      float4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = ld4(x + base + (size_t)(p + u * PL) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) upd(r[u]);
+    }
+    for (; p < HW; p += PL) upd(ld4(x + base + (size_t)p * C));
   }
   cq_reduce_minmax_w<CQ, NW>(mn, mx, red);
   const float4 inv = make_float4(1.f / (mx.x - mn.x), 1.f / (mx.y - mn.y), 1.f / (mx.z - mn.z), 1.f / (mx.w - mn.w));
-  for (int p = pl; p < HW; p += PL) {
-    const size_t i = base + (size_t)p * C;
-    const float4 v = mm_pre4(ld4(x + i), lk);
+  auto emit = [&](size_t i, const float4& raw) __attribute__((always_inline)) {
+    const float4 v = mm_pre4(raw, lk);
     st4(y + i, make_float4((v.x - mn.x) * inv.x, (v.y - mn.y) * inv.y, (v.z - mn.z) * inv.z, (v.w - mn.w) * inv.w));
+  };
+  {
+    int p = pl;
+    for (; p + 3 * PL < HW; p += 4 * PL) {
+      float4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = ld4(x + base + (size_t)(p + u * PL) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) emit(base + (size_t)(p + u * PL) * C, r[u]);
+    }
+    for (; p < HW; p += PL) emit(base + (size_t)p * C, ld4(x + base + (size_t)p * C));
   }
   if (pl == 0) {
     float* mp = mm + ((size_t)n * C + c) * 2;
@@ -889,13 +911,30 @@ __global__ __launch_bounds__(64 * NW) void minmax_bwd_v(const float* __restrict_
   const float4 a = ld4(mm + ((size_t)n * C + c) * 2), b = ld4(mm + ((size_t)n * C + c) * 2 + 4);
   const float mn[4] = {a.x, a.z, b.x, b.z}, mx[4] = {a.y, a.w, b.y, b.w};
   float4 s[4] = {f4_zero(), f4_zero(), f4_zero(), f4_zero()};  // sum g, sum g*(x-mn), count==mn, count==mx
-  for (int p = pl; p < HW; p += PL) {
-    const size_t i = base + (size_t)p * C;
-    const float4 v = mm_pre4(ld4(x + i), lk), g = ld4(dy + i);
+  auto acc1 = [&](const float4& xr, const float4& g) __attribute__((always_inline)) {
+    const float4 v = mm_pre4(xr, lk);
     s[0].x += g.x; s[0].y += g.y; s[0].z += g.z; s[0].w += g.w;
     s[1].x += g.x * (v.x - mn[0]); s[1].y += g.y * (v.y - mn[1]); s[1].z += g.z * (v.z - mn[2]); s[1].w += g.w * (v.w - mn[3]);
     s[2].x += v.x == mn[0] ? 1.f : 0.f; s[2].y += v.y == mn[1] ? 1.f : 0.f; s[2].z += v.z == mn[2] ? 1.f : 0.f; s[2].w += v.w == mn[3] ? 1.f : 0.f;
     s[3].x += v.x == mx[0] ? 1.f : 0.f; s[3].y += v.y == mx[1] ? 1.f : 0.f; s[3].z += v.z == mx[2] ? 1.f : 0.f; s[3].w += v.w == mx[3] ? 1.f : 0.f;
+  };
+  {   // (four pixels per step, their eight loads issued together; the sums keep the one-pixel loop's order)
+    int p = pl;
+    for (; p + 3 * PL < HW; p += 4 * PL) {
+      float4 xr[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t i = base + (size_t)(p + u * PL) * C;
+        xr[u] = ld4(x + i);
+        g[u] = ld4(dy + i);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc1(xr[u], g[u]);
+    }
+    for (; p < HW; p += PL) {
+      const size_t i = base + (size_t)p * C;
+      acc1(ld4(x + i), ld4(dy + i));
+    }
   }
   cq_reduce_w<4, CQ, NW>(s, red);
   const float S1[4] = {s[0].x, s[0].y, s[0].z, s[0].w}, S2[4] = {s[1].x, s[1].y, s[1].z, s[1].w},
@@ -908,9 +947,8 @@ __global__ __launch_bounds__(64 * NW) void minmax_bwd_v(const float* __restrict_
     dmx[j] = (-S2[j] / (d[j] * d[j])) / Cx[j];
   }
   float4 cs[1] = {f4_zero()};
-  for (int p = pl; p < HW; p += PL) {
-    const size_t i = base + (size_t)p * C;
-    const float4 xv = ld4(x + i), v = mm_pre4(xv, lk), g = ld4(dy + i);
+  auto apply2 = [&](size_t i, const float4& xv, const float4& g, const float4& t) __attribute__((always_inline)) {
+    const float4 v = mm_pre4(xv, lk);
     const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
     float r[4];
 #pragma unroll
@@ -921,10 +959,29 @@ __global__ __launch_bounds__(64 * NW) void minmax_bwd_v(const float* __restrict_
       r[j] *= mm_slope(xx[j], lk);
     }
     float4 o = make_float4(r[0], r[1], r[2], r[3]);
-    if (acc & 1) { const float4 t = ld4(dx + i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+    if (acc & 1) { o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
     if (!(acc & 2)) st4(dx + i, o);      // (bit 1 of the accumulate argument: the gradient is kept as its bf16 plane only, kernels.h: GRAD_PLANE_ONLY)
     if (dx_bf) st_bf4(dx_bf, i >> 2, o);
     cs[0].x += o.x; cs[0].y += o.y; cs[0].z += o.z; cs[0].w += o.w;
+  };
+  {
+    int p = pl;
+    for (; p + 3 * PL < HW; p += 4 * PL) {
+      float4 xr[4], g[4], t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t i = base + (size_t)(p + u * PL) * C;
+        xr[u] = ld4(x + i);
+        g[u] = ld4(dy + i);
+        t[u] = (acc & 1) ? ld4(dx + i) : f4_zero();
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) apply2(base + (size_t)(p + u * PL) * C, xr[u], g[u], t[u]);
+    }
+    for (; p < HW; p += PL) {
+      const size_t i = base + (size_t)p * C;
+      apply2(i, ld4(x + i), ld4(dy + i), (acc & 1) ? ld4(dx + i) : f4_zero());
+    }
   }
   if (colpart) {   // row n of the gate bias gradient's first stage (kernels.h: colpart)
     cq_reduce_w<1, CQ, NW>(cs, red);

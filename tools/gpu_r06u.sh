@@ -14,6 +14,6 @@ for L in prev cur; do
   bash tools/gpu_trace.sh $OUT/kernel_stats_bf16_$L.csv $LIB --dtype bf16 --no-side-legs --no-live-traffic
   bash tools/gpu_trace.sh $OUT/kernel_stats_b4_$L.csv $LIB --batch 4 --classes 0 --no-side-legs --no-live-traffic
 done
-for L in prev cur; do echo "== $L"; grep -h "in_bwd_vr\|TOTAL" $OUT/kernel_stats_bf16_$L.csv | cut -c1-40,150-220; grep -h "in_bwd_vr\|TOTAL" $OUT/kernel_stats_b4_$L.csv | cut -c1-40,150-220; done
+for L in prev cur; do echo "== $L"; grep -h "in_bwd_vr\|minmax\|TOTAL" $OUT/kernel_stats_bf16_$L.csv | cut -c1-40,150-220; grep -h "in_bwd_vr\|minmax\|TOTAL" $OUT/kernel_stats_b4_$L.csv | cut -c1-40,150-220; done
 python tools/gpu_ab_rounds.py edgegan_amd/libedgegan_hip_prev.so edgegan_amd/libedgegan_hip.so --rounds 3 --dtype bf16 > $OUT/ab_bf16.txt 2>&1; cat $OUT/ab_bf16.txt
 python tools/gpu_ab_rounds.py edgegan_amd/libedgegan_hip_prev.so edgegan_amd/libedgegan_hip.so --rounds 3 --dtype f32x3 > $OUT/ab_f32x3.txt 2>&1; cat $OUT/ab_f32x3.txt
