@@ -306,6 +306,7 @@ T in_act(Ctx& c, T x, int act, T* stats_out = nullptr, bool plane_only = false);
 T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int act);
 T act(Ctx& c, T x, int a);
 T act_tangent(Ctx& c, T tx, T out_prim, int a);
+float* in_chunk_scratch(Ctx& c, int NB, int HW, int C);   // ops.cpp: scratch of the chunked InstanceNorm kernels (large maps), or null
 T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int update_times, T* stats_out = nullptr);
 T bn_act(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int act, int update_times, T* stats_out = nullptr);
 T bn_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, Param* gamma, int act);

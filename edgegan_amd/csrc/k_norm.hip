@@ -516,10 +516,176 @@ __global__ __launch_bounds__(256, (NP == 8 ? 4 : NP == 16 ? 2 : 1)) void in_bwd_
   }
 }
 
+// =============================================================================================
+// InstanceNorm on LARGE maps (H W > 1,024: configs[4]'s 256 x 512 geometry -- 64 x 128 .. 128 x 256 pixel maps).  The per-(n, c)
+// kernels above give one block a whole map: at batch 16 that is 32 blocks walking 32,768 pixels each, three passes, one memory
+// round trip per iteration -- 294 us per launch, 22 % of the iteration's kernel time at 256 x 512 (round 6).  Here the pixels of
+// a map are split into chunks of IN_RPC rows, every reduction is two-stage (chunk partials, then a per-(n, c) combine in chunk
+// order: fixed order, no atomics; statistics as per-chunk mean + centred second moment merged pairwise), and the apply passes are
+// plain element-wise kernels over quads.  Same formulas as in_fwd_v / in_japply_v (eps outside the sqrt: normalization.py:16).
+// =============================================================================================
+constexpr int IN_RPC = 256;
+__global__ __launch_bounds__(256) void in_chunk_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C) {
+  __shared__ float red[1 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cx, n = blockIdx.z, nch = gridDim.x;
+  const bool cv = c < C;
+  const int r0 = blockIdx.x * IN_RPC, r1 = min(HW, r0 + IN_RPC);
+  const float* xp = x + (size_t)n * HW * C + c;
+  float s[1] = {0.f};
+  if (cv)
+    for (int p = r0 + py; p < r1; p += 4) s[0] += xp[(size_t)p * C];
+  lane4_reduce<1>(s, red, cx, py);
+  const float mean = s[0] / (float)(r1 - r0);
+  float q[1] = {0.f};
+  if (cv)
+    for (int p = r0 + py; p < r1; p += 4) {
+      const float d = xp[(size_t)p * C] - mean;
+      q[0] += d * d;
+    }
+  lane4_reduce<1>(q, red, cx, py);
+  if (cv && py == 0) {
+    float* o = part + (((size_t)n * nch + blockIdx.x) * C + c) * 2;
+    o[0] = mean;
+    o[1] = q[0];
+  }
+}
+__global__ void in_finalize_stats_kernel(const float* __restrict__ part, int nch, int HW, int C, float* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (c >= C) return;
+  float cnt = 0.f, mean = 0.f, m2 = 0.f;
+  for (int k = 0; k < nch; ++k) {
+    const float nk = (float)min(IN_RPC, HW - k * IN_RPC);
+    const float* o = part + (((size_t)n * nch + k) * C + c) * 2;
+    const float d = o[0] - mean, nt = cnt + nk;
+    mean += d * (nk / nt);
+    m2 += o[1] + d * d * (cnt * nk / nt);
+    cnt = nt;
+  }
+  stats[((size_t)n * C + c) * 2] = mean;
+  stats[((size_t)n * C + c) * 2 + 1] = sqrtf(m2 / (float)HW);
+}
+// y = act((x - mean) r) over the quads of image blockIdx.y
+__global__ __launch_bounds__(256) void in_apply_chunked_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                               float* __restrict__ out, unsigned short* __restrict__ out_bf, int HW,
+                                                               int C, int act) {
+  const int n = blockIdx.y, c4n = C >> 2;
+  const size_t per = (size_t)HW * c4n, ib = (size_t)n * HW * C;
+  for (size_t q = blockIdx.x * (size_t)256 + threadIdx.x; q < per; q += (size_t)gridDim.x * 256) {
+    const int c = (int)(q % c4n) * 4;
+    const size_t i = ib + q * 4;
+    const Stat4 st = load_stats4(stats, (size_t)n * C + c);
+    const float4 v = ld4(x + i);
+    const float4 y = act4(make_float4((v.x - st.mean.x) * st.r.x, (v.y - st.mean.y) * st.r.y, (v.z - st.mean.z) * st.r.z,
+                                      (v.w - st.mean.w) * st.r.w), act);
+    if (out) st4(out + i, y);
+    if (out_bf) st_bf4n(out_bf, i, y);
+  }
+}
+// chunk partials of sum e and sum e xc;  MODE 0 (backward): e = v act'(out), MODE 1 (forward tangent): e = v
+template <int MODE>
+__global__ __launch_bounds__(256) void in_chunk_j_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                         const float* __restrict__ stats, float* __restrict__ part, int HW, int C,
+                                                         int act) {
+  __shared__ float red[2 * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cx, n = blockIdx.z, nch = gridDim.x;
+  const bool cv = c < C;
+  const int r0 = blockIdx.x * IN_RPC, r1 = min(HW, r0 + IN_RPC);
+  const size_t base = (size_t)n * HW * C + c;
+  const float mean = cv ? stats[((size_t)n * C + c) * 2] : 0.f;
+  const float r = cv ? 1.f / (stats[((size_t)n * C + c) * 2 + 1] + IN_EPS) : 1.f;
+  float s[2] = {0.f, 0.f};
+  if (cv)
+    for (int p = r0 + py; p < r1; p += 4) {
+      const size_t i = base + (size_t)p * C;
+      const float xc = x[i] - mean;
+      float e = v[i];
+      if (MODE == 0) e *= act_grad_from_out(act_apply(xc * r, act), act);
+      s[0] += e;
+      s[1] += e * xc;
+    }
+  lane4_reduce<2>(s, red, cx, py);
+  if (cv && py == 0) {
+    float* o = part + (((size_t)n * nch + blockIdx.x) * C + c) * 2;
+    o[0] = s[0];
+    o[1] = s[1];
+  }
+}
+__global__ void in_finalize_j_kernel(const float* __restrict__ part, int nch, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nch; ++k) {
+    const float* o = part + (((size_t)n * nch + k) * C + c) * 2;
+    a += o[0];
+    b += o[1];
+  }
+  sums[((size_t)n * C + c) * 2] = a;
+  sums[((size_t)n * C + c) * 2 + 1] = b;
+}
+// res = r (e - mean(e)) - r^2 sum(e xc) / (HW sigma) xc;  MODE 0: dst (+)= res;  MODE 1: dst = act'(out) res
+template <int MODE>
+__global__ __launch_bounds__(256) void in_japply_chunked_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                                const float* __restrict__ stats, const float* __restrict__ sums,
+                                                                float* __restrict__ dst, int accumulate,
+                                                                unsigned short* __restrict__ dst_bf, int HW, int C, int act) {
+  const int n = blockIdx.y, c4n = C >> 2;
+  const size_t per = (size_t)HW * c4n, ib = (size_t)n * HW * C;
+  const float hw = (float)HW;
+  for (size_t q = blockIdx.x * (size_t)256 + threadIdx.x; q < per; q += (size_t)gridDim.x * 256) {
+    const int c = (int)(q % c4n) * 4;
+    const size_t i = ib + q * 4;
+    const Stat4 st = load_stats4(stats, (size_t)n * C + c);
+    const float4 sa = ld4(sums + ((size_t)n * C + c) * 2), sb = ld4(sums + ((size_t)n * C + c) * 2 + 4);
+    const float4 eb = make_float4(sa.x / hw, sa.z / hw, sb.x / hw, sb.z / hw);
+    const float4 k2 = make_float4(st.r.x * st.r.x * sa.y / (hw * st.sigma.x), st.r.y * st.r.y * sa.w / (hw * st.sigma.y),
+                                  st.r.z * st.r.z * sb.y / (hw * st.sigma.z), st.r.w * st.r.w * sb.w / (hw * st.sigma.w));
+    const float4 xv = ld4(x + i);
+    const float4 g = actg_from_x(xv, st, act);
+    float4 e = ld4(v + i);
+    if (MODE == 0) { e.x *= g.x; e.y *= g.y; e.z *= g.z; e.w *= g.w; }
+    float4 res = make_float4(st.r.x * (e.x - eb.x) - k2.x * (xv.x - st.mean.x), st.r.y * (e.y - eb.y) - k2.y * (xv.y - st.mean.y),
+                             st.r.z * (e.z - eb.z) - k2.z * (xv.z - st.mean.z), st.r.w * (e.w - eb.w) - k2.w * (xv.w - st.mean.w));
+    if (MODE == 1) { res.x *= g.x; res.y *= g.y; res.z *= g.z; res.w *= g.w; }
+    if (accumulate & 1) {
+      const float4 d = ld4(dst + i);
+      res.x += d.x; res.y += d.y; res.z += d.z; res.w += d.w;
+    }
+    if (dst && !(accumulate & 2)) st4(dst + i, res);
+    if (dst_bf) st_bf4n(dst_bf, i, res);
+  }
+}
+static inline int in_chunks(int HW) { return (HW + IN_RPC - 1) / IN_RPC; }
+bool in_chunked_shape(int HW, int C) { return HW > 1024 && C % 32 == 0; }
+size_t in_chunk_scratch_floats(int NB, int HW, int C) { return (size_t)NB * in_chunks(HW) * C * 2 + (size_t)NB * C * 2; }
+static inline int in_ew_blocks(int HW, int C) { return (int)std::min<size_t>(2048, ((size_t)HW * (C >> 2) + 255) / 256); }
+static void in_fwd_chunked(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s,
+                           unsigned short* out_bf, float* scratch) {
+  const int nch = in_chunks(HW);
+  hipLaunchKernelGGL(in_chunk_stats_kernel, dim3(nch, (C + 63) / 64, NB), dim3(256), 0, s, x, scratch, HW, C);
+  hipLaunchKernelGGL(in_finalize_stats_kernel, dim3((C + 63) / 64, NB), dim3(64), 0, s, scratch, nch, HW, C, stats);
+  hipLaunchKernelGGL(in_apply_chunked_kernel, dim3(in_ew_blocks(HW, C), NB), dim3(256), 0, s, x, stats, out, out_bf, HW, C, act);
+}
+template <int MODE>
+static void in_japply_chunked(const float* x, const float* v, const float* stats, float* dst, int accumulate, int NB, int HW, int C,
+                              int act, hipStream_t s, unsigned short* dst_bf, float* scratch) {
+  const int nch = in_chunks(HW);
+  float* sums = scratch + (size_t)NB * nch * C * 2;
+  hipLaunchKernelGGL(in_chunk_j_kernel<MODE>, dim3(nch, (C + 63) / 64, NB), dim3(256), 0, s, x, v, stats, scratch, HW, C, act);
+  hipLaunchKernelGGL(in_finalize_j_kernel, dim3((C + 63) / 64, NB), dim3(64), 0, s, scratch, nch, C, sums);
+  hipLaunchKernelGGL(in_japply_chunked_kernel<MODE>, dim3(in_ew_blocks(HW, C), NB), dim3(256), 0, s, x, v, stats, sums, dst,
+                     accumulate, dst_bf, HW, C, act);
+}
+
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s, int nslab,
-                   size_t slab_stride, const float* slab_bias, float* xsum, unsigned short* out_bf) {
+                   size_t slab_stride, const float* slab_bias, float* xsum, unsigned short* out_bf, float* chunk_scratch) {
   EG_CHECK(!out_bf || C % 32 == 0, "in_fwd: a bf16 plane was requested with C %% 32 != 0");
   EG_CHECK(out || out_bf, "in_fwd: neither an fp32 output nor a plane");
+  if (chunk_scratch && in_chunked_shape(HW, C) && nslab <= 1) {   // large maps: chunked two-stage form
+    in_fwd_chunked(x, out, stats, NB, HW, C, act, s, out_bf, chunk_scratch);
+    return;
+  }
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
 #define EG_IN_FWD(NP, CQ, G) hipLaunchKernelGGL((in_fwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, HW, C, act, nslab, slab_stride, slab_bias, xsum, out_bf)
@@ -539,7 +705,12 @@ bool in_bwd_takes_slabs(int HW, int C) { return C % 32 == 0 && HW <= 1024; }   /
 int in_bwd_colpart_rows(int NB, int HW, int C) { return in_bwd_takes_slabs(HW, C) ? NB : 0; }
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
                    int accumulate, int NB, int HW, int C, int act, hipStream_t s, unsigned short* dx_bf,
-                   const SlabSrc* dout_slabs, float* colpart) {
+                   const SlabSrc* dout_slabs, float* colpart, float* chunk_scratch) {
+  if (chunk_scratch && in_chunked_shape(HW, C) && !dout_slabs && !colpart) {   // large maps: chunked two-stage form
+    EG_CHECK(!(accumulate & GRAD_PLANE_ONLY) || dx_bf, "in_bwd: GRAD_PLANE_ONLY without a plane");
+    in_japply_chunked<0>(x, dout, stats, dx, accumulate, NB, HW, C, act, s, dx_bf, chunk_scratch);
+    return;
+  }
   EG_CHECK(!colpart || in_bwd_colpart_rows(NB, HW, C), "in_bwd: column partials need C %% 32 == 0 and HW <= 1024");
   EG_CHECK(!dx_bf || C % 32 == 0, "in_bwd: a bf16 plane was requested with C %% 32 != 0");
   EG_CHECK(!(accumulate & GRAD_PLANE_ONLY) || dx_bf, "in_bwd: GRAD_PLANE_ONLY without a plane");
@@ -564,7 +735,11 @@ void launch_in_bwd(const float* x, const float* out, const float* dout, const fl
                      accumulate, HW, C, act);
 }
 void launch_in_tangent_fwd(const float* x, const float* out, const float* stats, const float* tx, float* tout,
-                           int NB, int HW, int C, int act, hipStream_t s, unsigned short* tout_bf) {
+                           int NB, int HW, int C, int act, hipStream_t s, unsigned short* tout_bf, float* chunk_scratch) {
+  if (chunk_scratch && in_chunked_shape(HW, C)) {   // large maps: chunked two-stage form
+    in_japply_chunked<1>(x, tx, stats, tout, 0, NB, HW, C, act, s, tout_bf, chunk_scratch);
+    return;
+  }
   if (C % 32 == 0) {
     hipLaunchKernelGGL((in_japply_v<1, 8>), dim3(NB, C / 32), dim3(256), 0, s, x, out, tx, stats, tout, 0, HW, C, act, tout_bf);
     return;

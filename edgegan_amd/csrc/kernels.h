@@ -361,12 +361,18 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3,
 // and, with xsum, also stores that sum (training: the pre-norm tensor the backward reads)
 void launch_in_fwd(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s,
                    int nslab = 0, size_t slab_stride = 0, const float* slab_bias = nullptr, float* xsum = nullptr,
-                   unsigned short* out_bf = nullptr);   // *_bf: also store the bf16 plane of the output (bf16 mode, C % 32 == 0)
+                   unsigned short* out_bf = nullptr,   // *_bf: also store the bf16 plane of the output (bf16 mode, C % 32 == 0)
+                   float* chunk_scratch = nullptr);
+// chunk_scratch (launch_in_fwd / launch_in_bwd / launch_in_tangent_fwd): in_chunk_scratch_floats(NB, HW, C) floats of the caller's,
+// private to the launch until it has run.  With it, maps of more than 1,024 pixels (in_chunked_shape) take the chunked two-stage
+// form -- pixel chunks x channel groups x images instead of one block per (image, channel group).
+bool in_chunked_shape(int HW, int C);
+size_t in_chunk_scratch_floats(int NB, int HW, int C);
 // dx (+)= J * (dout * act'(out))   (J = IN Jacobian, symmetric)
 // dout_slabs (C % 32 == 0 and HW <= 1024 only): dout is that SlabSrc instead
 void launch_in_bwd(const float* x, const float* out, const float* dout, const float* stats, float* dx,
                    int accumulate, int NB, int HW, int C, int act, hipStream_t s, unsigned short* dx_bf = nullptr,
-                   const SlabSrc* dout_slabs = nullptr, float* colpart = nullptr);
+                   const SlabSrc* dout_slabs = nullptr, float* colpart = nullptr, float* chunk_scratch = nullptr);
 // colpart (here and in the other gradient writers below): per-block column sums of the gradient JUST WRITTEN -- the first
 // stage of the bias gradient of the convolution whose output gradient this is (conv.py:31-34: db = sum over pixels of dY), so
 // that no pass re-reads dY for it.  [rows][C] floats; the launcher returns `rows` through colpart_rows_* below (0: this form of
@@ -375,7 +381,8 @@ int in_bwd_colpart_rows(int NB, int HW, int C);
 bool in_bwd_takes_slabs(int HW, int C);
 // tangent forward: tout = act'(out_primal) * (J * tx)
 void launch_in_tangent_fwd(const float* x, const float* out, const float* stats, const float* tx, float* tout,
-                           int NB, int HW, int C, int act, hipStream_t s, unsigned short* tout_bf = nullptr);
+                           int NB, int HW, int C, int act, hipStream_t s, unsigned short* tout_bf = nullptr,
+                           float* chunk_scratch = nullptr);
 // tangent backward: given dtout, produce dtx (+)= ..., dx_primal (+)= ...
 void launch_in_tangent_bwd(const float* x, const float* out, const float* stats, const float* tx,
                            const float* dtout, float* dtx, int acc_dtx, float* dx, int acc_dx, int NB, int HW,

@@ -896,11 +896,12 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
         const size_t img = (size_t)HW * C;
         if (ne > 0)
           launch_in_fwd(yv->d, out[i]->d_plane_only ? nullptr : out[i]->d + (size_t)n0 * img, st[i]->d + (size_t)n0 * 2 * C, ne, HW, C,
-                        ACT_LRELU, c.stream, 0, 0, nullptr, nullptr, out[i]->d_bf ? out[i]->d_bf + (size_t)n0 * img : nullptr);
+                        ACT_LRELU, c.stream, 0, 0, nullptr, nullptr, out[i]->d_bf ? out[i]->d_bf + (size_t)n0 * img : nullptr,
+                        in_chunk_scratch(c, ne, HW, C));
         if (nt > 0)   // the tangent rows: linearised at the primal rows [0,B) (x, out, statistics)
           launch_in_tangent_fwd(pre[i]->d, out[i]->d, st[i]->d, yv->d + (size_t)ne * img,
                                 out[i]->d_plane_only ? nullptr : out[i]->d + (size_t)(n0 + ne) * img, nt, HW, C, ACT_LRELU, c.stream,
-                                out[i]->d_bf ? out[i]->d_bf + (size_t)(n0 + ne) * img : nullptr);
+                                out[i]->d_bf ? out[i]->d_bf + (size_t)(n0 + ne) * img : nullptr, in_chunk_scratch(c, nt, HW, C));
       }
       xin = rows(out[i], n0, n);
     }
@@ -919,7 +920,7 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
     const size_t img = (size_t)HW * C, o = (size_t)n0 * img;
     // (gpo: the fp32 gradient of pre[i] is not stored -- both gradient convolutions of layer i read the plane, Tensor::g_plane_only)
     launch_in_bwd(pre[i]->d + o, out[i]->d + o, out[i]->g + (size_t)gy0 * img, st[i]->d + (size_t)n0 * 2 * C, pre[i]->g + o, acc | (gpl[i] ? gpo : 0), n, HW, C,
-                  ACT_LRELU, c.stream, gpl[i] ? gpl[i] + o : nullptr);
+                  ACT_LRELU, c.stream, gpl[i] ? gpl[i] + o : nullptr, nullptr, nullptr, in_chunk_scratch(c, n, HW, C));
     pre[i]->g_bf = gpl[i];            // (rows [n0, n0 + n) of the plane are current; view_rows hands them on)
     pre[i]->g_bf_stream = nullptr;
     pre[i]->g_plane_only = gpl[i] && gpo;

@@ -1381,6 +1381,11 @@ T linear1(Ctx& c, T x, Param* w, Param* bias) {
 }
 
 // normalization.py:13-18 + activation.py:4-15 (fused)
+// scratch of the chunked InstanceNorm kernels (maps of more than 1,024 pixels: kernels.h in_chunked_shape), from the active arena
+float* in_chunk_scratch(Ctx& c, int NB, int HW, int C) {
+  return in_chunked_shape(HW, C) ? c.arena.allocf(in_chunk_scratch_floats(NB, HW, C)) : nullptr;
+}
+
 T in_act(Ctx& c, T x, int a, T* stats_out, bool plane_only) {
   T out = new_tensor(c, x->n, x->h, x->w, x->c, x->needs_grad);
   T st = new_tensor(c, x->n, 1, 1, 2 * x->c, false);
@@ -1398,7 +1403,7 @@ T in_act(Ctx& c, T x, int a, T* stats_out, bool plane_only) {
                   x->needs_grad ? x->d : nullptr, plane);
     if (x->needs_grad) x->nslab = 0;
   } else
-    launch_in_fwd(x->d, od, st->d, x->n, HW, x->c, a, c.stream, 0, 0, nullptr, nullptr, plane);
+    launch_in_fwd(x->d, od, st->d, x->n, HW, x->c, a, c.stream, 0, 0, nullptr, nullptr, plane, in_chunk_scratch(c, x->n, HW, x->c));
   if (stats_out) *stats_out = st;
   if (x->needs_grad) {
     out->g_slab_ok = in_bwd_takes_slabs(HW, x->c);
@@ -1413,7 +1418,7 @@ T in_act(Ctx& c, T x, int a, T* stats_out, bool plane_only) {
       float* part = colpart_for(c, x, acc, prow);
       unsigned short* gplane = producer_plane(c, x, true);
       launch_in_bwd(x->d, out->d, out->g, st->d, dx, plane_only_acc(c, x, acc, gplane), x->n, HW, x->c, a, c.stream, gplane,
-                    ds.n > 1 ? &ds : nullptr, part);
+                    ds.n > 1 ? &ds : nullptr, part, in_chunk_scratch(c, x->n, HW, x->c));
       colpart_done(x, part, prow);
     });
   }
@@ -1425,7 +1430,7 @@ T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int a) {
   T tout = new_tensor(c, tx->n, tx->h, tx->w, tx->c, true);
   const int HW = tx->h * tx->w;
   launch_in_tangent_fwd(x_prim->d, out_prim->d, stats_prim->d, tx->d, tout->d, tx->n, HW, tx->c, a, c.stream,
-                        producer_plane(c, tout, false));
+                        producer_plane(c, tout, false), in_chunk_scratch(c, tx->n, HW, tx->c));
   Ctx* cp = &c;
   c.tape.push([=]() {
     Ctx& c = *cp;
