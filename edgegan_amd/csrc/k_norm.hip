@@ -532,17 +532,30 @@ __global__ __launch_bounds__(256) void in_chunk_stats_kernel(const float* __rest
   const bool cv = c < C;
   const int r0 = blockIdx.x * IN_RPC, r1 = min(HW, r0 + IN_RPC);
   const float* xp = x + (size_t)n * HW * C + c;
+  // (the chunk's IN_RPC / 4 = 64 rows of a thread stay in registers between the two passes: one load each, all in flight)
+  constexpr int NR = IN_RPC / 4;
+  float xv[NR];
   float s[1] = {0.f};
-  if (cv)
-    for (int p = r0 + py; p < r1; p += 4) s[0] += xp[(size_t)p * C];
+  if (cv) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int p = r0 + py + 4 * k;
+      xv[k] = p < r1 ? xp[(size_t)p * C] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) s[0] += xv[k];
+  }
   lane4_reduce<1>(s, red, cx, py);
   const float mean = s[0] / (float)(r1 - r0);
   float q[1] = {0.f};
-  if (cv)
-    for (int p = r0 + py; p < r1; p += 4) {
-      const float d = xp[(size_t)p * C] - mean;
-      q[0] += d * d;
-    }
+  if (cv) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+      if (r0 + py + 4 * k < r1) {
+        const float d = xv[k] - mean;
+        q[0] += d * d;
+      }
+  }
   lane4_reduce<1>(q, red, cx, py);
   if (cv && py == 0) {
     float* o = part + (((size_t)n * nch + blockIdx.x) * C + c) * 2;
@@ -597,13 +610,24 @@ __global__ __launch_bounds__(256) void in_chunk_j_kernel(const float* __restrict
   const float r = cv ? 1.f / (stats[((size_t)n * C + c) * 2 + 1] + IN_EPS) : 1.f;
   float s[2] = {0.f, 0.f};
   if (cv)
-    for (int p = r0 + py; p < r1; p += 4) {
-      const size_t i = base + (size_t)p * C;
-      const float xc = x[i] - mean;
-      float e = v[i];
-      if (MODE == 0) e *= act_grad_from_out(act_apply(xc * r, act), act);
-      s[0] += e;
-      s[1] += e * xc;
+    for (int p0 = r0 + py; p0 < r1; p0 += 32) {   // eight rows per step, their sixteen loads issued together
+      float xr[8], er[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + 4 * u;
+        const size_t i = base + (size_t)(p < r1 ? p : r0) * C;
+        xr[u] = x[i];
+        er[u] = v[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p0 + 4 * u < r1) {
+          const float xc = xr[u] - mean;
+          float e = er[u];
+          if (MODE == 0) e *= act_grad_from_out(act_apply(xc * r, act), act);
+          s[0] += e;
+          s[1] += e * xc;
+        }
     }
   lane4_reduce<2>(s, red, cx, py);
   if (cv && py == 0) {
@@ -656,9 +680,116 @@ __global__ __launch_bounds__(256) void in_japply_chunked_kernel(const float* __r
     if (dst_bf) st_bf4n(dst_bf, i, res);
   }
 }
+// reverse of the forward tangent on large maps, three stages (as in_tangent_bwd_v: means first, then the centred moments -- the
+// uncentred forms cancel): partials of (sum e, sum t), then of (A, S_xt, S_ex), then the element-wise apply
+template <int STAGE>
+__global__ __launch_bounds__(256) void in_chunk_tb_kernel(const float* __restrict__ x, const float* __restrict__ tx,
+                                                          const float* __restrict__ dtout, const float* __restrict__ stats,
+                                                          const float* __restrict__ means, float* __restrict__ part, int HW, int C,
+                                                          int act) {
+  constexpr int NV = STAGE == 0 ? 2 : 3;
+  __shared__ float red[NV * 4 * 64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cx, n = blockIdx.z, nch = gridDim.x;
+  const bool cv = c < C;
+  const int r0 = blockIdx.x * IN_RPC, r1 = min(HW, r0 + IN_RPC);
+  const size_t base = (size_t)n * HW * C + c;
+  const float mean = cv ? stats[((size_t)n * C + c) * 2] : 0.f;
+  const float r = cv ? 1.f / (stats[((size_t)n * C + c) * 2 + 1] + IN_EPS) : 1.f;
+  const float eb = (STAGE == 1 && cv) ? means[((size_t)n * C + c) * 2] / (float)HW : 0.f;
+  const float ta = (STAGE == 1 && cv) ? means[((size_t)n * C + c) * 2 + 1] / (float)HW : 0.f;
+  float s[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) s[k] = 0.f;
+  if (cv)
+    for (int p0 = r0 + py; p0 < r1; p0 += 16) {   // four rows per step, their twelve loads issued together
+      float xr[4], tr[4], dr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + 4 * u;
+        const size_t i = base + (size_t)(p < r1 ? p : r0) * C;
+        xr[u] = x[i];
+        tr[u] = tx[i];
+        dr[u] = dtout[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p0 + 4 * u < r1) {
+          const float xc = xr[u] - mean, t = tr[u];
+          const float e = dr[u] * act_grad_from_out(act_apply(xc * r, act), act);
+          if (STAGE == 0) {
+            s[0] += e;
+            s[1] += t;
+          } else {
+            s[0] += (e - eb) * (t - ta);
+            s[1] += xc * t;
+            s[NV - 1] += e * xc;
+          }
+        }
+    }
+  lane4_reduce<NV>(s, red, cx, py);
+  if (cv && py == 0) {
+    float* o = part + (((size_t)n * nch + blockIdx.x) * C + c) * NV;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) o[k] = s[k];
+  }
+}
+template <int NV>
+__global__ void in_finalize_n_kernel(const float* __restrict__ part, int nch, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (c >= C) return;
+  float a[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) a[k] = 0.f;
+  for (int z = 0; z < nch; ++z) {
+    const float* o = part + (((size_t)n * nch + z) * C + c) * NV;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) a[k] += o[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) sums[((size_t)n * C + c) * NV + k] = a[k];
+}
+__global__ __launch_bounds__(256) void in_tb_apply_chunked_kernel(const float* __restrict__ x, const float* __restrict__ tx,
+                                                                  const float* __restrict__ dtout, const float* __restrict__ stats,
+                                                                  const float* __restrict__ means, const float* __restrict__ moments,
+                                                                  float* __restrict__ dtx, int acc_dtx, float* __restrict__ dx,
+                                                                  int acc_dx, unsigned short* __restrict__ dtx_bf, int HW, int C,
+                                                                  int act) {
+  const int n = blockIdx.y, c4n = C >> 2;
+  const size_t per = (size_t)HW * c4n, ib = (size_t)n * HW * C;
+  const float hw = (float)HW;
+  for (size_t q = blockIdx.x * (size_t)256 + threadIdx.x; q < per; q += (size_t)gridDim.x * 256) {
+    const int c = (int)(q % c4n) * 4;
+    const size_t i = ib + q * 4;
+    const Stat4 st = load_stats4(stats, (size_t)n * C + c);
+    const float* mp = means + ((size_t)n * C + c) * 2;
+    const float* qp = moments + ((size_t)n * C + c) * 3;
+    const float sg[4] = {st.sigma.x, st.sigma.y, st.sigma.z, st.sigma.w}, rr[4] = {st.r.x, st.r.y, st.r.z, st.r.w};
+    const float4 xv = ld4(x + i), tv = ld4(tx + i), dv = ld4(dtout + i), g = actg_from_x(xv, st, act);
+    const float e[4] = {dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w}, t[4] = {tv.x, tv.y, tv.z, tv.w};
+    const float xc[4] = {xv.x - st.mean.x, xv.y - st.mean.y, xv.z - st.mean.z, xv.w - st.mean.w};
+    float gt[4], gx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float eb = mp[2 * j] / hw, ta = mp[2 * j + 1] / hw;
+      const float A = qp[3 * j], Sxt = qp[3 * j + 1], Sex = qp[3 * j + 2];
+      const float B = Sxt * Sex / hw, r2 = rr[j] * rr[j];
+      const float c1 = (-A * r2 + 2.f * r2 * rr[j] * B / sg[j] + r2 * B / (sg[j] * sg[j])) / (hw * sg[j]);
+      const float c2 = -r2 * Sex / (hw * sg[j]), c3 = -r2 * Sxt / (hw * sg[j]), k2 = r2 * Sex / (hw * sg[j]);
+      gt[j] = rr[j] * (e[j] - eb) - k2 * xc[j];
+      gx[j] = c1 * xc[j] + c2 * (t[j] - ta) + c3 * (e[j] - eb);
+    }
+    float4 o1 = make_float4(gt[0], gt[1], gt[2], gt[3]), o2 = make_float4(gx[0], gx[1], gx[2], gx[3]);
+    if (acc_dtx & 1) { const float4 a = ld4(dtx + i); o1.x += a.x; o1.y += a.y; o1.z += a.z; o1.w += a.w; }
+    if (acc_dx) { const float4 a = ld4(dx + i); o2.x += a.x; o2.y += a.y; o2.z += a.z; o2.w += a.w; }
+    if (!(acc_dtx & 2)) st4(dtx + i, o1);   // (GRAD_PLANE_ONLY)
+    if (dtx_bf) st_bf4n(dtx_bf, i, o1);
+    st4(dx + i, o2);
+  }
+}
 static inline int in_chunks(int HW) { return (HW + IN_RPC - 1) / IN_RPC; }
 bool in_chunked_shape(int HW, int C) { return HW > 1024 && C % 32 == 0; }
-size_t in_chunk_scratch_floats(int NB, int HW, int C) { return (size_t)NB * in_chunks(HW) * C * 2 + (size_t)NB * C * 2; }
+size_t in_chunk_scratch_floats(int NB, int HW, int C) { return (size_t)NB * in_chunks(HW) * C * 3 + (size_t)NB * C * 5; }   // partials (<= 3 sums) + means (2) + moments (3)
 static inline int in_ew_blocks(int HW, int C) { return (int)std::min<size_t>(2048, ((size_t)HW * (C >> 2) + 255) / 256); }
 static void in_fwd_chunked(const float* x, float* out, float* stats, int NB, int HW, int C, int act, hipStream_t s,
                            unsigned short* out_bf, float* scratch) {
@@ -671,7 +802,7 @@ template <int MODE>
 static void in_japply_chunked(const float* x, const float* v, const float* stats, float* dst, int accumulate, int NB, int HW, int C,
                               int act, hipStream_t s, unsigned short* dst_bf, float* scratch) {
   const int nch = in_chunks(HW);
-  float* sums = scratch + (size_t)NB * nch * C * 2;
+  float* sums = scratch + (size_t)NB * nch * C * 3;
   hipLaunchKernelGGL(in_chunk_j_kernel<MODE>, dim3(nch, (C + 63) / 64, NB), dim3(256), 0, s, x, v, stats, scratch, HW, C, act);
   hipLaunchKernelGGL(in_finalize_j_kernel, dim3((C + 63) / 64, NB), dim3(64), 0, s, scratch, nch, C, sums);
   hipLaunchKernelGGL(in_japply_chunked_kernel<MODE>, dim3(in_ew_blocks(HW, C), NB), dim3(256), 0, s, x, v, stats, sums, dst,
@@ -909,9 +1040,22 @@ __global__ __launch_bounds__(256) void in_tangent_bwd_vr(const float* __restrict
 
 void launch_in_tangent_bwd(const float* x, const float* out, const float* stats, const float* tx,
                            const float* dtout, float* dtx, int acc_dtx, float* dx, int acc_dx, int NB, int HW,
-                           int C, int act, hipStream_t s, unsigned short* dtx_bf) {
+                           int C, int act, hipStream_t s, unsigned short* dtx_bf, float* chunk_scratch) {
   EG_CHECK(!dtx_bf || C % 32 == 0, "in_tangent_bwd: a bf16 plane was requested with C %% 32 != 0");
   EG_CHECK(!(acc_dtx & GRAD_PLANE_ONLY) || dtx_bf, "in_tangent_bwd: GRAD_PLANE_ONLY without a plane");
+  if (chunk_scratch && in_chunked_shape(HW, C)) {   // large maps: chunked three-stage form
+    const int nch = in_chunks(HW);
+    float* means = chunk_scratch + (size_t)NB * nch * C * 3;
+    float* moments = means + (size_t)NB * C * 2;
+    const dim3 cg(nch, (C + 63) / 64, NB), fg((C + 63) / 64, NB);
+    hipLaunchKernelGGL(in_chunk_tb_kernel<0>, cg, dim3(256), 0, s, x, tx, dtout, stats, nullptr, chunk_scratch, HW, C, act);
+    hipLaunchKernelGGL(in_finalize_n_kernel<2>, fg, dim3(64), 0, s, chunk_scratch, nch, C, means);
+    hipLaunchKernelGGL(in_chunk_tb_kernel<1>, cg, dim3(256), 0, s, x, tx, dtout, stats, means, chunk_scratch, HW, C, act);
+    hipLaunchKernelGGL(in_finalize_n_kernel<3>, fg, dim3(64), 0, s, chunk_scratch, nch, C, moments);
+    hipLaunchKernelGGL(in_tb_apply_chunked_kernel, dim3(in_ew_blocks(HW, C), NB), dim3(256), 0, s, x, tx, dtout, stats, means, moments,
+                       dtx, acc_dtx, dx, acc_dx, dtx_bf, HW, C, act);
+    return;
+  }
   if (C % 32 == 0) {
     const dim3 grid(NB, C / 32);
 #define EG_IN_TBWD(NP, CQ, G) hipLaunchKernelGGL((in_tangent_bwd_vr<NP, CQ>), G, dim3(256), 0, s, x, out, stats, tx, dtout, dtx, acc_dtx, dx, acc_dx, HW, C, act, dtx_bf)

@@ -386,7 +386,7 @@ void launch_in_tangent_fwd(const float* x, const float* out, const float* stats,
 // tangent backward: given dtout, produce dtx (+)= ..., dx_primal (+)= ...
 void launch_in_tangent_bwd(const float* x, const float* out, const float* stats, const float* tx,
                            const float* dtout, float* dtx, int acc_dtx, float* dx, int acc_dx, int NB, int HW,
-                           int C, int act, hipStream_t s, unsigned short* dtx_bf = nullptr);
+                           int C, int act, hipStream_t s, unsigned short* dtx_bf = nullptr, float* chunk_scratch = nullptr);
 // plain activation (no norm): fwd, bwd (dx (+)= dout*act'(out)), tangent (tout = act'(out)*tx)
 void launch_act_fwd(const float* x, float* out, size_t n, int act, hipStream_t s);
 void launch_act_bwd(const float* out, const float* dout, float* dx, int accumulate, size_t n, int act,

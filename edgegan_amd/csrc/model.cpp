@@ -981,7 +981,7 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
     // the tangent rows: reverse of the linearisation -- gradient w.r.t. the tangent (= phase 1's delta(pre_i), formed again by the
     // same kernel that forms the term below) AND w.r.t. the primal pre-norm rows [0,B)
     launch_in_tangent_bwd(pre[i]->d, out[i]->d, st[i]->d, pre[i]->d + ot, out[i]->g + ot, pre[i]->g + ot, gpl[i] ? gpo : 0, pre[i]->g, 0, B, HW, C,
-                          ACT_LRELU, c.stream, gpl[i] ? gpl[i] + ot : nullptr);
+                          ACT_LRELU, c.stream, gpl[i] ? gpl[i] + ot : nullptr, in_chunk_scratch(c, B, HW, C));
     norm_bwd(i, 0, B, 1, 0);                                   // the primal rows add their own first-order term
     pre[i]->g_set = true;
     conv_backward_w(c, out[i - 1], pre[i], w[i], 4, 2);

@@ -1439,7 +1439,7 @@ T in_act_tangent(Ctx& c, T tx, T x_prim, T out_prim, T stats_prim, int a) {
     float* dtx = grad_acc(c, tx, &acc_t);
     float* dx = grad_acc(c, x_prim, &acc_x);
     launch_in_tangent_bwd(x_prim->d, out_prim->d, stats_prim->d, tx->d, tout->g, dtx, acc_t, dx, acc_x, tx->n, HW,
-                          tx->c, a, c.stream);
+                          tx->c, a, c.stream, nullptr, in_chunk_scratch(c, tx->n, HW, tx->c));
   });
   return tout;
 }
