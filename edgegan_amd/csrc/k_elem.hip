@@ -1,6 +1,8 @@
 // HBM-bound kernels of the EdgeGAN step: data movement, pooling, legacy-bicubic resize, PReLU,
 // min-max gate, spectral norm, losses, RMSProp.  NHWC fp32.  All reductions are fixed-order
 // (two-stage, no float atomics) so replicas stay bit-identical under data parallelism.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 #include "cq_reduce.h"
@@ -989,10 +991,192 @@ __global__ __launch_bounds__(64 * NW) void minmax_bwd_v(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The min-max gate on LARGE maps (H W > 4,096: configs[4]'s 256 x 512 geometry -- up to 65,536 pixels per map).  The per-(n, c)
+// kernels above give a whole map to one block: 16 blocks at batch 16 for the 8-channel gate, 180 us per launch.  Here a map is
+// cut into chunks of MMC_ROWS rows; minima / maxima and the backward's four sums come from chunk partials combined per (n, c) in
+// chunk order (min / max are order-free, the sums have a fixed order), the apply passes are element-wise over quads.  Same
+// formulas and tie split as minmax_fwd_v / minmax_bwd_v.  Block = CG channels x 256 / CG row lanes (CG = 8 or 64).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int MMC_ROWS = 512;
+template <int CG>
+__global__ __launch_bounds__(256) void mmc_minmax_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C, float lk) {
+  constexpr int L = 256 / CG;
+  __shared__ float red[2 * L * CG];
+  const int cx = threadIdx.x % CG, py = threadIdx.x / CG;
+  const int c = blockIdx.y * CG + cx, n = blockIdx.z, nch = gridDim.x;
+  const bool cv = c < C;
+  const int r0 = blockIdx.x * MMC_ROWS, r1 = min(HW, r0 + MMC_ROWS);
+  const float* xp = x + (size_t)n * HW * C + c;
+  float mn = INFINITY, mx = -INFINITY;
+  if (cv)
+    for (int p0 = r0 + py; p0 < r1; p0 += 8 * L) {   // eight rows per step, their loads issued together
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + u * L;
+        v[u] = xp[(size_t)(p < r1 ? p : r0) * C];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p0 + u * L < r1) {
+          const float t = mm_pre(v[u], lk);
+          mn = fminf(mn, t);
+          mx = fmaxf(mx, t);
+        }
+    }
+  red[py * CG + cx] = mn;
+  red[(L + py) * CG + cx] = mx;
+  __syncthreads();
+  if (py == 0 && cv) {
+    for (int q = 1; q < L; ++q) {
+      mn = fminf(mn, red[q * CG + cx]);
+      mx = fmaxf(mx, red[(L + q) * CG + cx]);
+    }
+    float* o = part + (((size_t)n * nch + blockIdx.x) * C + c) * 2;
+    o[0] = mn;
+    o[1] = mx;
+  }
+}
+__global__ void mmc_minmax_finalize_kernel(const float* __restrict__ part, int nch, int C, float* __restrict__ mm) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (c >= C) return;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int k = 0; k < nch; ++k) {
+    const float* o = part + (((size_t)n * nch + k) * C + c) * 2;
+    mn = fminf(mn, o[0]);
+    mx = fmaxf(mx, o[1]);
+  }
+  mm[((size_t)n * C + c) * 2] = mn;
+  mm[((size_t)n * C + c) * 2 + 1] = mx;
+}
+__global__ __launch_bounds__(256) void mmc_fwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ mm,
+                                                            float* __restrict__ y, int HW, int C, float lk) {
+  const int n = blockIdx.y, c4n = C >> 2;
+  const size_t per = (size_t)HW * c4n, ib = (size_t)n * HW * C;
+  for (size_t q = blockIdx.x * (size_t)256 + threadIdx.x; q < per; q += (size_t)gridDim.x * 256) {
+    const int c = (int)(q % c4n) * 4;
+    const size_t i = ib + q * 4;
+    const float4 a = ld4(mm + ((size_t)n * C + c) * 2), b = ld4(mm + ((size_t)n * C + c) * 2 + 4);
+    const float4 v = mm_pre4(ld4(x + i), lk);
+    st4(y + i, make_float4((v.x - a.x) * (1.f / (a.y - a.x)), (v.y - a.z) * (1.f / (a.w - a.z)), (v.z - b.x) * (1.f / (b.y - b.x)),
+                           (v.w - b.z) * (1.f / (b.w - b.z))));
+  }
+}
+// chunk partials of S1 = sum g, S2 = sum g (v - mn), the tie counts of mn and mx
+template <int CG>
+__global__ __launch_bounds__(256) void mmc_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ mm,
+                                                           const float* __restrict__ dy, float* __restrict__ part, int HW, int C,
+                                                           float lk) {
+  constexpr int L = 256 / CG;
+  __shared__ float red[4 * L * CG];
+  const int cx = threadIdx.x % CG, py = threadIdx.x / CG;
+  const int c = blockIdx.y * CG + cx, n = blockIdx.z, nch = gridDim.x;
+  const bool cv = c < C;
+  const int r0 = blockIdx.x * MMC_ROWS, r1 = min(HW, r0 + MMC_ROWS);
+  const size_t base = (size_t)n * HW * C + c;
+  const float mn = cv ? mm[((size_t)n * C + c) * 2] : 0.f, mx = cv ? mm[((size_t)n * C + c) * 2 + 1] : 1.f;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (cv)
+    for (int p0 = r0 + py; p0 < r1; p0 += 4 * L) {   // four rows per step, their eight loads issued together
+      float xr[4], gr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + u * L;
+        const size_t i = base + (size_t)(p < r1 ? p : r0) * C;
+        xr[u] = x[i];
+        gr[u] = dy[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p0 + u * L < r1) {
+          const float v = mm_pre(xr[u], lk), g = gr[u];
+          s[0] += g;
+          s[1] += g * (v - mn);
+          s[2] += v == mn ? 1.f : 0.f;
+          s[3] += v == mx ? 1.f : 0.f;
+        }
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[(k * L + py) * CG + cx] = s[k];
+  __syncthreads();
+  if (py == 0 && cv) {
+    float* o = part + (((size_t)n * nch + blockIdx.x) * C + c) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = s[k];
+      for (int q = 1; q < L; ++q) t += red[(k * L + q) * CG + cx];
+      o[k] = t;
+    }
+  }
+}
+// coef[(n C + c) 3 ..] = d = mx - mn, dmn, dmx (the tie split of minmax_bwd_v)
+__global__ void mmc_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ mm, int nch, int C,
+                                        float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (c >= C) return;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < nch; ++k) {
+    const float* o = part + (((size_t)n * nch + k) * C + c) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] += o[j];
+  }
+  const float d = mm[((size_t)n * C + c) * 2 + 1] - mm[((size_t)n * C + c) * 2];
+  float* o = coef + ((size_t)n * C + c) * 3;
+  o[0] = d;
+  o[1] = (-s[0] / d + s[1] / (d * d)) / s[2];
+  o[2] = (-s[1] / (d * d)) / s[3];
+}
+__global__ __launch_bounds__(256) void mmc_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ mm,
+                                                            const float* __restrict__ dy, const float* __restrict__ coef,
+                                                            float* __restrict__ dx, int acc, unsigned short* __restrict__ dx_bf, int HW,
+                                                            int C, float lk) {
+  const int n = blockIdx.y, c4n = C >> 2;
+  const size_t per = (size_t)HW * c4n, ib = (size_t)n * HW * C;
+  for (size_t q = blockIdx.x * (size_t)256 + threadIdx.x; q < per; q += (size_t)gridDim.x * 256) {
+    const int c = (int)(q % c4n) * 4;
+    const size_t i = ib + q * 4;
+    const float* mp = mm + ((size_t)n * C + c) * 2;
+    const float* cp = coef + ((size_t)n * C + c) * 3;
+    const float4 xv = ld4(x + i), g = ld4(dy + i), v = mm_pre4(xv, lk);
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w}, vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[j] = gg[j] / cp[3 * j];
+      if (vv[j] == mp[2 * j]) r[j] += cp[3 * j + 1];
+      if (vv[j] == mp[2 * j + 1]) r[j] += cp[3 * j + 2];
+      r[j] *= mm_slope(xx[j], lk);
+    }
+    float4 o = make_float4(r[0], r[1], r[2], r[3]);
+    if (acc & 1) { const float4 t = ld4(dx + i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+    if (!(acc & 2)) st4(dx + i, o);
+    if (dx_bf) st_bf4(dx_bf, i >> 2, o);
+  }
+}
+// (more than 4,096 pixels per map, or at least 2,048 with fewer (image, 32-channel group) blocks than CUs: the 64 x 64 maps at
+//  configs[4]'s batch of 16)
+bool minmax_chunked_shape(int NB, int HW, int C) {
+  return C % 8 == 0 && (HW > 4096 || (HW >= 2048 && (long long)NB * ((C + 31) / 32) < 256));
+}
+size_t minmax_chunk_scratch_floats(int NB, int HW, int C) {
+  const size_t nch = (size_t)(HW + MMC_ROWS - 1) / MMC_ROWS;
+  return (size_t)NB * nch * C * 4 + (size_t)NB * C * 3;
+}
+static inline int mmc_ew_blocks(int HW, int C) { return (int)std::min<size_t>(2048, ((size_t)HW * (C >> 2) + 255) / 256); }
+
 void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s, float pre_leak,
-                       const SlabSrc* x_slabs, float* xsum) {
+                       const SlabSrc* x_slabs, float* xsum, float* chunk_scratch) {
   const SlabSrc xs = x_slabs ? *x_slabs : plain_src(x);
   EG_CHECK(xs.n <= 1 || (C % 8 == 0 && xsum), "minmax_fwd: a slab input needs C %% 8 == 0 and a destination for the sum");
+  if (chunk_scratch && xs.n <= 1 && minmax_chunked_shape(NB, HW, C)) {   // large maps: chunked two-stage form
+    const int nch = (HW + MMC_ROWS - 1) / MMC_ROWS;
+    if (C % 64 == 0) hipLaunchKernelGGL(mmc_minmax_kernel<64>, dim3(nch, C / 64, NB), dim3(256), 0, s, x, chunk_scratch, HW, C, pre_leak);
+    else hipLaunchKernelGGL(mmc_minmax_kernel<8>, dim3(nch, C / 8, NB), dim3(256), 0, s, x, chunk_scratch, HW, C, pre_leak);
+    hipLaunchKernelGGL(mmc_minmax_finalize_kernel, dim3((C + 63) / 64, NB), dim3(64), 0, s, chunk_scratch, nch, C, mm);
+    hipLaunchKernelGGL(mmc_fwd_apply_kernel, dim3(mmc_ew_blocks(HW, C), NB), dim3(256), 0, s, x, mm, y, HW, C, pre_leak);
+    return;
+  }
   if (C % 32 == 0) {
     hipLaunchKernelGGL((minmax_fwd_v<8, 4>), dim3(NB, C / 32), dim3(256), 0, s, xs, xsum, y, mm, HW, C, pre_leak);
     return;
@@ -1003,9 +1187,21 @@ void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int 
   }
   hipLaunchKernelGGL(minmax_fwd_kernel, dim3(NB, (C + 63) / 64), dim3(256), 0, s, x, y, mm, HW, C, pre_leak);
 }
-int minmax_bwd_colpart_rows(int NB, int C) { return C % 8 == 0 ? NB : 0; }
+int minmax_bwd_colpart_rows(int NB, int HW, int C) { return (C % 8 == 0 && !minmax_chunked_shape(NB, HW, C)) ? NB : 0; }
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
-                       int HW, int C, hipStream_t s, float pre_leak, unsigned short* dx_bf, float* colpart) {
+                       int HW, int C, hipStream_t s, float pre_leak, unsigned short* dx_bf, float* colpart, float* chunk_scratch) {
+  if (chunk_scratch && !colpart && minmax_chunked_shape(NB, HW, C)) {   // large maps: chunked two-stage form
+    EG_CHECK(!(accumulate & GRAD_PLANE_ONLY) || dx_bf, "minmax_bwd: GRAD_PLANE_ONLY without a plane");
+    EG_CHECK(!dx_bf || C % 32 == 0, "minmax_bwd: a bf16 plane was requested with C %% 32 != 0");
+    const int nch = (HW + MMC_ROWS - 1) / MMC_ROWS;
+    float* coef = chunk_scratch + (size_t)NB * nch * C * 4;
+    if (C % 64 == 0) hipLaunchKernelGGL(mmc_bwd_sums_kernel<64>, dim3(nch, C / 64, NB), dim3(256), 0, s, x, mm, dy, chunk_scratch, HW, C, pre_leak);
+    else hipLaunchKernelGGL(mmc_bwd_sums_kernel<8>, dim3(nch, C / 8, NB), dim3(256), 0, s, x, mm, dy, chunk_scratch, HW, C, pre_leak);
+    hipLaunchKernelGGL(mmc_bwd_finalize_kernel, dim3((C + 63) / 64, NB), dim3(64), 0, s, chunk_scratch, mm, nch, C, coef);
+    hipLaunchKernelGGL(mmc_bwd_apply_kernel, dim3(mmc_ew_blocks(HW, C), NB), dim3(256), 0, s, x, mm, dy, coef, dx, accumulate, dx_bf, HW, C,
+                       pre_leak);
+    return;
+  }
   EG_CHECK(!colpart || C % 8 == 0, "minmax_bwd: column partials need C %% 8 == 0");
   EG_CHECK(!(accumulate & GRAD_PLANE_ONLY) || dx_bf, "minmax_bwd: GRAD_PLANE_ONLY without a plane");
   if (C % 32 == 0) {

@@ -482,10 +482,15 @@ int flat_colpart_rows(size_t n, int C);   // prelu_bwd / gate_prelu_bwd (their f
 // pre_leak != 0: y = minmax(lrelu_{pre_leak}(x)) with the lrelu applied on load / its slope on the gradient store
 // x_slabs (C % 8 == 0 only): x is that SlabSrc and the summed value is stored to xsum (what the backward reads)
 void launch_minmax_fwd(const float* x, float* y, float* mm, int NB, int HW, int C, hipStream_t s, float pre_leak = 0.f,
-                       const SlabSrc* x_slabs = nullptr, float* xsum = nullptr);
+                       const SlabSrc* x_slabs = nullptr, float* xsum = nullptr, float* chunk_scratch = nullptr);
 void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* dx, int accumulate, int NB,
-                       int HW, int C, hipStream_t s, float pre_leak = 0.f, unsigned short* dx_bf = nullptr, float* colpart = nullptr);
-int minmax_bwd_colpart_rows(int NB, int C);
+                       int HW, int C, hipStream_t s, float pre_leak = 0.f, unsigned short* dx_bf = nullptr, float* colpart = nullptr,
+                       float* chunk_scratch = nullptr);
+int minmax_bwd_colpart_rows(int NB, int HW, int C);
+// chunk_scratch: minmax_chunk_scratch_floats(NB, HW, C) floats of the caller's; with it, large maps (minmax_chunked_shape: more than
+// 4,096 pixels, or at least 2,048 when the per-map blocks would not fill the chip) take the chunked two-stage form (no column partials there: minmax_bwd_colpart_rows returns 0)
+bool minmax_chunked_shape(int NB, int HW, int C);
+size_t minmax_chunk_scratch_floats(int NB, int HW, int C);
 // gate merge: out = h + rg*img ; backward
 void launch_gate_fwd(const float* h, const float* rg, const float* img, float* out, size_t n, hipStream_t s);
 void launch_gate_bwd(const float* rg, const float* img, const float* dout, float* dh, int acc_h, float* drg,

@@ -1947,7 +1947,8 @@ T minmax(Ctx& c, T x, float pre_leak) {
   T mm = new_tensor(c, x->n, 1, 1, 2 * x->c, false);
   const int HW = x->h * x->w;
   const SlabSrc xs = data_src(x);   // (conv2d with FEED_MINMAX: the pass sums the slabs and stores the sum to x->d)
-  launch_minmax_fwd(x->d, out->d, mm->d, x->n, HW, x->c, c.stream, pre_leak, xs.n > 1 ? &xs : nullptr, x->d);
+  auto mm_scratch = [](Ctx& c, int NB, int HW, int C) { return minmax_chunked_shape(NB, HW, C) ? c.arena.allocf(minmax_chunk_scratch_floats(NB, HW, C)) : nullptr; };
+  launch_minmax_fwd(x->d, out->d, mm->d, x->n, HW, x->c, c.stream, pre_leak, xs.n > 1 ? &xs : nullptr, x->d, mm_scratch(c, x->n, HW, x->c));
   x->nslab = 0;
   if (x->needs_grad) {
     Ctx* cp = &c;
@@ -1956,10 +1957,11 @@ T minmax(Ctx& c, T x, float pre_leak) {
       if (!out->g_set) return;
       int acc;
       float* dx = grad_acc(c, x, &acc);
-      const int prow = minmax_bwd_colpart_rows(x->n, x->c);
+      const int prow = minmax_bwd_colpart_rows(x->n, HW, x->c);
       float* part = colpart_for(c, x, acc, prow);
       unsigned short* gplane = producer_plane(c, x, true);
-      launch_minmax_bwd(x->d, mm->d, out->g, dx, plane_only_acc(c, x, acc, gplane), x->n, HW, x->c, c.stream, pre_leak, gplane, part);
+      launch_minmax_bwd(x->d, mm->d, out->g, dx, plane_only_acc(c, x, acc, gplane), x->n, HW, x->c, c.stream, pre_leak, gplane, part,
+                        mm_scratch(c, x->n, HW, x->c));
       colpart_done(x, part, prow);
     });
   }

@@ -390,6 +390,12 @@ def all_op_checks(net):
     for a in (0, 1, 2):
         rows += check_in_act(net, a)
     rows += check_in_act(net, 2, shape=(2, 4, 8, 512))
+    # maps of more than 1,024 pixels: the chunked two-stage InstanceNorm kernels (k_norm.hip; 256-row chunks, a partial last chunk,
+    # a partial 64-channel group) -- forward, backward, forward tangent and its reverse
+    rows += check_in_act(net, 1, shape=(2, 48, 40, 96), seed=21)
+    rows += check_in_act(net, 2, shape=(3, 33, 32, 64), seed=22)
+    rows += check_in_tangent(net, 2, shape=(2, 40, 36, 64), seed=23)
+    rows += check_in_tangent(net, 2, shape=(1, 64, 33, 160), seed=24)
     rows += check_in_tangent(net, 2)
     rows += check_in_tangent(net, 2, shape=(2, 4, 8, 128), seed=33)
     for i, shape in enumerate(TANGENT_SHAPES):
@@ -405,6 +411,9 @@ def all_op_checks(net):
         mn, mx = t.amin(dim=(1, 2), keepdim=True), t.amax(dim=(1, 2), keepdim=True)
         return (t - mn) / (mx - mn)
     rows += check_simple(net, 'minmax', (2, 8, 8, 40), 0, mm)
+    # maps of more than 4,096 pixels: the chunked min-max gate (k_elem.hip; 8-channel and 64-channel block forms, partial chunks)
+    rows += check_simple(net, 'minmax', (2, 80, 64, 40), 0, mm, seed=41)
+    rows += check_simple(net, 'minmax', (1, 72, 65, 64), 0, mm, seed=42)
     rows += check_bn(net)
     for act, shape in ((1, (3, 8, 8, 64)), (2, (2, 16, 32, 128)), (0, (3, 24, 16, 96)), (2, (64, 4, 8, 512)), (1, (2, 3, 32, 40))):
         rows += check_bn_act(net, act, shape)
