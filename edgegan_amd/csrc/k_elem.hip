@@ -1154,11 +1154,9 @@ __global__ __launch_bounds__(256) void mmc_bwd_apply_kernel(const float* __restr
     if (dx_bf) st_bf4(dx_bf, i >> 2, o);
   }
 }
-// (more than 4,096 pixels per map, or at least 2,048 with fewer (image, 32-channel group) blocks than CUs: the 64 x 64 maps at
-//  configs[4]'s batch of 16)
-bool minmax_chunked_shape(int NB, int HW, int C) {
-  return C % 8 == 0 && (HW > 4096 || (HW >= 2048 && (long long)NB * ((C + 31) / 32) < 256));
-}
+// (more than 4,096 pixels per map.  Also taking the 64 x 64 maps when the per-map blocks do not fill the chip -- batch 16 -- measured
+//  +-0 at 256 x 512: profiles/r06ad)
+bool minmax_chunked_shape(int NB, int HW, int C) { return C % 8 == 0 && HW > 4096; }
 size_t minmax_chunk_scratch_floats(int NB, int HW, int C) {
   const size_t nch = (size_t)(HW + MMC_ROWS - 1) / MMC_ROWS;
   return (size_t)NB * nch * C * 4 + (size_t)NB * C * 3;

@@ -487,8 +487,8 @@ void launch_minmax_bwd(const float* x, const float* mm, const float* dy, float* 
                        int HW, int C, hipStream_t s, float pre_leak = 0.f, unsigned short* dx_bf = nullptr, float* colpart = nullptr,
                        float* chunk_scratch = nullptr);
 int minmax_bwd_colpart_rows(int NB, int HW, int C);
-// chunk_scratch: minmax_chunk_scratch_floats(NB, HW, C) floats of the caller's; with it, large maps (minmax_chunked_shape: more than
-// 4,096 pixels, or at least 2,048 when the per-map blocks would not fill the chip) take the chunked two-stage form (no column partials there: minmax_bwd_colpart_rows returns 0)
+// chunk_scratch: minmax_chunk_scratch_floats(NB, HW, C) floats of the caller's; with it, maps of more than 4,096 pixels
+// (minmax_chunked_shape) take the chunked two-stage form (no column partials there: minmax_bwd_colpart_rows returns 0)
 bool minmax_chunked_shape(int NB, int HW, int C);
 size_t minmax_chunk_scratch_floats(int NB, int HW, int C);
 // gate merge: out = h + rg*img ; backward
