@@ -45,12 +45,18 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // channels ARE the 8 K-values v_mfma_f32_16x16x32_bf16 takes from lane (p, g), so the operand registers are split in place
 // (k_gemm_x3.hip: split_pair) and one K step of 32 channels is 6 limb MFMAs of 16 cycles per column tile instead of 8 fp32
 // MFMAs of 32; the filter image holds the three limb planes [limb][C / 8][NP][8] bf16 (one ds_read_b128 per plane).
+constexpr int kScatStripW = 62;   // output columns of a column strip (its 64 local columns = these + one halo column each side)
 template <int N, bool X3>
-__global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int S, int R, int lw) {
+__global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int S, int R, int lw, int xstrips) {
   constexpr int NT = (9 * N + 15) / 16;
   constexpr int NP = NT * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int C = a.C, H = a.IH, W = a.IW;
+  // Column strips (round 6: images wider than the product ring can hold -- 128 / 256 columns at configs[4]'s geometry): a block
+  // then owns kScatStripW output columns; its LOCAL width W = 64 is those plus one halo column each side, local column lc is image
+  // column gx0 + lc, columns outside the image load zeros (their products are zero), and only the inner columns are emitted.
+  // xstrips == 1: the whole row, W = the image width, gx0 = 0.
+  const int C = a.C, H = a.IH, WG = a.IW;
+  const int W = xstrips > 1 ? 64 : WG;
   float* Wl = smem;                        // [C / 8][NP][8] fp32, or X3: [3][C / 8][NP][8] bf16
   unsigned short* Wb = reinterpret_cast<unsigned short*>(smem);
   float* Pr = smem + (X3 ? (size_t)C * NP * 3 / 2 : (size_t)C * NP);       // [(2R + 2) rows][W][NP]
@@ -58,7 +64,11 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) == 0;
   const int strips = (H + S - 1) / S;
-  const int nb = (int)blockIdx.x / strips, ya = ((int)blockIdx.x % strips) * S;
+  const int bxy = (int)blockIdx.x / xstrips, xs = (int)blockIdx.x - bxy * xstrips;
+  const int nb = bxy / strips, ya = (bxy % strips) * S;
+  const int gx0 = xstrips > 1 ? xs * kScatStripW - 1 : 0;                 // image column of local column 0
+  const int ol0 = xstrips > 1 ? 1 : 0;                                    // local columns [ol0, ol1) are this block's outputs
+  const int ol1 = xstrips > 1 ? min(1 + kScatStripW, WG - gx0) : WG;
   const int yb = min(H, ya + S);
   const ConvPhase ph = a.ph[0];
   const int D = a.D;                       // +1: input pixel = out + tap - 1; -1: out - tap + 1 (offy == offx == -D)
@@ -132,8 +142,8 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
       }
       if constexpr (N % 4 == 0) {
         constexpr int NQ = N / 4;
-        for (int t = tid; t < W * NQ; t += 256) {
-          const int ox = t / NQ, q4 = t - ox * NQ;
+        for (int t = tid + ol0 * NQ; t < ol1 * NQ; t += 256) {
+          const int oxl = t / NQ, q4 = t - oxl * NQ, ox = gx0 + oxl;   // (oxl: local column of the ring, ox: image column)
           // branch-free: out-of-image taps read a clamped address and are multiplied by 0 (all 9 reads in flight at once)
           f32x4 pv[9];
           bool keep[9];
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
             const float* prow = Pr + (size_t)(slot[ty] < 0 ? 0 : slot[ty]) * W * NP + 4 * q4;
 #pragma unroll
             for (int tx = 0; tx < 3; ++tx) {
-              const int ix = ox + (tx - 1) * D;
+              const int ix = oxl + (tx - 1) * D;
               const bool ok = slot[ty] >= 0 && ix >= 0 && ix < W;
               const int ixc = min(max(ix, 0), W - 1);
               pv[ty * 3 + tx] = *reinterpret_cast<const f32x4*>(prow + ixc * NP + (ty * 3 + tx) * N);
@@ -182,7 +192,8 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
           }
         }
       } else {
-        for (int ox = tid; ox < W; ox += 256) {
+        for (int oxl = tid + ol0; oxl < ol1; oxl += 256) {
+          const int ox = gx0 + oxl;
           float v[N];
 #pragma unroll
           for (int n = 0; n < N; ++n) v[n] = 0.f;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
             const float* prow = Pr + (size_t)slot[ty] * W * NP;
 #pragma unroll
             for (int tx = 0; tx < 3; ++tx) {
-              const int ix = ox + (tx - 1) * D;
+              const int ix = oxl + (tx - 1) * D;
               if (ix < 0 || ix >= W) continue;
 #pragma unroll
               for (int n = 0; n < N; ++n) v[n] += prow[ix * NP + (ty * 3 + tx) * N + n];
@@ -239,9 +250,9 @@ __global__ __launch_bounds__(512) void conv_scatter_kernel(const ConvArgs a, int
   // this lane's pixel of tile j in round k: byte offset of its channel group, or out of range (-> zeros)
   auto pix_off = [&](int k, int j) -> unsigned {
     const int idx = ((wave + 4 * j) << 4) + p15;
-    const int row = lo + k * R + (idx >> lw), col = idx & (W - 1);
-    if (k >= rounds || row >= hi) return 0x80000000u;
-    return (unsigned)((((nb * H + row) * W + col) * a.x_ps + 8 * g) * 4);
+    const int row = lo + k * R + (idx >> lw), col = gx0 + (idx & (W - 1));
+    if (k >= rounds || row >= hi || col < 0 || col >= WG) return 0x80000000u;
+    return (unsigned)((((nb * H + row) * WG + col) * a.x_ps + 8 * g) * 4);
   };
   // flat sequence of this wave's work items (round, tile, K step); the operand loads run PD items ahead
 #ifndef EG_SCATTER_PD
@@ -380,23 +391,34 @@ static bool scatter_x3(const ConvArgs& a) {   // f32x3 / bf16 modes: limb produc
   return a.pk && !off;
 }
 
-static bool scatter_geometry(const ConvArgs& a, int* S, int* R, size_t* lds) {
-  const int W = a.IW, H = a.IH;
-  if (W < 4 || (W & (W - 1)) != 0) return false;
-  int r = std::max(1, 64 / W);
-  if (r > H || (H % r) != 0) return false;
-  if ((r * W) % 64 != 0) return false;
+// xstrips: 1 = a block takes whole image rows (the image's width must be a power of two and its product ring must fit the LDS);
+// > 1 = column strips of kScatStripW outputs with a 64-column local ring (any width >= 64)
+static bool scatter_geometry(const ConvArgs& a, int* S, int* R, size_t* lds, int* xstrips) {
+  const int H = a.IH;
   const int NP = ((9 * a.N + 15) / 16) * 16;
-  // strips: at least ~256 blocks when the batch alone does not give them, strip height a multiple of R
-  int strips = std::max(1, (256 + a.NB - 1) / a.NB);
-  strips = std::min(strips, H / r);
-  int s = (H + strips - 1) / strips;
-  s = (s + r - 1) / r * r;
-  *S = s;
-  *R = r;
   const bool x3 = scatter_x3(a);
-  *lds = ((x3 ? (size_t)a.C * NP * 3 / 2 : (size_t)a.C * NP) + (size_t)(2 * r + 2) * W * NP) * sizeof(float);
-  return *lds <= (x3 ? 160 : 150) * 1024;
+  const size_t cap = (size_t)(x3 ? 160 : 150) * 1024;
+  for (int strip = 0; strip < 2; ++strip) {
+    const int W = strip ? 64 : a.IW;
+    if (strip && a.IW < 64) return false;
+    if (W < 4 || (W & (W - 1)) != 0) continue;
+    const int r = std::max(1, 64 / W);
+    if (r > H || (H % r) != 0 || (r * W) % 64 != 0) continue;
+    const int xs = strip ? (a.IW + kScatStripW - 1) / kScatStripW : 1;
+    // row strips: at least ~256 blocks when the batch (and the column strips) alone do not give them, height a multiple of R
+    int strips = std::max(1, (256 + a.NB * xs - 1) / (a.NB * xs));
+    strips = std::min(strips, H / r);
+    int s = (H + strips - 1) / strips;
+    s = (s + r - 1) / r * r;
+    const size_t bytes = ((x3 ? (size_t)a.C * NP * 3 / 2 : (size_t)a.C * NP) + (size_t)(2 * r + 2) * W * NP) * sizeof(float);
+    if (bytes > cap) continue;
+    *S = s;
+    *R = r;
+    *lds = bytes;
+    *xstrips = xs;
+    return true;
+  }
+  return false;
 }
 
 bool conv_scatter_eligible(const ConvArgs& a) {
@@ -408,13 +430,13 @@ bool conv_scatter_eligible(const ConvArgs& a) {
   if (p.OHp != a.IH || p.OWp != a.IW || p.ophy != 0 || p.ophx != 0) return false;
   if (a.shuf ? (a.N != 12 || a.OHf != 2 * a.IH || a.OWf != 2 * a.IW) : (a.os != 1 || a.OHf != a.IH || a.OWf != a.IW)) return false;
   if (a.x_ps % 4 != 0 || (((uintptr_t)a.x) & 15) != 0 || a.x_bytes == 0) return false;
-  int S, R;
+  int S, R, xs;
   size_t lds;
-  return scatter_geometry(a, &S, &R, &lds);
+  return scatter_geometry(a, &S, &R, &lds, &xs);
 }
 
 template <int N, bool X3>
-static void scatter_launch(const ConvArgs& a, int S, int R, size_t lds, hipStream_t s) {
+static void scatter_launch(const ConvArgs& a, int S, int R, size_t lds, int xstrips, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_scatter_kernel<N, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -422,29 +444,30 @@ static void scatter_launch(const ConvArgs& a, int S, int R, size_t lds, hipStrea
     attr_set = true;
   }
   const int strips = (a.IH + S - 1) / S;
-  hipLaunchKernelGGL((conv_scatter_kernel<N, X3>), dim3(a.NB * strips), dim3(512), lds, s, a, S, R, ilog2(a.IW));
+  hipLaunchKernelGGL((conv_scatter_kernel<N, X3>), dim3(a.NB * strips * xstrips), dim3(512), lds, s, a, S, R,
+                     ilog2(xstrips > 1 ? 64 : a.IW), xstrips);
 }
 
 const char* launch_conv_scatter(const ConvArgs& a, hipStream_t s) {
-  int S, R;
+  int S, R, xs;
   size_t lds;
-  scatter_geometry(a, &S, &R, &lds);
+  scatter_geometry(a, &S, &R, &lds, &xs);
   if (scatter_x3(a)) {
     switch (a.N) {
-      case 3: scatter_launch<3, true>(a, S, R, lds, s); break;
-      case 4: scatter_launch<4, true>(a, S, R, lds, s); break;
-      case 8: scatter_launch<8, true>(a, S, R, lds, s); break;
-      default: scatter_launch<12, true>(a, S, R, lds, s); break;
+      case 3: scatter_launch<3, true>(a, S, R, lds, xs, s); break;
+      case 4: scatter_launch<4, true>(a, S, R, lds, xs, s); break;
+      case 8: scatter_launch<8, true>(a, S, R, lds, xs, s); break;
+      default: scatter_launch<12, true>(a, S, R, lds, xs, s); break;
     }
-    return "conv_scatter<3x3,N<=12,limbs>";
+    return xs > 1 ? "conv_scatter<3x3,N<=12,limbs,column strips>" : "conv_scatter<3x3,N<=12,limbs>";
   }
   switch (a.N) {
-    case 3: scatter_launch<3, false>(a, S, R, lds, s); break;
-    case 4: scatter_launch<4, false>(a, S, R, lds, s); break;
-    case 8: scatter_launch<8, false>(a, S, R, lds, s); break;
-    default: scatter_launch<12, false>(a, S, R, lds, s); break;
+    case 3: scatter_launch<3, false>(a, S, R, lds, xs, s); break;
+    case 4: scatter_launch<4, false>(a, S, R, lds, xs, s); break;
+    case 8: scatter_launch<8, false>(a, S, R, lds, xs, s); break;
+    default: scatter_launch<12, false>(a, S, R, lds, xs, s); break;
   }
-  return "conv_scatter<3x3,N<=12>";
+  return xs > 1 ? "conv_scatter<3x3,N<=12,column strips>" : "conv_scatter<3x3,N<=12>";
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

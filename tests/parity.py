@@ -91,6 +91,11 @@ CONV_CASES = [
     ('cls mru Conv 3x3 C3->8 64x64 (32-pixel segments)', 1, 64, 64, 3, 8, 3, 1, 0, True),
     ('cls h0 7x7 C3->8 64x64', 1, 64, 64, 3, 8, 7, 1, 0, True),
     ('thin REFLECT 3x3 C3->32 8x4 nb3', 3, 8, 4, 3, 32, 3, 1, 1, True),
+    # conv_scatter in column strips (k_thin.hip: rows wider than its product ring holds -- configs[4]'s 128 / 256-column maps): three
+    # strips with a 4-column last one, five strips, a width that is no power of two
+    ('thin 3x3 C64->12 32x128 (column strips)', 2, 32, 128, 64, 12, 3, 1, 0, True),
+    ('thin 3x3 C128->8 16x256 (column strips)', 1, 16, 256, 128, 8, 3, 1, 0, True),
+    ('thin 3x3 C32->4 8x192 (column strips, width 192)', 2, 8, 192, 32, 4, 3, 1, 0, False),
     # stride-1 layers with >= 128 output channels: the halo-staged kernel (k_gemm_x3h.hip) in the f32x3 / bf16 modes --
     # one 16x16 tile per image, 2x2 tiles per image, 4 images per tile, and the 2x2-tap phases of a stride-2 input gradient
     ('cls Conv_2 3x3 C128->128 16x16', 2, 16, 16, 128, 128, 3, 1, 0, True),
