@@ -1474,12 +1474,24 @@ __global__ __launch_bounds__(256) void bn_chunk_j_kernel(const float* __restrict
   const float mean = cv ? stats[c] : 0.f, rs = cv ? 1.f / sqrtf(stats[C + c] + eps) : 1.f;
   float s[2] = {0.f, 0.f};
   if (cv)
-    for (int p = r0 + py; p < r1; p += 4) {
-      const size_t i = (size_t)p * C + c;
-      float e = v[i];
-      if (MODE == 0) e *= act_grad_from_out(out[i], act);
-      s[0] += e;
-      s[1] += e * ((x[i] - mean) * rs);
+    for (int p0 = r0 + py; p0 < r1; p0 += 32) {   // eight rows per step, their loads issued together
+      float xr[8], er[8], orr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + 4 * u;
+        const size_t i = (size_t)(p < r1 ? p : r0) * C + c;
+        xr[u] = x[i];
+        er[u] = v[i];
+        orr[u] = MODE == 0 ? out[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p0 + 4 * u < r1) {
+          float e = er[u];
+          if (MODE == 0) e *= act_grad_from_out(orr[u], act);
+          s[0] += e;
+          s[1] += e * ((xr[u] - mean) * rs);
+        }
     }
   lane4_reduce<2>(s, red, cx, py);
   if (cv && py == 0) {

@@ -1480,9 +1480,17 @@ T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int upda
   const int C = x->c, R = (int)x->pixels();
   T out = new_tensor(c, x->n, x->h, x->w, C, true);
   T st = new_tensor(c, 1, 1, 1, 2 * C, false);
-  // (bf16 mode: the plane the first transposed convolution stages, from the same pass -- no cvt_bf16 launch behind it)
-  unsigned short* plane = C % 32 == 0 ? producer_plane(c, out, false) : nullptr;
-  if (!launch_bn_relu_fwd(x->d, gamma->w, beta->w, out->d, st->d, R, C, 1e-5f, c.stream, plane)) out->d_bf = nullptr;
+  // (R >= 4,096 rows -- configs[4]'s generator head, 16 x 16 x 32 positions -- : the chunked two-stage BatchNorm kernels of the block
+  //  norms, k_norm.hip; the one-block-per-32-channels form walks the rows in a loop: 88 us per launch there)
+  const bool big = R >= 4096;
+  if (big) {
+    launch_bn_act_fwd(x->d, gamma->w, beta->w, out->d, st->d, c.arena.allocf(bn_scratch_floats(R, C)), nullptr, nullptr, 0, R, C, 1e-5f,
+                      ACT_RELU, c.stream);
+  } else {
+    // (bf16 mode: the plane the first transposed convolution stages, from the same pass -- no cvt_bf16 launch behind it)
+    unsigned short* plane = C % 32 == 0 ? producer_plane(c, out, false) : nullptr;
+    if (!launch_bn_relu_fwd(x->d, gamma->w, beta->w, out->d, st->d, R, C, 1e-5f, c.stream, plane)) out->d_bf = nullptr;
+  }
   if (stats_out) *stats_out = st;
   if (update_times > 0) launch_bn_moving_update(mm->w, mv->w, st->d, C, R, 0.9f, update_times, c.stream);
   const bool need = x->needs_grad || gamma->want_grad;
@@ -1496,8 +1504,12 @@ T bn_relu(Ctx& c, T x, Param* gamma, Param* beta, Param* mm, Param* mv, int upda
       int acc = 0;
       if (x->needs_grad) dx = grad_acc(c, x, &acc);
       const bool pg = c.param_grad_enabled && gamma->want_grad;
-      launch_bn_relu_bwd(x->d, out->d, out->g, gamma->w, st->d, dx, acc, pg ? gamma->g : nullptr,
-                         gamma->g_set ? 1 : 0, pg ? beta->g : nullptr, beta->g_set ? 1 : 0, R, C, 1e-5f, c.stream);
+      if (big)
+        launch_bn_act_bwd(x->d, out->d, out->g, gamma->w, st->d, c.arena.allocf(bn_scratch_floats(R, C)), dx, acc, pg ? gamma->g : nullptr,
+                          gamma->g_set ? 1 : 0, pg ? beta->g : nullptr, beta->g_set ? 1 : 0, R, C, 1e-5f, ACT_RELU, c.stream);
+      else
+        launch_bn_relu_bwd(x->d, out->d, out->g, gamma->w, st->d, dx, acc, pg ? gamma->g : nullptr,
+                           gamma->g_set ? 1 : 0, pg ? beta->g : nullptr, beta->g_set ? 1 : 0, R, C, 1e-5f, c.stream);
       if (pg) gamma->g_set = beta->g_set = true;
     });
   }
