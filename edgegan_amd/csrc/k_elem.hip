@@ -1042,10 +1042,16 @@ __global__ void mmc_minmax_finalize_kernel(const float* __restrict__ part, int n
   const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
   if (c >= C) return;
   float mn = INFINITY, mx = -INFINITY;
-  for (int k = 0; k < nch; ++k) {
-    const float* o = part + (((size_t)n * nch + k) * C + c) * 2;
-    mn = fminf(mn, o[0]);
-    mx = fmaxf(mx, o[1]);
+  for (int k0 = 0; k0 < nch; k0 += 8) {   // (eight chunks' partials in flight)
+    float2 pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      pv[u] = *reinterpret_cast<const float2*>(part + (((size_t)n * nch + min(k0 + u, nch - 1)) * C + c) * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {   // (a repeated last chunk changes no minimum / maximum)
+      mn = fminf(mn, pv[u].x);
+      mx = fmaxf(mx, pv[u].y);
+    }
   }
   mm[((size_t)n * C + c) * 2] = mn;
   mm[((size_t)n * C + c) * 2 + 1] = mx;
@@ -1116,10 +1122,15 @@ __global__ void mmc_bwd_finalize_kernel(const float* __restrict__ part, const fl
   const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
   if (c >= C) return;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < nch; ++k) {
-    const float* o = part + (((size_t)n * nch + k) * C + c) * 4;
+  for (int k0 = 0; k0 < nch; k0 += 4) {   // (four chunks' partials in flight, summed in chunk order)
+    float4 pv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] += o[j];
+    for (int u = 0; u < 4; ++u) pv[u] = ld4(part + (((size_t)n * nch + min(k0 + u, nch - 1)) * C + c) * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + u < nch) {
+        s[0] += pv[u].x; s[1] += pv[u].y; s[2] += pv[u].z; s[3] += pv[u].w;
+      }
   }
   const float d = mm[((size_t)n * C + c) * 2 + 1] - mm[((size_t)n * C + c) * 2];
   float* o = coef + ((size_t)n * C + c) * 3;

@@ -567,13 +567,22 @@ __global__ void in_finalize_stats_kernel(const float* __restrict__ part, int nch
   const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
   if (c >= C) return;
   float cnt = 0.f, mean = 0.f, m2 = 0.f;
-  for (int k = 0; k < nch; ++k) {
-    const float nk = (float)min(IN_RPC, HW - k * IN_RPC);
-    const float* o = part + (((size_t)n * nch + k) * C + c) * 2;
-    const float d = o[0] - mean, nt = cnt + nk;
-    mean += d * (nk / nt);
-    m2 += o[1] + d * d * (cnt * nk / nt);
-    cnt = nt;
+  for (int k0 = 0; k0 < nch; k0 += 8) {   // (eight chunks' partials in flight; the merge itself stays in chunk order)
+    float2 pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      pv[u] = *reinterpret_cast<const float2*>(part + (((size_t)n * nch + min(k0 + u, nch - 1)) * C + c) * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      if (k < nch) {
+        const float nk = (float)min(IN_RPC, HW - k * IN_RPC);
+        const float d = pv[u].x - mean, nt = cnt + nk;
+        mean += d * (nk / nt);
+        m2 += pv[u].y + d * d * (cnt * nk / nt);
+        cnt = nt;
+      }
+    }
   }
   stats[((size_t)n * C + c) * 2] = mean;
   stats[((size_t)n * C + c) * 2 + 1] = sqrtf(m2 / (float)HW);
@@ -640,10 +649,17 @@ __global__ void in_finalize_j_kernel(const float* __restrict__ part, int nch, in
   const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
   if (c >= C) return;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < nch; ++k) {
-    const float* o = part + (((size_t)n * nch + k) * C + c) * 2;
-    a += o[0];
-    b += o[1];
+  for (int k0 = 0; k0 < nch; k0 += 8) {   // (eight chunks' partials in flight, summed in chunk order)
+    float2 pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      pv[u] = *reinterpret_cast<const float2*>(part + (((size_t)n * nch + min(k0 + u, nch - 1)) * C + c) * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < nch) {
+        a += pv[u].x;
+        b += pv[u].y;
+      }
   }
   sums[((size_t)n * C + c) * 2] = a;
   sums[((size_t)n * C + c) * 2 + 1] = b;

@@ -13,7 +13,7 @@ for L in prev cur; do
   LIB=edgegan_amd/libedgegan_hip_prev.so; [ $L = cur ] && LIB=edgegan_amd/libedgegan_hip.so
   bash tools/gpu_trace.sh $OUT/kernel_stats_256_bf16_$L.csv $LIB --dtype bf16 --height 256 --width 512 --batch 16 --steps 4 --warmup 2 --no-side-legs --no-live-traffic
 done
-for L in prev cur; do echo "== $L"; grep -h "bn_relu\|bn_chunk\|bn_apply\|bn_japply\|bn_finalize\|TOTAL" $OUT/kernel_stats_256_bf16_$L.csv | python3 -c "
+for L in prev cur; do echo "== $L"; grep -h "finalize\|TOTAL" $OUT/kernel_stats_256_bf16_$L.csv | python3 -c "
 import sys,csv
 for r in csv.reader(sys.stdin): print(r[0][:44].ljust(44), r[1].rjust(5), r[3].rjust(10), r[2].rjust(12))"; done
 python tools/gpu_ab_rounds.py edgegan_amd/libedgegan_hip_prev.so edgegan_amd/libedgegan_hip.so --rounds 3 --dtype bf16 --height 256 --width 512 --batch 16 --steps 5 | tee $OUT/ab_256_bf16.txt
