@@ -54,9 +54,9 @@ class Config:
     use_edge_discriminator: bool = True    # train.py:65-66
     image_dis_size: Optional[int] = None   # train.py:63-64 (None: dis_size)
     edge_dis_size: Optional[int] = None    # train.py:67    (None: dis_size)
-    E_norm: str = 'instance'   # train.py:54-59: 'instance' | 'batch' (nn/modules/normalization.py:10-29)
-    G_norm: str = 'instance'
-    D_norm: str = 'instance'
+    E_norm: Optional[str] = 'instance'   # train.py:54-59: 'instance' | 'batch' | None (nn/modules/normalization.py:10-29)
+    G_norm: Optional[str] = 'instance'
+    D_norm: Optional[str] = 'instance'
 
     @property
     def image_dis(self) -> int:
@@ -83,7 +83,7 @@ class Config:
                         _NORMS[self.E_norm], _NORMS[self.G_norm], _NORMS[self.D_norm])
 
 
-_NORMS = {'instance': 0, 'batch': 1}
+_NORMS = {'instance': 0, 'batch': 1, None: 2}   # (None: the identity branch, normalization.py:26-27)
 
 
 def _dtype_override(dtype: str) -> str:

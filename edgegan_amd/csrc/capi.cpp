@@ -42,10 +42,14 @@ static Config to_config(const eg_config* k) {
   c.device = k->device;
   c.bf16 = k->compute_dtype == 1;
   c.x3 = k->compute_dtype == 2;
-  EG_CHECK((unsigned)k->e_norm <= 1u && (unsigned)k->g_norm <= 1u && (unsigned)k->d_norm <= 1u, "e_norm / g_norm / d_norm: 0 = instance, 1 = batch");
+  EG_CHECK((unsigned)k->e_norm <= 2u && (unsigned)k->g_norm <= 2u && (unsigned)k->d_norm <= 2u,
+           "e_norm / g_norm / d_norm: 0 = instance, 1 = batch, 2 = None");
   c.e_bn = k->e_norm == 1;
   c.g_bn = k->g_norm == 1;
   c.d_bn = k->d_norm == 1;
+  c.e_nonorm = k->e_norm == 2;
+  c.g_nonorm = k->g_norm == 2;
+  c.d_nonorm = k->d_norm == 2;
   return c;
 }
 

@@ -19,6 +19,7 @@ struct Config {
   bool bf16 = false;  // dense contractions on the bf16 MFMA (operands rounded, fp32 accumulate / storage)
   bool x3 = false;    // fp32 contractions as three-limb bf16 splits on the bf16 MFMA (exact limb products, fp32 accumulate)
   bool e_bn = false, g_bn = false, d_bn = false;   // E_norm / G_norm / D_norm == 'batch' (train.py:54-59; default 'instance')
+  bool e_nonorm = false, g_nonorm = false, d_nonorm = false;   // ... == None: the block's norm is the identity (normalization.py:26-27)
   bool multiclasses() const { return num_classes > 0; }
   int g_in() const { return z_dim + (multiclasses() ? num_classes : 0); }
 };

@@ -417,7 +417,7 @@ T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out, flo
   const int ch[5] = {gf * 8, gf * 4, gf * 2, gf, cfg.c_dim};
   for (int i = 1; i <= 4; ++i) {
     const std::string b = p + "/g_dconv_" + std::to_string(i) + "/deconv2d/";
-    c.feeds_in = i < 4 && !cfg.g_bn;   // deconv_block: the InstanceNorm is the transposed convolution's only reader
+    c.feeds_in = i < 4 && !cfg.g_bn && !cfg.g_nonorm;   // deconv_block: the InstanceNorm is the transposed convolution's only reader
     x = deconv2d(c, x, wref_param(c, P(c, b + "w"), 25, ch[i], ch[i - 1]), P(c, b + "b"), ch[i], i == 4 ? ACT_TANH : 0,
                  i == 4 ? out_into : nullptr);
     // (bf16 mode, forward-only graph: the next transposed convolution stages the bf16 plane -- the fp32 copy is not written;
@@ -426,6 +426,8 @@ T generator_forward(Ctx& c, int group, T zin, int bn_times, T* bn_stats_out, flo
       T bst = nullptr;
       x = block_bn(c, x, p + "/g_dconv_" + std::to_string(i), ACT_RELU, bn_times, &bst);
       c.gen_blk_stats[i - 1] = bst;
+    } else if (i < 4 && cfg.g_nonorm) {   // G_norm = None (normalization.py:26-27): deconv -> ReLU
+      x = act(c, x, ACT_RELU);
     } else if (i < 4)
       x = in_act(c, x, ACT_RELU, nullptr, /*plane_only=*/cfg.bf16 && !x->needs_grad && i < 3);
   }
@@ -450,7 +452,7 @@ T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_o
     WRef* w = wref_param(c, P(c, p + "/" + kDiscNames[i] + "/conv2d/w"), 16, ch[i], ch[i + 1]);
     // (first block: conv + LeakyReLU, fused where the small-C kernel runs the conv; `pre` is then the activated output,
     //  which is all the tangent pass and the backward need of it)
-    c.feeds_in = i > 0 && !tangent_of && !cfg.d_bn;   // conv_block: the InstanceNorm is the convolution's only forward reader
+    c.feeds_in = i > 0 && !tangent_of && !cfg.d_bn && !cfg.d_nonorm;   // conv_block: the InstanceNorm is the convolution's only forward reader
     c.conv_plane_only_next = cfg.bf16 && i == 0 && !tangent_of && !save;   // (no tangent pass will read this output's values)
     T pre = conv2d(c, x, w, nullptr, 4, 2, PAD_SAME, nullptr, (i == 0 && !tangent_of) ? ACT_LRELU : 0);
     T out, st = nullptr;
@@ -463,6 +465,12 @@ T disc_forward(Ctx& c, int group, T x, DiscSave* save, const DiscSave* tangent_o
         save->pre[i] = pre;
         save->out[i] = out;
         save->stats[i] = st;
+      }
+    } else if (cfg.d_nonorm && i > 0) {   // D_norm = None (normalization.py:26-27): conv -> LeakyReLU, as block 1
+      out = !tangent_of ? act(c, pre, ACT_LRELU) : act_tangent(c, pre, tangent_of->out[i], ACT_LRELU);
+      if (save && !tangent_of) {
+        save->pre[i] = pre;
+        save->out[i] = out;
       }
     } else if (!tangent_of) {
       out = (i == 0) ? pre : in_act(c, pre, ACT_LRELU, &st, /*plane_only=*/cfg.bf16 && i < 3);   // (layer 3 feeds the linear head)
@@ -490,16 +498,18 @@ T encoder_forward(Ctx& c, T x, const float* eps_dev, T* mu_out, T* ls_out, T* z1
     const std::string b = "E/e_resnet_" + std::to_string(n) + "_" + std::to_string(i++);
     const int main_lane = c.cur_lane;
     if (c.infer_side >= 0) EG_HIP(hipEventRecord(c.ev_infer[main_lane], c.stream));   // the block's input is complete here
-    c.feeds_in = !cfg.e_bn;   // residual: both 3x3 convolutions are read by their InstanceNorm alone
+    c.feeds_in = !cfg.e_bn && !cfg.e_nonorm;   // residual: both 3x3 convolutions are read by their InstanceNorm alone
     T o1 = conv2d(c, E, wref_param(c, P(c, b + "/res1/conv2d/w"), 9, cin, n), P(c, b + "/res1/conv2d/b"), 3, 1,
                   PAD_REFLECT);
     // E_norm = 'batch' (encoder.py:67 through conv.py:70-85): BatchNorm in both halves of the block
+    // E_norm = None (normalization.py:26-27): conv -> ReLU -> conv
     o1 = cfg.e_bn ? block_bn(c, o1, b + "/res1", ACT_RELU, c.bn_times_block)
+         : cfg.e_nonorm ? act(c, o1, ACT_RELU)
                   : in_act(c, o1, ACT_RELU, nullptr, /*plane_only=*/cfg.bf16 && !o1->needs_grad);   // (forward-only graph: res2 stages the plane)
-    c.feeds_in = !cfg.e_bn;
+    c.feeds_in = !cfg.e_bn && !cfg.e_nonorm;
     T o2 = conv2d(c, o1, wref_param(c, P(c, b + "/res2/conv2d/w"), 9, n, n), P(c, b + "/res2/conv2d/b"), 3, 1,
                   PAD_REFLECT);
-    o2 = cfg.e_bn ? block_bn(c, o2, b + "/res2", ACT_NONE, c.bn_times_block) : in_act(c, o2, ACT_NONE);
+    if (!cfg.e_nonorm) o2 = cfg.e_bn ? block_bn(c, o2, b + "/res2", ACT_NONE, c.bn_times_block) : in_act(c, o2, ACT_NONE);
     if (c.infer_side >= 0) {
       use_lane(c, c.infer_side);
       EG_HIP(hipStreamWaitEvent(c.stream, c.ev_infer[main_lane], 0));
@@ -1019,7 +1029,7 @@ static void disc_substep_stacked(Ctx& c, int group, T real, T fake, const float*
 static void d_substep(Ctx& c, int group, T real, T fake, const float* alpha_dev, int slot_d, int slot_gp, bool apply) {
   static const bool tape_form = dbg_env("EG_D_TAPE") != nullptr;
   // (D_norm = 'batch': the tape form -- the stacked sweep's row classes are InstanceNorm's, and BatchNorm couples the rows of a call)
-  if (tape_form || c.cfg.d_bn) disc_substep(c, group, real, fake, alpha_dev, slot_d, slot_gp, apply);
+  if (tape_form || c.cfg.d_bn || c.cfg.d_nonorm) disc_substep(c, group, real, fake, alpha_dev, slot_d, slot_gp, apply);
   else disc_substep_stacked(c, group, real, fake, alpha_dev, slot_d, slot_gp, apply);
 }
 

@@ -57,7 +57,9 @@ typedef struct eg_config {
                           implementation: held to the fp32 tolerances, ~1.35x faster -- DESIGN.md 3.4); 1 = the
                           contractions take bf16-ROUNDED operands on the bf16 MFMA with fp32 accumulation; storage,
                           norms, losses and RMSProp stay fp32 in every mode (BASELINE configs 2,4,5) */
-  int e_norm, g_norm, d_norm; /* train.py:54-59 E_norm / G_norm / D_norm: 0 = 'instance' (the default), 1 = 'batch' -- the
+  int e_norm, g_norm, d_norm; /* train.py:54-59 E_norm / G_norm / D_norm: 0 = 'instance' (the default), 1 = 'batch', 2 = None
+                                 (normalization.py:26-27: the block keeps its activation only; reachable from Python, not from
+                                 the string flags, whose 'None' fails normalization.py:12's assertion) -- the
                                  normalisation of the encoder's residual blocks (models/encoder.py:67), the generators'
                                  transposed-convolution blocks (models/generator.py:54-68; the first norm is BatchNorm whatever
                                  the flag, generator.py:51-52) and the discriminators' blocks 2 - 4 (models/discriminator.py:

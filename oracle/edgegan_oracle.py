@@ -239,9 +239,9 @@ class Config:
     use_edge_discriminator: bool = True      # train.py:65-66
     image_dis_size: Optional[int] = None     # train.py:63-64
     edge_dis_size: Optional[int] = None      # train.py:67
-    E_norm: str = 'instance'                 # train.py:54-59: 'instance' | 'batch' (normalization.py:10-29)
-    G_norm: str = 'instance'
-    D_norm: str = 'instance'
+    E_norm: Optional[str] = 'instance'       # train.py:54-59: 'instance' | 'batch' | None (normalization.py:10-29)
+    G_norm: Optional[str] = 'instance'
+    D_norm: Optional[str] = 'instance'
 
     @property
     def image_dis(self) -> int:

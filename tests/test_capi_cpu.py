@@ -53,12 +53,14 @@ def test_registry_non_default_discriminator_flags(built_lib, flags):
 
 
 @pytest.mark.parametrize('flags', [dict(G_norm='batch'), dict(E_norm='batch'), dict(D_norm='batch'),
-                                   dict(E_norm='batch', G_norm='batch', D_norm='batch', num_classes=0)])
+                                   dict(E_norm='batch', G_norm='batch', D_norm='batch', num_classes=0),
+                                   dict(E_norm=None, G_norm=None, D_norm=None)])
 def test_registry_batch_norm_flags(built_lib, flags):
     """edgegan/train.py:54-59 E_norm / G_norm / D_norm = 'batch' (nn/modules/normalization.py:19-25): every normalised block
     gains contrib batch_norm's four variables under <block>/batch_norm/BatchNorm -- the generators' g_dconv_1..3
     (generator.py:54-68), the discriminators' d_conv_1, d_conv_3, d_conv_4 (discriminator.py:63-72; d_conv_0 has norm=None),
-    both halves of every residual block of the encoder (encoder.py:67, conv.py:73-80); beta / gamma trainable."""
+    both halves of every residual block of the encoder (encoder.py:67, conv.py:73-80); beta / gamma trainable.  None
+    (normalization.py:26-27) adds nothing: the registry of the InstanceNorm graph."""
     cfg = ea.Config(batch_size=2, **flags)
     got = [(s.name, tuple(s.shape), s.trainable) for s in ea.variable_specs(cfg)]
     want = [(s.name, tuple(s.shape), s.trainable) for s in O.variable_specs(O.Config(batch_size=2, **flags))]
