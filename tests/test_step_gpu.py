@@ -152,9 +152,18 @@ def test_substeps_batch_norm_flags(flags):
             net.close()
 
 
-def test_inference_matches_oracle():
-    cfg = ea.Config(batch_size=2)
+@pytest.mark.parametrize('flags', [dict(), dict(E_norm='batch', G_norm='batch'), dict(E_norm=None, G_norm=None)],
+                         ids=['default', 'batch_norms', 'no_norms'])
+def test_inference_matches_oracle(flags):
+    """The test graph (edgegan.py:492-517,591-609) under the three block norms of normalization.py:10-29."""
+    cfg = ea.Config(batch_size=2, **flags)
     values = ea.init_variables(cfg, 2)
+    rng = np.random.RandomState(6)
+    for n in values:      # (move BatchNorm's scale / shift off their initial 1 / 0)
+        if n.endswith('BatchNorm/gamma'):
+            values[n] = (1.0 + 0.2 * rng.standard_normal(values[n].shape)).astype(np.float32)
+        elif n.endswith('BatchNorm/beta'):
+            values[n] = (0.1 * rng.standard_normal(values[n].shape)).astype(np.float32)
     net = ea.EdgeGAN(cfg, values)
     om = O.OracleModel(parity.oracle_config(cfg), values, dtype=torch.float64)
     for nb in (1, 3):      # the reference tests with batch 1 (test.py:89); BN uses batch statistics

@@ -99,8 +99,10 @@ def test_x3_network_forwards(num_classes):
     test_step_gpu.test_network_forwards(num_classes)
 
 
-def test_x3_inference_matches_oracle():
-    test_step_gpu.test_inference_matches_oracle()
+@pytest.mark.parametrize('flags', [dict(), dict(E_norm='batch', G_norm='batch'), dict(E_norm=None, G_norm=None)],
+                         ids=['default', 'batch_norms', 'no_norms'])
+def test_x3_inference_matches_oracle(flags):
+    test_step_gpu.test_inference_matches_oracle(flags)
 
 
 def test_x3_substeps_14_classes():
