@@ -683,3 +683,35 @@ def test_mfma_probe_reports_the_matrix_pipes_sustained_rate():
     const, rnd = net.mfma_probe(4000, False), net.mfma_probe(4000, True)
     net.close()
     assert 500.0 < rnd <= const * 1.03 and const < 2600.0, (const, rnd)
+
+
+def test_engine_create_destroy_returns_its_device_memory():
+    """eg_create ... eg_destroy in a loop (a training job, an evaluation job, a restart in one process): every buffer, stream and
+    event of a context is released with it.  Free device memory (hipMemGetInfo) after the second and after the sixth cycle --
+    training iteration, evaluation and inference in each, all three arithmetic modes and the block-norm variants -- must agree."""
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+
+    def free_bytes():
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    kinds = [dict(), dict(compute_dtype='bf16'), dict(compute_dtype='f32x3'), dict(E_norm='batch', G_norm='batch', D_norm='batch'),
+             dict(D_norm=None), dict(compute_dtype='bf16', num_classes=0)]
+    seen = []
+    for rep in range(3):
+        for kw in kinds:
+            cfg = ea.Config(batch_size=8, **kw)
+            net = ea.EdgeGAN(cfg, ea.init_variables(cfg, 1))
+            b = ea.synthetic_batch(cfg, seed=3)
+            net.upload_batch(**b)
+            net.train_step()
+            assert all(np.isfinite(v) for v in net.losses().values())
+            net.evaluate()
+            net.infer(b['images'], None if not cfg.multiclasses else (np.arange(8) % cfg.num_classes).astype(np.int32), eps2=[0.1, 0.2])
+            net.close()
+        seen.append(free_bytes())
+    print('free device memory after each pass over the six configurations:', seen)
+    assert abs(seen[2] - seen[1]) < (32 << 20), seen      # (the first pass may leave the runtime's own pools / code objects behind)
